@@ -1,0 +1,380 @@
+"""Oracle restatement of the ocrs engine stages:
+  ocrs/src/lib.rs (OcrEngine), detection.rs (TextDetector),
+  recognition.rs (TextRecognizer), text_items.rs (TextLine/TextChar).
+
+TEST INFRASTRUCTURE ONLY (see oracle/csrc/ocrs_oracle.c header).  A "model" here
+is any object with `input_shape() -> list[int|None]` (None = symbolic) and
+`run(nchw: np.ndarray) -> np.ndarray`, mirroring `trait Model` (model.rs:6-17).
+"""
+import math
+
+import numpy as np
+
+from . import clib
+from .geometry import (Line, Rect, RectF, RotatedRect, as_i32, bounding_rect_of, downwards_line, f32,
+                       leftmost_edge, rightmost_edge, rround)
+from .layout import find_text_lines
+
+BLACK_VALUE = np.float32(-0.5)  # preprocess.rs:128
+
+# lib.rs:34 — 96 chars.  The checkout has ASCII 'E' where the EUR sign belongs
+# (comment lib.rs:33); count and indices are identical either way.
+DEFAULT_ALPHABET = " 0123456789!\"#$%&'()*+,-./:;<=>?@[\\]^_`{|}~€ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz"
+
+
+class ImageSourceError(ValueError):
+    pass
+
+
+class ImageSource:
+    """preprocess.rs:61-124."""
+
+    def __init__(self, data, chans_last):
+        self.data = data
+        self.chans_last = chans_last
+
+    @staticmethod
+    def from_bytes(buf, dimensions):
+        width, height = dimensions
+        channel_len = width * height
+        if channel_len == 0:
+            raise ImageSourceError("channel count is not 1, 3 or 4")
+        if len(buf) % channel_len != 0:
+            raise ImageSourceError("data length is not a multiple of `width * height`")
+        chans = len(buf) // channel_len
+        arr = np.frombuffer(buf, dtype=np.uint8).reshape(height, width, chans)
+        return ImageSource.from_tensor(arr, "hwc")
+
+    @staticmethod
+    def from_tensor(data, order):
+        chans_last = order.lower() == "hwc"
+        chans = data.shape[2] if chans_last else data.shape[0]
+        if chans not in (1, 3, 4):
+            raise ImageSourceError("channel count is not 1, 3 or 4")
+        return ImageSource(data, chans_last)
+
+
+def prepare_image(src):
+    return clib.prepare_image(src.data, src.chans_last)
+
+
+# ----------------------------------------------------------------- detection
+class TextDetector:
+    """detection.rs:66-201."""
+
+    def __init__(self, model, min_area=100.0, text_threshold=0.2):
+        self.model = model
+        self.min_area = np.float32(min_area)
+        self.text_threshold = np.float32(text_threshold)
+        self.input_shape = model.input_shape()
+
+    def threshold(self):
+        return self.text_threshold
+
+    def detect_text_pixels(self, image_chw):
+        _, img_h, img_w = image_chw.shape
+        in_h, in_w = self.input_shape[2], self.input_shape[3]
+        if in_h is None or in_w is None:
+            raise RuntimeError("failed to get model dims")
+        pad_bottom = max(in_h - img_h, 0)
+        pad_right = max(in_w - img_w, 0)
+        vh, vw = img_h + pad_bottom, img_w + pad_right
+        page = image_chw[0]
+        if vh != in_h or vw != in_w:
+            x = clib.resize_bilinear(page, in_h, in_w, vh, vw, float(BLACK_VALUE))
+        else:
+            x = np.full((in_h, in_w), BLACK_VALUE, np.float32)
+            x[:img_h, :img_w] = page
+        out = self.model.run(x.reshape(1, 1, in_h, in_w))
+        out = np.asarray(out, np.float32).reshape(in_h, in_w)
+        sl = np.ascontiguousarray(out[: in_h - pad_bottom, : in_w - pad_right])
+        if sl.shape != (img_h, img_w):
+            return clib.resize_bilinear(sl, img_h, img_w)
+        return sl
+
+    def detect_words(self, image_chw):
+        prob = self.detect_text_pixels(image_chw)
+        mask = clib.threshold(prob, float(self.text_threshold))
+        rects = clib.component_rects(mask, 3.0, float(self.min_area))
+        return [RotatedRect.from_array(r) for r in rects]
+
+
+# ----------------------------------------------------------------- recognition
+def line_polygon(words):
+    """recognition.rs:29-55 -> list of (x, y) int points."""
+    poly = []
+
+    def floor_point(p):
+        return (as_i32(p[0]), as_i32(p[1]))
+
+    for w in words:
+        left = downwards_line(leftmost_edge(w))
+        right = downwards_line(rightmost_edge(w))
+        poly.append(floor_point(left.start))
+        poly.append(floor_point(right.start))
+    for w in reversed(words):
+        left = downwards_line(leftmost_edge(w))
+        right = downwards_line(rightmost_edge(w))
+        poly.append(floor_point(right.end))
+        poly.append(floor_point(left.end))
+    return poly
+
+
+def resized_line_width(orig_width, orig_height, height):
+    """recognition.rs:58-75."""
+    aspect = f32(orig_width) / f32(orig_height)
+    v = f32(height) * aspect
+    # f32::clamp(10., 2400.); NaN propagates and `as u32` maps it to 0
+    if v != v:
+        return 0
+    v = min(max(v, f32(10.0)), f32(2400.0))
+    return int(v)
+
+
+def polygon_bounding_rect(poly):
+    xs = [p[0] for p in poly]
+    ys = [p[1] for p in poly]
+    return Rect(min(ys), min(xs), max(ys), max(xs))
+
+
+def polygon_slice_bounding_rect(poly, min_x, max_x):
+    """recognition.rs:162-193."""
+    out = None
+    n = len(poly)
+    for k in range(n):
+        e = Line(poly[k], poly[(k + 1) % n]).rightwards()
+        if (e.start[0] < min_x and e.end[0] < min_x) or (e.start[0] > max_x and e.end[0] > max_x):
+            continue
+        ef = e.to_f32()
+        y0 = ef.y_for_x(f32(min_x))
+        ts = e.start if y0 is None else (min_x, int(rround(y0)))
+        y1 = ef.y_for_x(f32(max_x))
+        te = e.end if y1 is None else (max_x, int(rround(y1)))
+        br = Line(ts, te).bounding_rect_i()
+        out = br if out is None else out.union(br)
+    return out
+
+
+class TextChar:
+    def __init__(self, char, rect):
+        self.char = char
+        self.rect = rect
+
+
+class TextLine:
+    """text_items.rs:61-82."""
+
+    def __init__(self, chars):
+        assert chars, "Text lines must not be empty"
+        self.chars = chars
+
+    def __str__(self):
+        return "".join(c.char for c in self.chars)
+
+    def words(self):
+        out, cur = [], []
+        for c in self.chars:
+            if c.char == " ":
+                if cur:
+                    out.append(cur)
+                cur = []
+            else:
+                cur.append(c)
+        if cur:
+            out.append(cur)
+        return out
+
+
+def ctc_beam_search(seq_tc, width):
+    """rten::ctc::CtcDecoder::decode_beam (recognition.rs:512-514): CTC prefix
+    beam search over log-probabilities.  Returns list of (label, pos) for the
+    best prefix; pos = time step at which the label was first appended.
+    [Published algorithm (Hannun et al. 2014, "First-Pass Large Vocabulary
+    Continuous Speech Recognition using Bi-Directional Recurrent DNNs",
+    Alg. 1) — rten's tie handling is unpinned.]"""
+    T, C = seq_tc.shape
+    NEG = -math.inf
+
+    def lse(a, b):
+        if a == NEG:
+            return b
+        if b == NEG:
+            return a
+        m = max(a, b)
+        return m + math.log(math.exp(a - m) + math.exp(b - m))
+
+    # prefix (tuple of (label,pos)) -> (p_blank, p_nonblank)
+    beams = {(): (0.0, NEG)}
+    for t in range(T):
+        row = seq_tc[t]
+        nxt = {}
+
+        def add(prefix, pb, pnb):
+            opb, opnb = nxt.get(prefix, (NEG, NEG))
+            nxt[prefix] = (lse(opb, pb), lse(opnb, pnb))
+
+        for prefix, (pb, pnb) in beams.items():
+            total = lse(pb, pnb)
+            add(prefix, total + float(row[0]), NEG)
+            last = prefix[-1][0] if prefix else None
+            for c in range(1, C):
+                lp = float(row[c])
+                if lp == NEG:
+                    continue
+                if c == last:
+                    add(prefix, NEG, pnb + lp)
+                    add(prefix + ((c, t),), NEG, pb + lp)
+                else:
+                    add(prefix + ((c, t),), NEG, total + lp)
+        # merge prefixes with identical label sequences (keep earliest positions)
+        merged = {}
+        for prefix, (pb, pnb) in nxt.items():
+            key = tuple(l for l, _ in prefix)
+            if key in merged:
+                opfx, opb, opnb = merged[key]
+                merged[key] = (min(opfx, prefix), lse(opb, pb), lse(opnb, pnb))
+            else:
+                merged[key] = (prefix, pb, pnb)
+        items = sorted(merged.values(), key=lambda v: -lse(v[1], v[2]))[:width]
+        beams = {pfx: (pb, pnb) for pfx, pb, pnb in items}
+    best = max(beams.items(), key=lambda kv: lse(kv[1][0], kv[1][1]))[0]
+    return [(l, p) for l, p in best]
+
+
+class TextRecognizer:
+    """recognition.rs:315-562."""
+
+    def __init__(self, model):
+        self.model = model
+        self.input_shape = model.input_shape()
+
+    def input_height(self):
+        h = self.input_shape[2]
+        return 50 if h is None else int(h)
+
+    def run(self, nchw):
+        out = np.asarray(self.model.run(nchw), np.float32)
+        if out.ndim != 3:
+            raise RuntimeError("model output had unexpected type or shape: expected recognition output to have 3 dims but it has %d" % out.ndim)
+        return np.ascontiguousarray(out.transpose(1, 0, 2))  # [seq,batch,class] -> [batch,seq,class]
+
+    def _line_geometry(self, word_rects):
+        line_rect = bounding_rect_of(w.bounding_rect() for w in word_rects).integral_bounding_rect()
+        h = self.input_height()
+        resized_width = resized_line_width(line_rect.width(), line_rect.height(), h)
+        return line_polygon(word_rects), resized_width
+
+    def prepare_input(self, image_chw, line):
+        poly, resized_width = self._line_geometry(line)
+        h = self.input_height()
+        out = np.full((h, resized_width), BLACK_VALUE, np.float32)
+        clib.prepare_text_line_into(image_chw[0], [(p[1], p[0]) for p in poly], resized_width, h, out)
+        return out
+
+    def recognize_text_lines(self, image_chw, lines, alphabet, decode_method=("greedy",), excluded_char_labels=None):
+        h = self.input_height()
+        groups = {}
+        order = []
+        for idx, word_rects in enumerate(lines):
+            poly, resized_width = self._line_geometry(word_rects)
+            group_width = -(-resized_width // 50) * 50  # next_multiple_of(50)
+            if group_width not in groups:
+                groups[group_width] = []
+                order.append(group_width)
+            groups[group_width].append((idx, poly, resized_width))
+        alphabet_len = len(alphabet)
+        results = {}
+        for gw in order:
+            members = groups[gw]
+            for c0 in range(0, len(members), 20):
+                chunk = members[c0:c0 + 20]
+                batch = np.full((len(chunk), 1, h, gw), BLACK_VALUE, np.float32)
+                for bi, (idx, poly, rw) in enumerate(chunk):
+                    clib.prepare_text_line_into(image_chw[0], [(p[1], p[0]) for p in poly], rw, h, batch[bi, 0])
+                rec_out = self.run(batch)
+                if alphabet_len + 1 != rec_out.shape[2]:
+                    raise RuntimeError("model output had unexpected type or shape: output column count (%d) does not match alphabet size (%d)" % (rec_out.shape[2], alphabet_len + 1))
+                ctc_len = rec_out.shape[1]
+                for bi, (idx, poly, rw) in enumerate(chunk):
+                    seq = rec_out[bi]
+                    if excluded_char_labels is not None:
+                        seq = seq.copy()
+                        seq[:, list(excluded_char_labels)] = -np.inf
+                    if decode_method[0] == "greedy":
+                        steps = clib.ctc_greedy(seq)
+                    else:
+                        steps = ctc_beam_search(seq, decode_method[1])
+                    results[idx] = (poly, rw, gw, ctc_len, steps)
+        out = []
+        for idx in range(len(lines)):
+            out.append(text_line_from_result(*results[idx], alphabet))
+        return out
+
+
+def text_line_from_result(poly, resized_width, rec_input_len, ctc_input_len, steps, alphabet):
+    """recognition.rs:241-311 for one line."""
+    line_rect = polygon_bounding_rect(poly)
+    x_scale = f32(line_rect.width()) / f32(resized_width)
+    downsample = int(rround(f32(rec_input_len) / f32(ctc_input_len)))
+    chars = []
+    for i, (label, pos) in enumerate(steps):
+        start_x = pos * downsample
+        end_x = steps[i + 1][1] * downsample if i + 1 < len(steps) else resized_width
+        sx = line_rect.left + as_i32(f32(start_x) * x_scale)
+        ex = line_rect.left + as_i32(f32(end_x) * x_scale)
+        if sx >= line_rect.right:
+            continue
+        ch = alphabet[label - 1] if 0 <= label - 1 < len(alphabet) else "?"
+        rect = polygon_slice_bounding_rect(poly, sx, ex)
+        assert rect is not None, "invalid X coords"
+        chars.append(TextChar(ch, rect))
+    return TextLine(chars) if chars else None
+
+
+# ----------------------------------------------------------------- engine
+class OcrEngine:
+    """lib.rs:111-301."""
+
+    def __init__(self, detection_model=None, recognition_model=None, decode_method=("greedy",), alphabet=None,
+                 allowed_chars=None):
+        self.detector = TextDetector(detection_model) if detection_model is not None else None
+        self.recognizer = TextRecognizer(recognition_model) if recognition_model is not None else None
+        self.alphabet = alphabet if alphabet is not None else DEFAULT_ALPHABET
+        self.decode_method = decode_method
+        self.excluded_char_labels = None
+        if allowed_chars is not None:
+            self.excluded_char_labels = [i + 1 for i, ch in enumerate(self.alphabet) if ch not in allowed_chars]
+
+    def prepare_input(self, image_source):
+        return prepare_image(image_source)
+
+    def detect_words(self, inp):
+        if self.detector is None:
+            raise RuntimeError("Detection model not loaded")
+        return self.detector.detect_words(inp)
+
+    def detect_text_pixels(self, inp):
+        if self.detector is None:
+            raise RuntimeError("Detection model not loaded")
+        return self.detector.detect_text_pixels(inp)
+
+    def find_text_lines(self, inp, words):
+        return find_text_lines(words)
+
+    def recognize_text(self, inp, lines):
+        if self.recognizer is None:
+            raise RuntimeError("Recognition model not loaded")
+        return self.recognizer.recognize_text_lines(inp, lines, self.alphabet, self.decode_method, self.excluded_char_labels)
+
+    def prepare_recognition_input(self, inp, line):
+        if self.recognizer is None:
+            raise RuntimeError("Recognition model not loaded")
+        return self.recognizer.prepare_input(inp, line)
+
+    def detection_threshold(self):
+        return self.detector.threshold() if self.detector is not None else np.float32(0.2)
+
+    def get_text(self, inp):
+        words = self.detect_words(inp)
+        lines = self.find_text_lines(inp, words)
+        return "\n".join(str(l) for l in self.recognize_text(inp, lines) if l is not None)
