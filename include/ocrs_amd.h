@@ -1,0 +1,235 @@
+/*
+ * ocrs_amd.h — C ABI of the MI355X-native OCR engine (libocrs_amd.so).
+ *
+ * This is the drop-in boundary for the hot path of robertknight/ocrs
+ * (prepare_input -> detect_words -> find_text_lines -> recognize_text).  Every
+ * entry point names the reference interface it replaces (paths relative to
+ * the reference tree).  Plain pointers and sizes only; no C++/torch types.
+ *
+ * Conventions
+ *   - every function returns an ocrs_status; on failure ocrs_last_error()
+ *     (thread-local) holds the message the reference would have put into its
+ *     anyhow::Error / ModelRunError (ocrs/src/errors.rs:6-25).  Nothing aborts.
+ *   - all handles are safe to use from several host threads at once (the
+ *     reference calls Model::run concurrently from a rayon pool,
+ *     ocrs/src/recognition.rs:465-485; models are `Send + Sync`,
+ *     detection.rs:67, recognition.rs:316).
+ *   - buffers returned through `T**` are allocated by the library and released
+ *     with ocrs_buffer_free().
+ *   - a RotatedRect crosses the boundary as 6 floats:
+ *     center.x, center.y, up.x, up.y, width, height
+ *     (rten_imageproc::RotatedRect::new(center, up_axis, width, height),
+ *     ctor order shown at recognition.rs:582).
+ */
+#ifndef OCRS_AMD_H
+#define OCRS_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#if defined(__GNUC__)
+#define OCRS_API __attribute__((visibility("default")))
+#else
+#define OCRS_API
+#endif
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum ocrs_status {
+    OCRS_OK = 0,
+    OCRS_ERR_INVALID_ARGUMENT = 1,
+    OCRS_ERR_MODEL_NOT_LOADED = 2, /* lib.rs:197,211,254,274 */
+    OCRS_ERR_MODEL_DIMS = 3,       /* detection.rs:141-144 "failed to get model dims" */
+    OCRS_ERR_RUN_FAILED = 4,       /* ModelRunError::RunFailed, errors.rs:8 */
+    OCRS_ERR_WRONG_OUTPUT = 5,     /* ModelRunError::WrongOutput, errors.rs:11 */
+    OCRS_ERR_IMAGE_SOURCE = 6,     /* ImageSourceError, preprocess.rs:38-46 */
+    OCRS_ERR_DEVICE = 7,           /* HIP runtime failure / no GPU */
+    OCRS_ERR_IO = 8,
+    OCRS_ERR_CAPACITY = 9
+} ocrs_status;
+
+/* Message for the last failure on the calling thread ("" if none). */
+OCRS_API const char* ocrs_last_error(void);
+
+/* Release any buffer handed out through a `T**` out-parameter. */
+OCRS_API void ocrs_buffer_free(void* p);
+
+/* Number of HIP devices visible; selects the device used by handles created
+ * afterwards on this thread (one process per GPU uses device LOCAL_RANK). */
+OCRS_API ocrs_status ocrs_device_count(int* n);
+OCRS_API ocrs_status ocrs_set_device(int device);
+
+/* ------------------------------------------------------------------------
+ * L2 seam: `trait Model` (ocrs/src/model.rs:6-17) and its rten impl
+ * (model.rs:19-41).  A Rust `impl Model for HipModel` binds these four calls
+ * (INTEGRATION.md §1).
+ * ---------------------------------------------------------------------- */
+typedef struct ocrs_model ocrs_model;
+
+/* rten::Model::load_file (ocrs-cli/src/models.rs:100-107): loads an `.ocrsm`
+ * fixed-graph file and uploads the weights to HBM. */
+OCRS_API ocrs_status ocrs_model_load_file(const char* path, ocrs_model** out);
+OCRS_API ocrs_status ocrs_model_load_bytes(const void* data, size_t len, ocrs_model** out);
+
+/* A model implemented by the caller — the counterpart of implementing
+ * `trait Model` in Rust (the reference's tests inject FakeDetectionModel /
+ * FakeRecognitionModel this way, lib.rs:339-422).  `run` receives a contiguous
+ * NCHW f32 input, must malloc() the output, fill out_shape/out_ndim (<= 4) and
+ * return 0; non-zero means failure (-> OCRS_ERR_RUN_FAILED). */
+typedef int (*ocrs_model_run_fn)(void* user, const float* input, const int64_t in_shape[4], float** output,
+                                 int64_t out_shape[4], int* out_ndim);
+OCRS_API ocrs_status ocrs_model_from_callback(const int64_t input_shape[4], /* -1 = symbolic */
+                                     ocrs_model_run_fn run, void* user, ocrs_model** out);
+
+/* Model::input_shape (model.rs:20-31): NCHW; dims[i] = -1 and is_fixed[i] = 0
+ * for Dimension::Symbolic. */
+OCRS_API ocrs_status ocrs_model_input_shape(const ocrs_model* m, int64_t dims[4], uint8_t is_fixed[4]);
+
+typedef struct ocrs_run_options {
+    int timing; /* RunOptions.timing (detection.rs:178-182): print per-op times */
+} ocrs_run_options;
+
+/* Model::run (model.rs:33-40).  `input` is host memory, contiguous NCHW f32.
+ * Detection graphs return [N,1,H,W] probabilities; recognition graphs return
+ * [T,N,C] log-probabilities (recognition.rs:399-401).  *output is host memory
+ * owned by the caller (ocrs_buffer_free). */
+OCRS_API ocrs_status ocrs_model_run(const ocrs_model* m, const float* input, const int64_t in_shape[4],
+                           const ocrs_run_options* opts, float** output, int64_t out_shape[4], int* out_ndim);
+
+/* Algorithmic FLOPs of one forward at the given input shape. */
+OCRS_API ocrs_status ocrs_model_flops(const ocrs_model* m, const int64_t in_shape[4], double* flops);
+
+OCRS_API void ocrs_model_free(ocrs_model* m);
+
+/* ------------------------------------------------------------------------
+ * L4 API: OcrEngine (ocrs/src/lib.rs:111-301) with the grey page resident in
+ * HBM between calls (OcrInput, lib.rs:125-128).
+ * ---------------------------------------------------------------------- */
+typedef struct ocrs_engine ocrs_engine;
+typedef struct ocrs_page ocrs_page; /* OcrInput */
+
+typedef enum ocrs_decode_method { /* DecodeMethod, recognition.rs:198-205 */
+    OCRS_DECODE_GREEDY = 0,
+    OCRS_DECODE_BEAM_SEARCH = 1
+} ocrs_decode_method;
+
+/* OcrEngineParams (lib.rs:38-71).  Models are borrowed: they must outlive the
+ * engine.  NULL strings select the defaults (DEFAULT_ALPHABET, lib.rs:34). */
+typedef struct ocrs_engine_params {
+    const ocrs_model* detection_model;   /* may be NULL */
+    const ocrs_model* recognition_model; /* may be NULL */
+    int debug;
+    ocrs_decode_method decode_method;
+    uint32_t beam_width;
+    const char* alphabet;      /* UTF-8 */
+    const char* allowed_chars; /* UTF-8 */
+} ocrs_engine_params;
+
+/* OcrEngine::new (lib.rs:132-180). */
+OCRS_API ocrs_status ocrs_engine_new(const ocrs_engine_params* params, ocrs_engine** out);
+OCRS_API void ocrs_engine_free(ocrs_engine* e);
+
+typedef enum ocrs_dim_order { OCRS_HWC = 0, OCRS_CHW = 1 } ocrs_dim_order; /* DimOrder, preprocess.rs:50-57 */
+typedef enum ocrs_pixel_type { OCRS_U8 = 0, OCRS_F32 = 1 } ocrs_pixel_type; /* ImagePixels, preprocess.rs:9-14 */
+
+/* ImageSource::from_bytes (preprocess.rs:81-101): validates only. */
+OCRS_API ocrs_status ocrs_image_source_check_bytes(size_t len, uint32_t width, uint32_t height, uint32_t* channels);
+
+/* ImageSource::from_tensor + OcrEngine::prepare_input (preprocess.rs:105-123,
+ * lib.rs:183-187): converts to greyscale f32 [1,H,W] in [-0.5,0.5] on the GPU.
+ * `pixels` is host memory. */
+OCRS_API ocrs_status ocrs_engine_prepare_input(const ocrs_engine* e, const void* pixels, ocrs_pixel_type type,
+                                      ocrs_dim_order order, int height, int width, int channels,
+                                      ocrs_page** out);
+/* Same, with `pixels` already resident in HBM (device pointer): the form
+ * bench.py times, and the one a GPU image decoder would hand over. */
+OCRS_API ocrs_status ocrs_engine_prepare_input_device(const ocrs_engine* e, const void* d_pixels, ocrs_pixel_type type,
+                                             ocrs_dim_order order, int height, int width, int channels,
+                                             ocrs_page** out);
+OCRS_API void ocrs_page_free(ocrs_page* p);
+OCRS_API ocrs_status ocrs_page_dims(const ocrs_page* p, int* height, int* width);
+/* Copy the prepared grey page [H,W] f32 to host (OcrInput.image, lib.rs:127). */
+OCRS_API ocrs_status ocrs_page_image(const ocrs_page* p, float* out_hw);
+
+/* OcrEngine::detect_words (lib.rs:193-199 -> detection.rs:104-122).
+ * *rects receives n x 6 floats in contour discovery order. */
+OCRS_API ocrs_status ocrs_engine_detect_words(const ocrs_engine* e, const ocrs_page* page, float** rects, size_t* n);
+/* Batched form: pages must share one size; rects of page i are
+ * (*rects)[6*offsets[i] .. 6*offsets[i+1]); offsets has n_pages+1 entries. */
+OCRS_API ocrs_status ocrs_engine_detect_words_batch(const ocrs_engine* e, const ocrs_page* const* pages, size_t n_pages,
+                                           float** rects, size_t* offsets);
+
+/* OcrEngine::detect_text_pixels (lib.rs:207-213 -> detection.rs:131-200):
+ * writes the [H,W] probability map. */
+OCRS_API ocrs_status ocrs_engine_detect_text_pixels(const ocrs_engine* e, const ocrs_page* page, float* out_hw);
+
+/* OcrEngine::detection_threshold (lib.rs:282-287). */
+OCRS_API float ocrs_engine_detection_threshold(const ocrs_engine* e);
+
+/* OcrEngine::find_text_lines (lib.rs:222-228 -> layout_analysis.rs:158-233).
+ * Host-side.  *line_rects receives the same n_words rects permuted into
+ * reading order; line i owns rects [line_offsets[i], line_offsets[i+1]). */
+OCRS_API ocrs_status ocrs_engine_find_text_lines(const ocrs_engine* e, const ocrs_page* page, const float* word_rects,
+                                        size_t n_words, float** line_rects, size_t** line_offsets,
+                                        size_t* n_lines);
+
+/* One recognised character: TextChar (text_items.rs:48-54). */
+typedef struct ocrs_text_char {
+    uint32_t ch;                      /* Unicode scalar value */
+    int32_t top, left, bottom, right; /* rten_imageproc::Rect */
+} ocrs_text_char;
+
+/* OcrEngine::recognize_text (lib.rs:237-256 -> recognition.rs:404-540).
+ * Lines are given as in ocrs_engine_find_text_lines' output.  chars of line i
+ * are (*chars)[char_offsets[i] .. char_offsets[i+1]); an empty range is the
+ * reference's `None`.  char_offsets has n_lines+1 entries. */
+OCRS_API ocrs_status ocrs_engine_recognize_text(const ocrs_engine* e, const ocrs_page* page, const float* line_rects,
+                                       const size_t* line_offsets, size_t n_lines, ocrs_text_char** chars,
+                                       size_t** char_offsets);
+/* Batched form over several pages (lines of all pages share recognition
+ * batches; padded widths stay those of recognition.rs:437).  page_line_offsets
+ * has n_pages+1 entries indexing into line_offsets' line numbering. */
+OCRS_API ocrs_status ocrs_engine_recognize_text_batch(const ocrs_engine* e, const ocrs_page* const* pages, size_t n_pages,
+                                             const size_t* page_line_offsets, const float* line_rects,
+                                             const size_t* line_offsets, size_t n_lines,
+                                             ocrs_text_char** chars, size_t** char_offsets);
+
+/* Raw CTC output for the same lines (labels and time steps of
+ * CtcHypothesis::steps(), recognition.rs:257-289), for token-level parity. */
+OCRS_API ocrs_status ocrs_engine_recognize_tokens(const ocrs_engine* e, const ocrs_page* page, const float* line_rects,
+                                         const size_t* line_offsets, size_t n_lines, uint32_t** labels,
+                                         uint32_t** positions, size_t** token_offsets);
+
+/* OcrEngine::prepare_recognition_input (lib.rs:268-278 -> recognition.rs:366-392):
+ * *out receives a [height, width] f32 line image. */
+OCRS_API ocrs_status ocrs_engine_prepare_recognition_input(const ocrs_engine* e, const ocrs_page* page, const float* line,
+                                                  size_t n_words, float** out, int* height, int* width);
+
+/* OcrEngine::get_text (lib.rs:290-300): UTF-8, lines joined by '\n'. */
+OCRS_API ocrs_status ocrs_engine_get_text(const ocrs_engine* e, const ocrs_page* page, char** text);
+
+/* ------------------------------------------------------------------------
+ * Measurement hooks (bench.py; not part of the reference surface).
+ * ---------------------------------------------------------------------- */
+/* Device memory helpers so that bench inputs can be made HBM-resident without
+ * torch in the loop. */
+OCRS_API ocrs_status ocrs_device_malloc(size_t bytes, void** d_ptr);
+OCRS_API ocrs_status ocrs_device_free(void* d_ptr);
+OCRS_API ocrs_status ocrs_device_upload(void* d_dst, const void* h_src, size_t bytes);
+OCRS_API ocrs_status ocrs_device_synchronize(void);
+
+/* Per-stage timers: when enabled, every GPU stage is bracketed by HIP events
+ * on the stream it is launched on; ocrs_engine_stage_times returns accumulated
+ * milliseconds and launch counts since the last reset.  Stage names:
+ * ocrs_stage_name(i), i < ocrs_stage_count(). */
+OCRS_API ocrs_status ocrs_engine_enable_timing(ocrs_engine* e, int enable);
+OCRS_API int ocrs_stage_count(void);
+OCRS_API const char* ocrs_stage_name(int stage);
+OCRS_API ocrs_status ocrs_engine_stage_times(ocrs_engine* e, double* ms, uint64_t* launches, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OCRS_AMD_H */

@@ -1,0 +1,430 @@
+"""ocrs_amd — MI355X-native engine behind the robertknight/ocrs `OcrEngine` API.
+
+Python mirror (ctypes) of the reference's public surface (ocrs/src/lib.rs:29-31,
+111-301): `OcrEngine`, `OcrEngineParams`, `ImageSource`, `DimOrder`,
+`DecodeMethod`, `TextLine`/`TextWord`/`TextChar`, plus `Model` for the
+`trait Model` seam (ocrs/src/model.rs:6-17).  All compute happens in
+libocrs_amd.so (HIP, gfx950); this module only marshals arrays.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import OcrsError, check, lib
+
+__all__ = ["OcrEngine", "OcrEngineParams", "ImageSource", "ImageSourceError", "DimOrder", "DecodeMethod", "Model",
+           "OcrInput", "TextLine", "TextWord", "TextChar", "OcrsError", "DEFAULT_ALPHABET"]
+
+# lib.rs:34 (with the EUR sign the comment at lib.rs:33 asks for)
+DEFAULT_ALPHABET = " 0123456789!\"#$%&'()*+,-./:;<=>?@[\\]^_`{|}~€ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz"
+
+
+class DimOrder:  # preprocess.rs:50-57
+    Hwc = 0
+    Chw = 1
+
+
+class DecodeMethod:  # recognition.rs:198-205
+    Greedy = ("greedy", 0)
+
+    @staticmethod
+    def BeamSearch(width):
+        return ("beam", int(width))
+
+
+class ImageSourceError(ValueError):  # preprocess.rs:38-46
+    pass
+
+
+class ImageSource:
+    """preprocess.rs:61-124 — a borrowed view of u8 or f32 pixels, HWC or CHW."""
+
+    def __init__(self, data, order):
+        self.data = data
+        self.order = order
+
+    @staticmethod
+    def from_bytes(buf, dimensions):
+        width, height = dimensions
+        ch = C.c_uint32(0)
+        st = lib().ocrs_image_source_check_bytes(C.c_size_t(len(buf)), C.c_uint32(width), C.c_uint32(height), C.byref(ch))
+        if st != 0:
+            raise ImageSourceError(lib().ocrs_last_error().decode())
+        arr = np.frombuffer(buf, dtype=np.uint8).reshape(height, width, ch.value)
+        return ImageSource(arr, DimOrder.Hwc)
+
+    @staticmethod
+    def from_tensor(data, order):
+        data = np.asarray(data)
+        if data.ndim != 3:
+            raise ImageSourceError("expected a 3-dimensional image tensor")
+        chans = data.shape[2] if order == DimOrder.Hwc else data.shape[0]
+        if chans not in (1, 3, 4):
+            raise ImageSourceError("channel count is not 1, 3 or 4")
+        if data.dtype not in (np.uint8, np.float32):
+            raise ImageSourceError("pixels must be uint8 in [0,255] or float32 in [0,1]")
+        return ImageSource(data, order)
+
+
+class Model:
+    """`trait Model` (model.rs:6-17): either an `.ocrsm` fixed graph executed by
+    the HIP executor, or a Python callable (the reference's tests inject fake
+    models through the same seam, lib.rs:339-422)."""
+
+    def __init__(self, handle, keepalive=None):
+        self._h = handle
+        self._keep = keepalive
+
+    @staticmethod
+    def load_file(path):
+        h = C.c_void_p()
+        check(lib().ocrs_model_load_file(str(path).encode(), C.byref(h)))
+        return Model(h)
+
+    @staticmethod
+    def load_bytes(buf):
+        h = C.c_void_p()
+        check(lib().ocrs_model_load_bytes(C.c_char_p(bytes(buf)), C.c_size_t(len(buf)), C.byref(h)))
+        return Model(h)
+
+    @staticmethod
+    def from_callable(input_shape, fn):
+        """input_shape: NCHW with None for symbolic dims; fn(np [N,C,H,W] f32) -> np (<= 4 dims)."""
+        libc = C.CDLL(None)
+        libc.malloc.restype = C.c_void_p
+        libc.malloc.argtypes = [C.c_size_t]
+        err = []
+
+        def _run(user, inp, in_shape, out, out_shape, out_ndim):
+            try:
+                shp = [in_shape[i] for i in range(4)]
+                x = np.ctypeslib.as_array(inp, shape=(int(np.prod(shp)),)).reshape(shp).copy()
+                y = np.ascontiguousarray(fn(x), dtype=np.float32)
+                if y.ndim < 1 or y.ndim > 4:
+                    return 2
+                p = libc.malloc(max(y.nbytes, 4))
+                C.memmove(p, y.ctypes.data, y.nbytes)
+                out[0] = C.cast(p, C.POINTER(C.c_float))
+                for i, d in enumerate(y.shape):
+                    out_shape[i] = d
+                out_ndim[0] = y.ndim
+                return 0
+            except Exception as e:  # surfaces as ModelRunError::RunFailed
+                err.append(e)
+                return 1
+
+        cb = _lib.RUN_FN(_run)
+        shape = (C.c_int64 * 4)(*[-1 if d is None else int(d) for d in input_shape])
+        h = C.c_void_p()
+        check(lib().ocrs_model_from_callback(shape, cb, None, C.byref(h)))
+        return Model(h, keepalive=(cb, err))
+
+    def input_shape(self):
+        dims = (C.c_int64 * 4)()
+        fixed = (C.c_uint8 * 4)()
+        check(lib().ocrs_model_input_shape(self._h, dims, fixed))
+        return [int(dims[i]) if fixed[i] else None for i in range(4)]
+
+    def run(self, nchw, timing=False):
+        x = np.ascontiguousarray(nchw, dtype=np.float32)
+        assert x.ndim == 4
+        shape = (C.c_int64 * 4)(*x.shape)
+        out = C.POINTER(C.c_float)()
+        oshape = (C.c_int64 * 4)()
+        ond = C.c_int(0)
+        opts = _lib.RunOptions(1 if timing else 0)
+        check(lib().ocrs_model_run(self._h, x.ctypes.data_as(C.POINTER(C.c_float)), shape, C.byref(opts), C.byref(out),
+                                   oshape, C.byref(ond)))
+        shp = [int(oshape[i]) for i in range(ond.value)]
+        y = np.ctypeslib.as_array(out, shape=(int(np.prod(shp)),)).reshape(shp).copy()
+        lib().ocrs_buffer_free(out)
+        return y
+
+    def flops(self, n, h, w):
+        shape = (C.c_int64 * 4)(n, 1, h, w)
+        f = C.c_double(0)
+        check(lib().ocrs_model_flops(self._h, shape, C.byref(f)))
+        return f.value
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().ocrs_model_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+class OcrEngineParams:  # lib.rs:38-71
+    def __init__(self, detection_model=None, recognition_model=None, debug=False, decode_method=DecodeMethod.Greedy,
+                 alphabet=None, allowed_chars=None):
+        self.detection_model = detection_model
+        self.recognition_model = recognition_model
+        self.debug = debug
+        self.decode_method = decode_method
+        self.alphabet = alphabet
+        self.allowed_chars = allowed_chars
+
+
+class OcrInput:
+    """lib.rs:125-128 — the prepared grey page, resident in HBM."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    @property
+    def shape(self):
+        h, w = C.c_int(0), C.c_int(0)
+        check(lib().ocrs_page_dims(self._h, C.byref(h), C.byref(w)))
+        return (1, h.value, w.value)
+
+    def image(self):
+        _, h, w = self.shape
+        out = np.empty((1, h, w), np.float32)
+        check(lib().ocrs_page_image(self._h, out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().ocrs_page_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+class TextChar:  # text_items.rs:48-54
+    __slots__ = ("char", "rect")
+
+    def __init__(self, char, rect):
+        self.char = char
+        self.rect = rect  # (top, left, bottom, right)
+
+
+class _TextItem:
+    def __init__(self, chars):
+        self._chars = chars
+
+    def chars(self):
+        return self._chars
+
+    def bounding_rect(self):
+        a = np.array([c.rect for c in self._chars])
+        return (int(a[:, 0].min()), int(a[:, 1].min()), int(a[:, 2].max()), int(a[:, 3].max()))
+
+    def __str__(self):
+        return "".join(c.char for c in self._chars)
+
+
+class TextWord(_TextItem):  # text_items.rs:92-107
+    pass
+
+
+class TextLine(_TextItem):  # text_items.rs:61-82
+    def __init__(self, chars):
+        assert chars, "Text lines must not be empty"
+        super().__init__(chars)
+
+    def words(self):
+        out, cur = [], []
+        for c in self._chars:
+            if c.char == " ":
+                if cur:
+                    out.append(TextWord(cur))
+                cur = []
+            else:
+                cur.append(c)
+        if cur:
+            out.append(TextWord(cur))
+        return out
+
+
+def _rects_to_array(rects):
+    a = np.ascontiguousarray(np.asarray(rects, dtype=np.float32).reshape(-1, 6))
+    return a
+
+
+def _pack_lines(lines):
+    offs = [0]
+    flat = []
+    for l in lines:
+        a = _rects_to_array(l)
+        flat.append(a)
+        offs.append(offs[-1] + len(a))
+    rects = np.concatenate(flat) if flat else np.zeros((0, 6), np.float32)
+    return np.ascontiguousarray(rects, np.float32), np.array(offs, dtype=np.uintp)
+
+
+class OcrEngine:
+    """lib.rs:111-301.  Word rects are rows of 6 floats
+    (center.x, center.y, up.x, up.y, width, height)."""
+
+    def __init__(self, params=None, **kw):
+        params = params or OcrEngineParams(**kw)
+        self._params = params
+        p = _lib.EngineParams()
+        p.detection_model = params.detection_model._h if params.detection_model else None
+        p.recognition_model = params.recognition_model._h if params.recognition_model else None
+        p.debug = 1 if params.debug else 0
+        p.decode_method = 0 if params.decode_method[0] == "greedy" else 1
+        p.beam_width = params.decode_method[1]
+        p.alphabet = params.alphabet.encode("utf-8") if params.alphabet is not None else None
+        p.allowed_chars = params.allowed_chars.encode("utf-8") if params.allowed_chars is not None else None
+        self._h = C.c_void_p()
+        check(lib().ocrs_engine_new(C.byref(p), C.byref(self._h)))
+
+    # ---- lib.rs:183-187
+    def prepare_input(self, image):
+        a = np.ascontiguousarray(image.data)
+        if image.order == DimOrder.Hwc:
+            h, w, c = a.shape
+        else:
+            c, h, w = a.shape
+        h_out = C.c_void_p()
+        check(lib().ocrs_engine_prepare_input(self._h, a.ctypes.data_as(C.c_void_p), 0 if a.dtype == np.uint8 else 1,
+                                              image.order, h, w, c, C.byref(h_out)))
+        return OcrInput(h_out)
+
+    def prepare_input_device(self, d_ptr, dtype, order, h, w, c):
+        """Pixels already in HBM (a raw device pointer), e.g. from bench.py."""
+        h_out = C.c_void_p()
+        check(lib().ocrs_engine_prepare_input_device(self._h, C.c_void_p(d_ptr), 0 if dtype == np.uint8 else 1, order,
+                                                     h, w, c, C.byref(h_out)))
+        return OcrInput(h_out)
+
+    # ---- lib.rs:193-199
+    def detect_words(self, inp):
+        rects = C.POINTER(C.c_float)()
+        n = C.c_size_t(0)
+        check(lib().ocrs_engine_detect_words(self._h, inp._h, C.byref(rects), C.byref(n)))
+        out = np.ctypeslib.as_array(rects, shape=(max(n.value, 1) * 6,))[: n.value * 6].reshape(-1, 6).copy()
+        lib().ocrs_buffer_free(rects)
+        return out
+
+    def detect_words_batch(self, inputs):
+        n = len(inputs)
+        pages = (C.c_void_p * n)(*[i._h for i in inputs])
+        rects = C.POINTER(C.c_float)()
+        offs = (C.c_size_t * (n + 1))()
+        check(lib().ocrs_engine_detect_words_batch(self._h, pages, C.c_size_t(n), C.byref(rects), offs))
+        total = offs[n]
+        flat = np.ctypeslib.as_array(rects, shape=(max(total, 1) * 6,))[: total * 6].reshape(-1, 6).copy()
+        lib().ocrs_buffer_free(rects)
+        return [flat[offs[i]:offs[i + 1]] for i in range(n)]
+
+    # ---- lib.rs:207-213
+    def detect_text_pixels(self, inp):
+        _, h, w = inp.shape
+        out = np.empty((h, w), np.float32)
+        check(lib().ocrs_engine_detect_text_pixels(self._h, inp._h, out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
+
+    # ---- lib.rs:222-228
+    def find_text_lines(self, inp, words):
+        a = _rects_to_array(words)
+        lr = C.POINTER(C.c_float)()
+        lo = C.POINTER(C.c_size_t)()
+        nl = C.c_size_t(0)
+        check(lib().ocrs_engine_find_text_lines(self._h, inp._h if inp is not None else None,
+                                                a.ctypes.data_as(C.POINTER(C.c_float)), C.c_size_t(len(a)), C.byref(lr),
+                                                C.byref(lo), C.byref(nl)))
+        offs = [lo[i] for i in range(nl.value + 1)]
+        flat = np.ctypeslib.as_array(lr, shape=(max(len(a), 1) * 6,))[: len(a) * 6].reshape(-1, 6).copy()
+        lib().ocrs_buffer_free(lr)
+        lib().ocrs_buffer_free(lo)
+        return [flat[offs[i]:offs[i + 1]] for i in range(nl.value)]
+
+    # ---- lib.rs:237-256
+    def recognize_text(self, inp, lines):
+        return self.recognize_text_batch([inp], [lines])[0]
+
+    def recognize_text_batch(self, inputs, lines_per_page):
+        n = len(inputs)
+        pages = (C.c_void_p * n)(*[i._h for i in inputs])
+        all_lines = [l for lines in lines_per_page for l in lines]
+        plo = [0]
+        for lines in lines_per_page:
+            plo.append(plo[-1] + len(lines))
+        rects, offs = _pack_lines(all_lines)
+        plo_a = np.array(plo, dtype=np.uintp)
+        chars = C.POINTER(_lib.TextCharC)()
+        coffs = C.POINTER(C.c_size_t)()
+        check(lib().ocrs_engine_recognize_text_batch(
+            self._h, pages, C.c_size_t(n), plo_a.ctypes.data_as(C.POINTER(C.c_size_t)),
+            rects.ctypes.data_as(C.POINTER(C.c_float)), offs.ctypes.data_as(C.POINTER(C.c_size_t)),
+            C.c_size_t(len(all_lines)), C.byref(chars), C.byref(coffs)))
+        result = []
+        li = 0
+        for lines in lines_per_page:
+            page_out = []
+            for _ in lines:
+                a, b = coffs[li], coffs[li + 1]
+                if b > a:
+                    page_out.append(TextLine([TextChar(chr(chars[k].ch), (chars[k].top, chars[k].left, chars[k].bottom,
+                                                                           chars[k].right)) for k in range(a, b)]))
+                else:
+                    page_out.append(None)
+                li += 1
+            result.append(page_out)
+        lib().ocrs_buffer_free(chars)
+        lib().ocrs_buffer_free(coffs)
+        return result
+
+    def recognize_tokens(self, inp, lines):
+        """Raw greedy-CTC output per line: list of (label, pos) — CtcHypothesis::steps()."""
+        rects, offs = _pack_lines(lines)
+        lab = C.POINTER(C.c_uint32)()
+        pos = C.POINTER(C.c_uint32)()
+        toff = C.POINTER(C.c_size_t)()
+        check(lib().ocrs_engine_recognize_tokens(self._h, inp._h, rects.ctypes.data_as(C.POINTER(C.c_float)),
+                                                 offs.ctypes.data_as(C.POINTER(C.c_size_t)), C.c_size_t(len(lines)),
+                                                 C.byref(lab), C.byref(pos), C.byref(toff)))
+        out = []
+        for i in range(len(lines)):
+            out.append([(int(lab[k]), int(pos[k])) for k in range(toff[i], toff[i + 1])])
+        for p in (lab, pos, toff):
+            lib().ocrs_buffer_free(p)
+        return out
+
+    # ---- lib.rs:268-278
+    def prepare_recognition_input(self, inp, line):
+        a = _rects_to_array(line)
+        out = C.POINTER(C.c_float)()
+        h, w = C.c_int(0), C.c_int(0)
+        check(lib().ocrs_engine_prepare_recognition_input(self._h, inp._h, a.ctypes.data_as(C.POINTER(C.c_float)),
+                                                          C.c_size_t(len(a)), C.byref(out), C.byref(h), C.byref(w)))
+        img = np.ctypeslib.as_array(out, shape=(max(h.value * w.value, 1),))[: h.value * w.value].reshape(h.value, w.value).copy()
+        lib().ocrs_buffer_free(out)
+        return img
+
+    # ---- lib.rs:282-287
+    def detection_threshold(self):
+        return float(lib().ocrs_engine_detection_threshold(self._h))
+
+    # ---- lib.rs:290-300
+    def get_text(self, inp):
+        txt = C.c_char_p()
+        check(lib().ocrs_engine_get_text(self._h, inp._h, C.byref(txt)))
+        s = txt.value.decode("utf-8")
+        lib().ocrs_buffer_free(txt)
+        return s
+
+    # ---- measurement hooks
+    def enable_timing(self, on=True):
+        check(lib().ocrs_engine_enable_timing(self._h, 1 if on else 0))
+
+    def stage_times(self, reset=True):
+        n = lib().ocrs_stage_count()
+        ms = (C.c_double * n)()
+        cnt = (C.c_uint64 * n)()
+        check(lib().ocrs_engine_stage_times(self._h, ms, cnt, 1 if reset else 0))
+        return {lib().ocrs_stage_name(i).decode(): (ms[i], int(cnt[i])) for i in range(n)}
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().ocrs_engine_free(self._h)
+                self._h = None
+        except Exception:
+            pass

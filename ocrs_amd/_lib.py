@@ -1,0 +1,97 @@
+"""ctypes binding of libocrs_amd.so (include/ocrs_amd.h).
+
+The library is the product: there is NO Python/CPU fallback.  If the shared
+object is missing or no GPU is visible, calls fail loudly.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libocrs_amd.so")
+
+OCRS_OK = 0
+STATUS_NAMES = {
+    0: "OK", 1: "INVALID_ARGUMENT", 2: "MODEL_NOT_LOADED", 3: "MODEL_DIMS", 4: "RUN_FAILED", 5: "WRONG_OUTPUT",
+    6: "IMAGE_SOURCE", 7: "DEVICE", 8: "IO", 9: "CAPACITY",
+}
+
+RUN_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int64), C.POINTER(C.POINTER(C.c_float)),
+                     C.POINTER(C.c_int64), C.POINTER(C.c_int))
+
+
+class EngineParams(C.Structure):
+    _fields_ = [("detection_model", C.c_void_p), ("recognition_model", C.c_void_p), ("debug", C.c_int),
+                ("decode_method", C.c_int), ("beam_width", C.c_uint32), ("alphabet", C.c_char_p),
+                ("allowed_chars", C.c_char_p)]
+
+
+class RunOptions(C.Structure):
+    _fields_ = [("timing", C.c_int)]
+
+
+class TextCharC(C.Structure):
+    _fields_ = [("ch", C.c_uint32), ("top", C.c_int32), ("left", C.c_int32), ("bottom", C.c_int32),
+                ("right", C.c_int32)]
+
+
+class OcrsError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__(message)
+        self.status = status
+        self.status_name = STATUS_NAMES.get(status, str(status))
+
+
+# Every symbol include/ocrs_amd.h declares (tests check they are all exported).
+DECLARED_SYMBOLS = [
+    "ocrs_last_error", "ocrs_buffer_free", "ocrs_device_count", "ocrs_set_device", "ocrs_model_load_file",
+    "ocrs_model_load_bytes", "ocrs_model_from_callback", "ocrs_model_input_shape", "ocrs_model_run",
+    "ocrs_model_flops", "ocrs_model_free", "ocrs_engine_new", "ocrs_engine_free", "ocrs_image_source_check_bytes",
+    "ocrs_engine_prepare_input", "ocrs_engine_prepare_input_device", "ocrs_page_free", "ocrs_page_dims",
+    "ocrs_page_image", "ocrs_engine_detect_words", "ocrs_engine_detect_words_batch",
+    "ocrs_engine_detect_text_pixels", "ocrs_engine_detection_threshold", "ocrs_engine_find_text_lines",
+    "ocrs_engine_recognize_text", "ocrs_engine_recognize_text_batch", "ocrs_engine_recognize_tokens",
+    "ocrs_engine_prepare_recognition_input", "ocrs_engine_get_text", "ocrs_device_malloc", "ocrs_device_free",
+    "ocrs_device_upload", "ocrs_device_synchronize", "ocrs_engine_enable_timing", "ocrs_stage_count",
+    "ocrs_stage_name", "ocrs_engine_stage_times",
+]
+
+_lib = None
+
+
+def lib():
+    """Load the shared object (building it is __graft_entry__.build()'s job)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise OcrsError(7, "libocrs_amd.so is not built: run `python -m ocrs_amd.build` "
+                               "(there is no CPU fallback for the HIP engine)")
+        L = C.CDLL(LIB_PATH)
+        L.ocrs_last_error.restype = C.c_char_p
+        L.ocrs_engine_detection_threshold.restype = C.c_float
+        L.ocrs_engine_detection_threshold.argtypes = [C.c_void_p]
+        L.ocrs_stage_name.restype = C.c_char_p
+        L.ocrs_buffer_free.argtypes = [C.c_void_p]
+        for name in ("ocrs_model_free", "ocrs_engine_free", "ocrs_page_free"):
+            getattr(L, name).argtypes = [C.c_void_p]
+            getattr(L, name).restype = None
+        _lib = L
+    return _lib
+
+
+def check(status):
+    if status != OCRS_OK:
+        msg = lib().ocrs_last_error()
+        raise OcrsError(status, msg.decode("utf-8", "replace") if msg else STATUS_NAMES.get(status, "error"))
+
+
+def device_count():
+    n = C.c_int(0)
+    check(lib().ocrs_device_count(C.byref(n)))
+    return n.value
+
+
+def require_gpu():
+    n = device_count()
+    if n < 1:
+        raise OcrsError(7, "no HIP device visible: the ocrs_amd engine has no CPU fallback")
+    return n

@@ -1,0 +1,534 @@
+// extern "C" surface of libocrs_amd.so (include/ocrs_amd.h).  Every entry point
+// converts C++ exceptions into (status, thread-local message); nothing aborts.
+#include <cstdio>
+#include <fstream>
+#include <thread>
+
+#include "engine.hpp"
+#include "kernels.hpp"
+
+using namespace ocrs;
+using namespace ocrs::geom;
+
+namespace {
+
+template <class F>
+ocrs_status guarded(F&& f) {
+    try {
+        f();
+        set_last_error("");
+        return OCRS_OK;
+    } catch (const Error& e) {
+        set_last_error(e.what());
+        return e.status;
+    } catch (const std::bad_alloc&) {
+        set_last_error("out of host memory");
+        return OCRS_ERR_DEVICE;
+    } catch (const std::exception& e) {
+        set_last_error(e.what());
+        return OCRS_ERR_RUN_FAILED;
+    }
+}
+
+template <class T>
+T* dup_buffer(const std::vector<T>& v) {
+    T* p = static_cast<T*>(malloc(std::max<size_t>(v.size(), 1) * sizeof(T)));
+    if (!p) throw std::bad_alloc();
+    if (!v.empty()) memcpy(p, v.data(), v.size() * sizeof(T));
+    return p;
+}
+
+std::u32string decode_utf8(const char* s) {
+    std::u32string out;
+    const unsigned char* p = reinterpret_cast<const unsigned char*>(s);
+    while (*p) {
+        uint32_t c = *p++;
+        int extra = c >= 0xF0 ? 3 : c >= 0xE0 ? 2 : c >= 0xC0 ? 1 : 0;
+        if (extra) c &= (0x3F >> extra);
+        while (extra-- > 0 && *p) c = (c << 6) | (*p++ & 0x3F);
+        out.push_back((char32_t)c);
+    }
+    return out;
+}
+
+void append_utf8(std::string& s, uint32_t c) {
+    if (c < 0x80) s.push_back((char)c);
+    else if (c < 0x800) { s.push_back((char)(0xC0 | (c >> 6))); s.push_back((char)(0x80 | (c & 0x3F))); }
+    else if (c < 0x10000) {
+        s.push_back((char)(0xE0 | (c >> 12))); s.push_back((char)(0x80 | ((c >> 6) & 0x3F)));
+        s.push_back((char)(0x80 | (c & 0x3F)));
+    } else {
+        s.push_back((char)(0xF0 | (c >> 18))); s.push_back((char)(0x80 | ((c >> 12) & 0x3F)));
+        s.push_back((char)(0x80 | ((c >> 6) & 0x3F))); s.push_back((char)(0x80 | (c & 0x3F)));
+    }
+}
+
+// lib.rs:34 with the EUR sign restored (lib.rs:33)
+const char kDefaultAlphabet[] =
+    " 0123456789!\"#$%&'()*+,-./:;<=>?@[\\]^_`{|}~\xE2\x82\xAC"
+    "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz";
+
+std::vector<std::vector<RotatedRect>> unpack_lines(const float* rects, const size_t* offsets, size_t first,
+                                                   size_t last) {
+    std::vector<std::vector<RotatedRect>> lines;
+    for (size_t i = first; i < last; i++) {
+        std::vector<RotatedRect> words;
+        for (size_t k = offsets[i]; k < offsets[i + 1]; k++) words.push_back(RotatedRect::from_array(rects + 6 * k));
+        lines.push_back(std::move(words));
+    }
+    return lines;
+}
+
+ocrs_page* make_page(const void* d_pixels, ocrs_pixel_type type, ocrs_dim_order order, int height, int width,
+                     int channels, hipStream_t st, StageTimers* T) {
+    auto page = std::make_unique<ocrs_page>();
+    page->h = height;
+    page->w = width;
+    page->grey = DevBuf((size_t)height * width * sizeof(float));
+    {
+        StageScope sc(T, ST_PREPARE, st);
+        k::prepare_image(d_pixels, type == OCRS_U8, order == OCRS_HWC, height, width, channels, page->grey.as<float>(), st);
+    }
+    OCRS_HIP(hipGetLastError());
+    return page.release();
+}
+
+void check_image_args(const void* pixels, int height, int width, int channels) {
+    if (!pixels) fail(OCRS_ERR_INVALID_ARGUMENT, "pixels is null");
+    // ImageSource::from_tensor (preprocess.rs:116-122)
+    if (!(channels == 1 || channels == 3 || channels == 4)) fail(OCRS_ERR_IMAGE_SOURCE, "channel count is not 1, 3 or 4");
+    if (height <= 0 || width <= 0) fail(OCRS_ERR_INVALID_ARGUMENT, "image has no pixels");
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* ocrs_last_error(void) { return last_error().c_str(); }
+
+void ocrs_buffer_free(void* p) { free(p); }
+
+ocrs_status ocrs_device_count(int* n) {
+    return guarded([&] {
+        int c = 0;
+        hipError_t e = hipGetDeviceCount(&c);
+        if (e != hipSuccess) c = 0;
+        *n = c;
+    });
+}
+
+ocrs_status ocrs_set_device(int device) {
+    return guarded([&] { OCRS_HIP(hipSetDevice(device)); });
+}
+
+// ------------------------------------------------------------------ models
+ocrs_status ocrs_model_load_bytes(const void* data, size_t len, ocrs_model** out) {
+    return guarded([&] {
+        if (!data || !out) fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
+        auto m = std::make_unique<ocrs_model>();
+        m->impl = HipModel::load(data, len);
+        *out = m.release();
+    });
+}
+
+ocrs_status ocrs_model_load_file(const char* path, ocrs_model** out) {
+    return guarded([&] {
+        if (!path || !out) fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
+        std::ifstream f(path, std::ios::binary);
+        if (!f) fail(OCRS_ERR_IO, "cannot open model file %s", path);
+        std::vector<char> buf((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+        auto m = std::make_unique<ocrs_model>();
+        m->impl = HipModel::load(buf.data(), buf.size());
+        *out = m.release();
+    });
+}
+
+ocrs_status ocrs_model_from_callback(const int64_t input_shape[4], ocrs_model_run_fn run, void* user,
+                                     ocrs_model** out) {
+    return guarded([&] {
+        if (!input_shape || !run || !out) fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
+        auto cb = std::make_unique<CallbackModel>();
+        for (int i = 0; i < 4; i++) cb->input_shape[i] = input_shape[i];
+        cb->fn = run;
+        cb->user = user;
+        auto m = std::make_unique<ocrs_model>();
+        m->impl = std::move(cb);
+        *out = m.release();
+    });
+}
+
+ocrs_status ocrs_model_input_shape(const ocrs_model* m, int64_t dims[4], uint8_t is_fixed[4]) {
+    return guarded([&] {
+        if (!m || !dims || !is_fixed) fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
+        for (int i = 0; i < 4; i++) {
+            dims[i] = m->impl->input_shape[i];
+            is_fixed[i] = dims[i] >= 0;
+        }
+    });
+}
+
+ocrs_status ocrs_model_run(const ocrs_model* m, const float* input, const int64_t in_shape[4],
+                           const ocrs_run_options* opts, float** output, int64_t out_shape[4], int* out_ndim) {
+    return guarded([&] {
+        if (!m || !input || !in_shape || !output || !out_shape || !out_ndim)
+            fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
+        const int64_t n = in_shape[0], c = in_shape[1], h = in_shape[2], w = in_shape[3];
+        if (n <= 0 || h <= 0 || w <= 0) fail(OCRS_ERR_RUN_FAILED, "model run failed: empty input");
+        if (m->impl->is_callback()) {
+            std::vector<float> out;
+            static_cast<const CallbackModel*>(m->impl.get())->run(input, in_shape, out, out_shape, out_ndim);
+            *output = dup_buffer(out);
+            return;
+        }
+        const auto* hm = static_cast<const HipModel*>(m->impl.get());
+        if (c != 1) fail(OCRS_ERR_RUN_FAILED, "model run failed: expected 1 input channel, got %lld", (long long)c);
+        for (int i = 2; i < 4; i++)
+            if (hm->input_shape[i] >= 0 && hm->input_shape[i] != in_shape[i])
+                fail(OCRS_ERR_RUN_FAILED, "model run failed: input dim %d is %lld, model expects %lld", i,
+                     (long long)in_shape[i], (long long)hm->input_shape[i]);
+        Workspace ws;
+        const size_t cnt = (size_t)n * h * w;
+        float* d_in = ws.alloc_n<float>(cnt);
+        OCRS_HIP(hipMemcpyAsync(d_in, input, cnt * sizeof(float), hipMemcpyHostToDevice, ws.s()));
+        TensorShape os;
+        float* d_out = hm->run_device(ws, d_in, (int)n, (int)h, (int)w, &os, nullptr, nullptr, nullptr, true,
+                                      opts && opts->timing);
+        std::vector<float> host((size_t)os.count());
+        OCRS_HIP(hipMemcpyAsync(host.data(), d_out, host.size() * sizeof(float), hipMemcpyDeviceToHost, ws.s()));
+        ws.sync();
+        if (os.seq) {  // [T, N, C]
+            out_shape[0] = os.n; out_shape[1] = os.h; out_shape[2] = os.c; out_shape[3] = 1;
+            *out_ndim = 3;
+        } else {  // NHWC with C == channels -> report NCHW; C == 1 needs no transpose
+            if (os.c != 1) {
+                std::vector<float> t(host.size());
+                for (int64_t b = 0; b < os.n; b++)
+                    for (int64_t y = 0; y < os.h; y++)
+                        for (int64_t x = 0; x < os.w; x++)
+                            for (int64_t ch = 0; ch < os.c; ch++)
+                                t[((b * os.c + ch) * os.h + y) * os.w + x] = host[((b * os.h + y) * os.w + x) * os.c + ch];
+                host.swap(t);
+            }
+            out_shape[0] = os.n; out_shape[1] = os.c; out_shape[2] = os.h; out_shape[3] = os.w;
+            *out_ndim = 4;
+        }
+        *output = dup_buffer(host);
+    });
+}
+
+ocrs_status ocrs_model_flops(const ocrs_model* m, const int64_t in_shape[4], double* flops) {
+    return guarded([&] {
+        if (!m || !in_shape || !flops) fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
+        if (m->impl->is_callback()) { *flops = 0; return; }
+        *flops = static_cast<const HipModel*>(m->impl.get())->flops((int)in_shape[0], (int)in_shape[2], (int)in_shape[3]);
+    });
+}
+
+void ocrs_model_free(ocrs_model* m) { delete m; }
+
+// ------------------------------------------------------------------ engine
+ocrs_status ocrs_engine_new(const ocrs_engine_params* params, ocrs_engine** out) {
+    return guarded([&] {
+        if (!params || !out) fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
+        auto e = std::make_unique<ocrs_engine>();
+        e->detection = params->detection_model ? params->detection_model->impl.get() : nullptr;
+        e->recognition = params->recognition_model ? params->recognition_model->impl.get() : nullptr;
+        e->debug = params->debug != 0;
+        e->decode_method = params->decode_method;
+        e->beam_width = params->beam_width ? params->beam_width : 100;
+        e->alphabet = decode_utf8(params->alphabet ? params->alphabet : kDefaultAlphabet);
+        if (params->allowed_chars) {  // lib.rs:153-170
+            const std::u32string allowed = decode_utf8(params->allowed_chars);
+            e->excluded.assign(e->alphabet.size() + 1, 0);
+            for (size_t i = 0; i < e->alphabet.size(); i++)
+                if (allowed.find(e->alphabet[i]) == std::u32string::npos) e->excluded[i + 1] = 1;
+            e->has_excluded = true;
+            e->d_excluded = DevBuf(e->excluded.size());
+            OCRS_HIP(hipMemcpy(e->d_excluded.p, e->excluded.data(), e->excluded.size(), hipMemcpyHostToDevice));
+        }
+        *out = e.release();
+    });
+}
+
+void ocrs_engine_free(ocrs_engine* e) { delete e; }
+
+ocrs_status ocrs_image_source_check_bytes(size_t len, uint32_t width, uint32_t height, uint32_t* channels) {
+    return guarded([&] {  // preprocess.rs:81-101
+        const size_t channel_len = (size_t)width * height;
+        if (channel_len == 0) fail(OCRS_ERR_IMAGE_SOURCE, "channel count is not 1, 3 or 4");
+        if (len % channel_len != 0) fail(OCRS_ERR_IMAGE_SOURCE, "data length is not a multiple of `width * height`");
+        const size_t ch = len / channel_len;
+        if (!(ch == 1 || ch == 3 || ch == 4)) fail(OCRS_ERR_IMAGE_SOURCE, "channel count is not 1, 3 or 4");
+        if (channels) *channels = (uint32_t)ch;
+    });
+}
+
+ocrs_status ocrs_engine_prepare_input(const ocrs_engine* e, const void* pixels, ocrs_pixel_type type,
+                                      ocrs_dim_order order, int height, int width, int channels, ocrs_page** out) {
+    return guarded([&] {
+        if (!e || !out) fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
+        check_image_args(pixels, height, width, channels);
+        Workspace ws;
+        const size_t bytes = (size_t)height * width * channels * (type == OCRS_U8 ? 1 : 4);
+        void* d_px = ws.alloc(bytes);
+        OCRS_HIP(hipMemcpyAsync(d_px, pixels, bytes, hipMemcpyHostToDevice, ws.s()));
+        ocrs_page* p = make_page(d_px, type, order, height, width, channels, ws.s(), e->tm());
+        ws.sync();
+        if (e->tm()) e->tm()->collect();
+        *out = p;
+    });
+}
+
+ocrs_status ocrs_engine_prepare_input_device(const ocrs_engine* e, const void* d_pixels, ocrs_pixel_type type,
+                                             ocrs_dim_order order, int height, int width, int channels,
+                                             ocrs_page** out) {
+    return guarded([&] {
+        if (!e || !out) fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
+        check_image_args(d_pixels, height, width, channels);
+        Workspace ws;
+        ocrs_page* p = make_page(d_pixels, type, order, height, width, channels, ws.s(), e->tm());
+        ws.sync();
+        if (e->tm()) e->tm()->collect();
+        *out = p;
+    });
+}
+
+void ocrs_page_free(ocrs_page* p) { delete p; }
+
+ocrs_status ocrs_page_dims(const ocrs_page* p, int* height, int* width) {
+    return guarded([&] {
+        if (!p) fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
+        if (height) *height = p->h;
+        if (width) *width = p->w;
+    });
+}
+
+ocrs_status ocrs_page_image(const ocrs_page* p, float* out_hw) {
+    return guarded([&] {
+        if (!p || !out_hw) fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
+        OCRS_HIP(hipMemcpy(out_hw, p->grey.p, (size_t)p->h * p->w * sizeof(float), hipMemcpyDeviceToHost));
+    });
+}
+
+ocrs_status ocrs_engine_detect_words_batch(const ocrs_engine* e, const ocrs_page* const* pages, size_t n_pages,
+                                           float** rects, size_t* offsets) {
+    return guarded([&] {
+        if (!e || !pages || !rects || !offsets) fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
+        std::vector<std::vector<RotatedRect>> rr;
+        e->detect(pages, n_pages, &rr, nullptr);
+        std::vector<float> flat;
+        offsets[0] = 0;
+        for (size_t i = 0; i < n_pages; i++) {
+            for (const RotatedRect& r : rr[i]) {
+                float a[6];
+                r.to_array(a);
+                flat.insert(flat.end(), a, a + 6);
+            }
+            offsets[i + 1] = flat.size() / 6;
+        }
+        *rects = dup_buffer(flat);
+    });
+}
+
+ocrs_status ocrs_engine_detect_words(const ocrs_engine* e, const ocrs_page* page, float** rects, size_t* n) {
+    size_t offs[2] = {0, 0};
+    ocrs_status s = ocrs_engine_detect_words_batch(e, &page, page ? 1 : 0, rects, offs);
+    if (s == OCRS_OK && n) *n = offs[1];
+    return s;
+}
+
+ocrs_status ocrs_engine_detect_text_pixels(const ocrs_engine* e, const ocrs_page* page, float* out_hw) {
+    return guarded([&] {
+        if (!e || !page || !out_hw) fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
+        e->detect(&page, 1, nullptr, out_hw);
+    });
+}
+
+float ocrs_engine_detection_threshold(const ocrs_engine* e) { return e ? e->text_threshold : 0.2f; }
+
+ocrs_status ocrs_engine_find_text_lines(const ocrs_engine* e, const ocrs_page* page, const float* word_rects,
+                                        size_t n_words, float** line_rects, size_t** line_offsets, size_t* n_lines) {
+    (void)e; (void)page;
+    return guarded([&] {
+        if (!line_rects || !line_offsets || !n_lines || (n_words && !word_rects))
+            fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
+        std::vector<RotatedRect> words(n_words);
+        for (size_t i = 0; i < n_words; i++) words[i] = RotatedRect::from_array(word_rects + 6 * i);
+        auto lines = find_text_lines(words);
+        std::vector<float> flat;
+        std::vector<size_t> offs{0};
+        for (const auto& l : lines) {
+            for (const RotatedRect& r : l) {
+                float a[6];
+                r.to_array(a);
+                flat.insert(flat.end(), a, a + 6);
+            }
+            offs.push_back(flat.size() / 6);
+        }
+        *line_rects = dup_buffer(flat);
+        *line_offsets = dup_buffer(offs);
+        *n_lines = lines.size();
+    });
+}
+
+ocrs_status ocrs_engine_recognize_text_batch(const ocrs_engine* e, const ocrs_page* const* pages, size_t n_pages,
+                                             const size_t* page_line_offsets, const float* line_rects,
+                                             const size_t* line_offsets, size_t n_lines, ocrs_text_char** chars,
+                                             size_t** char_offsets) {
+    return guarded([&] {
+        if (!e || !pages || !page_line_offsets || !line_offsets || !chars || !char_offsets)
+            fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
+        if (page_line_offsets[n_pages] != n_lines) fail(OCRS_ERR_INVALID_ARGUMENT, "page_line_offsets do not cover n_lines");
+        std::vector<std::vector<std::vector<RotatedRect>>> lpp(n_pages);
+        for (size_t p = 0; p < n_pages; p++)
+            lpp[p] = unpack_lines(line_rects, line_offsets, page_line_offsets[p], page_line_offsets[p + 1]);
+        std::vector<std::vector<CtcStep>> steps;
+        std::vector<RecLine> rl;
+        std::vector<uint32_t> ctc_len;
+        e->recognize(pages, n_pages, lpp, &steps, &rl, &ctc_len);
+        std::vector<ocrs_text_char> flat;
+        std::vector<size_t> offs{0};
+        for (size_t i = 0; i < rl.size(); i++) {
+            for (const TextChar& c : e->text_line_from_result(rl[i], ctc_len[i], steps[i]))
+                flat.push_back(ocrs_text_char{c.ch, c.rect.top, c.rect.left, c.rect.bottom, c.rect.right});
+            offs.push_back(flat.size());
+        }
+        *chars = dup_buffer(flat);
+        *char_offsets = dup_buffer(offs);
+    });
+}
+
+ocrs_status ocrs_engine_recognize_text(const ocrs_engine* e, const ocrs_page* page, const float* line_rects,
+                                       const size_t* line_offsets, size_t n_lines, ocrs_text_char** chars,
+                                       size_t** char_offsets) {
+    size_t plo[2] = {0, n_lines};
+    return ocrs_engine_recognize_text_batch(e, &page, 1, plo, line_rects, line_offsets, n_lines, chars, char_offsets);
+}
+
+ocrs_status ocrs_engine_recognize_tokens(const ocrs_engine* e, const ocrs_page* page, const float* line_rects,
+                                         const size_t* line_offsets, size_t n_lines, uint32_t** labels,
+                                         uint32_t** positions, size_t** token_offsets) {
+    return guarded([&] {
+        if (!e || !page || !line_offsets || !labels || !positions || !token_offsets)
+            fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
+        std::vector<std::vector<std::vector<RotatedRect>>> lpp(1);
+        lpp[0] = unpack_lines(line_rects, line_offsets, 0, n_lines);
+        std::vector<std::vector<CtcStep>> steps;
+        std::vector<RecLine> rl;
+        std::vector<uint32_t> ctc_len;
+        e->recognize(&page, 1, lpp, &steps, &rl, &ctc_len);
+        std::vector<uint32_t> fl, fp;
+        std::vector<size_t> offs{0};
+        for (const auto& s : steps) {
+            for (const CtcStep& c : s) { fl.push_back(c.label); fp.push_back(c.pos); }
+            offs.push_back(fl.size());
+        }
+        *labels = dup_buffer(fl);
+        *positions = dup_buffer(fp);
+        *token_offsets = dup_buffer(offs);
+    });
+}
+
+ocrs_status ocrs_engine_prepare_recognition_input(const ocrs_engine* e, const ocrs_page* page, const float* line,
+                                                  size_t n_words, float** out, int* height, int* width) {
+    return guarded([&] {
+        if (!e || !page || !line || !out || !height || !width) fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
+        if (!e->recognition) fail(OCRS_ERR_MODEL_NOT_LOADED, "Recognition model not loaded");
+        std::vector<RotatedRect> words(n_words);
+        for (size_t i = 0; i < n_words; i++) words[i] = RotatedRect::from_array(line + 6 * i);
+        RecLine ln = e->make_rec_line(words, 0, 0);
+        const int rec_h = (int)e->rec_input_height();
+        const int rw = (int)ln.resized_width;
+        if (ln.polygon.size() > 512) fail(OCRS_ERR_CAPACITY, "text line has more than 128 words");
+        Workspace ws;
+        k::LineDesc d{};
+        d.page = 0; d.poly_off = 0; d.poly_n = (int32_t)ln.polygon.size();
+        d.top = ln.bounds.top; d.left = ln.bounds.left; d.bh = ln.bounds.height(); d.bw = ln.bounds.width();
+        d.resized_w = rw; d.out_row = 0;
+        std::vector<int32_t> poly;
+        for (const PointI& p : ln.polygon) { poly.push_back(p.y); poly.push_back(p.x); }
+        const float* hp = page->grey.as<float>();
+        const int32_t hw[2] = {page->h, page->w};
+        const float** d_pages = ws.alloc_n<const float*>(1);
+        int32_t* d_hw = ws.alloc_n<int32_t>(2);
+        k::LineDesc* d_desc = ws.alloc_n<k::LineDesc>(1);
+        int32_t* d_poly = ws.alloc_n<int32_t>(poly.size());
+        float* d_out = ws.alloc_n<float>((size_t)rec_h * std::max(rw, 1));
+        OCRS_HIP(hipMemcpyAsync(d_pages, &hp, sizeof hp, hipMemcpyHostToDevice, ws.s()));
+        OCRS_HIP(hipMemcpyAsync(d_hw, hw, sizeof hw, hipMemcpyHostToDevice, ws.s()));
+        OCRS_HIP(hipMemcpyAsync(d_desc, &d, sizeof d, hipMemcpyHostToDevice, ws.s()));
+        OCRS_HIP(hipMemcpyAsync(d_poly, poly.data(), poly.size() * 4, hipMemcpyHostToDevice, ws.s()));
+        std::vector<float> host((size_t)rec_h * rw);
+        if (rw > 0) {
+            k::crop_lines(d_pages, d_hw, d_desc, d_poly, 1, rec_h, rw, d_out, ws.s());
+            OCRS_HIP(hipMemcpyAsync(host.data(), d_out, host.size() * 4, hipMemcpyDeviceToHost, ws.s()));
+        }
+        ws.sync();
+        *out = dup_buffer(host);
+        *height = rec_h;
+        *width = rw;
+    });
+}
+
+ocrs_status ocrs_engine_get_text(const ocrs_engine* e, const ocrs_page* page, char** text) {
+    return guarded([&] {  // lib.rs:290-300
+        if (!e || !page || !text) fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
+        std::vector<std::vector<RotatedRect>> rr;
+        e->detect(&page, 1, &rr, nullptr);
+        std::vector<std::vector<std::vector<RotatedRect>>> lpp(1);
+        lpp[0] = find_text_lines(rr[0]);
+        std::vector<std::vector<CtcStep>> steps;
+        std::vector<RecLine> rl;
+        std::vector<uint32_t> ctc_len;
+        e->recognize(&page, 1, lpp, &steps, &rl, &ctc_len);
+        std::string out;
+        bool first = true;
+        for (size_t i = 0; i < rl.size(); i++) {
+            auto chars = e->text_line_from_result(rl[i], ctc_len[i], steps[i]);
+            if (chars.empty()) continue;
+            if (!first) out.push_back('\n');
+            first = false;
+            for (const TextChar& c : chars) append_utf8(out, c.ch);
+        }
+        char* p = static_cast<char*>(malloc(out.size() + 1));
+        if (!p) throw std::bad_alloc();
+        memcpy(p, out.c_str(), out.size() + 1);
+        *text = p;
+    });
+}
+
+// ------------------------------------------------------------------ measurement hooks
+ocrs_status ocrs_device_malloc(size_t bytes, void** d_ptr) {
+    return guarded([&] { OCRS_HIP(hipMalloc(d_ptr, bytes)); });
+}
+ocrs_status ocrs_device_free(void* d_ptr) {
+    return guarded([&] { OCRS_HIP(hipFree(d_ptr)); });
+}
+ocrs_status ocrs_device_upload(void* d_dst, const void* h_src, size_t bytes) {
+    return guarded([&] { OCRS_HIP(hipMemcpy(d_dst, h_src, bytes, hipMemcpyHostToDevice)); });
+}
+ocrs_status ocrs_device_synchronize(void) {
+    return guarded([&] { OCRS_HIP(hipDeviceSynchronize()); });
+}
+
+ocrs_status ocrs_engine_enable_timing(ocrs_engine* e, int enable) {
+    return guarded([&] {
+        if (!e) fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
+        e->timers.enabled = enable != 0;
+    });
+}
+int ocrs_stage_count(void) { return ST_COUNT; }
+const char* ocrs_stage_name(int stage) { return stage >= 0 && stage < ST_COUNT ? kStageNames[stage] : ""; }
+ocrs_status ocrs_engine_stage_times(ocrs_engine* e, double* ms, uint64_t* launches, int reset) {
+    return guarded([&] {
+        if (!e) fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
+        e->timers.collect();
+        for (int i = 0; i < ST_COUNT; i++) {
+            if (ms) ms[i] = e->timers.ms[i];
+            if (launches) launches[i] = e->timers.launches[i];
+        }
+        if (reset) e->timers.reset();
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,141 @@
+#include "common.hpp"
+
+namespace ocrs {
+
+static thread_local std::string g_last_error;
+
+void set_last_error(const std::string& msg) { g_last_error = msg; }
+const std::string& last_error() { return g_last_error; }
+
+const char* const kStageNames[ST_COUNT] = {
+    "prepare_image", "resize_to_model", "detection_cnn", "resize_threshold", "ccl",      "contour_rects",
+    "line_crop",     "rec_conv",        "rec_gru",       "rec_head",         "ctc_decode"};
+
+// ---------------------------------------------------------------- DevicePool
+static size_t round_size(size_t n) {
+    // 256 B granularity below 1 MiB, then 1/8-octave buckets: bounded waste, good reuse.
+    if (n <= (1u << 20)) return (n + 255) & ~size_t(255);
+    size_t p = size_t(1) << 20;
+    while (p * 2 <= n) p *= 2;
+    size_t step = p / 8;
+    return ((n + step - 1) / step) * step;
+}
+
+void* DevicePool::alloc(size_t bytes) {
+    size_t sz = round_size(bytes);
+    {
+        std::lock_guard<std::mutex> g(mu_);
+        auto it = free_.find(sz);
+        if (it != free_.end()) {
+            void* p = it->second;
+            free_.erase(it);
+            live_[p] = sz;
+            return p;
+        }
+    }
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, sz);
+    if (e != hipSuccess) {
+        trim();
+        OCRS_HIP(hipMalloc(&p, sz));
+    }
+    std::lock_guard<std::mutex> g(mu_);
+    live_[p] = sz;
+    return p;
+}
+
+void DevicePool::release(void* p) {
+    if (!p) return;
+    std::lock_guard<std::mutex> g(mu_);
+    auto it = live_.find(p);
+    if (it == live_.end()) return;
+    free_.emplace(it->second, p);
+    live_.erase(it);
+}
+
+void DevicePool::trim() {
+    std::lock_guard<std::mutex> g(mu_);
+    for (auto& kv : free_) (void)hipFree(kv.second);
+    free_.clear();
+}
+
+DevicePool::~DevicePool() {
+    // Process teardown: the HIP runtime may already be gone; leak on purpose.
+}
+
+DevicePool& pool() {
+    static DevicePool* p = new DevicePool();
+    return *p;
+}
+
+// ---------------------------------------------------------------- streams
+namespace {
+std::mutex g_stream_mu;
+std::vector<hipStream_t> g_streams;
+}  // namespace
+
+StreamLease::StreamLease() {
+    {
+        std::lock_guard<std::mutex> g(g_stream_mu);
+        if (!g_streams.empty()) {
+            s_ = g_streams.back();
+            g_streams.pop_back();
+            return;
+        }
+    }
+    OCRS_HIP(hipStreamCreateWithFlags(&s_, hipStreamNonBlocking));
+}
+
+StreamLease::~StreamLease() {
+    std::lock_guard<std::mutex> g(g_stream_mu);
+    g_streams.push_back(s_);
+}
+
+// ---------------------------------------------------------------- timers
+hipEvent_t StageTimers::get_event() {
+    if (!free_events_.empty()) {
+        hipEvent_t e = free_events_.back();
+        free_events_.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    OCRS_HIP(hipEventCreate(&e));
+    return e;
+}
+
+int StageTimers::begin(int stage, hipStream_t s, uint64_t n_launches) {
+    if (!enabled) return -1;
+    std::lock_guard<std::mutex> g(mu);
+    Pending p{stage, get_event(), get_event(), n_launches};
+    OCRS_HIP(hipEventRecord(p.a, s));
+    pending.push_back(p);
+    return (int)pending.size() - 1;
+}
+
+void StageTimers::end(int token, hipStream_t s) {
+    if (!enabled || token < 0) return;
+    std::lock_guard<std::mutex> g(mu);
+    if ((size_t)token < pending.size()) (void)hipEventRecord(pending[token].b, s);
+}
+
+void StageTimers::collect() {
+    if (!enabled) return;
+    std::lock_guard<std::mutex> g(mu);
+    for (auto& p : pending) {
+        float t = 0.f;
+        if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&t, p.a, p.b) == hipSuccess) {
+            ms[p.stage] += t;
+            launches[p.stage] += p.n;
+        }
+        free_events_.push_back(p.a);
+        free_events_.push_back(p.b);
+    }
+    pending.clear();
+}
+
+void StageTimers::reset() {
+    std::lock_guard<std::mutex> g(mu);
+    for (int i = 0; i < ST_COUNT; i++) { ms[i] = 0; launches[i] = 0; }
+}
+
+}  // namespace ocrs

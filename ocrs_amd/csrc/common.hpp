@@ -1,0 +1,164 @@
+// Shared host-side plumbing for libocrs_amd: error reporting, HIP checks,
+// a caching device allocator and per-call streams.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/ocrs_amd.h"
+
+namespace ocrs {
+
+// Error carried up to the C ABI, where it becomes (status, thread-local message).
+struct Error : std::runtime_error {
+    ocrs_status status;
+    Error(ocrs_status s, const std::string& msg) : std::runtime_error(msg), status(s) {}
+};
+
+[[noreturn]] inline void fail(ocrs_status s, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    throw Error(s, buf);
+}
+
+#define OCRS_HIP(expr)                                                                              \
+    do {                                                                                            \
+        hipError_t _e = (expr);                                                                     \
+        if (_e != hipSuccess)                                                                       \
+            ::ocrs::fail(OCRS_ERR_DEVICE, "HIP error %s at %s:%d (%s)", hipGetErrorString(_e), __FILE__, \
+                         __LINE__, #expr);                                                          \
+    } while (0)
+
+void set_last_error(const std::string& msg);
+
+// Size-bucketed caching allocator: hipMalloc is far too slow to sit on the
+// per-page path, and stages need scratch whose size depends on the page.
+class DevicePool {
+  public:
+    ~DevicePool();
+    void* alloc(size_t bytes);
+    void release(void* p);
+    void trim();
+
+  private:
+    std::mutex mu_;
+    std::multimap<size_t, void*> free_;
+    std::map<void*, size_t> live_;
+};
+
+DevicePool& pool();
+
+// RAII device buffer from the pool.
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    DevBuf() = default;
+    explicit DevBuf(size_t n) : p(n ? pool().alloc(n) : nullptr), bytes(n) {}
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr; o.bytes = 0; }
+    DevBuf& operator=(DevBuf&& o) noexcept {
+        if (this != &o) { reset(); p = o.p; bytes = o.bytes; o.p = nullptr; o.bytes = 0; }
+        return *this;
+    }
+    ~DevBuf() { reset(); }
+    void reset() { if (p) pool().release(p); p = nullptr; bytes = 0; }
+    template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
+// Pinned host staging buffer.
+struct PinnedBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    PinnedBuf() = default;
+    explicit PinnedBuf(size_t n) : bytes(n) { if (n) OCRS_HIP(hipHostMalloc(&p, n, hipHostMallocDefault)); }
+    PinnedBuf(const PinnedBuf&) = delete;
+    PinnedBuf& operator=(const PinnedBuf&) = delete;
+    ~PinnedBuf() { if (p) (void)hipHostFree(p); }
+    template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
+// One stream per API call, recycled: calls from different host threads run on
+// different streams (the reference calls Model::run concurrently,
+// recognition.rs:465-485).
+class StreamLease {
+  public:
+    StreamLease();
+    ~StreamLease();
+    hipStream_t get() const { return s_; }
+    void sync() const { OCRS_HIP(hipStreamSynchronize(s_)); }
+
+  private:
+    hipStream_t s_;
+};
+
+// Stage timers (HIP events on the launching stream).
+enum Stage {
+    ST_PREPARE = 0,
+    ST_RESIZE_IN,
+    ST_DET_CNN,
+    ST_RESIZE_THRESH,
+    ST_CCL,
+    ST_CONTOUR_RECTS,
+    ST_LINE_CROP,
+    ST_REC_CONV,
+    ST_REC_GRU,
+    ST_REC_HEAD,
+    ST_CTC,
+    ST_COUNT
+};
+extern const char* const kStageNames[ST_COUNT];
+
+struct StageTimers {
+    bool enabled = false;
+    std::mutex mu;
+    double ms[ST_COUNT] = {0};
+    uint64_t launches[ST_COUNT] = {0};
+    struct Pending { int stage; hipEvent_t a, b; uint64_t n; };
+    std::vector<Pending> pending;
+    int begin(int stage, hipStream_t s, uint64_t n_launches);  // returns token (-1 when disabled)
+    void end(int token, hipStream_t s);
+    void collect();  // after a stream sync
+    void reset();
+  private:
+    std::vector<hipEvent_t> free_events_;
+    hipEvent_t get_event();
+};
+
+inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+struct StageScope {
+    StageTimers* t; int token; hipStream_t s;
+    StageScope(StageTimers* timers, int stage, hipStream_t stream, uint64_t n_launches = 1)
+        : t(timers), token(timers ? timers->begin(stage, stream, n_launches) : -1), s(stream) {}
+    ~StageScope() { if (t && token >= 0) t->end(token, s); }
+};
+
+// Everything one API call launches: a leased stream plus the scratch buffers its
+// kernels use.  The destructor drains the stream BEFORE the buffers go back to
+// the pool, so no other call can be handed memory that is still in flight.
+struct Workspace {
+    StreamLease stream;
+    std::vector<DevBuf> bufs;
+    hipStream_t s() const { return stream.get(); }
+    void* alloc(size_t bytes) { bufs.emplace_back(bytes ? bytes : 4); return bufs.back().p; }
+    template <class T> T* alloc_n(size_t n) { return static_cast<T*>(alloc(n * sizeof(T))); }
+    void sync() { stream.sync(); }
+    ~Workspace() { (void)hipStreamSynchronize(stream.get()); }
+};
+
+const std::string& last_error();
+
+}  // namespace ocrs

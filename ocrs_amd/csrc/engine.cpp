@@ -1,0 +1,412 @@
+#include "engine.hpp"
+
+#include <algorithm>
+#include <map>
+
+#include "kernels.hpp"
+
+using namespace ocrs;
+using namespace ocrs::geom;
+
+// ===========================================================================
+// Detection — detection.rs:104-200
+// ===========================================================================
+void ocrs_engine::detect(const ocrs_page* const* pages, size_t n, std::vector<std::vector<RotatedRect>>* rects_out,
+                         float* host_map) const {
+    if (!detection) fail(OCRS_ERR_MODEL_NOT_LOADED, "Detection model not loaded");
+    if (n == 0) {
+        if (rects_out) rects_out->clear();
+        return;
+    }
+    const int64_t in_h64 = detection->input_shape[2], in_w64 = detection->input_shape[3];
+    if (in_h64 <= 0 || in_w64 <= 0) fail(OCRS_ERR_MODEL_DIMS, "failed to get model dims");  // detection.rs:141-144
+    const int in_h = (int)in_h64, in_w = (int)in_w64;
+    const int h = pages[0]->h, w = pages[0]->w;
+    for (size_t i = 1; i < n; i++)
+        if (pages[i]->h != h || pages[i]->w != w)
+            fail(OCRS_ERR_INVALID_ARGUMENT, "pages in one detection batch must share a size");
+    if (h <= 0 || w <= 0 || h > 65535 || w > 65535) fail(OCRS_ERR_INVALID_ARGUMENT, "unsupported page size %dx%d", h, w);
+
+    const int pad_bottom = std::max(in_h - h, 0), pad_right = std::max(in_w - w, 0);  // detection.rs:155-156
+    const int vh = h + pad_bottom, vw = w + pad_right;
+    const int N = (int)n;
+
+    Workspace ws;
+    hipStream_t st = ws.s();
+    StageTimers* T = tm();
+
+    // page pointer table
+    std::vector<const float*> hp(n);
+    for (size_t i = 0; i < n; i++) hp[i] = pages[i]->grey.as<float>();
+    const float** d_ptrs = ws.alloc_n<const float*>(n);
+    OCRS_HIP(hipMemcpyAsync(d_ptrs, hp.data(), n * sizeof(float*), hipMemcpyHostToDevice, st));
+
+    float* d_in = ws.alloc_n<float>((size_t)N * in_h * in_w);
+    {
+        StageScope sc(T, ST_RESIZE_IN, st);
+        k::resize_pages_to_model(d_ptrs, N, h, w, vh, vw, d_in, in_h, in_w, st);
+    }
+
+    const float* d_prob = nullptr;
+    if (detection->is_callback()) {
+        // `trait Model` implemented by the caller: one run per page, host tensors (detection.rs:184).
+        const auto* cb = static_cast<const CallbackModel*>(detection);
+        std::vector<float> hin((size_t)in_h * in_w), hout;
+        float* d_out = ws.alloc_n<float>((size_t)N * in_h * in_w);
+        for (int i = 0; i < N; i++) {
+            OCRS_HIP(hipMemcpyAsync(hin.data(), d_in + (size_t)i * in_h * in_w, hin.size() * sizeof(float),
+                                    hipMemcpyDeviceToHost, st));
+            ws.sync();
+            const int64_t ishape[4] = {1, 1, in_h, in_w};
+            int64_t oshape[4];
+            int ond = 0;
+            cb->run(hin.data(), ishape, hout, oshape, &ond);
+            if (ond != 4 || oshape[2] != in_h || oshape[3] != in_w || oshape[0] * oshape[1] != 1)
+                fail(OCRS_ERR_WRONG_OUTPUT, "model output had unexpected type or shape: detection output is not [1,1,%d,%d]",
+                     in_h, in_w);
+            OCRS_HIP(hipMemcpyAsync(d_out + (size_t)i * in_h * in_w, hout.data(), hout.size() * sizeof(float),
+                                    hipMemcpyHostToDevice, st));
+            ws.sync();
+        }
+        d_prob = d_out;
+    } else {
+        const auto* hm = static_cast<const HipModel*>(detection);
+        TensorShape os;
+        d_prob = hm->run_device(ws, d_in, N, in_h, in_w, &os, T, nullptr, nullptr, true, debug);
+        if (os.n != N || os.h != in_h || os.w != in_w || os.c != 1)
+            fail(OCRS_ERR_WRONG_OUTPUT, "model output had unexpected type or shape: detection output [%d,%d,%d,%d]", os.n,
+                 os.c, os.h, os.w);
+    }
+
+    // slice off the padded region, resize back, threshold (detection.rs:187-194,110)
+    const int sh = in_h - pad_bottom, sw = in_w - pad_right;
+    uint8_t* d_mask = ws.alloc_n<uint8_t>((size_t)N * h * w);
+    float* d_map = host_map ? ws.alloc_n<float>((size_t)N * h * w) : nullptr;
+    {
+        StageScope sc(T, ST_RESIZE_THRESH, st);
+        k::resize_threshold(d_prob, N, in_h, in_w, sh, sw, text_threshold, d_mask, d_map, h, w, st);
+    }
+    if (host_map)
+        OCRS_HIP(hipMemcpyAsync(host_map, d_map, (size_t)N * h * w * sizeof(float), hipMemcpyDeviceToHost, st));
+    if (!rects_out) {
+        ws.sync();
+        if (T) T->collect();
+        return;
+    }
+
+    // connected components -> rects (detection.rs:41-62)
+    const int64_t px = (int64_t)h * w;
+    const int max_comp = (int)std::min<int64_t>(65536, px / 2 + 16);
+    const int64_t arena = 2 * px + 64;
+    k::CclBuffers b{};
+    b.labels = ws.alloc_n<int32_t>((size_t)N * px);
+    b.row_counts = ws.alloc_n<int32_t>((size_t)N * h);
+    b.row_offsets = ws.alloc_n<int32_t>((size_t)N * h);
+    b.n_roots = ws.alloc_n<int32_t>(N);
+    b.roots = ws.alloc_n<int32_t>((size_t)N * max_comp);
+    b.lengths = ws.alloc_n<int32_t>((size_t)N * max_comp);
+    b.offsets = ws.alloc_n<int32_t>((size_t)N * max_comp);
+    b.overflow = ws.alloc_n<int32_t>(N);
+    b.pts = ws.alloc_n<uint32_t>((size_t)N * arena);
+    b.tmp = ws.alloc_n<uint32_t>((size_t)N * arena * 4);
+    b.keep = ws.alloc_n<uint8_t>((size_t)N * arena);
+    b.stack = nullptr;
+    b.rects = ws.alloc_n<float>((size_t)N * max_comp * 6);
+    b.valid = ws.alloc_n<uint8_t>((size_t)N * max_comp);
+    OCRS_HIP(hipMemsetAsync(b.overflow, 0, N * sizeof(int32_t), st));
+    {
+        StageScope sc(T, ST_CCL, st, 6);
+        k::ccl_label(d_mask, N, h, w, b, max_comp, st);
+    }
+    {
+        StageScope sc(T, ST_CONTOUR_RECTS, st, 3);
+        k::contour_rects(d_mask, N, h, w, b, max_comp, arena, /*expand*/ 3.0f, min_area, /*eps*/ 2.0f, st);
+    }
+    std::vector<int32_t> counts(N), ovf(N);
+    OCRS_HIP(hipMemcpyAsync(counts.data(), b.n_roots, N * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    OCRS_HIP(hipMemcpyAsync(ovf.data(), b.overflow, N * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    ws.sync();
+    for (int i = 0; i < N; i++)
+        if (ovf[i] || counts[i] > max_comp)
+            fail(OCRS_ERR_CAPACITY, "text mask of page %d has too many components or border pixels (%d components)", i,
+                 counts[i]);
+    rects_out->assign(n, {});
+    std::vector<float> hr;
+    std::vector<uint8_t> hv;
+    for (int i = 0; i < N; i++) {
+        const int cnt = counts[i];
+        if (cnt == 0) continue;
+        hr.resize((size_t)cnt * 6);
+        hv.resize(cnt);
+        OCRS_HIP(hipMemcpyAsync(hr.data(), b.rects + (size_t)i * max_comp * 6, hr.size() * sizeof(float),
+                                hipMemcpyDeviceToHost, st));
+        OCRS_HIP(hipMemcpyAsync(hv.data(), b.valid + (size_t)i * max_comp, cnt, hipMemcpyDeviceToHost, st));
+        ws.sync();
+        auto& out = (*rects_out)[i];
+        for (int c = 0; c < cnt; c++)
+            if (hv[c]) out.push_back(RotatedRect::from_array(&hr[(size_t)c * 6]));
+    }
+    if (T) T->collect();
+}
+
+// ===========================================================================
+// Recognition — recognition.rs
+// ===========================================================================
+uint32_t ocrs_engine::rec_input_height() const {  // recognition.rs:332-337
+    const int64_t hgt = recognition->input_shape[2];
+    return hgt > 0 ? (uint32_t)hgt : 50u;
+}
+
+namespace {
+
+// recognition.rs:58-75
+uint32_t resized_line_width(int32_t orig_width, int32_t orig_height, int32_t height) {
+    const float aspect = (float)orig_width / (float)orig_height;
+    float v = (float)height * aspect;
+    if (v != v) return 0;  // clamp keeps NaN; `as u32` maps it to 0
+    v = v < 10.0f ? 10.0f : v;
+    v = v > 2400.0f ? 2400.0f : v;
+    return (uint32_t)v;
+}
+
+// recognition.rs:29-55
+std::vector<PointI> line_polygon(const std::vector<RotatedRect>& words) {
+    std::vector<PointI> poly;
+    poly.reserve(words.size() * 4);
+    auto floor_point = [](PointF p) { return PointI{as_i32(p.x), as_i32(p.y)}; };
+    for (const RotatedRect& w : words) {
+        LineF left = downwards_line(leftmost_edge(w)), right = downwards_line(rightmost_edge(w));
+        poly.push_back(floor_point(left.start));
+        poly.push_back(floor_point(right.start));
+    }
+    for (auto it = words.rbegin(); it != words.rend(); ++it) {
+        LineF left = downwards_line(leftmost_edge(*it)), right = downwards_line(rightmost_edge(*it));
+        poly.push_back(floor_point(right.end));
+        poly.push_back(floor_point(left.end));
+    }
+    return poly;
+}
+
+// recognition.rs:162-193
+bool polygon_slice_bounding_rect(const std::vector<PointI>& poly, int32_t min_x, int32_t max_x, Rect* out) {
+    bool have = false;
+    Rect acc{0, 0, 0, 0};
+    const size_t n = poly.size();
+    for (size_t k = 0; k < n; k++) {
+        PointI s = poly[k], e = poly[(k + 1) % n];
+        if (s.x > e.x) std::swap(s, e);  // rightwards()
+        if ((s.x < min_x && e.x < min_x) || (s.x > max_x && e.x > max_x)) continue;
+        LineF ef{PointF{(float)s.x, (float)s.y}, PointF{(float)e.x, (float)e.y}};
+        PointI ts = s, te = e;
+        if (auto y = ef.y_for_x((float)min_x)) ts = PointI{min_x, (int32_t)rround(*y)};
+        if (auto y = ef.y_for_x((float)max_x)) te = PointI{max_x, (int32_t)rround(*y)};
+        Rect br{std::min(ts.y, te.y), std::min(ts.x, te.x), std::max(ts.y, te.y), std::max(ts.x, te.x)};
+        acc = have ? acc.unite(br) : br;
+        have = true;
+    }
+    if (have) *out = acc;
+    return have;
+}
+
+}  // namespace
+
+RecLine ocrs_engine::make_rec_line(const std::vector<RotatedRect>& words, size_t page, size_t index) const {
+    if (words.empty()) fail(OCRS_ERR_INVALID_ARGUMENT, "line has no words");  // recognition.rs:433
+    RectF br = words[0].bounding_rect();
+    for (size_t i = 1; i < words.size(); i++) br = br.unite(words[i].bounding_rect());
+    const Rect line_rect = br.integral_bounding_rect();
+    RecLine l;
+    l.page = page;
+    l.index = index;
+    l.resized_width = resized_line_width(line_rect.width(), line_rect.height(), (int32_t)rec_input_height());
+    l.group_width = (l.resized_width + 49) / 50 * 50;  // next_multiple_of(50), recognition.rs:437
+    l.polygon = line_polygon(words);
+    int32_t t = l.polygon[0].y, bt = t, lf = l.polygon[0].x, rt = lf;
+    for (const PointI& p : l.polygon) {
+        t = std::min(t, p.y); bt = std::max(bt, p.y);
+        lf = std::min(lf, p.x); rt = std::max(rt, p.x);
+    }
+    l.bounds = Rect{t, lf, bt, rt};
+    return l;
+}
+
+void ocrs_engine::recognize(const ocrs_page* const* pages, size_t n_pages,
+                            const std::vector<std::vector<std::vector<RotatedRect>>>& lines_per_page,
+                            std::vector<std::vector<CtcStep>>* steps_out, std::vector<RecLine>* rec_lines_out,
+                            std::vector<uint32_t>* ctc_len_out) const {
+    if (!recognition) fail(OCRS_ERR_MODEL_NOT_LOADED, "Recognition model not loaded");
+    if (decode_method == OCRS_DECODE_BEAM_SEARCH)
+        fail(OCRS_ERR_INVALID_ARGUMENT, "beam search decoding is not available in this build (SURVEY.md §8 f3)");
+    const uint32_t rec_h = rec_input_height();
+    const size_t alphabet_len = alphabet.size();
+
+    std::vector<RecLine> lines;
+    for (size_t p = 0; p < n_pages; p++)
+        for (const auto& words : lines_per_page[p]) lines.push_back(make_rec_line(words, p, lines.size()));
+    const size_t L = lines.size();
+    steps_out->assign(L, {});
+    ctc_len_out->assign(L, 0);
+    if (L == 0) {
+        *rec_lines_out = std::move(lines);
+        return;
+    }
+
+    // group by padded width (recognition.rs:430-446); std::map gives a deterministic order
+    std::map<uint32_t, std::vector<size_t>> groups;
+    for (size_t i = 0; i < L; i++) {
+        if (lines[i].polygon.size() > 512) fail(OCRS_ERR_CAPACITY, "text line %zu has more than 128 words", i);
+        groups[lines[i].group_width].push_back(i);
+    }
+
+    Workspace ws;
+    hipStream_t st = ws.s();
+    StageTimers* T = tm();
+
+    std::vector<const float*> hp(n_pages);
+    std::vector<int32_t> hhw(2 * n_pages);
+    for (size_t i = 0; i < n_pages; i++) {
+        hp[i] = pages[i]->grey.as<float>();
+        hhw[2 * i] = pages[i]->h;
+        hhw[2 * i + 1] = pages[i]->w;
+    }
+    const float** d_pages = ws.alloc_n<const float*>(n_pages);
+    int32_t* d_hw = ws.alloc_n<int32_t>(2 * n_pages);
+    OCRS_HIP(hipMemcpyAsync(d_pages, hp.data(), n_pages * sizeof(float*), hipMemcpyHostToDevice, st));
+    OCRS_HIP(hipMemcpyAsync(d_hw, hhw.data(), hhw.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+
+    const bool callback = recognition->is_callback();
+    const uint8_t* d_excl = has_excluded ? d_excluded.as<uint8_t>() : nullptr;
+
+    for (auto& kv : groups) {
+        const uint32_t gw = kv.first;
+        const std::vector<size_t>& members = kv.second;
+        if (gw == 0) continue;  // zero-width lines produce no input and no text
+        // reference: chunks of 20 (recognition.rs:450); rows are independent, so the HIP
+        // executor takes bigger chunks, bounded by activation memory.
+        const size_t max_chunk = callback ? 20 : std::max<size_t>(1, 307200 / gw);
+        for (size_t c0 = 0; c0 < members.size(); c0 += max_chunk) {
+            const size_t nb = std::min(max_chunk, members.size() - c0);
+            // ---- crop + resize + pad (recognition.rs:135-158)
+            std::vector<k::LineDesc> descs(nb);
+            std::vector<int32_t> poly;
+            for (size_t j = 0; j < nb; j++) {
+                const RecLine& ln = lines[members[c0 + j]];
+                k::LineDesc& d = descs[j];
+                d.page = (int32_t)ln.page;
+                d.poly_off = (int32_t)(poly.size() / 2);
+                d.poly_n = (int32_t)ln.polygon.size();
+                d.top = ln.bounds.top; d.left = ln.bounds.left;
+                d.bh = ln.bounds.height(); d.bw = ln.bounds.width();
+                d.resized_w = (int32_t)ln.resized_width;
+                d.out_row = (int32_t)j;
+                for (const PointI& p : ln.polygon) { poly.push_back(p.y); poly.push_back(p.x); }
+            }
+            k::LineDesc* d_descs = ws.alloc_n<k::LineDesc>(nb);
+            int32_t* d_poly = ws.alloc_n<int32_t>(poly.size());
+            OCRS_HIP(hipMemcpyAsync(d_descs, descs.data(), nb * sizeof(k::LineDesc), hipMemcpyHostToDevice, st));
+            OCRS_HIP(hipMemcpyAsync(d_poly, poly.data(), poly.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+            float* d_batch = ws.alloc_n<float>(nb * rec_h * gw);
+            {
+                StageScope sc(T, ST_LINE_CROP, st);
+                k::crop_lines(d_pages, d_hw, d_descs, d_poly, (int)nb, (int)rec_h, (int)gw, d_batch, st);
+            }
+            ws.sync();  // descs/poly are host temporaries
+
+            // ---- model (recognition.rs:341-360, :485-493)
+            int Tn = 0, C = 0;
+            int32_t* d_labels = nullptr;
+            if (callback) {
+                const auto* cb = static_cast<const CallbackModel*>(recognition);
+                std::vector<float> hin(nb * rec_h * gw), hout;
+                OCRS_HIP(hipMemcpyAsync(hin.data(), d_batch, hin.size() * sizeof(float), hipMemcpyDeviceToHost, st));
+                ws.sync();
+                const int64_t ishape[4] = {(int64_t)nb, 1, rec_h, gw};
+                int64_t oshape[4];
+                int ond = 0;
+                cb->run(hin.data(), ishape, hout, oshape, &ond);
+                if (ond != 3)
+                    fail(OCRS_ERR_WRONG_OUTPUT,
+                         "model output had unexpected type or shape: expected recognition output to have 3 dims but it has %d", ond);
+                if ((size_t)oshape[1] != nb)
+                    fail(OCRS_ERR_WRONG_OUTPUT, "model output had unexpected type or shape: batch size %lld != %zu",
+                         (long long)oshape[1], nb);
+                Tn = (int)oshape[0];
+                C = (int)oshape[2];
+                if (alphabet_len + 1 != (size_t)C)
+                    fail(OCRS_ERR_WRONG_OUTPUT,
+                         "model output had unexpected type or shape: output column count (%d) does not match alphabet size (%zu)",
+                         C, alphabet_len + 1);
+                float* d_logp = ws.alloc_n<float>(hout.size());
+                OCRS_HIP(hipMemcpyAsync(d_logp, hout.data(), hout.size() * sizeof(float), hipMemcpyHostToDevice, st));
+                d_labels = ws.alloc_n<int32_t>((size_t)Tn * nb);
+                {
+                    StageScope sc(T, ST_CTC, st);
+                    k::argmax_rows(d_logp, (int64_t)Tn * nb, C, d_excl, d_labels, st);
+                }
+                ws.sync();
+            } else {
+                const auto* hm = static_cast<const HipModel*>(recognition);
+                TensorShape os = hm->infer((int)nb, (int)rec_h, (int)gw);
+                if (!os.seq)
+                    fail(OCRS_ERR_WRONG_OUTPUT,
+                         "model output had unexpected type or shape: expected recognition output to have 3 dims but it has 4");
+                Tn = os.n;
+                C = os.c;
+                if (alphabet_len + 1 != (size_t)C)
+                    fail(OCRS_ERR_WRONG_OUTPUT,
+                         "model output had unexpected type or shape: output column count (%d) does not match alphabet size (%zu)",
+                         C, alphabet_len + 1);
+                d_labels = ws.alloc_n<int32_t>((size_t)Tn * nb);
+                hm->run_device(ws, d_batch, (int)nb, (int)rec_h, (int)gw, nullptr, T, d_excl, d_labels, false, false);
+            }
+
+            // ---- greedy CTC (recognition.rs:511)
+            uint32_t* d_ol = ws.alloc_n<uint32_t>((size_t)nb * Tn);
+            uint32_t* d_op = ws.alloc_n<uint32_t>((size_t)nb * Tn);
+            int32_t* d_cnt = ws.alloc_n<int32_t>(nb);
+            {
+                StageScope sc(T, ST_CTC, st);
+                k::ctc_collapse(d_labels, Tn, (int)nb, d_ol, d_op, d_cnt, st);
+            }
+            std::vector<uint32_t> hl((size_t)nb * Tn), hpz((size_t)nb * Tn);
+            std::vector<int32_t> hc(nb);
+            OCRS_HIP(hipMemcpyAsync(hl.data(), d_ol, hl.size() * 4, hipMemcpyDeviceToHost, st));
+            OCRS_HIP(hipMemcpyAsync(hpz.data(), d_op, hpz.size() * 4, hipMemcpyDeviceToHost, st));
+            OCRS_HIP(hipMemcpyAsync(hc.data(), d_cnt, nb * 4, hipMemcpyDeviceToHost, st));
+            ws.sync();
+            for (size_t j = 0; j < nb; j++) {
+                const size_t li = members[c0 + j];
+                auto& s = (*steps_out)[li];
+                s.resize(hc[j]);
+                for (int q = 0; q < hc[j]; q++) s[q] = CtcStep{hl[j * Tn + q], hpz[j * Tn + q]};
+                (*ctc_len_out)[li] = (uint32_t)Tn;
+            }
+        }
+    }
+    if (T) T->collect();
+    *rec_lines_out = std::move(lines);
+}
+
+// recognition.rs:241-311 for one line
+std::vector<TextChar> ocrs_engine::text_line_from_result(const RecLine& line, uint32_t ctc_input_len,
+                                                         const std::vector<CtcStep>& steps) const {
+    std::vector<TextChar> out;
+    if (steps.empty() || ctc_input_len == 0) return out;
+    const Rect line_rect = line.bounds;
+    const float x_scale = (float)line_rect.width() / (float)line.resized_width;
+    const uint32_t downsample = (uint32_t)rround((float)line.group_width / (float)ctc_input_len);
+    for (size_t i = 0; i < steps.size(); i++) {
+        const uint32_t start_x = steps[i].pos * downsample;
+        const uint32_t end_x = i + 1 < steps.size() ? steps[i + 1].pos * downsample : line.resized_width;
+        const int32_t sx = line_rect.left + as_i32((float)start_x * x_scale);
+        const int32_t ex = line_rect.left + as_i32((float)end_x * x_scale);
+        if (sx >= line_rect.right) continue;  // character starts in the padding
+        const uint32_t idx = steps[i].label - 1;
+        const uint32_t ch = idx < alphabet.size() ? (uint32_t)alphabet[idx] : (uint32_t)'?';
+        Rect r;
+        if (!polygon_slice_bounding_rect(line.polygon, sx, ex, &r))
+            fail(OCRS_ERR_RUN_FAILED, "invalid X coords");  // recognition.rs:299
+        out.push_back(TextChar{ch, r});
+    }
+    return out;
+}

@@ -1,0 +1,68 @@
+// OcrEngine (ocrs/src/lib.rs:111-301) on MI355X: the grey page stays in HBM
+// between prepare_input / detect_words / recognize_text.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "common.hpp"
+#include "geometry.hpp"
+#include "model.hpp"
+
+struct ocrs_page {  // OcrInput (lib.rs:125-128)
+    ocrs::DevBuf grey;  // [h, w] fp32 in [-0.5, 0.5]
+    int h = 0, w = 0;
+};
+
+namespace ocrs {
+
+struct CtcStep { uint32_t label, pos; };
+
+struct TextChar {  // text_items.rs:48-54
+    uint32_t ch;
+    geom::Rect rect;
+};
+
+struct RecLine {  // TextRecLine (recognition.rs:80-89) + owning page
+    size_t page = 0;
+    size_t index = 0;                    // line index in the caller's order
+    std::vector<geom::PointI> polygon;   // line_polygon (recognition.rs:29-55)
+    geom::Rect bounds{0, 0, 0, 0};       // Polygon::bounding_rect
+    uint32_t resized_width = 0;
+    uint32_t group_width = 0;
+};
+
+}  // namespace ocrs
+
+struct ocrs_engine {
+    const ocrs::ModelBase* detection = nullptr;
+    const ocrs::ModelBase* recognition = nullptr;
+    bool debug = false;
+    ocrs_decode_method decode_method = OCRS_DECODE_GREEDY;
+    uint32_t beam_width = 100;
+    std::u32string alphabet;
+    bool has_excluded = false;
+    std::vector<uint8_t> excluded;  // [alphabet_len + 1] flags by label
+    ocrs::DevBuf d_excluded;
+    // TextDetectorParams::default() (detection.rs:25-37)
+    float min_area = 100.0f;
+    float text_threshold = 0.2f;
+    mutable ocrs::StageTimers timers;
+
+    ocrs::StageTimers* tm() const { return timers.enabled ? &timers : nullptr; }
+
+    // detection.rs:104-200 over a batch of equally sized pages.
+    void detect(const ocrs_page* const* pages, size_t n, std::vector<std::vector<ocrs::geom::RotatedRect>>* rects,
+                float* host_map /* [n,h,w] or null */) const;
+
+    // recognition.rs:404-540 over the lines of several pages.
+    void recognize(const ocrs_page* const* pages, size_t n_pages,
+                   const std::vector<std::vector<std::vector<ocrs::geom::RotatedRect>>>& lines_per_page,
+                   std::vector<std::vector<ocrs::CtcStep>>* steps, std::vector<ocrs::RecLine>* rec_lines,
+                   std::vector<uint32_t>* ctc_input_len) const;
+
+    std::vector<ocrs::TextChar> text_line_from_result(const ocrs::RecLine& line, uint32_t ctc_input_len,
+                                                      const std::vector<ocrs::CtcStep>& steps) const;
+
+    uint32_t rec_input_height() const;
+    ocrs::RecLine make_rec_line(const std::vector<ocrs::geom::RotatedRect>& words, size_t page, size_t index) const;
+};

@@ -1,0 +1,110 @@
+// Launch wrappers for every HIP kernel in libocrs_amd (gfx950).  All take the
+// stream to launch on; none synchronises.  Activations are NHWC fp32.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace ocrs {
+namespace k {
+
+// ---- kernels_image.hip ----------------------------------------------------
+// prepare_image (preprocess.rs:149-248): pixels -> grey f32 [H,W] in [-0.5,0.5].
+void prepare_image(const void* d_pixels, bool is_u8, bool chans_last, int h, int w, int chans, float* d_out,
+                   hipStream_t s);
+// pad(-0.5) + bilinear resize of N equally sized pages to the model input
+// (detection.rs:155-171).  src_ptrs: device array of N page pointers [sh,sw].
+void resize_pages_to_model(const float* const* d_src_ptrs, int n, int sh, int sw, int vh, int vw, float* d_dst,
+                           int dh, int dw, hipStream_t s);
+// slice + bilinear resize back + strict threshold (detection.rs:187-194,110).
+// prob: [n, mh, mw] (only the top-left [sh, sw] is read); mask: [n, h, w] u8;
+// d_map (optional, may be null): [n, h, w] f32 probability map.
+void resize_threshold(const float* d_prob, int n, int mh, int mw, int sh, int sw, float thr, uint8_t* d_mask,
+                      float* d_map, int h, int w, hipStream_t s);
+void threshold_only(const float* d_prob, float thr, uint8_t* d_mask, int64_t count, hipStream_t s);
+
+// ---- kernels_ccl.hip ------------------------------------------------------
+struct CclBuffers {
+    int32_t* labels;      // [n, h, w]
+    int32_t* row_counts;  // [n, h]
+    int32_t* row_offsets; // [n, h]
+    int32_t* n_roots;     // [n]  external components per page
+    int32_t* roots;       // [n, max_comp]  raster-ordered start pixels
+    int32_t* lengths;     // [n, max_comp]  contour lengths
+    int32_t* offsets;     // [n, max_comp]  arena offsets (exclusive scan of lengths)
+    int32_t* overflow;    // [n]  set if a capacity was exceeded
+    uint32_t* pts;        // [n, arena]  packed (y << 16 | x) contour points
+    uint32_t* tmp;        // [n, arena]  simplified / sorted / hull scratch (3 regions of arena/1)
+    uint8_t* keep;        // [n, arena]
+    int32_t* stack;       // [n, arena * 2 + 4]
+    float* rects;         // [n, max_comp, 6]
+    uint8_t* valid;       // [n, max_comp]
+};
+size_t ccl_workspace_bytes(int n, int h, int w, int max_comp, int64_t arena);
+// mask [n,h,w] -> per page: raster-ordered external components -> rects
+// (find_contours(External) -> simplify_polygon(2) -> min_area_rect -> resize(+2*expand)
+//  -> area >= min_area; detection.rs:41-62).
+void ccl_label(const uint8_t* d_mask, int n, int h, int w, const CclBuffers& b, int max_comp, hipStream_t s);
+void contour_rects(const uint8_t* d_mask, int n, int h, int w, const CclBuffers& b, int max_comp, int64_t arena,
+                   float expand, float min_area, float eps, hipStream_t s);
+
+// ---- kernels_nn.hip -------------------------------------------------------
+// C[M,N] = act(A[M,K] . B[K,N] + bias[N]) as an exact fp32 MFMA chain, k ascending.
+struct GemmDesc {
+    const float* A; int lda;      // dense: row-major [M][lda]
+    const float* B; int ldb;      // row-major [K][ldb]
+    const float* bias;            // [N] (may be null -> 0)
+    float* C; int ldc;
+    int M, N, K;
+    int relu;
+    // im2col (3x3, pad 1) view of an NHWC tensor [n, H, W, Cin]: M = n*H*W, K = 9*Cin
+    int im2col; int H, W, Cin;
+    // ConvTranspose2x2/s2 scatter epilogue: rows are input pixels [n,H,W], columns (dy,dx,co)
+    int convt; int Cout;
+    // batched (blockIdx.z) strides, elements
+    int batch; int64_t strideA, strideB, strideBias, strideC;
+};
+void gemm(const GemmDesc& d, hipStream_t s);
+// Direct conv (k x k, same padding, Cout % 4 == 0) for tiny contractions / odd shapes.
+void conv_direct(const float* x, int n, int h, int w, int cin, const float* wt, const float* bias, int kh, int kw,
+                 int cout, int relu, float* y, hipStream_t s);
+void dwconv3x3(const float* x, int n, int h, int w, int c, const float* wt, const float* bias, int relu, float* y,
+               hipStream_t s);
+void maxpool(const float* x, int n, int h, int w, int c, int kh, int kw, float* y, hipStream_t s);
+void avgpool(const float* x, int n, int h, int w, int c, int kh, int kw, float* y, hipStream_t s);
+void padcat(const float* skip, int n, int sh, int sw, int cs, const float* x, int h, int w, int cx, float* y,
+            hipStream_t s);
+void sigmoid(const float* x, float* y, int64_t count, hipStream_t s);
+// pointwise conv with Cout == 1 (+ optional sigmoid): y[p] = act(b + sum_c x[p,c] w[c])
+void conv1x1_cout1(const float* x, int64_t pixels, int cin, const float* wt, const float* bias, int do_sigmoid,
+                   float* y, hipStream_t s);
+// [N,1,W,C] -> [W,N,C]
+void to_seq(const float* x, int n, int w, int c, float* y, hipStream_t s);
+// GRU gates for one time step, both directions (grid.z = dir).
+// gx: [2][T*N][3H] (dir-major), gh: [2][N][3H], h: [2][N][H], y: [T][N][2H].
+void gru_gates(const float* gx, const float* gh, float* h, float* y, int T, int N, int H, int step, hipStream_t s);
+// log_softmax over C (+ optional -inf masking of excluded labels) + argmax.
+// logits/logp: [rows][C]; labels: [rows] (first max).  logp may be null.
+void log_softmax_argmax(const float* logits, int64_t rows, int c, const uint8_t* d_excluded /*[C] or null*/,
+                        float* logp, int32_t* labels, hipStream_t s);
+void argmax_rows(const float* x, int64_t rows, int c, const uint8_t* d_excluded, int32_t* labels, hipStream_t s);
+// Greedy CTC collapse (rten decode_greedy): labels [T][N] -> per line (label,pos) lists.
+void ctc_collapse(const int32_t* labels, int T, int N, uint32_t* out_labels, uint32_t* out_pos, int32_t* out_count,
+                  hipStream_t s);
+
+// ---- kernels_lines.hip ----------------------------------------------------
+struct LineDesc {      // one text line to crop (recognition.rs:91-126)
+    int32_t page;      // index into page pointer table
+    int32_t poly_off;  // first vertex in the packed polygon array
+    int32_t poly_n;    // vertex count
+    int32_t top, left, bh, bw;  // polygon bounding rect (exclusive bottom/right)
+    int32_t resized_w;
+    int32_t out_row;   // row (line slot) in the batch tensor
+};
+// Fill + gather + bilinear resize + pad into batch [n_lines, out_h, out_w] (pre-filled here with -0.5).
+void crop_lines(const float* const* d_pages, const int32_t* d_page_hw /*[pages][2]*/, const LineDesc* d_lines,
+                const int32_t* d_poly /*(y,x) pairs*/, int n_lines, int out_h, int out_w, float* d_batch,
+                hipStream_t s);
+
+}  // namespace k
+}  // namespace ocrs

@@ -1,0 +1,512 @@
+// Text-mask post-processing on the GPU (detection.rs:41-62):
+//   find_contours(mask, External) -> simplify_polygon(eps=2) -> min_area_rect
+//   -> resize(w + 2*expand, h + 2*expand) -> keep area >= min_area.
+//
+// Design:
+//  1. Connected-component labelling by union-find over BOTH pixel classes in
+//     one pass: foreground with 8-connectivity, background with 4-connectivity,
+//     plus a virtual frame node (-1).  Union is by minimum linear index, so
+//       * the root of a foreground component is its raster-first pixel — exactly
+//         the pixel at which Suzuki-Abe's raster scan starts that component's
+//         outer border, and roots in index order are the reference's contour
+//         discovery order;
+//       * a background component touching the image frame flattens to -1, so a
+//         component is an OUTERMOST one (RetrievalMode::External) iff the
+//         background pixel left of its root is frame-connected (or x == 0).
+//  2. Ordered compaction of the external roots (row counts -> scan -> write).
+//  3. Border following from each root.  The walk only tests pixels for
+//     non-zero, so it needs the binary mask, not Suzuki's marks.  Two passes:
+//     count (one lane per component), scan, then write + simplify + rectangle
+//     with one wavefront per component.
+// Everything here is integer/byte work or latency-bound geometry on a 1 MiB
+// mask that lives in L2: there is no MFMA-shaped computation in this stage.
+#include "kernels.hpp"
+
+namespace ocrs {
+namespace k {
+
+// ---------------------------------------------------------------------------
+// Union-find helpers (labels are page-local linear indices; -1 = frame).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int uf_find(const int32_t* L, int x) {
+    while (x >= 0) {
+        int p = __hip_atomic_load(&L[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (p == x) return x;
+        x = p;
+    }
+    return -1;
+}
+
+__device__ __forceinline__ void uf_union(int32_t* L, int a, int b) {
+    for (;;) {
+        a = uf_find(L, a);
+        b = uf_find(L, b);
+        if (a == b) return;
+        if (a < b) { int t = a; a = b; b = t; }  // a > b, a >= 0
+        int old = atomicMin(&L[a], b);
+        if (old == a) return;
+        a = old;
+    }
+}
+
+// Initial labels: start of the horizontal run of equal pixels inside the
+// lane's 64-pixel segment (one ballot + clz instead of 63 unions).
+__global__ void __launch_bounds__(256)
+ccl_init_kernel(const uint8_t* __restrict__ mask, int32_t* __restrict__ labels, int h, int w) {
+    const int n = blockIdx.z;
+    const int y = blockIdx.y;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint8_t* m = mask + (int64_t)n * h * w;
+    int32_t* L = labels + (int64_t)n * h * w;
+    const int lane = threadIdx.x & 63;
+    const bool inb = x < w;
+    const int v = inb ? m[y * w + x] : 2;
+    const int vl = (inb && x > 0) ? m[y * w + x - 1] : 3;
+    const bool boundary = (lane == 0) || (v != vl);
+    const unsigned long long bal = __ballot(boundary);
+    if (!inb) return;
+    const unsigned long long upto = bal & (~0ull >> (63 - lane));
+    const int start_lane = 63 - __clzll(upto);
+    L[y * w + x] = y * w + (x - (lane - start_lane));
+}
+
+__global__ void __launch_bounds__(256)
+ccl_merge_kernel(const uint8_t* __restrict__ mask, int32_t* __restrict__ labels, int h, int w) {
+    const int n = blockIdx.z;
+    const int y = blockIdx.y;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= w) return;
+    const uint8_t* m = mask + (int64_t)n * h * w;
+    int32_t* L = labels + (int64_t)n * h * w;
+    const int p = y * w + x;
+    const int v = m[p];
+    const bool hasW = x > 0, hasN = y > 0, hasE = x + 1 < w;
+    const int vW = hasW ? m[p - 1] : -1;
+    const int vN = hasN ? m[p - w] : -1;
+    const int vNW = (hasW && hasN) ? m[p - w - 1] : -1;
+    const bool run_start = ((threadIdx.x & 63) == 0) || vW != v;
+    if (run_start && vW == v) uf_union(L, p, p - 1);
+    if (v) {
+        // 8-connectivity.  p~N unless already implied through W and NW.
+        if (vN == 1) {
+            if (!(vW == 1 && vNW == 1)) uf_union(L, p, p - w);
+        } else {
+            if (vNW == 1 && vW != 1) uf_union(L, p, p - w - 1);
+            if (hasN && hasE && m[p - w + 1] == 1 && m[p + 1] != 1) uf_union(L, p, p - w + 1);
+        }
+    } else {
+        // 4-connectivity + virtual frame node.
+        if (vN == 0 && !(vW == 0 && vNW == 0)) uf_union(L, p, p - w);
+        const bool on_frame = (y == 0 || y == h - 1) ? run_start : false;
+        if (on_frame || x == 0 || x == w - 1) uf_union(L, p, -1);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+ccl_flatten_kernel(int32_t* __restrict__ labels, int64_t total_per_page, int n_pages) {
+    const int64_t total = total_per_page * n_pages;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        int32_t* L = labels + (i / total_per_page) * total_per_page;
+        int p = (int)(i % total_per_page);
+        L[p] = uf_find(L, p);
+    }
+}
+
+__device__ __forceinline__ bool is_external_root(const uint8_t* m, const int32_t* L, int w, int p, int x) {
+    return m[p] && L[p] == p && (x == 0 || L[p - 1] < 0);
+}
+
+// One block per (row, page).
+__global__ void __launch_bounds__(256)
+count_roots_kernel(const uint8_t* __restrict__ mask, const int32_t* __restrict__ labels, int h, int w,
+                   int32_t* __restrict__ row_counts) {
+    const int y = blockIdx.x, n = blockIdx.y;
+    const uint8_t* m = mask + (int64_t)n * h * w;
+    const int32_t* L = labels + (int64_t)n * h * w;
+    int cnt = 0;
+    for (int x = threadIdx.x; x < w; x += blockDim.x) cnt += is_external_root(m, L, w, y * w + x, x) ? 1 : 0;
+    __shared__ int red[256];
+    red[threadIdx.x] = cnt;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) row_counts[n * h + y] = red[0];
+}
+
+// Exclusive scan of `count` ints per page (one block per page), total -> totals[n].
+__global__ void __launch_bounds__(256)
+scan_kernel(const int32_t* __restrict__ in, int32_t* __restrict__ out, int32_t* __restrict__ totals,
+            const int32_t* __restrict__ counts_per_page, int stride, int fixed_count, int cap,
+            int32_t* __restrict__ overflow) {
+    const int n = blockIdx.x;
+    const int count = counts_per_page ? min(counts_per_page[n], stride) : fixed_count;
+    const int32_t* src = in + (int64_t)n * stride;
+    int32_t* dst = out + (int64_t)n * stride;
+    __shared__ int part[256];
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < count; base += 256) {
+        int i = base + threadIdx.x;
+        int v = i < count ? src[i] : 0;
+        part[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < 256; off <<= 1) {
+            int t = (int)threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+            __syncthreads();
+            part[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (i < count) dst[i] = carry + part[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 255) carry += part[255];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        if (totals) totals[n] = carry;
+        if (cap > 0 && carry > cap && overflow) overflow[n] = 1;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+write_roots_kernel(const uint8_t* __restrict__ mask, const int32_t* __restrict__ labels, int h, int w,
+                   const int32_t* __restrict__ row_offsets, int32_t* __restrict__ roots, int max_comp) {
+    const int y = blockIdx.x, n = blockIdx.y;
+    const uint8_t* m = mask + (int64_t)n * h * w;
+    const int32_t* L = labels + (int64_t)n * h * w;
+    __shared__ int wave_cnt[4];
+    __shared__ int base;
+    if (threadIdx.x == 0) base = row_offsets[n * h + y];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int x0 = 0; x0 < w; x0 += 256) {
+        int x = x0 + threadIdx.x;
+        bool r = x < w && is_external_root(m, L, w, y * w + x, x);
+        unsigned long long bal = __ballot(r);
+        if (lane == 0) wave_cnt[wv] = __popcll(bal);
+        __syncthreads();
+        int off = base;
+        for (int i = 0; i < wv; i++) off += wave_cnt[i];
+        if (r) {
+            int idx = off + __popcll(bal & ((1ull << lane) - 1));
+            if (idx < max_comp) roots[(int64_t)n * max_comp + idx] = y * w + x;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) base += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+        __syncthreads();
+    }
+}
+
+void ccl_label(const uint8_t* d_mask, int n, int h, int w, const CclBuffers& b, int max_comp, hipStream_t s) {
+    dim3 grid((w + 255) / 256, h, n);
+    hipLaunchKernelGGL(ccl_init_kernel, grid, dim3(256), 0, s, d_mask, b.labels, h, w);
+    hipLaunchKernelGGL(ccl_merge_kernel, grid, dim3(256), 0, s, d_mask, b.labels, h, w);
+    int64_t total = (int64_t)h * w;
+    int fgrid = (int)((total * n + 255) / 256 < 8192 ? (total * n + 255) / 256 : 8192);
+    hipLaunchKernelGGL(ccl_flatten_kernel, dim3(fgrid), dim3(256), 0, s, b.labels, total, n);
+    hipLaunchKernelGGL(count_roots_kernel, dim3(h, n), dim3(256), 0, s, d_mask, b.labels, h, w, b.row_counts);
+    hipLaunchKernelGGL(scan_kernel, dim3(n), dim3(256), 0, s, b.row_counts, b.row_offsets, b.n_roots,
+                       (const int32_t*)nullptr, h, h, max_comp, b.overflow);
+    hipLaunchKernelGGL(write_roots_kernel, dim3(h, n), dim3(256), 0, s, d_mask, b.labels, h, w, b.row_offsets,
+                       b.roots, max_comp);
+}
+
+// ---------------------------------------------------------------------------
+// Border following (Suzuki-Abe steps 3.1-3.5) from the raster-first pixel.
+// Directions are indexed clockwise on screen: W NW N NE E SE S SW.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int dir_dy(int d) { return (int)((0xA901u >> (2 * d)) & 3u) - 1; }  // {0,-1,-1,-1,0,1,1,1}+1
+__device__ __forceinline__ int dir_dx(int d) { return (int)((0x1A90u >> (2 * d)) & 3u) - 1; }  // {-1,-1,0,1,1,1,0,-1}+1
+
+template <bool WRITE>
+__device__ int trace_border(const uint8_t* __restrict__ m, int h, int w, int sy, int sx, uint32_t* out) {
+    auto at = [&](int y, int x) -> bool {
+        return (unsigned)y < (unsigned)h && (unsigned)x < (unsigned)w && m[y * w + x] != 0;
+    };
+    int first = -1;
+    for (int d = 0; d < 8; d++)  // 3.1: clockwise from W
+        if (at(sy + dir_dy(d), sx + dir_dx(d))) { first = d; break; }
+    if (first < 0) {
+        if (WRITE) out[0] = ((uint32_t)sy << 16) | (uint32_t)sx;
+        return 1;
+    }
+    const int i1 = sy + dir_dy(first), j1 = sx + dir_dx(first);
+    int i3 = sy, j3 = sx, d0 = first, n = 0;
+    for (;;) {
+        int i4 = i3, j4 = j3, dn = d0;
+        for (int s = 1; s <= 8; s++) {  // 3.3: counter-clockwise from the element after (i2,j2)
+            int d = (d0 - s) & 7;
+            int yy = i3 + dir_dy(d), xx = j3 + dir_dx(d);
+            if (at(yy, xx)) { i4 = yy; j4 = xx; dn = d; break; }
+        }
+        if (WRITE) out[n] = ((uint32_t)i3 << 16) | (uint32_t)j3;
+        n++;
+        if (i4 == sy && j4 == sx && i3 == i1 && j3 == j1) break;  // 3.5
+        i3 = i4; j3 = j4;
+        d0 = (dn + 4) & 7;  // the pixel we came from, seen from the new current pixel
+    }
+    return n;
+}
+
+__global__ void __launch_bounds__(64)
+trace_count_kernel(const uint8_t* __restrict__ mask, int h, int w, const int32_t* __restrict__ n_roots,
+                   const int32_t* __restrict__ roots, int32_t* __restrict__ lengths, int max_comp) {
+    const int n = blockIdx.y;
+    const int cnt = min(n_roots[n], max_comp);
+    const uint8_t* m = mask + (int64_t)n * h * w;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += gridDim.x * blockDim.x) {
+        int r = roots[(int64_t)n * max_comp + i];
+        lengths[(int64_t)n * max_comp + i] = trace_border<false>(m, h, w, r / w, r % w, nullptr);
+    }
+}
+
+// ---- geometry restated from rten-imageproc ------------
+struct P2 { float x, y; };
+__device__ __forceinline__ P2 unpack_pt(uint32_t v) { return P2{(float)(v & 0xffffu), (float)(v >> 16)}; }
+
+__device__ __forceinline__ float seg_distance(P2 a, P2 b, P2 p) {
+    float abx = b.x - a.x, aby = b.y - a.y;
+    float apx = p.x - a.x, apy = p.y - a.y;
+    float len2 = abx * abx + aby * aby;
+    if (len2 == 0.0f) return sqrtf(apx * apx + apy * apy);
+    float t = (apx * abx + apy * aby) / len2;
+    t = t < 0.0f ? 0.0f : t;
+    t = t > 1.0f ? 1.0f : t;
+    float qx = a.x + t * abx, qy = a.y + t * aby;
+    float dx = p.x - qx, dy = p.y - qy;
+    return sqrtf(dx * dx + dy * dy);
+}
+
+__device__ __forceinline__ float cross3(P2 o, P2 a, P2 b) {
+    return (a.x - o.x) * (b.y - o.y) - (a.y - o.y) * (b.x - o.x);
+}
+
+#define WAVE_SYNC()                                              \
+    do {                                                         \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   \
+        __builtin_amdgcn_s_barrier();                            \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   \
+    } while (0)
+
+// One wavefront (= one 64-thread block) per component.
+__global__ void __launch_bounds__(64)
+contour_rect_kernel(const uint8_t* __restrict__ mask, int h, int w, const int32_t* __restrict__ n_roots,
+                    const int32_t* __restrict__ roots, const int32_t* __restrict__ lengths,
+                    const int32_t* __restrict__ offsets, const int32_t* __restrict__ overflow,
+                    uint32_t* __restrict__ pts_all, uint32_t* __restrict__ tmp_all, uint8_t* __restrict__ keep_all,
+                    float* __restrict__ rects, uint8_t* __restrict__ valid, int max_comp, int64_t arena,
+                    float expand, float min_area, float eps) {
+    const int page = blockIdx.y;
+    if (overflow[page]) return;
+    const int cnt = min(n_roots[page], max_comp);
+    const uint8_t* m = mask + (int64_t)page * h * w;
+    const int lane = threadIdx.x;
+    for (int ci = blockIdx.x; ci < cnt; ci += gridDim.x) {
+        const int64_t slot = (int64_t)page * max_comp + ci;
+        const int n = lengths[slot];
+        const int64_t off = (int64_t)page * arena + offsets[slot];
+        uint32_t* pts = pts_all + off;
+        uint8_t* keep = keep_all + off;
+        // three scratch regions per component: simplified / sorted / hull (<= 2m + 2)
+        uint32_t* simp = tmp_all + (int64_t)page * arena * 4 + (int64_t)offsets[slot] * 4;
+        uint32_t* sorted = simp + n;
+        uint32_t* hull = sorted + n;  // 2n words
+        const int root = roots[slot];
+
+        // ---- 1. border following (serial by nature): lane 0 writes the points
+        if (lane == 0) trace_border<true>(m, h, w, root / w, root % w, pts);
+        for (int k = lane; k < n; k += 64) keep[k] = 0;
+        WAVE_SYNC();
+
+        // ---- 2. Ramer-Douglas-Peucker on the closed polyline p[0..n] (p[n] = p[0]).
+        // Stack-free: each round walks the current kept points in order and splits
+        // every not-yet-final segment once.  keep: 0 = dropped, 1 = kept, 2 = kept and
+        // the segment starting here is final.  The surviving set does not depend on
+        // the order in which segments are split.
+        // index n (the duplicated start) is implicit: always kept.
+        if (lane == 0) keep[0] = 1;
+        WAVE_SYNC();
+        bool changed = true;
+        while (changed) {
+            changed = false;
+            int lo = 0;
+            while (lo < n) {
+                // next kept index after lo (or n)
+                int hi = n;
+                for (int base = lo + 1; base < n; base += 64) {
+                    int k = base + lane;
+                    unsigned long long bal = __ballot(k < n && keep[k] != 0);
+                    if (bal) { hi = base + __ffsll((long long)bal) - 1; break; }
+                }
+                const bool final_seg = keep[lo] == 2;
+                if (!final_seg) {
+                    const P2 a = unpack_pt(pts[lo]);
+                    const P2 b = unpack_pt(pts[hi == n ? 0 : hi]);
+                    float maxd = 0.0f;
+                    int maxi = -1;
+                    for (int k = lo + 1 + lane; k < hi; k += 64) {
+                        float d = seg_distance(a, b, unpack_pt(pts[k]));
+                        if (d > maxd) { maxd = d; maxi = k; }
+                    }
+                    // wave arg-max, ties -> smallest index (first maximum)
+                    for (int o = 32; o > 0; o >>= 1) {
+                        float od = __shfl_xor(maxd, o);
+                        int oi = __shfl_xor(maxi, o);
+                        bool take = (oi >= 0) && (maxi < 0 || od > maxd || (od == maxd && oi < maxi));
+                        if (take) { maxd = od; maxi = oi; }
+                    }
+                    if (maxi >= 0 && maxd > eps) {
+                        if (lane == 0) keep[maxi] = 1;
+                        changed = true;
+                    } else {
+                        if (lane == 0) keep[lo] = 2;
+                    }
+                }
+                lo = hi;
+            }
+            WAVE_SYNC();
+        }
+
+        // ---- 3. ordered gather of the simplified polygon
+        int mcount = 0;
+        for (int base = 0; base < n; base += 64) {
+            int k = base + lane;
+            bool kp = k < n && keep[k] != 0;
+            unsigned long long bal = __ballot(kp);
+            if (kp) simp[mcount + __popcll(bal & ((1ull << lane) - 1))] = pts[k];
+            mcount += __popcll(bal);
+        }
+        WAVE_SYNC();
+
+        // ---- 4. rank sort by (x, y) (index breaks ties) for the monotone chain
+        for (int i = lane; i < mcount; i += 64) {
+            uint32_t pi = simp[i];
+            uint32_t key_i = ((pi & 0xffffu) << 16) | (pi >> 16);
+            int rank = 0;
+            for (int j = 0; j < mcount; j++) {
+                uint32_t pj = simp[j];
+                uint32_t key_j = ((pj & 0xffffu) << 16) | (pj >> 16);
+                rank += (key_j < key_i || (key_j == key_i && j < i)) ? 1 : 0;
+            }
+            sorted[rank] = pi;
+        }
+        WAVE_SYNC();
+
+        // ---- 5. convex hull (Andrew monotone chain, duplicates and collinear points dropped)
+        __shared__ int s_hn;
+        if (lane == 0) {
+            int un = 0;  // dedupe in place
+            for (int i = 0; i < mcount; i++)
+                if (un == 0 || sorted[i] != sorted[un - 1]) sorted[un++] = sorted[i];
+            int kk = 0;
+            if (un <= 2) {
+                for (int i = 0; i < un; i++) hull[kk++] = sorted[i];
+            } else {
+                for (int i = 0; i < un; i++) {
+                    P2 c = unpack_pt(sorted[i]);
+                    while (kk >= 2 && cross3(unpack_pt(hull[kk - 2]), unpack_pt(hull[kk - 1]), c) <= 0.0f) kk--;
+                    hull[kk++] = sorted[i];
+                }
+                int lower = kk + 1;
+                for (int i = un - 2; i >= 0; i--) {
+                    P2 c = unpack_pt(sorted[i]);
+                    while (kk >= lower && cross3(unpack_pt(hull[kk - 2]), unpack_pt(hull[kk - 1]), c) <= 0.0f) kk--;
+                    hull[kk++] = sorted[i];
+                }
+                kk -= 1;
+            }
+            s_hn = kk;
+        }
+        WAVE_SYNC();
+        const int hn = s_hn;
+
+        // ---- 6. minimum-area rectangle: exhaustive search over hull edges
+        float best_area = 3.40282347e+38f;
+        int best_e = -1;
+        for (int e = lane; e < hn; e += 64) {
+            P2 a = unpack_pt(hull[e]), b = unpack_pt(hull[e + 1 == hn ? 0 : e + 1]);
+            float ex = b.x - a.x, ey = b.y - a.y;
+            float len = sqrtf(ex * ex + ey * ey);
+            float parx = ex / len, pary = ey / len;
+            float perx = -pary, pery = parx;
+            float min_par = 3.40282347e+38f, max_par = -3.40282347e+38f, max_perp = -3.40282347e+38f;
+            for (int q = 0; q < hn; q++) {
+                P2 c = unpack_pt(hull[q]);
+                float dx = c.x - a.x, dy = c.y - a.y;
+                float pp = parx * dx + pary * dy;
+                float qq = perx * dx + pery * dy;
+                min_par = pp < min_par ? pp : min_par;
+                max_par = pp > max_par ? pp : max_par;
+                max_perp = qq > max_perp ? qq : max_perp;
+            }
+            float area = max_perp * (max_par - min_par);
+            if (area < best_area) { best_area = area; best_e = e; }
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            float oa = __shfl_xor(best_area, o);
+            int oe = __shfl_xor(best_e, o);
+            bool take = (oe >= 0) && (best_e < 0 || oa < best_area || (oa == best_area && oe < best_e));
+            if (take) { best_area = oa; best_e = oe; }
+        }
+        if (lane == 0) {
+            uint8_t ok = 0;
+            float* rr = rects + slot * 6;
+            if (best_e >= 0) {
+                const int e = best_e;
+                P2 a = unpack_pt(hull[e]), b = unpack_pt(hull[e + 1 == hn ? 0 : e + 1]);
+                float ex = b.x - a.x, ey = b.y - a.y;
+                float len = sqrtf(ex * ex + ey * ey);
+                float parx = ex / len, pary = ey / len;
+                float perx = -pary, pery = parx;
+                float min_par = 3.40282347e+38f, max_par = -3.40282347e+38f, max_perp = -3.40282347e+38f;
+                for (int q = 0; q < hn; q++) {
+                    P2 c = unpack_pt(hull[q]);
+                    float dx = c.x - a.x, dy = c.y - a.y;
+                    float pp = parx * dx + pary * dy;
+                    float qq = perx * dx + pery * dy;
+                    min_par = pp < min_par ? pp : min_par;
+                    max_par = pp > max_par ? pp : max_par;
+                    max_perp = qq > max_perp ? qq : max_perp;
+                }
+                float height = max_perp;
+                float width = max_par - min_par;
+                float along = min_par + width / 2.0f;
+                float half_h = height / 2.0f;
+                float ul = sqrtf(perx * perx + pery * pery);
+                rr[0] = a.x + along * parx + half_h * perx;
+                rr[1] = a.y + along * pary + half_h * pery;
+                rr[2] = perx / ul;
+                rr[3] = pery / ul;
+                float ew = width + 2.0f * expand, eh = height + 2.0f * expand;
+                rr[4] = ew;
+                rr[5] = eh;
+                ok = (ew * eh >= min_area) ? 1 : 0;
+            }
+            valid[slot] = ok;
+        }
+        WAVE_SYNC();
+    }
+}
+
+size_t ccl_workspace_bytes(int n, int h, int w, int max_comp, int64_t arena) {
+    size_t px = (size_t)n * h * w;
+    return px * 4 + (size_t)n * h * 8 + (size_t)n * 8 + (size_t)n * max_comp * (4 * 3 + 24 + 1) +
+           (size_t)n * arena * (4 + 16 + 1) + 4096;
+}
+
+void contour_rects(const uint8_t* d_mask, int n, int h, int w, const CclBuffers& b, int max_comp, int64_t arena,
+                   float expand, float min_area, float eps, hipStream_t s) {
+    hipLaunchKernelGGL(trace_count_kernel, dim3(64, n), dim3(64), 0, s, d_mask, h, w, b.n_roots, b.roots, b.lengths,
+                       max_comp);
+    hipLaunchKernelGGL(scan_kernel, dim3(n), dim3(256), 0, s, b.lengths, b.offsets, (int32_t*)nullptr, b.n_roots,
+                       max_comp, 0, (int)(arena < 0x7fffffff ? arena : 0x7fffffff), b.overflow);
+    hipLaunchKernelGGL(contour_rect_kernel, dim3(2048, n), dim3(64), 0, s, d_mask, h, w, b.n_roots, b.roots, b.lengths,
+                       b.offsets, b.overflow, b.pts, b.tmp, b.keep, b.rects, b.valid, max_comp, arena, expand, min_area,
+                       eps);
+}
+
+}  // namespace k
+}  // namespace ocrs

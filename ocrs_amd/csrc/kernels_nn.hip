@@ -1,0 +1,624 @@
+// Neural-network kernels of the fixed-graph executor (the `Model::run` side of
+// ocrs/src/model.rs:33-40).  Activations are NHWC fp32.
+//
+// NUMERIC SPEC.  The reference computes in fp32; so does this
+// file, and in one canonical order, so that results are bit-identical to the
+// CPU oracle:
+//   * every contraction is  acc = bias;  acc = fmaf(a_k, b_k, acc)  for k
+//     ascending (conv: k = (ky, kx, ci)).  gfx950's v_mfma_f32_32x32x2_f32 is
+//     bit-for-bit that fmaf chain (no wider internal accumulation), so the
+//     dense contractions run on the matrix cores without changing a bit;
+//   * exp / log / sigmoid / tanh are the fixed polynomials below (only fmaf,
+//     rint, IEEE divide and exponent-field arithmetic), never libm/ocml.
+// Built with -ffp-contract=off: an fma happens only where fmaf() is written.
+#include "kernels.hpp"
+
+namespace ocrs {
+namespace k {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---------------------------------------------------------------------------
+// Transcendentals
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float spec_expf(float x) {
+    if (x != x) return x;
+    x = x > 88.0f ? 88.0f : x;
+    x = x < -87.0f ? -87.0f : x;
+    float kf = rintf(x * 1.44269504088896341f);
+    float r = fmaf(kf, -0.693145751953125f, x);
+    r = fmaf(kf, -1.42860682030941723212e-6f, r);
+    float p = 1.98412698412698413e-4f;
+    p = fmaf(p, r, 1.38888888888888894e-3f);
+    p = fmaf(p, r, 8.33333333333333322e-3f);
+    p = fmaf(p, r, 4.16666666666666644e-2f);
+    p = fmaf(p, r, 1.66666666666666657e-1f);
+    p = fmaf(p, r, 0.5f);
+    p = fmaf(p, r, 1.0f);
+    p = fmaf(p, r, 1.0f);
+    int bits = __float_as_int(p) + (((int)kf) << 23);
+    return __int_as_float(bits);
+}
+
+__device__ __forceinline__ float spec_logf(float s) {
+    unsigned u = __float_as_uint(s);
+    int e = (int)((u >> 23) & 0xffu) - 127;
+    float m = __uint_as_float((u & 0x007fffffu) | 0x3f800000u);
+    if (m > 1.41421356237309515f) { m = m * 0.5f; e += 1; }
+    float t = (m - 1.0f) / (m + 1.0f);
+    float t2 = t * t;
+    float p = 1.11111111111111105e-1f;
+    p = fmaf(p, t2, 1.42857142857142849e-1f);
+    p = fmaf(p, t2, 0.2f);
+    p = fmaf(p, t2, 3.33333333333333315e-1f);
+    p = fmaf(p, t2, 1.0f);
+    float lm = (2.0f * t) * p;
+    return fmaf((float)e, 0.693147180559945286f, lm);
+}
+
+__device__ __forceinline__ float spec_sigmoidf(float x) { return 1.0f / (1.0f + spec_expf(-x)); }
+__device__ __forceinline__ float spec_tanhf(float x) {
+    float t = spec_expf(2.0f * x);
+    return (t - 1.0f) / (t + 1.0f);
+}
+
+// ---------------------------------------------------------------------------
+// GEMM on the fp32 matrix cores:  C = act(A . B + bias), k ascending.
+//
+// Work decomposition: a block is 4 wavefronts; each wavefront owns 32 rows of
+// A and NT 32-column tiles of C (NT accumulators of 16 VGPRs).  A is read
+// straight from global/L2 by the lane that needs it (lane l feeds row l&31;
+// both half-waves read the same float4 and pick k or k+1 — v_mfma_f32_32x32x2
+// wants A[i=l&31][k=l>>5]); B (the weights: small, shared by every row) is
+// staged through LDS in k-major chunks so the B operand read is one
+// conflict-free ds_read_b32 per MFMA.
+//
+// Loader variants: dense rows, or the im2col view of a 3x3/pad-1 NHWC
+// convolution (K = 9*Cin, zero outside the image).  Epilogue variants: plain
+// row-major store, or the ConvTranspose2x2/s2 scatter.
+// Roofline: dense 3x3 convs / GRU / linear -> fp32 MFMA (157 TFLOP/s peak);
+// the pointwise convs of the detection U-Net have K <= 64 and are HBM-bound
+// (A is streamed exactly once).
+// ---------------------------------------------------------------------------
+constexpr int GEMM_BK = 32;
+
+template <int NT, bool IM2COL, bool CONVT>
+__global__ void __launch_bounds__(256) gemm_mfma_kernel(GemmDesc d) {
+    extern __shared__ __attribute__((aligned(16))) float lds_b[];  // [GEMM_BK][32*NT]
+    constexpr int BN = 32 * NT;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int half = lane >> 5;
+    const int l31 = lane & 31;
+    const int z = blockIdx.z;
+    const float* __restrict__ A = d.A + (int64_t)z * d.strideA;
+    const float* __restrict__ B = d.B + (int64_t)z * d.strideB;
+    const float* __restrict__ bias = d.bias ? d.bias + (int64_t)z * d.strideBias : nullptr;
+    float* __restrict__ C = d.C + (int64_t)z * d.strideC;
+
+    const int n0 = blockIdx.y * BN;
+    const int64_t row = (int64_t)blockIdx.x * 128 + wave * 32 + l31;
+    const bool row_ok = row < d.M;
+    const int64_t rowc = row_ok ? row : (int64_t)d.M - 1;
+
+    // im2col row decomposition
+    int py = 0, px = 0;
+    int64_t img_base = 0;
+    if (IM2COL) {
+        int64_t hw = (int64_t)d.H * d.W;
+        int64_t img = rowc / hw;
+        int rem = (int)(rowc - img * hw);
+        py = rem / d.W;
+        px = rem - py * d.W;
+        img_base = img * hw * d.Cin;
+    }
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+        int col = n0 + t * 32 + l31;
+        float bv = (bias && col < d.N) ? bias[col] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[t][r] = bv;
+    }
+
+    for (int k0 = 0; k0 < d.K; k0 += GEMM_BK) {
+        const int kc = min(GEMM_BK, d.K - k0);
+        // ---- stage B[k0:k0+kc][n0:n0+BN] into LDS (zero-filled outside N / K)
+        __syncthreads();
+        for (int i = tid; i < GEMM_BK * BN / 4; i += 256) {
+            int kk = (i * 4) / BN;
+            int nn = (i * 4) % BN;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (kk < kc) {
+                const float* src = B + (int64_t)(k0 + kk) * d.ldb + n0 + nn;
+                if (n0 + nn + 3 < d.N && ((d.ldb & 3) == 0) && (((uintptr_t)B & 15) == 0)) {
+                    v = *reinterpret_cast<const float4*>(src);
+                } else {
+                    if (n0 + nn + 0 < d.N) v.x = src[0];
+                    if (n0 + nn + 1 < d.N) v.y = src[1];
+                    if (n0 + nn + 2 < d.N) v.z = src[2];
+                    if (n0 + nn + 3 < d.N) v.w = src[3];
+                }
+            }
+            *reinterpret_cast<float4*>(&lds_b[kk * BN + nn]) = v;
+        }
+        __syncthreads();
+
+        // ---- A pointer for this chunk
+        const float* arow;
+        bool a_ok = true;
+        if (IM2COL) {
+            int tap = k0 / d.Cin;  // chunks never straddle taps (Cin % GEMM_BK == 0 or Cin % kc == 0)
+            int ci0 = k0 - tap * d.Cin;
+            int ky = tap / 3, kx = tap - ky * 3;
+            int iy = py + ky - 1, ix = px + kx - 1;
+            a_ok = (unsigned)iy < (unsigned)d.H && (unsigned)ix < (unsigned)d.W;
+            arow = A + img_base + ((int64_t)(a_ok ? iy : 0) * d.W + (a_ok ? ix : 0)) * d.Cin + ci0;
+        } else {
+            arow = A + rowc * d.lda + k0;
+        }
+
+        for (int kk = 0; kk < kc; kk += 4) {
+            float4 av = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a_ok) av = *reinterpret_cast<const float4*>(arow + kk);
+            const float a0 = half ? av.y : av.x;
+            const float a1 = half ? av.w : av.z;
+            const float* b0p = &lds_b[(kk + half) * BN + l31];
+            const float* b1p = &lds_b[(kk + 2 + half) * BN + l31];
+#pragma unroll
+            for (int t = 0; t < NT; t++)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0p[t * 32], acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NT; t++)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1p[t * 32], acc[t], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue.  C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const int64_t row_base = (int64_t)blockIdx.x * 128 + wave * 32;
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+        const int col = n0 + t * 32 + l31;
+        if (col >= d.N) continue;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int64_t rr = row_base + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (rr >= d.M) continue;
+            float v = acc[t][r];
+            if (d.relu) v = v > 0.0f ? v : 0.0f;
+            if (CONVT) {
+                // row = input pixel (img, y, x); col = (dy, dx, co)
+                int64_t hw = (int64_t)d.H * d.W;
+                int64_t img = rr / hw;
+                int rem = (int)(rr - img * hw);
+                int y = rem / d.W, x = rem - y * d.W;
+                int q = col / d.Cout, co = col - q * d.Cout;
+                int dy = q >> 1, dx = q & 1;
+                C[((img * 2 * d.H + 2 * y + dy) * (2 * (int64_t)d.W) + 2 * x + dx) * d.Cout + co] = v;
+            } else {
+                C[rr * d.ldc + col] = v;
+            }
+        }
+    }
+}
+
+template <int NT>
+static void launch_gemm(const GemmDesc& d, hipStream_t s) {
+    dim3 grid((unsigned)((d.M + 127) / 128), (unsigned)((d.N + 32 * NT - 1) / (32 * NT)), (unsigned)(d.batch > 0 ? d.batch : 1));
+    size_t lds = (size_t)GEMM_BK * 32 * NT * sizeof(float);
+    if (d.im2col)
+        hipLaunchKernelGGL((gemm_mfma_kernel<NT, true, false>), grid, dim3(256), lds, s, d);
+    else if (d.convt)
+        hipLaunchKernelGGL((gemm_mfma_kernel<NT, false, true>), grid, dim3(256), lds, s, d);
+    else
+        hipLaunchKernelGGL((gemm_mfma_kernel<NT, false, false>), grid, dim3(256), lds, s, d);
+}
+
+void gemm(const GemmDesc& d, hipStream_t s) {
+    if (d.M <= 0 || d.N <= 0) return;
+    if (d.N <= 32) launch_gemm<1>(d, s);
+    else if (d.N <= 64) launch_gemm<2>(d, s);
+    else launch_gemm<4>(d, s);
+}
+
+// ---------------------------------------------------------------------------
+// Direct convolution for tiny contractions (Cin == 1: first conv of the CRNN,
+// first pointwise of the U-Net) and the fallback for shapes the MFMA GEMM does
+// not take (Cout % 4 == 0 required).  One thread = one output pixel x 4 output channels; the 8-32
+// output channels of a pixel are written by adjacent lanes (coalesced).
+// acc = bias; taps (ky, kx) ascending; out-of-image taps contribute fmaf(0,w,acc).
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+conv_direct_kernel(const float* __restrict__ x, int n, int h, int w, int cin, const float* __restrict__ wt,
+                   const float* __restrict__ bias, int kh, int kw, int cout, int relu, float* __restrict__ y) {
+    const int cq = cout >> 2;  // float4 groups per pixel
+    const int64_t total = (int64_t)n * h * w * cq;
+    const int ph = kh / 2, pw = kw / 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int g = (int)(i % cq);
+        const int64_t pix = i / cq;
+        const int ox = (int)(pix % w);
+        const int oy = (int)((pix / w) % h);
+        const int64_t img = pix / ((int64_t)w * h);
+        float4 acc = *reinterpret_cast<const float4*>(bias + 4 * g);
+        for (int ky = 0; ky < kh; ky++)
+            for (int kx = 0; kx < kw; kx++) {
+                int iy = oy + ky - ph, ix = ox + kx - pw;
+                const bool inb = (unsigned)iy < (unsigned)h && (unsigned)ix < (unsigned)w;
+                const float* xp = x + ((img * h + (inb ? iy : 0)) * w + (inb ? ix : 0)) * cin;
+                const float* wp = wt + (int64_t)(ky * kw + kx) * cin * cout + 4 * g;
+                for (int ci = 0; ci < cin; ci++) {
+                    float xv = inb ? xp[ci] : 0.0f;
+                    float4 wv = *reinterpret_cast<const float4*>(wp + (int64_t)ci * cout);
+                    acc.x = fmaf(xv, wv.x, acc.x);
+                    acc.y = fmaf(xv, wv.y, acc.y);
+                    acc.z = fmaf(xv, wv.z, acc.z);
+                    acc.w = fmaf(xv, wv.w, acc.w);
+                }
+            }
+        if (relu) {
+            acc.x = acc.x > 0.f ? acc.x : 0.f; acc.y = acc.y > 0.f ? acc.y : 0.f;
+            acc.z = acc.z > 0.f ? acc.z : 0.f; acc.w = acc.w > 0.f ? acc.w : 0.f;
+        }
+        *reinterpret_cast<float4*>(y + pix * cout + 4 * g) = acc;
+    }
+}
+
+void conv_direct(const float* x, int n, int h, int w, int cin, const float* wt, const float* bias, int kh, int kw,
+                 int cout, int relu, float* y, hipStream_t s) {
+    int64_t total = (int64_t)n * h * w * (cout / 4);
+    int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(conv_direct_kernel, dim3(grid), dim3(256), 0, s, x, n, h, w, cin, wt, bias, kh, kw, cout, relu, y);
+}
+
+// ---------------------------------------------------------------------------
+// Depthwise 3x3, pad 1, NHWC.  HBM-bound: 4*C bytes in + 4*C bytes out per
+// pixel (the 9-tap re-reads are served by L1/L2).  acc = bias; (ky,kx) ascending.
+// ---------------------------------------------------------------------------
+template <int VEC>
+__global__ void __launch_bounds__(256)
+dwconv3x3_kernel(const float* __restrict__ x, int n, int h, int w, int c, const float* __restrict__ wt,
+                 const float* __restrict__ bias, int relu, float* __restrict__ y) {
+    const int cq = c / VEC;
+    const int64_t total = (int64_t)n * h * w * cq;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int g = (int)(i % cq);
+        const int64_t pix = i / cq;
+        const int ox = (int)(pix % w);
+        const int oy = (int)((pix / w) % h);
+        const int64_t img = pix / ((int64_t)w * h);
+        float acc[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; v++) acc[v] = bias[g * VEC + v];
+#pragma unroll
+        for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+            for (int kx = 0; kx < 3; kx++) {
+                int iy = oy + ky - 1, ix = ox + kx - 1;
+                bool inb = (unsigned)iy < (unsigned)h && (unsigned)ix < (unsigned)w;
+                const float* xp = x + ((img * h + (inb ? iy : 0)) * w + (inb ? ix : 0)) * c + g * VEC;
+                const float* wp = wt + (ky * 3 + kx) * c + g * VEC;
+                if (VEC == 4) {
+                    float4 xv = inb ? *reinterpret_cast<const float4*>(xp) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    float4 wv = *reinterpret_cast<const float4*>(wp);
+                    acc[0] = fmaf(xv.x, wv.x, acc[0]);
+                    acc[1 % VEC] = fmaf(xv.y, wv.y, acc[1 % VEC]);
+                    acc[2 % VEC] = fmaf(xv.z, wv.z, acc[2 % VEC]);
+                    acc[3 % VEC] = fmaf(xv.w, wv.w, acc[3 % VEC]);
+                } else {
+                    acc[0] = fmaf(inb ? xp[0] : 0.0f, wp[0], acc[0]);
+                }
+            }
+        float* yp = y + pix * c + g * VEC;
+#pragma unroll
+        for (int v = 0; v < VEC; v++) {
+            float r = acc[v];
+            if (relu) r = r > 0.f ? r : 0.f;
+            acc[v] = r;
+        }
+        if (VEC == 4) *reinterpret_cast<float4*>(yp) = make_float4(acc[0], acc[1 % VEC], acc[2 % VEC], acc[3 % VEC]);
+        else yp[0] = acc[0];
+    }
+}
+
+void dwconv3x3(const float* x, int n, int h, int w, int c, const float* wt, const float* bias, int relu, float* y,
+               hipStream_t s) {
+    const bool v4 = (c % 4) == 0;
+    int64_t total = (int64_t)n * h * w * (v4 ? c / 4 : c);
+    int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    if (grid < 1) grid = 1;
+    if (v4) hipLaunchKernelGGL((dwconv3x3_kernel<4>), dim3(grid), dim3(256), 0, s, x, n, h, w, c, wt, bias, relu, y);
+    else hipLaunchKernelGGL((dwconv3x3_kernel<1>), dim3(grid), dim3(256), 0, s, x, n, h, w, c, wt, bias, relu, y);
+}
+
+// ---------------------------------------------------------------------------
+// Pools.  m = v0; m = v > m ? v : m  /  s = ((v0+v1)+...)*(1/k).
+// ---------------------------------------------------------------------------
+template <bool AVG>
+__global__ void __launch_bounds__(256)
+pool_kernel(const float* __restrict__ x, int n, int h, int w, int c, int kh, int kw, float* __restrict__ y) {
+    const int oh = h / kh, ow = w / kw;
+    const int64_t total = (int64_t)n * oh * ow * c;
+    const float inv = 1.0f / (float)(kh * kw);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % c);
+        const int64_t pix = i / c;
+        const int ox = (int)(pix % ow);
+        const int oy = (int)((pix / ow) % oh);
+        const int64_t img = pix / ((int64_t)ow * oh);
+        const float* xp = x + ((img * h + (int64_t)oy * kh) * w + (int64_t)ox * kw) * c + ch;
+        float acc = AVG ? 0.0f : xp[0];
+        for (int ky = 0; ky < kh; ky++)
+            for (int kx = 0; kx < kw; kx++) {
+                float v = xp[((int64_t)ky * w + kx) * c];
+                if (AVG) acc = acc + v;
+                else acc = v > acc ? v : acc;
+            }
+        y[i] = AVG ? acc * inv : acc;
+    }
+}
+
+void maxpool(const float* x, int n, int h, int w, int c, int kh, int kw, float* y, hipStream_t s) {
+    int64_t total = (int64_t)n * (h / kh) * (w / kw) * c;
+    int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL((pool_kernel<false>), dim3(grid), dim3(256), 0, s, x, n, h, w, c, kh, kw, y);
+}
+
+void avgpool(const float* x, int n, int h, int w, int c, int kh, int kw, float* y, hipStream_t s) {
+    int64_t total = (int64_t)n * (h / kh) * (w / kw) * c;
+    int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL((pool_kernel<true>), dim3(grid), dim3(256), 0, s, x, n, h, w, c, kh, kw, y);
+}
+
+// ---------------------------------------------------------------------------
+// Zero-pad x to skip's spatial size (before = d/2, after = d - d/2) and
+// concatenate channels [skip, x].
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+padcat_kernel(const float* __restrict__ skip, int n, int sh, int sw, int cs, const float* __restrict__ x, int h,
+              int w, int cx, float* __restrict__ y) {
+    const int ct = cs + cx;
+    const int py = (sh - h) / 2, px = (sw - w) / 2;
+    const int64_t total = (int64_t)n * sh * sw * ct;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % ct);
+        const int64_t pix = i / ct;
+        float v;
+        if (ch < cs) {
+            v = skip[pix * cs + ch];
+        } else {
+            const int ox = (int)(pix % sw);
+            const int oy = (int)((pix / sw) % sh);
+            const int64_t img = pix / ((int64_t)sw * sh);
+            const int iy = oy - py, ix = ox - px;
+            v = ((unsigned)iy < (unsigned)h && (unsigned)ix < (unsigned)w) ? x[((img * h + iy) * w + ix) * cx + (ch - cs)] : 0.0f;
+        }
+        y[i] = v;
+    }
+}
+
+void padcat(const float* skip, int n, int sh, int sw, int cs, const float* x, int h, int w, int cx, float* y,
+            hipStream_t s) {
+    int64_t total = (int64_t)n * sh * sw * (cs + cx);
+    int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(padcat_kernel, dim3(grid), dim3(256), 0, s, skip, n, sh, sw, cs, x, h, w, cx, y);
+}
+
+__global__ void __launch_bounds__(256) sigmoid_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t count) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x)
+        y[i] = spec_sigmoidf(x[i]);
+}
+
+void sigmoid(const float* x, float* y, int64_t count, hipStream_t s) {
+    int grid = (int)((count + 255) / 256 < 16384 ? (count + 255) / 256 : 16384);
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(sigmoid_kernel, dim3(grid), dim3(256), 0, s, x, y, count);
+}
+
+// Pointwise conv with a single output channel (+ fused sigmoid): the U-Net's
+// output layer.  y[p] = act(b + chain_c fmaf(x[p,c], w[c])).
+__global__ void __launch_bounds__(256)
+conv1x1_cout1_kernel(const float* __restrict__ x, int64_t pixels, int cin, const float* __restrict__ wt,
+                     const float* __restrict__ bias, int do_sigmoid, float* __restrict__ y) {
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < pixels; p += (int64_t)gridDim.x * blockDim.x) {
+        float acc = bias[0];
+        const float* xp = x + p * cin;
+        if ((cin & 3) == 0) {
+            for (int c = 0; c < cin; c += 4) {
+                float4 v = *reinterpret_cast<const float4*>(xp + c);
+                acc = fmaf(v.x, wt[c], acc);
+                acc = fmaf(v.y, wt[c + 1], acc);
+                acc = fmaf(v.z, wt[c + 2], acc);
+                acc = fmaf(v.w, wt[c + 3], acc);
+            }
+        } else {
+            for (int c = 0; c < cin; c++) acc = fmaf(xp[c], wt[c], acc);
+        }
+        y[p] = do_sigmoid ? spec_sigmoidf(acc) : acc;
+    }
+}
+
+void conv1x1_cout1(const float* x, int64_t pixels, int cin, const float* wt, const float* bias, int do_sigmoid,
+                   float* y, hipStream_t s) {
+    int grid = (int)((pixels + 255) / 256 < 16384 ? (pixels + 255) / 256 : 16384);
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(conv1x1_cout1_kernel, dim3(grid), dim3(256), 0, s, x, pixels, cin, wt, bias, do_sigmoid, y);
+}
+
+// [N,1,W,C] -> [W,N,C]
+__global__ void __launch_bounds__(256) to_seq_kernel(const float* __restrict__ x, int n, int w, int c, float* __restrict__ y) {
+    const int64_t total = (int64_t)n * w * c;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % c);
+        const int64_t r = i / c;       // output row = t * n + b
+        const int b = (int)(r % n);
+        const int t = (int)(r / n);
+        y[i] = x[((int64_t)b * w + t) * c + ch];
+    }
+}
+
+void to_seq(const float* x, int n, int w, int c, float* y, hipStream_t s) {
+    int64_t total = (int64_t)n * w * c;
+    int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(to_seq_kernel, dim3(grid), dim3(256), 0, s, x, n, w, c, y);
+}
+
+// ---------------------------------------------------------------------------
+// GRU gates for one time step (PyTorch / ONNX linear_before_reset=1):
+//   r = sig(gx_r + gh_r); z = sig(gx_z + gh_z); n = tanh(fmaf(r, gh_n, gx_n));
+//   h' = fmaf(z, h - n, n)
+// dir = blockIdx.y; forward uses t = step, reverse t = T-1-step.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+gru_gates_kernel(const float* __restrict__ gx, const float* __restrict__ gh, float* __restrict__ h,
+                 float* __restrict__ y, int T, int N, int H, int step) {
+    const int dir = blockIdx.y;
+    const int t = dir ? T - 1 - step : step;
+    const int64_t total = (int64_t)N * H;
+    const float* gxp = gx + (int64_t)dir * T * N * 3 * H + (int64_t)t * N * 3 * H;
+    const float* ghp = gh + (int64_t)dir * N * 3 * H;
+    float* hp = h + (int64_t)dir * N * H;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int j = (int)(i % H);
+        const int64_t b = i / H;
+        const float* gxr = gxp + b * 3 * H;
+        const float* ghr = ghp + b * 3 * H;
+        float r = spec_sigmoidf(gxr[j] + ghr[j]);
+        float z = spec_sigmoidf(gxr[H + j] + ghr[H + j]);
+        float nn = spec_tanhf(fmaf(r, ghr[2 * H + j], gxr[2 * H + j]));
+        float hprev = hp[i];
+        float hn = fmaf(z, hprev - nn, nn);
+        hp[i] = hn;
+        y[((int64_t)t * N + b) * 2 * H + (int64_t)dir * H + j] = hn;
+    }
+}
+
+void gru_gates(const float* gx, const float* gh, float* h, float* y, int T, int N, int H, int step, hipStream_t s) {
+    int64_t total = (int64_t)N * H;
+    int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(gru_gates_kernel, dim3(grid, 2), dim3(256), 0, s, gx, gh, h, y, T, N, H, step);
+}
+
+// ---------------------------------------------------------------------------
+// LogSoftmax over C, then -inf masking (recognition.rs:547-561) + arg-max (first
+// maximum, rten decode_greedy).  Spec order: m = max; s = sum_c exp(v_c - m)
+// with c ascending from s = 0; out = v - (m + log(s)).
+// Rows are staged through LDS so global traffic stays coalesced while each
+// lane walks its own row in the canonical order.
+// ---------------------------------------------------------------------------
+constexpr int LSM_ROWS = 64;
+
+__global__ void __launch_bounds__(LSM_ROWS)
+log_softmax_argmax_kernel(const float* __restrict__ logits, int64_t rows, int c, const uint8_t* __restrict__ excl,
+                          float* __restrict__ logp, int32_t* __restrict__ labels) {
+    extern __shared__ float tile[];  // [LSM_ROWS][c] (c odd or padded -> conflict-free row walks)
+    const int cp = (c & 1) ? c : c + 1;
+    const int64_t r0 = (int64_t)blockIdx.x * LSM_ROWS;
+    const int nrows = (int)min((int64_t)LSM_ROWS, rows - r0);
+    for (int i = threadIdx.x; i < nrows * c; i += LSM_ROWS) {
+        int rr = i / c, cc = i - rr * c;
+        tile[rr * cp + cc] = logits[r0 * c + i];
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < nrows) {
+        float* row = tile + threadIdx.x * cp;
+        float m = row[0];
+        for (int j = 1; j < c; j++) m = row[j] > m ? row[j] : m;
+        float ssum = 0.0f;
+        for (int j = 0; j < c; j++) ssum = ssum + spec_expf(row[j] - m);
+        const float lse = m + spec_logf(ssum);
+        // the reference masks excluded labels on the model OUTPUT, then arg-maxes
+        const float ninf = -__builtin_huge_valf();
+        int best = 0;
+        float bv = row[0] - lse;
+        row[0] = bv;
+        if (excl && excl[0]) bv = ninf;
+        for (int j = 1; j < c; j++) {
+            float v = row[j] - lse;
+            row[j] = v;
+            if (excl && excl[j]) v = ninf;
+            if (v > bv) { bv = v; best = j; }
+        }
+        if (labels) labels[r0 + threadIdx.x] = best;
+    }
+    __syncthreads();
+    if (logp)
+        for (int i = threadIdx.x; i < nrows * c; i += LSM_ROWS) {
+            int rr = i / c, cc = i - rr * c;
+            logp[r0 * c + i] = tile[rr * cp + cc];
+        }
+}
+
+void log_softmax_argmax(const float* logits, int64_t rows, int c, const uint8_t* d_excluded, float* logp,
+                        int32_t* labels, hipStream_t s) {
+    if (rows <= 0) return;
+    int cp = (c & 1) ? c : c + 1;
+    size_t lds = (size_t)LSM_ROWS * cp * sizeof(float);
+    int grid = (int)((rows + LSM_ROWS - 1) / LSM_ROWS);
+    hipLaunchKernelGGL(log_softmax_argmax_kernel, dim3(grid), dim3(LSM_ROWS), lds, s, logits, rows, c, d_excluded, logp,
+                       labels);
+}
+
+// Arg-max only (for caller-implemented models whose output is already
+// [T,N,C]); excluded labels read as -inf (recognition.rs:547-561).  First maximum.
+__global__ void __launch_bounds__(256)
+argmax_rows_kernel(const float* __restrict__ x, int64_t rows, int c, const uint8_t* __restrict__ excl,
+                   int32_t* __restrict__ labels) {
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (int64_t)gridDim.x * blockDim.x) {
+        const float* row = x + r * c;
+        const float ninf = -__builtin_huge_valf();
+        int best = 0;
+        float bv = (excl && excl[0]) ? ninf : row[0];
+        for (int j = 1; j < c; j++) {
+            float v = (excl && excl[j]) ? ninf : row[j];
+            if (v > bv) { bv = v; best = j; }
+        }
+        labels[r] = best;
+    }
+}
+
+void argmax_rows(const float* x, int64_t rows, int c, const uint8_t* d_excluded, int32_t* labels, hipStream_t s) {
+    if (rows <= 0) return;
+    int grid = (int)((rows + 255) / 256 < 4096 ? (rows + 255) / 256 : 4096);
+    hipLaunchKernelGGL(argmax_rows_kernel, dim3(grid), dim3(256), 0, s, x, rows, c, d_excluded, labels);
+}
+
+// ---------------------------------------------------------------------------
+// Greedy CTC collapse: one lane per line.  labels: [T][N].
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+ctc_collapse_kernel(const int32_t* __restrict__ labels, int T, int N, uint32_t* __restrict__ out_labels,
+                    uint32_t* __restrict__ out_pos, int32_t* __restrict__ out_count) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= N) return;
+    int last = 0, cnt = 0;
+    for (int t = 0; t < T; t++) {
+        int l = labels[(int64_t)t * N + b];
+        if (l == last) continue;
+        last = l;
+        if (l > 0) {
+            out_labels[(int64_t)b * T + cnt] = (uint32_t)l;
+            out_pos[(int64_t)b * T + cnt] = (uint32_t)t;
+            cnt++;
+        }
+    }
+    out_count[b] = cnt;
+}
+
+void ctc_collapse(const int32_t* labels, int T, int N, uint32_t* out_labels, uint32_t* out_pos, int32_t* out_count,
+                  hipStream_t s) {
+    if (N <= 0) return;
+    hipLaunchKernelGGL(ctc_collapse_kernel, dim3((N + 63) / 64), dim3(64), 0, s, labels, T, N, out_labels, out_pos,
+                       out_count);
+}
+
+}  // namespace k
+}  // namespace ocrs

@@ -1,0 +1,279 @@
+// Layout analysis: words -> lines in reading order.  Host side by design
+// (O(n^2) on ~600 rects, branchy, sub-millisecond) — mirrors
+// ocrs/src/layout_analysis.rs:19-233 and layout_analysis/empty_rects.rs:47-229.
+#include <cmath>
+#include <functional>
+
+#include "geometry.hpp"
+
+namespace ocrs {
+using namespace geom;
+
+namespace {
+
+// std::collections::BinaryHeap<Partition> with Rust's exact sift order, so that
+// partitions with equal scores pop in the same order as in the reference
+// (empty_rects.rs:20-24 compares scores only; ties are decided by heap mechanics).
+struct Partition {
+    float score;
+    Rect boundary;
+    std::vector<Rect> obstacles;
+};
+
+class RustBinaryHeap {
+  public:
+    void push(Partition&& p) {
+        data_.push_back(std::move(p));
+        sift_up(0, data_.size() - 1);
+    }
+    bool pop(Partition& out) {
+        if (data_.empty()) return false;
+        Partition item = std::move(data_.back());
+        data_.pop_back();
+        if (!data_.empty()) {
+            std::swap(item, data_[0]);
+            sift_down_to_bottom(0);
+        }
+        out = std::move(item);
+        return true;
+    }
+
+  private:
+    // f32::total_cmp on scores that are never NaN here
+    static bool le(const Partition& a, const Partition& b) { return a.score <= b.score; }
+    size_t sift_up(size_t start, size_t pos) {
+        Partition elt = std::move(data_[pos]);
+        while (pos > start) {
+            size_t parent = (pos - 1) / 2;
+            if (le(elt, data_[parent])) break;
+            data_[pos] = std::move(data_[parent]);
+            pos = parent;
+        }
+        data_[pos] = std::move(elt);
+        return pos;
+    }
+    void sift_down_to_bottom(size_t pos) {
+        const size_t end = data_.size();
+        const size_t start = pos;
+        Partition elt = std::move(data_[pos]);
+        size_t child = 2 * pos + 1;
+        while (end >= 2 && child <= end - 2) {
+            if (le(data_[child], data_[child + 1])) child += 1;
+            data_[pos] = std::move(data_[child]);
+            pos = child;
+            child = 2 * pos + 1;
+        }
+        if (child == end - 1) {
+            data_[pos] = std::move(data_[child]);
+            pos = child;
+        }
+        data_[pos] = std::move(elt);
+        sift_up(start, pos);
+    }
+    std::vector<Partition> data_;
+};
+
+// empty_rects.rs:80-138 + FilterRectIter (:184-221) + take(n)
+std::vector<Rect> max_empty_rects_filtered(const std::vector<Rect>& obstacles_in, Rect boundary,
+                                           const std::function<float(const Rect&)>& score, uint32_t min_width,
+                                           uint32_t min_height, float iou_threshold, size_t take) {
+    std::vector<Rect> obstacles = obstacles_in;
+    std::stable_sort(obstacles.begin(), obstacles.end(), [](const Rect& a, const Rect& b) {
+        PointI ca = a.center(), cb = b.center();
+        return ca.x != cb.x ? ca.x < cb.x : ca.y < cb.y;
+    });
+    RustBinaryHeap queue;
+    if (!boundary.is_empty()) queue.push(Partition{score(boundary), boundary, obstacles});
+    std::vector<Rect> found;
+    Partition part;
+    while (found.size() < take && queue.pop(part)) {
+        const Rect b = part.boundary;
+        if (part.obstacles.empty()) {
+            bool overlaps = false;
+            for (const Rect& f : found)
+                if (f.iou(b) >= iou_threshold) { overlaps = true; break; }
+            if (!overlaps) found.push_back(b);
+            continue;
+        }
+        const Rect pivot = part.obstacles[part.obstacles.size() / 2];
+        const Rect right_rect = Rect::from_tlbr(b.top, pivot.right, b.bottom, b.right);
+        const Rect left_rect = Rect::from_tlbr(b.top, b.left, b.bottom, pivot.left);
+        const Rect top_rect = Rect::from_tlbr(b.top, b.left, pivot.top, b.right);
+        const Rect bottom_rect = Rect::from_tlbr(pivot.bottom, b.left, b.bottom, b.right);
+        const Rect subs[4] = {top_rect, left_rect, bottom_rect, right_rect};
+        for (const Rect& sr : subs) {
+            if ((uint32_t)std::max(sr.width(), 0) < min_width || (uint32_t)std::max(sr.height(), 0) < min_height ||
+                sr.is_empty())
+                continue;
+            std::vector<Rect> sub_obs;
+            for (const Rect& o : part.obstacles)
+                if (o.intersects(sr)) sub_obs.push_back(o);
+            queue.push(Partition{score(sr), sr, std::move(sub_obs)});
+        }
+    }
+    return found;
+}
+
+struct WordInfo {  // cached per-word quantities for group_into_lines
+    RotatedRect rect;
+    int32_t left_i;
+    LineF ledge, redge;
+    float ledge_cx, redge_cx;
+    int32_t cx_i;
+};
+
+// layout_analysis.rs:19-71
+std::vector<std::vector<RotatedRect>> group_into_lines(const std::vector<RotatedRect>& rects,
+                                                       const std::vector<LineF>& separators) {
+    std::vector<WordInfo> ws;
+    ws.reserve(rects.size());
+    for (const RotatedRect& r : rects) {
+        WordInfo w;
+        w.rect = r;
+        w.left_i = as_i32(r.bounding_rect().left);
+        w.ledge = leftmost_edge(r);
+        w.redge = rightmost_edge(r);
+        w.ledge_cx = w.ledge.center().x;
+        w.redge_cx = w.redge.center().x;
+        w.cx_i = as_i32(r.cx);
+        ws.push_back(w);
+    }
+    std::stable_sort(ws.begin(), ws.end(), [](const WordInfo& a, const WordInfo& b) { return a.left_i < b.left_i; });
+
+    const float overlap_threshold = 5.0f;
+    const float max_h_overlap = 5.0f;
+    std::vector<char> used(ws.size(), 0);
+    std::vector<std::vector<RotatedRect>> lines;
+    size_t first_unused = 0;
+    while (true) {
+        while (first_unused < ws.size() && used[first_unused]) first_unused++;
+        if (first_unused >= ws.size()) break;
+        std::vector<RotatedRect> line;
+        size_t last_i = first_unused;
+        used[last_i] = 1;
+        line.push_back(ws[last_i].rect);
+        while (true) {
+            const WordInfo& last = ws[last_i];
+            long best = -1;
+            int32_t best_key = 0;
+            for (size_t i = first_unused; i < ws.size(); i++) {  // remaining rects keep their sorted order
+                if (used[i]) continue;
+                const WordInfo& w = ws[i];
+                if (!(w.rect.cx > last.rect.cx)) continue;
+                if (!(w.ledge_cx - last.redge_cx >= -max_h_overlap)) continue;
+                if (!(last.redge.vertical_overlap(w.ledge) >= overlap_threshold)) continue;
+                if (!separators.empty()) {
+                    LineF a_to_b{last.rect.center(), w.rect.center()};
+                    bool sep = false;
+                    for (const LineF& s : separators)
+                        if (a_to_b.intersects(s)) { sep = true; break; }
+                    if (sep) continue;
+                }
+                if (best < 0 || w.cx_i < best_key) {  // min_by_key keeps the first minimum
+                    best = (long)i;
+                    best_key = w.cx_i;
+                }
+            }
+            if (best < 0) break;
+            used[best] = 1;
+            line.push_back(ws[best].rect);
+            last_i = (size_t)best;
+        }
+        lines.push_back(std::move(line));
+    }
+    return lines;
+}
+
+LineF midpoint_line(const std::vector<RotatedRect>& words) {
+    return LineF{words.front().bounding_rect().left_edge().center(), words.back().bounding_rect().right_edge().center()};
+}
+
+}  // namespace
+
+// layout_analysis.rs:83-155
+std::vector<Rect> find_block_separators(const std::vector<RotatedRect>& words) {
+    if (words.empty()) return {};
+    RectF br = words[0].bounding_rect();
+    for (size_t i = 1; i < words.size(); i++) br = br.unite(words[i].bounding_rect());
+    const Rect page_rect = br.integral_bounding_rect();
+
+    auto lines = group_into_lines(words, {});
+    std::stable_sort(lines.begin(), lines.end(), [](const auto& a, const auto& b) {
+        return (int32_t)rround(a.front().bounding_rect().top) < (int32_t)rround(b.front().bounding_rect().top);
+    });
+
+    std::vector<int32_t> all_spacings;
+    for (const auto& line : lines) {
+        if (line.size() > 1) {
+            std::vector<int32_t> sp;
+            for (size_t i = 0; i + 1 < line.size(); i++) {
+                float v = line[i + 1].bounding_rect().left - line[i].bounding_rect().right;
+                v = v > 0.0f ? v : 0.0f;
+                sp.push_back((int32_t)rround(v));
+            }
+            std::sort(sp.begin(), sp.end());
+            all_spacings.insert(all_spacings.end(), sp.begin(), sp.end());
+        }
+    }
+    std::sort(all_spacings.begin(), all_spacings.end());
+    const int32_t median_word_spacing = all_spacings.empty() ? 10 : all_spacings[all_spacings.size() / 2];
+    const int32_t median_height = (int32_t)rround(words[words.size() / 2].h);
+
+    // Shafait/Keysers/Breuel score favouring tall rectangles (layout_analysis.rs:127-135).
+    auto score = [](const Rect& r) -> float {
+        float aspect = (float)r.height() / (float)r.width();
+        float lg = std::fabs((float)std::log2((double)aspect));
+        float wgt = lg < 3.0f ? 0.5f : (lg < 5.0f ? 1.5f : lg);
+        return std::sqrt((float)r.area() * wgt);
+    };
+
+    std::vector<Rect> boxes;
+    boxes.reserve(words.size());
+    for (const RotatedRect& w : words) boxes.push_back(w.bounding_rect().integral_bounding_rect());
+    const uint32_t min_width = (uint32_t)(median_word_spacing * 3);
+    const uint32_t min_height = (uint32_t)(3 * std::max(median_height, 0));
+    return max_empty_rects_filtered(boxes, page_rect, score, min_width, min_height, 0.5f, 80);
+}
+
+// layout_analysis.rs:158-233
+std::vector<std::vector<RotatedRect>> find_text_lines(const std::vector<RotatedRect>& words) {
+    const std::vector<Rect> separators = find_block_separators(words);
+    std::vector<LineF> vertical, horizontal;
+    for (const Rect& r : separators) {
+        PointI c = r.center();
+        vertical.push_back(LineF{PointF{(float)c.x, (float)r.top}, PointF{(float)c.x, (float)r.bottom}});
+        horizontal.push_back(LineF{PointF{(float)r.left, (float)c.y}, PointF{(float)r.right, (float)c.y}});
+    }
+    auto lines = group_into_lines(words, vertical);
+    std::stable_sort(lines.begin(), lines.end(), [](const auto& a, const auto& b) {
+        return as_i32(midpoint_line(a).center().y) < as_i32(midpoint_line(b).center().y);
+    });
+
+    auto is_separated_by = [&](const LineF& a, const LineF& b) {
+        LineF a_to_b{a.center(), b.center()};
+        for (const LineF& s : horizontal)
+            if (s.intersects(a_to_b)) return true;
+        return false;
+    };
+
+    std::vector<std::vector<RotatedRect>> out;
+    std::vector<char> used(lines.size(), 0);
+    for (size_t seed = 0; seed < lines.size(); seed++) {
+        if (used[seed]) continue;
+        used[seed] = 1;
+        out.push_back(lines[seed]);
+        LineF prev = midpoint_line(lines[seed]);
+        for (size_t i = seed + 1; i < lines.size(); i++) {
+            if (used[i]) continue;
+            LineF cand = midpoint_line(lines[i]);
+            if (prev.horizontal_overlap(cand) > 0.0f && !is_separated_by(prev, cand)) {
+                used[i] = 1;
+                out.push_back(lines[i]);
+                prev = cand;
+            }
+        }
+    }
+    return out;
+}
+
+}  // namespace ocrs

@@ -1,0 +1,370 @@
+#include "model.hpp"
+
+#include <cstdio>
+#include <map>
+
+#include "kernels.hpp"
+
+namespace ocrs {
+
+namespace {
+#pragma pack(push, 1)
+struct FileHeader {
+    char magic[8];
+    uint32_t version, kind;
+    int64_t input_shape[4];
+    uint32_t n_ops, n_slots, out_slot, reserved;
+    uint64_t blob_floats;
+};
+struct FileOp {
+    uint32_t type;
+    int32_t in0, in1, out, relu, kh, kw, cin, cout, hidden;
+    uint32_t n_w, reserved;
+    struct { uint64_t off, cnt; } w[8];
+};
+#pragma pack(pop)
+static_assert(sizeof(FileHeader) == 72, "header layout");
+static_assert(sizeof(FileOp) == 176, "op layout");
+
+const char* const kOpNames[OP_COUNT] = {"conv", "dwconv3", "maxpool", "avgpool", "convt2", "padcat",
+                                        "sigmoid", "toseq", "gru", "linear", "logsoftmax"};
+}  // namespace
+
+void CallbackModel::run(const float* input, const int64_t in_shape[4], std::vector<float>& out,
+                        int64_t out_shape[4], int* out_ndim) const {
+    float* o = nullptr;
+    int64_t os[4] = {0, 0, 0, 0};
+    int nd = 0;
+    int rc = fn(user, input, in_shape, &o, os, &nd);
+    if (rc != 0 || !o || nd < 1 || nd > 4) {
+        if (o) free(o);
+        fail(OCRS_ERR_RUN_FAILED, "model run failed: callback returned %d", rc);
+    }
+    int64_t cnt = 1;
+    for (int i = 0; i < nd; i++) cnt *= os[i];
+    out.assign(o, o + cnt);
+    free(o);
+    for (int i = 0; i < 4; i++) out_shape[i] = i < nd ? os[i] : 1;
+    *out_ndim = nd;
+}
+
+std::unique_ptr<HipModel> HipModel::load(const void* data, size_t len) {
+    if (len < sizeof(FileHeader)) fail(OCRS_ERR_IO, "model file too short");
+    FileHeader hd;
+    memcpy(&hd, data, sizeof hd);
+    if (memcmp(hd.magic, "OCRSMDL1", 8) != 0 || hd.version != 1) fail(OCRS_ERR_IO, "not an OCRSMDL1 model file");
+    const size_t table = sizeof(FileHeader) + (size_t)hd.n_ops * sizeof(FileOp);
+    if (len < table + hd.blob_floats * sizeof(float)) fail(OCRS_ERR_IO, "model file truncated");
+    const float* blob = reinterpret_cast<const float*>(static_cast<const char*>(data) + table);
+
+    auto m = std::make_unique<HipModel>();
+    m->kind = hd.kind;
+    for (int i = 0; i < 4; i++) m->input_shape[i] = hd.input_shape[i];
+    m->n_slots = hd.n_slots;
+    m->out_slot = hd.out_slot;
+
+    // Host image of the device slab: the file blob followed by derived tensors.
+    std::vector<float> slab(blob, blob + hd.blob_floats);
+    auto pad16 = [&]() { while (slab.size() % 4) slab.push_back(0.f); };
+    pad16();
+    struct Fix { size_t op; int which; size_t off; };
+    std::vector<Fix> fixes;
+    std::vector<FileOp> fops(hd.n_ops);
+    for (uint32_t i = 0; i < hd.n_ops; i++) {
+        memcpy(&fops[i], static_cast<const char*>(data) + sizeof(FileHeader) + (size_t)i * sizeof(FileOp), sizeof(FileOp));
+        const FileOp& f = fops[i];
+        if (f.type >= OP_COUNT || f.n_w > 8) fail(OCRS_ERR_IO, "bad op record %u", i);
+        for (uint32_t j = 0; j < f.n_w; j++)
+            if (f.w[j].off + f.w[j].cnt > hd.blob_floats) fail(OCRS_ERR_IO, "weight reference out of range in op %u", i);
+        GraphOp op{};
+        op.type = f.type; op.in0 = f.in0; op.in1 = f.in1; op.out = f.out;
+        op.relu = f.relu; op.kh = f.kh; op.kw = f.kw; op.cin = f.cin; op.cout = f.cout; op.hidden = f.hidden;
+        for (uint32_t j = 0; j < f.n_w; j++) op.wcount[j] = f.w[j].cnt;
+        if (f.type == OP_CONVT2) {
+            // file: [2][2][Cin][Cout] -> GEMM B [Cin][(dy,dx,co)], bias repeated per (dy,dx)
+            const float* w = blob + f.w[0].off;
+            const float* b = blob + f.w[1].off;
+            fixes.push_back({i, 0, slab.size()});
+            for (int ci = 0; ci < f.cin; ci++)
+                for (int q = 0; q < 4; q++)
+                    for (int co = 0; co < f.cout; co++) slab.push_back(w[((size_t)q * f.cin + ci) * f.cout + co]);
+            pad16();
+            fixes.push_back({i, 1, slab.size()});
+            for (int q = 0; q < 4; q++)
+                for (int co = 0; co < f.cout; co++) slab.push_back(b[co]);
+            pad16();
+        } else if (f.type == OP_GRU) {
+            if (f.n_w != 8) fail(OCRS_ERR_IO, "GRU op %u needs 8 weight tensors", i);
+            // pack both directions contiguously: Wi [2][I][3H], bi [2][3H], Wh [2][H][3H], bh [2][3H]
+            for (int part = 0; part < 4; part++) {
+                fixes.push_back({i, part, slab.size()});
+                for (int d = 0; d < 2; d++) {
+                    const float* src = blob + f.w[4 * d + part].off;
+                    slab.insert(slab.end(), src, src + f.w[4 * d + part].cnt);
+                }
+                pad16();
+            }
+        }
+        m->ops.push_back(op);
+    }
+    m->weights = DevBuf(slab.size() * sizeof(float));
+    OCRS_HIP(hipMemcpy(m->weights.p, slab.data(), slab.size() * sizeof(float), hipMemcpyHostToDevice));
+    const float* base = m->weights.as<float>();
+    for (uint32_t i = 0; i < hd.n_ops; i++)
+        for (uint32_t j = 0; j < fops[i].n_w; j++) m->ops[i].w[j] = base + fops[i].w[j].off;
+    for (const Fix& fx : fixes) {
+        GraphOp& op = m->ops[fx.op];
+        const float* p = base + fx.off;
+        if (fx.which == 0) op.aux0 = p;
+        else if (fx.which == 1) op.aux1 = p;
+        else if (fx.which == 2) op.aux2 = p;
+        else op.aux3 = p;
+    }
+    // Fold SIGMOID into a directly preceding Cout==1 pointwise conv.
+    for (size_t i = 0; i + 1 < m->ops.size(); i++) {
+        GraphOp& a = m->ops[i];
+        GraphOp& b = m->ops[i + 1];
+        if (a.type == OP_CONV && a.cout == 1 && a.kh == 1 && a.kw == 1 && b.type == OP_SIGMOID && b.in0 == a.out) {
+            bool other_use = false;
+            for (size_t j = i + 2; j < m->ops.size(); j++)
+                if (m->ops[j].in0 == a.out || m->ops[j].in1 == a.out) other_use = true;
+            if (!other_use && (uint32_t)a.out != m->out_slot) b.fused_into_prev = true;
+        }
+    }
+    return m;
+}
+
+TensorShape HipModel::infer(int n, int h, int w, std::vector<TensorShape>* slots_out) const {
+    std::vector<TensorShape> s(n_slots);
+    s[0] = TensorShape{n, h, w, 1, false};
+    for (const GraphOp& op : ops) {
+        const TensorShape a = s[op.in0];
+        TensorShape o = a;
+        switch (op.type) {
+            case OP_CONV: o.c = op.cout; break;
+            case OP_DWCONV3: break;
+            case OP_MAXPOOL:
+            case OP_AVGPOOL: o.h = a.h / op.kh; o.w = a.w / op.kw; break;
+            case OP_CONVT2: o.h = 2 * a.h; o.w = 2 * a.w; o.c = op.cout; break;
+            case OP_PADCAT: o.c = a.c + s[op.in1].c; break;
+            case OP_SIGMOID:
+            case OP_LOGSOFTMAX: break;
+            case OP_TOSEQ: o = TensorShape{a.w, a.n, 1, a.c, true}; break;  // [T,N,C]
+            case OP_GRU: o.c = 2 * op.hidden; break;
+            case OP_LINEAR: o.c = op.cout; break;
+            default: fail(OCRS_ERR_IO, "bad op type %u", op.type);
+        }
+        s[op.out] = o;
+    }
+    TensorShape out = s[out_slot];
+    if (slots_out) *slots_out = std::move(s);
+    return out;
+}
+
+double HipModel::flops(int n, int h, int w) const {
+    std::vector<TensorShape> s;
+    infer(n, h, w, &s);
+    double total = 0;
+    for (const GraphOp& op : ops) {
+        const TensorShape a = s[op.in0];
+        const double px = (double)a.n * a.h * a.w;
+        switch (op.type) {
+            case OP_CONV: total += 2.0 * px * op.cout * op.cin * op.kh * op.kw; break;
+            case OP_DWCONV3: total += 2.0 * px * a.c * 9; break;
+            case OP_CONVT2: total += 2.0 * px * op.cin * op.cout * 4; break;
+            case OP_GRU: total += 2.0 * 2.0 * px * 3 * op.hidden * (op.cin + op.hidden); break;
+            case OP_LINEAR: total += 2.0 * px * op.cin * op.cout; break;
+            default: break;
+        }
+    }
+    return total;
+}
+
+float* HipModel::run_device(Workspace& ws, const float* d_in, int n, int h, int w, TensorShape* out_shape,
+                            StageTimers* timers, const uint8_t* d_excluded, int32_t* d_labels, bool want_logp,
+                            bool print_timing) const {
+    std::vector<TensorShape> shp;
+    const TensorShape out = infer(n, h, w, &shp);
+    if (out_shape) *out_shape = out;
+    hipStream_t st = ws.s();
+
+    // liveness: last op index that reads each slot
+    std::vector<int> last_use(n_slots, -1);
+    for (size_t i = 0; i < ops.size(); i++) {
+        last_use[ops[i].in0] = (int)i;
+        if (ops[i].in1 >= 0) last_use[ops[i].in1] = (int)i;
+    }
+    last_use[out_slot] = (int)ops.size() + 1;
+    std::vector<float*> ptr(n_slots, nullptr);
+    std::vector<size_t> cap(n_slots, 0);
+    std::multimap<size_t, float*> free_local;
+    auto get = [&](size_t floats) -> std::pair<float*, size_t> {
+        size_t bytes = floats * sizeof(float);
+        auto it = free_local.lower_bound(bytes);
+        if (it != free_local.end() && it->first <= bytes * 2 + 4096) {
+            auto r = std::make_pair(it->second, it->first);
+            free_local.erase(it);
+            return r;
+        }
+        size_t rounded = (bytes + 255) & ~size_t(255);
+        return {static_cast<float*>(ws.alloc(rounded)), rounded};
+    };
+    ptr[0] = const_cast<float*>(d_in);
+
+    std::vector<hipEvent_t> ev;
+    if (print_timing) {
+        ev.resize(ops.size() + 1);
+        for (auto& e : ev) OCRS_HIP(hipEventCreate(&e));
+        OCRS_HIP(hipEventRecord(ev[0], st));
+    }
+
+    int stage_token = -1;
+    int cur_stage = -1;
+    auto enter_stage = [&](int stage) {
+        if (!timers || stage == cur_stage) return;
+        if (cur_stage >= 0) timers->end(stage_token, st);
+        stage_token = timers->begin(stage, st, 0);
+        cur_stage = stage;
+    };
+    bool seen_seq = false;
+
+    for (size_t i = 0; i < ops.size(); i++) {
+        const GraphOp& op = ops[i];
+        const TensorShape a = shp[op.in0];
+        const TensorShape o = shp[op.out];
+        if (kind == 0) enter_stage(ST_DET_CNN);
+        else if (op.type == OP_GRU) enter_stage(ST_REC_GRU);
+        else if (op.type == OP_LINEAR || op.type == OP_LOGSOFTMAX) enter_stage(seen_seq ? ST_REC_HEAD : ST_REC_CONV);
+        else enter_stage(seen_seq ? ST_REC_GRU : ST_REC_CONV);
+        if (op.type == OP_TOSEQ) seen_seq = true;
+
+        const float* x = ptr[op.in0];
+        float* y = nullptr;
+        const bool is_final_logsoftmax = op.type == OP_LOGSOFTMAX && (uint32_t)op.out == out_slot;
+        if (op.fused_into_prev) {
+            ptr[op.out] = ptr[op.in0];  // already holds sigmoid(conv)
+            cap[op.out] = cap[op.in0];
+            cap[op.in0] = 0;
+            ptr[op.in0] = nullptr;
+        } else {
+        if (!(is_final_logsoftmax && !want_logp)) {
+            auto r = get((size_t)o.count());
+            y = r.first;
+            ptr[op.out] = y;
+            cap[op.out] = r.second;
+        }
+        switch (op.type) {
+            case OP_CONV: {
+                const int64_t px = (int64_t)a.n * a.h * a.w;
+                const bool next_sigmoid = i + 1 < ops.size() && ops[i + 1].fused_into_prev;
+                if (op.kh == 1 && op.kw == 1 && op.cout == 1) {
+                    k::conv1x1_cout1(x, px, op.cin, op.w[0], op.w[1], next_sigmoid ? 1 : 0, y, st);
+                } else if (op.kh == 1 && op.kw == 1 && (op.cin % 4) == 0) {
+                    k::GemmDesc d{};
+                    d.A = x; d.lda = op.cin; d.B = op.w[0]; d.ldb = op.cout; d.bias = op.w[1];
+                    d.C = y; d.ldc = op.cout; d.M = (int)px; d.N = op.cout; d.K = op.cin; d.relu = op.relu;
+                    k::gemm(d, st);
+                } else if (op.kh == 3 && op.kw == 3 && (op.cin % 32) == 0) {
+                    k::GemmDesc d{};
+                    d.A = x; d.B = op.w[0]; d.ldb = op.cout; d.bias = op.w[1];
+                    d.C = y; d.ldc = op.cout; d.M = (int)px; d.N = op.cout; d.K = 9 * op.cin; d.relu = op.relu;
+                    d.im2col = 1; d.H = a.h; d.W = a.w; d.Cin = op.cin;
+                    k::gemm(d, st);
+                } else if ((op.cout % 4) == 0) {
+                    k::conv_direct(x, a.n, a.h, a.w, op.cin, op.w[0], op.w[1], op.kh, op.kw, op.cout, op.relu, y, st);
+                } else {
+                    fail(OCRS_ERR_RUN_FAILED, "model run failed: unsupported conv shape %dx%d %d->%d", op.kh, op.kw,
+                         op.cin, op.cout);
+                }
+                break;
+            }
+            case OP_DWCONV3: k::dwconv3x3(x, a.n, a.h, a.w, a.c, op.w[0], op.w[1], op.relu, y, st); break;
+            case OP_MAXPOOL: k::maxpool(x, a.n, a.h, a.w, a.c, op.kh, op.kw, y, st); break;
+            case OP_AVGPOOL: k::avgpool(x, a.n, a.h, a.w, a.c, op.kh, op.kw, y, st); break;
+            case OP_CONVT2: {
+                k::GemmDesc d{};
+                d.A = x; d.lda = op.cin; d.B = op.aux0; d.ldb = 4 * op.cout; d.bias = op.aux1;
+                d.C = y; d.M = (int)((int64_t)a.n * a.h * a.w); d.N = 4 * op.cout; d.K = op.cin;
+                d.convt = 1; d.H = a.h; d.W = a.w; d.Cout = op.cout;
+                k::gemm(d, st);
+                break;
+            }
+            case OP_PADCAT: {
+                const TensorShape b = shp[op.in1];
+                k::padcat(x, a.n, a.h, a.w, a.c, ptr[op.in1], b.h, b.w, b.c, y, st);
+                break;
+            }
+            case OP_SIGMOID: k::sigmoid(x, y, a.count(), st); break;
+            case OP_TOSEQ:
+                if (a.h != 1) fail(OCRS_ERR_RUN_FAILED, "model run failed: TOSEQ expects height 1, got %d", a.h);
+                k::to_seq(x, a.n, a.w, a.c, y, st);
+                break;
+            case OP_GRU: {
+                const int T = a.n, N = a.h, I = a.c, H = op.hidden;
+                auto gx = get((size_t)2 * T * N * 3 * H);
+                auto gh = get((size_t)2 * N * 3 * H);
+                auto hs = get((size_t)2 * N * H);
+                OCRS_HIP(hipMemsetAsync(hs.first, 0, (size_t)2 * N * H * sizeof(float), st));
+                k::GemmDesc d{};
+                d.A = x; d.lda = I; d.B = op.aux0; d.ldb = 3 * H; d.bias = op.aux1; d.C = gx.first; d.ldc = 3 * H;
+                d.M = T * N; d.N = 3 * H; d.K = I; d.batch = 2;
+                d.strideA = 0; d.strideB = (int64_t)I * 3 * H; d.strideBias = 3 * H; d.strideC = (int64_t)T * N * 3 * H;
+                k::gemm(d, st);
+                k::GemmDesc r{};
+                r.A = hs.first; r.lda = H; r.B = op.aux2; r.ldb = 3 * H; r.bias = op.aux3; r.C = gh.first; r.ldc = 3 * H;
+                r.M = N; r.N = 3 * H; r.K = H; r.batch = 2;
+                r.strideA = (int64_t)N * H; r.strideB = (int64_t)H * 3 * H; r.strideBias = 3 * H; r.strideC = (int64_t)N * 3 * H;
+                for (int step = 0; step < T; step++) {
+                    k::gemm(r, st);
+                    k::gru_gates(gx.first, gh.first, hs.first, y, T, N, H, step, st);
+                }
+                free_local.emplace(gx.second, gx.first);
+                free_local.emplace(gh.second, gh.first);
+                free_local.emplace(hs.second, hs.first);
+                break;
+            }
+            case OP_LINEAR: {
+                k::GemmDesc d{};
+                d.A = x; d.lda = op.cin; d.B = op.w[0]; d.ldb = op.cout; d.bias = op.w[1];
+                d.C = y; d.ldc = op.cout; d.M = (int)((int64_t)a.n * a.h * a.w); d.N = op.cout; d.K = op.cin;
+                d.relu = op.relu;
+                k::gemm(d, st);
+                break;
+            }
+            case OP_LOGSOFTMAX:
+                k::log_softmax_argmax(x, (int64_t)a.n * a.h * a.w, a.c, is_final_logsoftmax ? d_excluded : nullptr, y,
+                                      is_final_logsoftmax ? d_labels : nullptr, st);
+                break;
+            default: fail(OCRS_ERR_RUN_FAILED, "model run failed: bad op");
+        }
+        }
+        if (print_timing) OCRS_HIP(hipEventRecord(ev[i + 1], st));
+        // release inputs whose last reader this was (slot 0 is the caller's)
+        for (int sl : {op.in0, op.in1}) {
+            if (sl > 0 && last_use[sl] == (int)i && ptr[sl] && cap[sl]) {
+                free_local.emplace(cap[sl], ptr[sl]);
+                ptr[sl] = nullptr;
+                cap[sl] = 0;
+            }
+        }
+    }
+    if (timers && cur_stage >= 0) timers->end(stage_token, st);
+    OCRS_HIP(hipGetLastError());
+
+    if (print_timing) {
+        OCRS_HIP(hipStreamSynchronize(st));
+        float total = 0.f;
+        for (size_t i = 0; i < ops.size(); i++) {
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, ev[i], ev[i + 1]);
+            total += ms;
+            const TensorShape o = shp[ops[i].out];
+            printf("%-10s [%d,%d,%d,%d] %.3fms\n", kOpNames[ops[i].type], o.n, o.h, o.w, o.c, ms);
+        }
+        printf("total %.3fms\n", total);
+        for (auto& e : ev) (void)hipEventDestroy(e);
+    }
+    return ptr[out_slot];
+}
+
+}  // namespace ocrs

@@ -1,0 +1,81 @@
+// Fixed-graph HIP executor: the MI355X replacement for `rten::Model`
+// behind `trait Model` (ocrs/src/model.rs:6-41).
+#pragma once
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "common.hpp"
+
+namespace ocrs {
+
+enum OpType : uint32_t {
+    OP_CONV = 0, OP_DWCONV3, OP_MAXPOOL, OP_AVGPOOL, OP_CONVT2, OP_PADCAT, OP_SIGMOID, OP_TOSEQ, OP_GRU, OP_LINEAR,
+    OP_LOGSOFTMAX, OP_COUNT
+};
+
+struct GraphOp {
+    uint32_t type;
+    int32_t in0, in1, out;
+    int32_t relu, kh, kw, cin, cout, hidden;
+    // device weights (owned by the model's weight slab)
+    const float* w[8] = {nullptr};
+    size_t wcount[8] = {0};
+    // derived device tensors built at load time
+    const float* aux0 = nullptr;  // convT: B re-laid out as [Cin][4*Cout]; GRU: Wi of both dirs [2][I][3H]
+    const float* aux1 = nullptr;  // convT: bias x4; GRU: bi [2][3H]
+    const float* aux2 = nullptr;  // GRU: Wh [2][H][3H]
+    const float* aux3 = nullptr;  // GRU: bh [2][3H]
+    bool fused_into_prev = false; // e.g. SIGMOID folded into the preceding Cout==1 conv
+};
+
+struct TensorShape {  // NHWC activations, or [T,N,C] sequences (n=T, h=N, w=1, c=C)
+    int n = 0, h = 0, w = 0, c = 0;
+    bool seq = false;
+    int64_t count() const { return (int64_t)n * h * w * c; }
+};
+
+// What a caller-implemented model looks like to the engine (`trait Model`).
+struct ModelBase {
+    virtual ~ModelBase() = default;
+    int64_t input_shape[4] = {-1, -1, -1, -1};  // NCHW, -1 = symbolic
+    virtual bool is_callback() const = 0;
+};
+
+struct CallbackModel : ModelBase {
+    ocrs_model_run_fn fn = nullptr;
+    void* user = nullptr;
+    bool is_callback() const override { return true; }
+    // host NCHW in -> host out (malloc'ed by callee, adopted here)
+    void run(const float* input, const int64_t in_shape[4], std::vector<float>& out, int64_t out_shape[4],
+             int* out_ndim) const;
+};
+
+struct HipModel : ModelBase {
+    uint32_t kind = 0;  // 0 detection, 1 recognition
+    std::vector<GraphOp> ops;
+    uint32_t n_slots = 0, out_slot = 0;
+    DevBuf weights;      // one slab: file blob + derived tensors
+    bool is_callback() const override { return false; }
+
+    static std::unique_ptr<HipModel> load(const void* data, size_t len);
+
+    // Shape inference for an input of n x h x w (C = 1); returns the output shape.
+    TensorShape infer(int n, int h, int w, std::vector<TensorShape>* slots = nullptr) const;
+    double flops(int n, int h, int w) const;
+
+    // Run on device.  d_in: [n,h,w,1] fp32.  Returns the output tensor, allocated from
+    // `ws` (detection: [n,H,W,1] probabilities; recognition: [T,n,C] log-probs or, when
+    // want_logp is false, nothing but the arg-max labels).  Recognition extras:
+    //   d_excluded: [C] bytes or null; d_labels: [T*n] arg-max labels or null.
+    float* run_device(Workspace& ws, const float* d_in, int n, int h, int w, TensorShape* out_shape,
+                      StageTimers* timers, const uint8_t* d_excluded = nullptr, int32_t* d_labels = nullptr,
+                      bool want_logp = true, bool print_timing = false) const;
+};
+
+}  // namespace ocrs
+
+// The opaque C handle.
+struct ocrs_model {
+    std::unique_ptr<ocrs::ModelBase> impl;
+};

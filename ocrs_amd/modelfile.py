@@ -319,3 +319,18 @@ def build_recognition(n_classes=97, in_h=64, seed=2, hidden=256, chans=(32, 64, 
     B.ops.append(Op(OP_LINEAR, x, o, cin=feat, cout=n_classes, weights=(w, b)))
     x = B.simple(OP_LOGSOFTMAX, o)
     return Graph(KIND_RECOGNITION, [-1, 1, in_h, -1], B.ops, B.n_slots, x)
+
+
+def calibrate_recognition_head(graph, run, crops_nchw, blank_boost=1.0):
+    """Random CRNN weights decode to one or two classes whatever the input.  Shift
+    the final Linear bias by the per-class mean log-probability measured on a
+    sample batch so that the arg-max follows the input; `run(graph_bytes, nchw)`
+    -> [T,N,C] log-probs may be the HIP executor or any other executor of the
+    container (the result is just another synthetic weight file)."""
+    lp = np.asarray(run(graph.to_bytes(), crops_nchw), dtype=np.float64)
+    mean = lp.reshape(-1, lp.shape[-1]).mean(axis=0)
+    lin = [op for op in graph.ops if op.type == OP_LINEAR][-1]
+    b = lin.weights[1].astype(np.float64) - (mean - mean.mean())
+    b[0] += blank_boost
+    lin.weights[1] = b.astype(np.float32)
+    return graph

@@ -1,0 +1,329 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on
+the same seeded inputs.  Integer / byte / index results must match bit for bit;
+fp32 model outputs must match bit for bit too (both sides evaluate the
+canonical fmaf-chain order of DESIGN.md §4) and additionally stay within 1e-4
+(probabilities) / 1e-3 (log-probs) of the PyTorch-CPU fp32 evaluation.
+
+Run with:  python -m pytest tests -m gpu
+"""
+import numpy as np
+import pytest
+
+import kat_util as K
+import models_util as M
+import ocrs_amd
+from ocrs_amd import DimOrder, ImageSource, Model, OcrEngine, synth
+from oracle import clib
+from oracle import pipeline as OP
+from oracle.geometry import Rect, RotatedRect
+from oracle.nn import OracleGraph, OracleModel
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu():
+    from ocrs_amd import _lib
+    _lib.require_gpu()  # fail loudly: there is no CPU fallback to "pass" on
+
+
+def rects_of(words):
+    return np.array([w.to_array() for w in words], np.float32).reshape(-1, 6)
+
+
+# ------------------------------------------------------------------ stage 0
+@pytest.mark.parametrize("dtype", [np.uint8, np.float32])
+@pytest.mark.parametrize("order", ["hwc", "chw"])
+@pytest.mark.parametrize("chans", [1, 3, 4])
+def test_prepare_input_bit_exact(dtype, order, chans):
+    rng = np.random.default_rng(chans * 10 + (order == "hwc"))
+    h, w = 37, 53
+    shape = (h, w, chans) if order == "hwc" else (chans, h, w)
+    px = rng.integers(0, 256, shape).astype(np.uint8) if dtype == np.uint8 else rng.random(shape, dtype=np.float32)
+    eng = OcrEngine()
+    got = eng.prepare_input(ImageSource.from_tensor(px, DimOrder.Hwc if order == "hwc" else DimOrder.Chw)).image()
+    exp = OP.prepare_image(OP.ImageSource.from_tensor(px, order))
+    assert got.shape == exp.shape and np.array_equal(got, exp)
+
+
+def test_prepare_input_rgb8_fast_path_full_page():
+    px = synth.synthetic_page(3)
+    got = OcrEngine().prepare_input(ImageSource.from_tensor(px, DimOrder.Hwc)).image()
+    assert np.array_equal(got, OP.prepare_image(OP.ImageSource.from_tensor(px, "hwc")))
+
+
+# ------------------------------------------------------------------ reference KATs through the engine
+def test_kat_detect_words_fake_model():  # lib.rs:466-488
+    det = Model.from_callable(K.FAKE_DETECTION_SHAPE, K.fake_detection_run)
+    eng = OcrEngine(detection_model=det)
+    inp = eng.prepare_input(ImageSource.from_tensor(K.gen_test_image(3), DimOrder.Chw))
+    assert inp.shape == (1, 100, 200)
+    words = eng.detect_words(inp)
+    assert len(words) == 3
+    boxes = sorted((RotatedRect.from_array(w).bounding_rect().tlhw() for w in words), key=lambda b: (int(b[0]), int(b[1])))
+    assert boxes == K.EXPECTED_WORD_BOXES_TLHW
+
+
+def _recognize(engine, image):
+    inp = engine.prepare_input(ImageSource.from_tensor(image, DimOrder.Chw))
+    line = rects_of([RotatedRect.from_rect(Rect.from_tlhw(0, 0, image.shape[1], image.shape[2]))])
+    lines = engine.recognize_text(inp, [line])
+    assert len(lines) == 1 and lines[0] is not None
+    return str(lines[0])
+
+
+def test_kat_recognize_lines_fake_model():  # lib.rs:527-577
+    rec = Model.from_callable(K.FAKE_RECOGNITION_SHAPE, K.fake_recognition_run)
+    image = np.zeros((1, 64, 32), np.float32)
+    image[:, 2, :] = 1.0
+    assert _recognize(OcrEngine(recognition_model=rec, alphabet=K.make_alphabet()), image) == "0"
+    image[:, 2, :] = 0.7
+    image[:, 3, :] = 0.3
+    assert _recognize(OcrEngine(recognition_model=rec, alphabet=K.make_alphabet()), image) == "0"
+    assert _recognize(OcrEngine(recognition_model=rec, alphabet=K.make_alphabet(), allowed_chars="123456789"), image) == "1"
+
+
+def test_engine_errors():  # lib.rs:197,211,254,274 ; detection.rs:141-144 ; recognition.rs:487-493
+    eng = OcrEngine()
+    inp = eng.prepare_input(ImageSource.from_tensor(np.zeros((1, 8, 8), np.float32), DimOrder.Chw))
+    with pytest.raises(ocrs_amd.OcrsError, match="Detection model not loaded"):
+        eng.detect_words(inp)
+    with pytest.raises(ocrs_amd.OcrsError, match="Recognition model not loaded"):
+        eng.recognize_text(inp, [])
+    assert abs(eng.detection_threshold() - 0.2) < 1e-7
+    sym = Model.from_callable([None, 1, None, None], K.fake_detection_run)
+    with pytest.raises(ocrs_amd.OcrsError, match="failed to get model dims"):
+        OcrEngine(detection_model=sym).detect_words(inp)
+    rec = Model.from_callable(K.FAKE_RECOGNITION_SHAPE, K.fake_recognition_run)
+    image = np.zeros((1, 64, 32), np.float32)
+    with pytest.raises(ocrs_amd.OcrsError, match="does not match alphabet size"):
+        _recognize(OcrEngine(recognition_model=rec), image)  # 96-char default alphabet vs 64 columns
+    bad = Model.from_callable(K.FAKE_RECOGNITION_SHAPE, lambda x: np.zeros((3, 3), np.float32))
+    with pytest.raises(ocrs_amd.OcrsError, match="expected recognition output to have 3 dims but it has 2"):
+        _recognize(OcrEngine(recognition_model=bad, alphabet=K.make_alphabet()), image)
+
+    def boom(x):
+        raise RuntimeError("boom")
+
+    with pytest.raises(ocrs_amd.OcrsError, match="model run failed"):
+        _recognize(OcrEngine(recognition_model=Model.from_callable(K.FAKE_RECOGNITION_SHAPE, boom),
+                             alphabet=K.make_alphabet()), image)
+
+
+# ------------------------------------------------------------------ Model::run parity
+def test_mfma_chain_is_bitwise_fmaf_chain():
+    """The premise of the numeric spec: fp32 MFMA == k-ordered fmaf chain."""
+    from ocrs_amd import modelfile as mf
+    rng = np.random.default_rng(5)
+    for cin, cout in [(8, 8), (16, 32), (64, 64), (128, 96), (256, 40)]:
+        w = (rng.standard_normal((1, 1, cin, cout)) * 0.3).astype(np.float32)
+        b = rng.standard_normal(cout).astype(np.float32)
+        lift_w = rng.standard_normal((1, 1, 1, cin)).astype(np.float32)
+        ops = [mf.Op(mf.OP_CONV, 0, 1, kh=1, kw=1, cin=1, cout=cin, weights=(lift_w, np.zeros(cin, np.float32))),
+               mf.Op(mf.OP_CONV, 1, 2, relu=0, kh=1, kw=1, cin=cin, cout=cout, weights=(w, b))]
+        # output channels > 1 come back NCHW; compare against the oracle's NHWC result
+        g = mf.Graph(mf.KIND_DETECTION, [-1, 1, -1, -1], ops, 3, 2)
+        x = rng.standard_normal((2, 1, 13, 11)).astype(np.float32)
+        got = Model.load_bytes(g.to_bytes()).run(x)
+        exp, slots = OracleGraph(g.to_bytes()).run_exact(x, return_slots=True)
+        exp = slots[2].transpose(0, 3, 1, 2)
+        assert got.shape == exp.shape and np.array_equal(got, exp), (cin, cout)
+
+
+@pytest.mark.parametrize("in_hw,n", [((96, 64), 3), ((800, 600), 1)])
+def test_detection_model_run_bit_exact(in_hw, n):
+    buf = M.detection_model_bytes(in_hw) if in_hw == (800, 600) else M.detection_model_bytes(in_hw, (8, 16, 32, 32))
+    rng = np.random.default_rng(11)
+    x = (rng.random((n, 1) + in_hw, dtype=np.float32) - 0.5).astype(np.float32)
+    m = Model.load_bytes(buf)
+    assert m.input_shape() == [None, 1, in_hw[0], in_hw[1]]
+    got = m.run(x)
+    og = OracleGraph(buf)
+    exp = og.run_exact(x)
+    assert got.shape == exp.shape == (n, 1) + in_hw
+    assert np.array_equal(got, exp)
+    assert np.abs(got - og.run_torch(x)).max() < 1e-4  # fp32 tolerance vs the ONNX-operator semantics
+
+
+@pytest.mark.parametrize("n,width", [(3, 100), (5, 300), (1, 50)])
+def test_recognition_model_run_bit_exact(n, width):
+    buf = M.recognition_model_bytes()
+    crops = synth.synthetic_line_crops(1000 + n, n=n, width=min(width, 256))
+    x = np.full((n, 1, 64, width), -0.5, np.float32)
+    x[:, 0, :, :crops.shape[2]] = crops[:, :, :width]
+    m = Model.load_bytes(buf)
+    assert m.input_shape() == [None, 1, 64, None]
+    got = m.run(x)
+    og = OracleGraph(buf)
+    exp = og.run_exact(x)
+    assert got.shape == exp.shape == (width // 4, n, 97)
+    assert np.array_equal(got, exp)
+    assert np.abs(got - og.run_torch(x)).max() < 1e-3
+
+
+# ------------------------------------------------------------------ detection post-processing
+def _mask_engine_pair(h, w):
+    """Engines whose detection 'model' returns a chosen probability map, with model
+    dims == page dims, so that only threshold + components + rects are exercised."""
+    box = {}
+
+    def run(x):
+        return box["prob"].reshape(1, 1, h, w)
+
+    gpu = OcrEngine(detection_model=Model.from_callable([None, 1, h, w], run))
+
+    class Fake:
+        def input_shape(self):
+            return [None, 1, h, w]
+
+        def run(self, x):
+            return box["prob"].reshape(1, 1, h, w)
+
+    return box, gpu, OP.OcrEngine(detection_model=Fake())
+
+
+def _adversarial_masks(h, w):
+    rng = np.random.default_rng(42)
+    yield "empty", np.zeros((h, w), np.uint8)
+    yield "full", np.ones((h, w), np.uint8)
+    m = np.zeros((h, w), np.uint8)
+    m[10:60, 10:100] = 1
+    m[20:50, 20:90] = 0       # ring
+    m[28:42, 30:80] = 1       # island in the hole: NOT external
+    m[32:38, 40:70] = 0
+    m[34:36, 50:60] = 1       # island in the island's hole
+    yield "nested rings", m
+    m = np.zeros((h, w), np.uint8)
+    m[5, 5:60] = 1            # 1-px lines, single pixels, diagonals
+    m[10:70, 7] = 1
+    m[80, 80] = 1
+    for i in range(40):
+        m[20 + i, 100 + i] = 1
+        m[20 + i, 160 - i] = 1
+    m[0, :] = 1               # touching the frame
+    m[:, w - 1] = 1
+    yield "thin", m
+    m = (rng.random((h, w)) < 0.35).astype(np.uint8)
+    yield "noise35", m
+    m = (rng.random((h, w)) < 0.6).astype(np.uint8)
+    yield "noise60", m
+    m = np.zeros((h, w), np.uint8)
+    m[::2, ::2] = 1           # isolated pixels
+    yield "dots", m
+    m = np.zeros((h, w), np.uint8)
+    yy, xx = np.mgrid[0:h, 0:w]
+    m[((yy // 7 + xx // 9) % 2) == 0] = 1  # checkerboard of blocks: diagonal 8-connections
+    yield "checker", m
+    m = np.zeros((h, w), np.uint8)
+    for k in range(12):       # rotated blobs
+        cy, cx = rng.integers(15, h - 15), rng.integers(30, w - 30)
+        ang = rng.random() * np.pi
+        d = np.abs((yy - cy) * np.cos(ang) - (xx - cx) * np.sin(ang)) < 5
+        e = np.abs((yy - cy) * np.sin(ang) + (xx - cx) * np.cos(ang)) < 22
+        m[d & e] = 1
+    yield "rotated", m
+
+
+def test_component_rects_bit_exact_on_adversarial_masks():
+    h, w = 120, 200
+    box, gpu, ora = _mask_engine_pair(h, w)
+    page = np.zeros((1, h, w), np.float32)
+    inp = gpu.prepare_input(ImageSource.from_tensor(page, DimOrder.Chw))
+    for name, mask in _adversarial_masks(h, w):
+        box["prob"] = mask.astype(np.float32)
+        got = gpu.detect_words(inp)
+        exp = rects_of(ora.detect_words(page))
+        assert got.shape == exp.shape, name
+        assert np.array_equal(got, exp), name
+        # and the low-level pieces the oracle is built from agree on contour discovery order
+        if name == "nested rings":
+            assert len(clib.find_contours_external(mask)) == 1
+
+
+def test_detect_text_pixels_and_words_bit_exact_on_synthetic_pages():
+    buf = M.detection_model_bytes()
+    gpu = OcrEngine(detection_model=Model.load_bytes(buf))
+    ora = OP.OcrEngine(detection_model=OracleModel(OracleGraph(buf), "exact"))
+    for seed, hw in [(0, (1024, 1024)), (1, (700, 500)), (2, (1300, 900))]:
+        px = synth.synthetic_page(seed, hw[0], hw[1], lines=60)
+        inp = gpu.prepare_input(ImageSource.from_tensor(px, DimOrder.Hwc))
+        oin = ora.prepare_input(OP.ImageSource.from_tensor(px, "hwc"))
+        assert np.array_equal(gpu.detect_text_pixels(inp), ora.detect_text_pixels(oin)), hw
+        got = gpu.detect_words(inp)
+        exp = rects_of(ora.detect_words(oin))
+        assert len(exp) > 50
+        assert got.shape == exp.shape and np.array_equal(got, exp), hw
+
+
+def test_detect_words_batch_equals_single():
+    buf = M.detection_model_bytes()
+    gpu = OcrEngine(detection_model=Model.load_bytes(buf))
+    inps = [gpu.prepare_input(ImageSource.from_tensor(synth.synthetic_page(s, 512, 512, lines=30), DimOrder.Hwc)) for s in range(3)]
+    batch = gpu.detect_words_batch(inps)
+    for i, inp in enumerate(inps):
+        assert np.array_equal(batch[i], gpu.detect_words(inp))
+
+
+# ------------------------------------------------------------------ recognition
+def test_prepare_recognition_input_bit_exact():
+    rec = Model.load_bytes(M.recognition_model_bytes())
+    gpu = OcrEngine(recognition_model=rec)
+    ora = OP.OcrEngine(recognition_model=OracleModel(OracleGraph(M.recognition_model_bytes()), "exact"))
+    px = synth.synthetic_page(4, 400, 600, lines=20)
+    inp = gpu.prepare_input(ImageSource.from_tensor(px, DimOrder.Hwc))
+    oin = ora.prepare_input(OP.ImageSource.from_tensor(px, "hwc"))
+    rng = np.random.default_rng(9)
+    for _ in range(6):
+        words, x = [], 30 + int(rng.integers(0, 100))
+        y = int(rng.integers(20, 330))
+        for _ in range(int(rng.integers(1, 6))):
+            ww, hh = int(rng.integers(20, 70)), int(rng.integers(10, 26))
+            ang = float(rng.normal(0, 0.06))
+            up = (np.float32(np.sin(ang)), np.float32(np.cos(ang)))
+            words.append(RotatedRect.new((np.float32(x + ww / 2), np.float32(y + hh / 2 + rng.normal(0, 1.5))), up,
+                                         np.float32(ww), np.float32(hh)))
+            x += ww + int(rng.integers(4, 12))
+        got = gpu.prepare_recognition_input(inp, rects_of(words))
+        exp = ora.prepare_recognition_input(oin, words)
+        assert got.shape == exp.shape and np.array_equal(got, exp)
+    # a line hanging over the page edge (bounds checks of recognition.rs:100,112)
+    edge = [RotatedRect.new((np.float32(590.0), np.float32(395.0)), (np.float32(0.0), np.float32(1.0)), np.float32(60.0), np.float32(20.0))]
+    assert np.array_equal(gpu.prepare_recognition_input(inp, rects_of(edge)), ora.prepare_recognition_input(oin, edge))
+
+
+def test_full_pipeline_tokens_boxes_and_text_identical():
+    dbuf, rbuf = M.detection_model_bytes(), M.recognition_model_bytes()
+    gpu = OcrEngine(detection_model=Model.load_bytes(dbuf), recognition_model=Model.load_bytes(rbuf))
+    ora = OP.OcrEngine(detection_model=OracleModel(OracleGraph(dbuf), "exact"),
+                       recognition_model=OracleModel(OracleGraph(rbuf), "exact"))
+    px = synth.synthetic_page(5, 640, 768, lines=24)
+    inp = gpu.prepare_input(ImageSource.from_tensor(px, DimOrder.Hwc))
+    oin = ora.prepare_input(OP.ImageSource.from_tensor(px, "hwc"))
+    words = gpu.detect_words(inp)
+    owords = ora.detect_words(oin)
+    assert np.array_equal(words, rects_of(owords))
+    lines = gpu.find_text_lines(inp, words)
+    olines = ora.find_text_lines(oin, owords)
+    assert len(lines) == len(olines) > 10
+    for a, b in zip(lines, olines):
+        assert np.array_equal(a, rects_of(b))
+    got = gpu.recognize_text(inp, lines)
+    exp = ora.recognize_text(oin, olines)
+    assert len(got) == len(exp)
+    n_chars = 0
+    for g, e in zip(got, exp):
+        assert (g is None) == (e is None)
+        if g is None:
+            continue
+        assert str(g) == str(e)
+        assert [c.rect for c in g.chars()] == [c.rect.tlbr() for c in e.chars]
+        n_chars += len(e.chars)
+    assert n_chars > 100
+    assert gpu.get_text(inp) == ora.get_text(oin)
+    # allowed_chars masking (recognition.rs:547-561) on the real graph
+    gpu_d = OcrEngine(recognition_model=Model.load_bytes(rbuf), allowed_chars="0123456789")
+    ora_d = OP.OcrEngine(recognition_model=OracleModel(OracleGraph(rbuf), "exact"), allowed_chars="0123456789")
+    gd = gpu_d.recognize_text(gpu_d.prepare_input(ImageSource.from_tensor(px, DimOrder.Hwc)), lines[:6])
+    ed = ora_d.recognize_text(oin, olines[:6])
+    assert [str(x) if x else None for x in gd] == [str(x) if x else None for x in ed]
+    assert all(ch in "0123456789" for x in gd if x for ch in str(x))

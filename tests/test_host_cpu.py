@@ -1,0 +1,125 @@
+"""CPU-side checks of the product: the C-ABI library loads and exports every
+symbol include/ocrs_amd.h declares, and the host-only entry points
+(find_text_lines, ImageSource validation, error reporting) agree with the
+oracle.  No GPU compute is invoked here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import kat_util as K
+import ocrs_amd
+from ocrs_amd import _lib
+from oracle.geometry import Rect, RotatedRect
+from oracle.layout import find_text_lines as oracle_find_text_lines
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from ocrs_amd import build
+    build.build()
+    return _lib.lib()
+
+
+def test_library_exports_every_declared_symbol(lib):
+    hdr = open(os.path.join(ROOT, "include", "ocrs_amd.h")).read()
+    declared = set(re.findall(r"OCRS_API[^;(]*?\b(ocrs_\w+)\s*\(", hdr))
+    assert declared == set(_lib.DECLARED_SYMBOLS)
+    for name in sorted(declared):
+        assert hasattr(lib, name), name
+
+
+def test_header_cites_reference_for_every_entry_point():
+    hdr = open(os.path.join(ROOT, "include", "ocrs_amd.h")).read()
+    assert hdr.count(".rs:") >= 25
+
+
+def test_image_source_check_bytes(lib):  # preprocess.rs:274-321
+    for ln, w, h, err in [(100, 10, 10, None), (50, 10, 10, "length"), (128, 8, 8, "channel"), (0, 0, 10, "channel")]:
+        if err is None:
+            ocrs_amd.ImageSource.from_bytes(bytes(ln), (w, h))
+        else:
+            with pytest.raises(ocrs_amd.ImageSourceError, match=err):
+                ocrs_amd.ImageSource.from_bytes(bytes(ln), (w, h))
+
+
+def test_image_source_from_tensor():  # preprocess.rs:323-360
+    a = np.arange(25, dtype=np.uint8).reshape(1, 5, 5)
+    ocrs_amd.ImageSource.from_tensor(a, ocrs_amd.DimOrder.Chw)
+    with pytest.raises(ocrs_amd.ImageSourceError):
+        ocrs_amd.ImageSource.from_tensor(a, ocrs_amd.DimOrder.Hwc)
+    with pytest.raises(ocrs_amd.ImageSourceError):
+        ocrs_amd.ImageSource.from_tensor(np.zeros((0, 5, 5), np.uint8), ocrs_amd.DimOrder.Chw)
+
+
+def _host_find_text_lines(lib, words):
+    a = np.ascontiguousarray(np.array([w.to_array() for w in words], np.float32).reshape(-1, 6))
+    lr = C.POINTER(C.c_float)()
+    lo = C.POINTER(C.c_size_t)()
+    nl = C.c_size_t(0)
+    _lib.check(lib.ocrs_engine_find_text_lines(None, None, a.ctypes.data_as(C.POINTER(C.c_float)), C.c_size_t(len(a)),
+                                               C.byref(lr), C.byref(lo), C.byref(nl)))
+    offs = [lo[i] for i in range(nl.value + 1)]
+    flat = np.ctypeslib.as_array(lr, shape=(max(len(a), 1) * 6,))[: len(a) * 6].reshape(-1, 6).copy()
+    lib.ocrs_buffer_free(lr)
+    lib.ocrs_buffer_free(lo)
+    return [flat[offs[i]:offs[i + 1]] for i in range(nl.value)]
+
+
+def _same_lines(got, exp):
+    assert len(got) == len(exp)
+    for g, e in zip(got, exp):
+        ea = np.array([w.to_array() for w in e], np.float32).reshape(-1, 6)
+        assert g.shape == ea.shape
+        assert np.array_equal(g, ea)
+
+
+def test_find_text_lines_kat(lib):  # layout_analysis.rs:294-350
+    left = K.gen_rect_grid((0, 0), (10, 5), (5, 5), (3, 2))
+    lb = K.union_rects(left)
+    right = K.gen_rect_grid((0, lb[3] + 20), (10, 5), (5, 5), (3, 2))
+    words = K.xorshift_shuffle([RotatedRect.from_rect(Rect(*r)) for r in left + right], 1234)
+    got = _host_find_text_lines(lib, words)
+    assert len(got) == 20 and all(len(l) == 5 for l in got)
+    _same_lines(got, oracle_find_text_lines(words))
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_find_text_lines_matches_oracle_on_random_layouts(lib, seed):
+    rng = np.random.default_rng(seed)
+    words = []
+    cols = int(rng.integers(1, 4))
+    for c in range(cols):
+        x0 = 20 + c * 330
+        y = 20
+        for _ in range(int(rng.integers(8, 25))):
+            h = int(rng.integers(10, 22))
+            x = x0 + int(rng.integers(0, 20))
+            for _ in range(int(rng.integers(1, 8))):
+                w = int(rng.integers(15, 60))
+                if x + w > x0 + 300:
+                    break
+                ang = float(rng.normal(0, 0.03))
+                up = (np.float32(np.sin(ang)), np.float32(np.cos(ang)))
+                words.append(RotatedRect.new((np.float32(x + w / 2), np.float32(y + h / 2)), up, np.float32(w + 6), np.float32(h + 6)))
+                x += w + int(rng.integers(4, 14))
+            y += h + int(rng.integers(4, 30))
+    order = rng.permutation(len(words))
+    words = [words[i] for i in order]
+    _same_lines(_host_find_text_lines(lib, words), oracle_find_text_lines(words))
+
+
+def test_find_text_lines_empty(lib):
+    assert _host_find_text_lines(lib, []) == []
+
+
+def test_model_file_errors_are_reported_not_fatal(lib):
+    h = C.c_void_p()
+    st = lib.ocrs_model_load_bytes(C.c_char_p(b"garbage"), C.c_size_t(7), C.byref(h))
+    assert st == 8 and b"model file" in lib.ocrs_last_error()
+    st = lib.ocrs_model_load_file(b"/nonexistent/model.ocrsm", C.byref(h))
+    assert st == 8 and b"cannot open" in lib.ocrs_last_error()
