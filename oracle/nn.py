@@ -95,8 +95,8 @@ class OracleGraph:
                 raise ValueError("bad op %d" % t)
             slots[op["out"]] = y
         out = slots[self.out_slot]
-        if self.kind == 0:  # detection: NHWC with C=1 -> NCHW
-            out = out.reshape(out.shape[0], 1, out.shape[1], out.shape[2])
+        if self.kind == 0:  # detection: NHWC -> NCHW
+            out = np.ascontiguousarray(out.transpose(0, 3, 1, 2))
         return (out, slots) if return_slots else out
 
     # ------------------------------------------------------------ torch back-end
