@@ -1,0 +1,258 @@
+#!/usr/bin/env python
+"""bench.py — ocrs hot path on MI355X (BASELINE.json metric: pages/sec end-to-end
+on 1024x1024 pages + lines/sec recognition).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the full pipeline over one batch of synthetic pages
+that are already resident in HBM:  prepare_input -> detect_words (CNN @ 800x600,
+threshold, components -> rects) -> find_text_lines (host) -> recognize_text
+(line crops, CRNN, greedy CTC) -> TextLines on the host.  N>1: one process per
+GPU (torch.distributed / RCCL), pages sharded across ranks with no collective
+on the compute path (weak scaling: every rank owns `--pages` pages per step);
+the only exchange is the final result gather.
+
+Prints ONE JSON line (rank 0).  Real weights are not obtainable offline, so
+the models are the SURVEY.md §2.4 architectures with seeded synthetic weights.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+# cap host OpenMP pools before numpy/torch/oracle load (256-core GPU hosts)
+os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+os.environ.setdefault("GOMP_SPINCOUNT", "0")
+_PHYS = max(1, (os.cpu_count() or 2) // 2)
+os.environ.setdefault("OMP_NUM_THREADS", str(min(_PHYS, 32)))
+os.environ.setdefault("MKL_NUM_THREADS", os.environ["OMP_NUM_THREADS"])
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md "Peak FP32 (matrix)"
+PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md "HBM3E peak BW" (spec)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--pages", type=int, default=8, help="pages per step per GPU")
+    ap.add_argument("--lines", type=int, default=80, help="text lines per synthetic page")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-pages", type=int, default=3, help="pages in the bounded CPU-baseline sample")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--profile-hint", action="store_true", help="print per-stage and per-kernel tables to stderr")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    import torch.distributed as dist
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the ocrs_amd engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    import ocrs_amd
+    from ocrs_amd import DimOrder, Model, OcrEngine, _lib, models, synth
+    from ocrs_amd import dist as D
+
+    if not os.path.exists(_lib.LIB_PATH):
+        from ocrs_amd import build
+        build.build()
+    L = _lib.lib()
+    _lib.check(L.ocrs_set_device(local_rank))
+
+    det = Model.load_bytes(models.synthetic_detection_bytes())
+    rec = Model.load_bytes(models.synthetic_recognition_bytes())
+    engine = OcrEngine(detection_model=det, recognition_model=rec)
+
+    # ---- synthetic pages, resident in HBM before the timed region
+    B, H, W = args.pages, 1024, 1024
+    host_pages = [synth.synthetic_page(rank * B + i, H, W, lines=args.lines) for i in range(B)]
+    dptrs = []
+    for pg in host_pages:
+        p = C.c_void_p()
+        _lib.check(L.ocrs_device_malloc(C.c_size_t(pg.nbytes), C.byref(p)))
+        _lib.check(L.ocrs_device_upload(p, pg.ctypes.data_as(C.c_void_p), C.c_size_t(pg.nbytes)))
+        dptrs.append(p)
+
+    def step():
+        inputs = [engine.prepare_input_device(p.value, np.uint8, DimOrder.Hwc, H, W, 3) for p in dptrs]
+        words = engine.detect_words_batch(inputs)
+        rects, loffs, poffs = engine.find_text_lines_batch_raw(words)
+        chars, coffs = engine.recognize_text_batch_raw(inputs, rects, loffs, poffs)
+        return words, (rects, loffs, poffs), (chars, coffs)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        _lib.check(L.ocrs_device_synchronize())
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        out = step()
+    engine.enable_timing(0 if args.no_kernel_timing else 2)
+    engine.stage_times(reset=True)
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    stages = engine.stage_times(reset=False)
+    kstats = engine.kernel_stats(reset=True)
+    engine.enable_timing(0)
+
+    words, (rects, loffs, poffs), (chars, coffs) = out
+    n_lines = len(loffs) - 1
+    n_words = sum(len(w) for w in words)
+    n_chars = len(chars)
+    # final result gather (the only inter-GPU exchange): decoded text of every page to rank 0
+    codes = chars["ch"]
+    local_payload = {}
+    for i in range(B):
+        page_lines = []
+        for li in range(int(poffs[i]), int(poffs[i + 1])):
+            a, b = int(coffs[li]), int(coffs[li + 1])
+            page_lines.append("".join(map(chr, codes[a:b])) if b > a else None)
+        local_payload[str(rank * B + i)] = page_lines
+    gathered = D.gather_results(local_payload)
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        cnt = torch.tensor([n_lines, n_words, n_chars], dtype=torch.int64, device="cuda")
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+        n_lines_all = int(cnt[0].item())
+    else:
+        n_lines_all = n_lines
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    pages_total = world * B * args.steps
+    value = pages_total / elapsed
+    result = {
+        "metric": "pages/sec end-to-end (1024x1024)",
+        "value": round(value, 3),
+        "unit": "pages/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(1000.0 * elapsed / args.steps, 3),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": "full pipeline (BASELINE.json configs[3]): %d synthetic 1024x1024 RGB u8 pages per step per GPU, "
+                        "~%d lines/page; prepare_input -> detect_words (U-Net @800x600 + threshold + components->rects) "
+                        "-> find_text_lines (host) -> recognize_text (crops, CRNN, greedy CTC)" % (B, args.lines),
+            "pages_per_step_per_gpu": B,
+            "lines_per_page": round(n_lines / B, 1),
+            "words_per_page": round(n_words / B, 1),
+            "weights": "seeded synthetic weights on the SURVEY.md §2.4 architectures (real ocrs weights unobtainable offline)",
+            "parallelism": "page-sharded, %d process(es) x 1 GPU, no data-path collective" % world,
+        },
+        "lines_per_s": round(n_lines_all * args.steps / elapsed, 1),
+        "chars_last_step": n_chars,
+        "gathered_pages": sum(len(g) for g in gathered if g),
+    }
+
+    # ---- stage table + roofline of the dominant kernel (HIP events, timed region)
+    result["stages_ms_per_step"] = {k: round(v[0] / args.steps, 4) for k, v in stages.items() if v[0] > 0}
+    kt = {k: v for k, v in kstats.items() if v["launches"] > 0}
+    if kt:
+        dom_name, dom = max(kt.items(), key=lambda kv: kv[1]["ms"])
+        is_mfma = dom_name.startswith("gemm_") and dom_name not in ("gemm_pointwise_mfma", "gemm_convt_mfma")
+        avg_ms = dom["ms"] / dom["launches"]
+        if is_mfma:
+            achieved = dom["flops"] / dom["launches"] / (avg_ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4)}
+        else:
+            achieved = dom["bytes"] / dom["launches"] / (avg_ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": PEAK_HBM_GBS,
+                    "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBS, 4)}
+        roof["avg_launch_ms"] = round(avg_ms, 5)
+        roof["launches_per_step"] = round(dom["launches"] / args.steps, 2)
+        roof["share_of_gpu_time"] = round(dom["ms"] / max(1e-9, sum(v["ms"] for v in kt.values())), 3)
+        roof["traffic"] = None  # HBM bytes from PMC counters: profiles/ (separate rocprofv3 --pmc pass)
+        result["roofline"] = roof
+        result["kernels_ms_per_step"] = {k: round(v["ms"] / args.steps, 4) for k, v in sorted(kt.items(), key=lambda kv: -kv[1]["ms"])}
+        if args.profile_hint:
+            for k, v in sorted(kt.items(), key=lambda kv: -kv[1]["ms"]):
+                tf = v["flops"] / max(v["ms"], 1e-9) / 1e9
+                gb = v["bytes"] / max(v["ms"], 1e-9) / 1e6
+                print("%-24s %8.3f ms/step %6d launches/step %8.2f TFLOP/s %8.1f GB/s" % (
+                    k, v["ms"] / args.steps, v["launches"] // args.steps, tf, gb), file=sys.stderr)
+            for k, v in stages.items():
+                print("stage %-18s %8.3f ms/step" % (k, v[0] / args.steps), file=sys.stderr)
+
+    # ---- CPU baseline: the oracle on the host cores, bounded sample (rank 0, N=1 only)
+    if world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(host_pages[: args.cpu_pages], engine)
+    print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(pages, engine):
+    """The CPU restatement (oracle/) timed on this box's host cores: C for image ops,
+    contours, crops and CTC; PyTorch-CPU fp32 for the two networks (what RTen's CPU path
+    does); layout analysis through the product's host C++ (it is host code in both
+    paths).  Reported next to the GPU number; it is not the target."""
+    import torch
+    from oracle import pipeline as OP
+    from oracle.nn import OracleGraph, OracleModel
+    from ocrs_amd import models
+
+    cores = int(os.environ["OMP_NUM_THREADS"])
+    torch.set_num_threads(cores)
+    det = OracleModel(OracleGraph(models.synthetic_detection_bytes()), "torch")
+    rec = OracleModel(OracleGraph(models.synthetic_recognition_bytes()), "torch")
+    ora = OP.OcrEngine(detection_model=det, recognition_model=rec)
+    from oracle.geometry import RotatedRect
+
+    def run(pg):
+        inp = ora.prepare_input(OP.ImageSource.from_tensor(pg, "hwc"))
+        words = ora.detect_words(inp)
+        arr = np.array([w.to_array() for w in words], np.float32).reshape(-1, 6)
+        lines = engine.find_text_lines(None, arr)  # host C++ (no GPU work)
+        olines = [[RotatedRect.from_array(r) for r in l] for l in lines]
+        return ora.recognize_text(inp, olines), len(olines)
+
+    run(pages[0][:256, :256].copy())  # warm torch / oneDNN
+    t0 = time.perf_counter()
+    n_lines = 0
+    for pg in pages:
+        _, nl = run(pg)
+        n_lines += nl
+    dt = time.perf_counter() - t0
+    return {"value": round(len(pages) / dt, 4), "unit": "pages/s", "cores": cores, "kind": "port",
+            "lines_per_s": round(n_lines / dt, 2),
+            "sample": "%d of the same synthetic 1024x1024 pages, full pipeline, oracle (C image/contour/crop/CTC + "
+                      "torch-CPU fp32 networks, %d threads) in %.1f s" % (len(pages), cores, dt)}
+
+
+if __name__ == "__main__":
+    main()

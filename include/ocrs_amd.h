@@ -175,6 +175,15 @@ OCRS_API ocrs_status ocrs_engine_find_text_lines(const ocrs_engine* e, const ocr
                                         size_t n_words, float** line_rects, size_t** line_offsets,
                                         size_t* n_lines);
 
+/* The same for several pages at once (one host thread per page).  Words of page p
+ * are word_rects[6*word_offsets[p] .. 6*word_offsets[p+1]).  *line_rects receives all
+ * words, permuted into reading order page by page; line i (numbered across pages) owns
+ * rects [line_offsets[i], line_offsets[i+1]); page p owns lines
+ * [page_line_offsets[p], page_line_offsets[p+1]). */
+OCRS_API ocrs_status ocrs_engine_find_text_lines_batch(const ocrs_engine* e, size_t n_pages, const float* word_rects,
+                                                       const size_t* word_offsets, float** line_rects,
+                                                       size_t** line_offsets, size_t** page_line_offsets);
+
 /* One recognised character: TextChar (text_items.rs:48-54). */
 typedef struct ocrs_text_char {
     uint32_t ch;                      /* Unicode scalar value */
@@ -224,10 +233,18 @@ OCRS_API ocrs_status ocrs_device_synchronize(void);
  * on the stream it is launched on; ocrs_engine_stage_times returns accumulated
  * milliseconds and launch counts since the last reset.  Stage names:
  * ocrs_stage_name(i), i < ocrs_stage_count(). */
-OCRS_API ocrs_status ocrs_engine_enable_timing(ocrs_engine* e, int enable);
+OCRS_API ocrs_status ocrs_engine_enable_timing(ocrs_engine* e, int enable); /* 0 off, 1 stages, 2 stages + kernels */
 OCRS_API int ocrs_stage_count(void);
 OCRS_API const char* ocrs_stage_name(int stage);
 OCRS_API ocrs_status ocrs_engine_stage_times(ocrs_engine* e, double* ms, uint64_t* launches, int reset);
+
+/* Kernel-class timers of the model executor (enable_timing(e, 2)): every launch
+ * is bracketed by HIP events on its stream; flops/bytes are the ALGORITHMIC
+ * figures of DESIGN.md §6 summed over the launches. */
+OCRS_API int ocrs_kernel_class_count(void);
+OCRS_API const char* ocrs_kernel_class_name(int cls);
+OCRS_API ocrs_status ocrs_engine_kernel_stats(ocrs_engine* e, double* ms, uint64_t* launches, double* flops,
+                                              double* bytes, int reset);
 
 #ifdef __cplusplus
 }

@@ -335,6 +335,54 @@ class OcrEngine:
         lib().ocrs_buffer_free(lo)
         return [flat[offs[i]:offs[i + 1]] for i in range(nl.value)]
 
+    def find_text_lines_batch_raw(self, words_per_page):
+        """Threaded over pages.  Returns (rects [n,6], line_offsets, page_line_offsets) as numpy arrays."""
+        n = len(words_per_page)
+        woffs = np.zeros(n + 1, dtype=np.uintp)
+        for i, w in enumerate(words_per_page):
+            woffs[i + 1] = woffs[i] + len(w)
+        allw = np.ascontiguousarray(np.concatenate([_rects_to_array(w) for w in words_per_page]) if n else np.zeros((0, 6), np.float32))
+        lr = C.POINTER(C.c_float)()
+        lo = C.POINTER(C.c_size_t)()
+        po = C.POINTER(C.c_size_t)()
+        check(lib().ocrs_engine_find_text_lines_batch(self._h, C.c_size_t(n), allw.ctypes.data_as(C.POINTER(C.c_float)),
+                                                      woffs.ctypes.data_as(C.POINTER(C.c_size_t)), C.byref(lr), C.byref(lo),
+                                                      C.byref(po)))
+        poffs = np.ctypeslib.as_array(po, shape=(n + 1,)).astype(np.uintp)
+        nl = int(poffs[n])
+        loffs = np.ctypeslib.as_array(lo, shape=(nl + 1,)).astype(np.uintp)
+        rects = np.ctypeslib.as_array(lr, shape=(max(len(allw), 1) * 6,))[: len(allw) * 6].reshape(-1, 6).copy()
+        for p in (lr, lo, po):
+            lib().ocrs_buffer_free(p)
+        return rects, loffs, poffs
+
+    def recognize_text_batch_raw(self, inputs, rects, line_offsets, page_line_offsets):
+        """Packed form of recognize_text_batch: returns (chars, char_offsets) where chars is a
+        structured array (ch, top, left, bottom, right) and line i owns chars[char_offsets[i]:char_offsets[i+1]]."""
+        n = len(inputs)
+        pages = (C.c_void_p * n)(*[i._h for i in inputs])
+        rects = np.ascontiguousarray(rects, np.float32)
+        lo = np.ascontiguousarray(line_offsets, np.uintp)
+        po = np.ascontiguousarray(page_line_offsets, np.uintp)
+        nl = len(lo) - 1
+        chars = C.POINTER(_lib.TextCharC)()
+        coffs = C.POINTER(C.c_size_t)()
+        check(lib().ocrs_engine_recognize_text_batch(
+            self._h, pages, C.c_size_t(n), po.ctypes.data_as(C.POINTER(C.c_size_t)),
+            rects.ctypes.data_as(C.POINTER(C.c_float)), lo.ctypes.data_as(C.POINTER(C.c_size_t)), C.c_size_t(nl),
+            C.byref(chars), C.byref(coffs)))
+        co = np.ctypeslib.as_array(coffs, shape=(nl + 1,)).astype(np.uintp)
+        total = int(co[nl])
+        dt = np.dtype([("ch", np.uint32), ("top", np.int32), ("left", np.int32), ("bottom", np.int32), ("right", np.int32)])
+        if total:
+            buf = (C.c_char * (total * dt.itemsize)).from_address(C.addressof(chars.contents))
+            arr = np.frombuffer(buf, dtype=dt, count=total).copy()
+        else:
+            arr = np.zeros(0, dt)
+        lib().ocrs_buffer_free(chars)
+        lib().ocrs_buffer_free(coffs)
+        return arr, co
+
     # ---- lib.rs:237-256
     def recognize_text(self, inp, lines):
         return self.recognize_text_batch([inp], [lines])[0]
@@ -411,8 +459,19 @@ class OcrEngine:
         return s
 
     # ---- measurement hooks
-    def enable_timing(self, on=True):
-        check(lib().ocrs_engine_enable_timing(self._h, 1 if on else 0))
+    def enable_timing(self, level=1):
+        """0 off, 1 per-stage HIP-event timers, 2 also per-launch kernel-class timers."""
+        check(lib().ocrs_engine_enable_timing(self._h, int(level)))
+
+    def kernel_stats(self, reset=True):
+        n = lib().ocrs_kernel_class_count()
+        ms = (C.c_double * n)()
+        cnt = (C.c_uint64 * n)()
+        fl = (C.c_double * n)()
+        by = (C.c_double * n)()
+        check(lib().ocrs_engine_kernel_stats(self._h, ms, cnt, fl, by, 1 if reset else 0))
+        return {lib().ocrs_kernel_class_name(i).decode(): dict(ms=ms[i], launches=int(cnt[i]), flops=fl[i], bytes=by[i])
+                for i in range(n)}
 
     def stage_times(self, reset=True):
         n = lib().ocrs_stage_count()

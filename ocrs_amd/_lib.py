@@ -49,10 +49,12 @@ DECLARED_SYMBOLS = [
     "ocrs_engine_prepare_input", "ocrs_engine_prepare_input_device", "ocrs_page_free", "ocrs_page_dims",
     "ocrs_page_image", "ocrs_engine_detect_words", "ocrs_engine_detect_words_batch",
     "ocrs_engine_detect_text_pixels", "ocrs_engine_detection_threshold", "ocrs_engine_find_text_lines",
+    "ocrs_engine_find_text_lines_batch",
     "ocrs_engine_recognize_text", "ocrs_engine_recognize_text_batch", "ocrs_engine_recognize_tokens",
     "ocrs_engine_prepare_recognition_input", "ocrs_engine_get_text", "ocrs_device_malloc", "ocrs_device_free",
     "ocrs_device_upload", "ocrs_device_synchronize", "ocrs_engine_enable_timing", "ocrs_stage_count",
-    "ocrs_stage_name", "ocrs_engine_stage_times",
+    "ocrs_stage_name", "ocrs_engine_stage_times", "ocrs_kernel_class_count", "ocrs_kernel_class_name",
+    "ocrs_engine_kernel_stats",
 ]
 
 _lib = None
@@ -70,6 +72,7 @@ def lib():
         L.ocrs_engine_detection_threshold.restype = C.c_float
         L.ocrs_engine_detection_threshold.argtypes = [C.c_void_p]
         L.ocrs_stage_name.restype = C.c_char_p
+        L.ocrs_kernel_class_name.restype = C.c_char_p
         L.ocrs_buffer_free.argtypes = [C.c_void_p]
         for name in ("ocrs_model_free", "ocrs_engine_free", "ocrs_page_free"):
             getattr(L, name).argtypes = [C.c_void_p]

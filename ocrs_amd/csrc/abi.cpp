@@ -371,6 +371,53 @@ ocrs_status ocrs_engine_find_text_lines(const ocrs_engine* e, const ocrs_page* p
     });
 }
 
+ocrs_status ocrs_engine_find_text_lines_batch(const ocrs_engine* e, size_t n_pages, const float* word_rects,
+                                              const size_t* word_offsets, float** line_rects, size_t** line_offsets,
+                                              size_t** page_line_offsets) {
+    (void)e;
+    return guarded([&] {
+        if (!word_offsets || !line_rects || !line_offsets || !page_line_offsets)
+            fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
+        std::vector<std::vector<std::vector<RotatedRect>>> per_page(n_pages);
+        std::vector<std::string> errors(n_pages);
+        auto work = [&](size_t p) {
+            try {
+                std::vector<RotatedRect> words;
+                for (size_t k = word_offsets[p]; k < word_offsets[p + 1]; k++)
+                    words.push_back(RotatedRect::from_array(word_rects + 6 * k));
+                per_page[p] = find_text_lines(words);
+            } catch (const std::exception& ex) {
+                errors[p] = ex.what();
+            }
+        };
+        if (n_pages <= 1) {
+            for (size_t p = 0; p < n_pages; p++) work(p);
+        } else {
+            std::vector<std::thread> th;
+            for (size_t p = 0; p < n_pages; p++) th.emplace_back(work, p);
+            for (auto& t : th) t.join();
+        }
+        for (const std::string& er : errors)
+            if (!er.empty()) fail(OCRS_ERR_RUN_FAILED, "%s", er.c_str());
+        std::vector<float> flat;
+        std::vector<size_t> loffs{0}, poffs{0};
+        for (size_t p = 0; p < n_pages; p++) {
+            for (const auto& l : per_page[p]) {
+                for (const RotatedRect& r : l) {
+                    float a[6];
+                    r.to_array(a);
+                    flat.insert(flat.end(), a, a + 6);
+                }
+                loffs.push_back(flat.size() / 6);
+            }
+            poffs.push_back(loffs.size() - 1);
+        }
+        *line_rects = dup_buffer(flat);
+        *line_offsets = dup_buffer(loffs);
+        *page_line_offsets = dup_buffer(poffs);
+    });
+}
+
 ocrs_status ocrs_engine_recognize_text_batch(const ocrs_engine* e, const ocrs_page* const* pages, size_t n_pages,
                                              const size_t* page_line_offsets, const float* line_rects,
                                              const size_t* line_offsets, size_t n_lines, ocrs_text_char** chars,
@@ -444,7 +491,7 @@ ocrs_status ocrs_engine_prepare_recognition_input(const ocrs_engine* e, const oc
         k::LineDesc d{};
         d.page = 0; d.poly_off = 0; d.poly_n = (int32_t)ln.polygon.size();
         d.top = ln.bounds.top; d.left = ln.bounds.left; d.bh = ln.bounds.height(); d.bw = ln.bounds.width();
-        d.resized_w = rw; d.out_row = 0;
+        d.resized_w = rw; d.out_w = rw; d.out_off = 0;
         std::vector<int32_t> poly;
         for (const PointI& p : ln.polygon) { poly.push_back(p.y); poly.push_back(p.x); }
         const float* hp = page->grey.as<float>();
@@ -460,7 +507,7 @@ ocrs_status ocrs_engine_prepare_recognition_input(const ocrs_engine* e, const oc
         OCRS_HIP(hipMemcpyAsync(d_poly, poly.data(), poly.size() * 4, hipMemcpyHostToDevice, ws.s()));
         std::vector<float> host((size_t)rec_h * rw);
         if (rw > 0) {
-            k::crop_lines(d_pages, d_hw, d_desc, d_poly, 1, rec_h, rw, d_out, ws.s());
+            k::crop_lines(d_pages, d_hw, d_desc, d_poly, 1, rec_h, d_out, ws.s());
             OCRS_HIP(hipMemcpyAsync(host.data(), d_out, host.size() * 4, hipMemcpyDeviceToHost, ws.s()));
         }
         ws.sync();
@@ -515,6 +562,23 @@ ocrs_status ocrs_engine_enable_timing(ocrs_engine* e, int enable) {
     return guarded([&] {
         if (!e) fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
         e->timers.enabled = enable != 0;
+        e->timers.kernels_enabled = enable >= 2;
+    });
+}
+int ocrs_kernel_class_count(void) { return KC_COUNT; }
+const char* ocrs_kernel_class_name(int cls) { return cls >= 0 && cls < KC_COUNT ? kKernelClassNames[cls] : ""; }
+ocrs_status ocrs_engine_kernel_stats(ocrs_engine* e, double* ms, uint64_t* launches, double* flops, double* bytes,
+                                     int reset) {
+    return guarded([&] {
+        if (!e) fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
+        e->timers.collect();
+        for (int i = 0; i < KC_COUNT; i++) {
+            if (ms) ms[i] = e->timers.kms[i];
+            if (launches) launches[i] = e->timers.klaunches[i];
+            if (flops) flops[i] = e->timers.kflops[i];
+            if (bytes) bytes[i] = e->timers.kbytes[i];
+        }
+        if (reset) e->timers.reset();
     });
 }
 int ocrs_stage_count(void) { return ST_COUNT; }

@@ -11,6 +11,11 @@ const char* const kStageNames[ST_COUNT] = {
     "prepare_image", "resize_to_model", "detection_cnn", "resize_threshold", "ccl",      "contour_rects",
     "line_crop",     "rec_conv",        "rec_gru",       "rec_head",         "ctc_decode"};
 
+const char* const kKernelClassNames[KC_COUNT] = {
+    "gemm_conv3x3_mfma", "gemm_pointwise_mfma", "gemm_convt_mfma", "gemm_gru_input_mfma", "gemm_gru_hidden_mfma",
+    "gemm_linear_mfma",  "dwconv3x3",           "conv_direct",     "pool",                "padcat",
+    "conv1x1_sigmoid",   "gru_gates",           "logsoftmax_argmax", "other"};
+
 // ---------------------------------------------------------------- DevicePool
 static size_t round_size(size_t n) {
     // 256 B granularity below 1 MiB, then 1/8-octave buckets: bounded waste, good reuse.
@@ -106,7 +111,16 @@ hipEvent_t StageTimers::get_event() {
 int StageTimers::begin(int stage, hipStream_t s, uint64_t n_launches) {
     if (!enabled) return -1;
     std::lock_guard<std::mutex> g(mu);
-    Pending p{stage, get_event(), get_event(), n_launches};
+    Pending p{stage, get_event(), get_event(), n_launches, false, 0.0, 0.0};
+    OCRS_HIP(hipEventRecord(p.a, s));
+    pending.push_back(p);
+    return (int)pending.size() - 1;
+}
+
+int StageTimers::kbegin(int cls, hipStream_t s, double flops, double bytes) {
+    if (!enabled || !kernels_enabled) return -1;
+    std::lock_guard<std::mutex> g(mu);
+    Pending p{cls, get_event(), get_event(), 1, true, flops, bytes};
     OCRS_HIP(hipEventRecord(p.a, s));
     pending.push_back(p);
     return (int)pending.size() - 1;
@@ -124,8 +138,15 @@ void StageTimers::collect() {
     for (auto& p : pending) {
         float t = 0.f;
         if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&t, p.a, p.b) == hipSuccess) {
-            ms[p.stage] += t;
-            launches[p.stage] += p.n;
+            if (p.kernel) {
+                kms[p.stage] += t;
+                klaunches[p.stage] += 1;
+                kflops[p.stage] += p.flops;
+                kbytes[p.stage] += p.bytes;
+            } else {
+                ms[p.stage] += t;
+                launches[p.stage] += p.n;
+            }
         }
         free_events_.push_back(p.a);
         free_events_.push_back(p.b);
@@ -136,6 +157,7 @@ void StageTimers::collect() {
 void StageTimers::reset() {
     std::lock_guard<std::mutex> g(mu);
     for (int i = 0; i < ST_COUNT; i++) { ms[i] = 0; launches[i] = 0; }
+    for (int i = 0; i < KC_COUNT; i++) { kms[i] = 0; klaunches[i] = 0; kflops[i] = 0; kbytes[i] = 0; }
 }
 
 }  // namespace ocrs

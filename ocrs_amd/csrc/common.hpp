@@ -121,14 +121,29 @@ enum Stage {
 };
 extern const char* const kStageNames[ST_COUNT];
 
+// Kernel classes of the model executor, timed individually (HIP events around each
+// launch) when kernel timing is on; flops/bytes are ALGORITHMIC.
+enum KernelClass {
+    KC_GEMM_CONV3X3 = 0, KC_GEMM_POINTWISE, KC_GEMM_CONVT, KC_GEMM_GRU_INPUT, KC_GEMM_GRU_HIDDEN, KC_GEMM_LINEAR,
+    KC_DWCONV3X3, KC_CONV_DIRECT, KC_POOL, KC_PADCAT, KC_CONV1X1_SIGMOID, KC_GRU_GATES, KC_LOGSOFTMAX_ARGMAX,
+    KC_OTHER, KC_COUNT
+};
+extern const char* const kKernelClassNames[KC_COUNT];
+
 struct StageTimers {
     bool enabled = false;
+    bool kernels_enabled = false;
     std::mutex mu;
     double ms[ST_COUNT] = {0};
     uint64_t launches[ST_COUNT] = {0};
-    struct Pending { int stage; hipEvent_t a, b; uint64_t n; };
+    double kms[KC_COUNT] = {0};
+    uint64_t klaunches[KC_COUNT] = {0};
+    double kflops[KC_COUNT] = {0};
+    double kbytes[KC_COUNT] = {0};
+    struct Pending { int stage; hipEvent_t a, b; uint64_t n; bool kernel; double flops, bytes; };
     std::vector<Pending> pending;
     int begin(int stage, hipStream_t s, uint64_t n_launches);  // returns token (-1 when disabled)
+    int kbegin(int cls, hipStream_t s, double flops, double bytes);
     void end(int token, hipStream_t s);
     void collect();  // after a stream sync
     void reset();

@@ -277,96 +277,96 @@ void ocrs_engine::recognize(const ocrs_page* const* pages, size_t n_pages,
     const bool callback = recognition->is_callback();
     const uint8_t* d_excl = has_excluded ? d_excluded.as<uint8_t>() : nullptr;
 
-    for (auto& kv : groups) {
-        const uint32_t gw = kv.first;
-        const std::vector<size_t>& members = kv.second;
-        if (gw == 0) continue;  // zero-width lines produce no input and no text
-        // reference: chunks of 20 (recognition.rs:450); rows are independent, so the HIP
-        // executor takes bigger chunks, bounded by activation memory.
-        const size_t max_chunk = callback ? 20 : std::max<size_t>(1, 307200 / gw);
-        for (size_t c0 = 0; c0 < members.size(); c0 += max_chunk) {
-            const size_t nb = std::min(max_chunk, members.size() - c0);
-            // ---- crop + resize + pad (recognition.rs:135-158)
-            std::vector<k::LineDesc> descs(nb);
-            std::vector<int32_t> poly;
-            for (size_t j = 0; j < nb; j++) {
-                const RecLine& ln = lines[members[c0 + j]];
-                k::LineDesc& d = descs[j];
+    // ---- crop + resize + pad every line into its width group's batch (recognition.rs:135-158),
+    // one launch for all lines of all groups
+    struct Chunk { uint32_t gw; std::vector<size_t> members; int64_t off; float* ptr = nullptr; };
+    std::vector<Chunk> chunks;
+    {
+        int64_t off = 0;
+        for (auto& kv : groups) {
+            const uint32_t gw = kv.first;
+            if (gw == 0) continue;  // zero-width lines produce no input and no text
+            // reference: chunks of 20 (recognition.rs:450); rows are independent, so the HIP
+            // executor takes bigger chunks, bounded by activation memory (~8 KB per input pixel column).
+            const size_t max_chunk = callback ? 20 : std::max<size_t>(1, 2457600 / gw);
+            for (size_t c0 = 0; c0 < kv.second.size(); c0 += max_chunk) {
+                Chunk ch;
+                ch.gw = gw;
+                ch.members.assign(kv.second.begin() + c0, kv.second.begin() + std::min(kv.second.size(), c0 + max_chunk));
+                ch.off = off;
+                off += (int64_t)ch.members.size() * rec_h * gw;
+                chunks.push_back(std::move(ch));
+            }
+        }
+        std::vector<k::LineDesc> descs;
+        std::vector<int32_t> poly;
+        for (const Chunk& ch : chunks)
+            for (size_t j = 0; j < ch.members.size(); j++) {
+                const RecLine& ln = lines[ch.members[j]];
+                k::LineDesc d{};
                 d.page = (int32_t)ln.page;
                 d.poly_off = (int32_t)(poly.size() / 2);
                 d.poly_n = (int32_t)ln.polygon.size();
                 d.top = ln.bounds.top; d.left = ln.bounds.left;
                 d.bh = ln.bounds.height(); d.bw = ln.bounds.width();
                 d.resized_w = (int32_t)ln.resized_width;
-                d.out_row = (int32_t)j;
+                d.out_w = (int32_t)ch.gw;
+                d.out_off = ch.off + (int64_t)j * rec_h * ch.gw;
+                descs.push_back(d);
                 for (const PointI& p : ln.polygon) { poly.push_back(p.y); poly.push_back(p.x); }
             }
-            k::LineDesc* d_descs = ws.alloc_n<k::LineDesc>(nb);
-            int32_t* d_poly = ws.alloc_n<int32_t>(poly.size());
-            OCRS_HIP(hipMemcpyAsync(d_descs, descs.data(), nb * sizeof(k::LineDesc), hipMemcpyHostToDevice, st));
-            OCRS_HIP(hipMemcpyAsync(d_poly, poly.data(), poly.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
-            float* d_batch = ws.alloc_n<float>(nb * rec_h * gw);
-            {
-                StageScope sc(T, ST_LINE_CROP, st);
-                k::crop_lines(d_pages, d_hw, d_descs, d_poly, (int)nb, (int)rec_h, (int)gw, d_batch, st);
-            }
-            ws.sync();  // descs/poly are host temporaries
+        if (descs.empty()) {
+            *rec_lines_out = std::move(lines);
+            return;
+        }
+        k::LineDesc* d_descs = ws.alloc_n<k::LineDesc>(descs.size());
+        int32_t* d_poly = ws.alloc_n<int32_t>(poly.size());
+        OCRS_HIP(hipMemcpyAsync(d_descs, descs.data(), descs.size() * sizeof(k::LineDesc), hipMemcpyHostToDevice, st));
+        OCRS_HIP(hipMemcpyAsync(d_poly, poly.data(), poly.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+        float* d_all = ws.alloc_n<float>((size_t)off);
+        {
+            StageScope sc(T, ST_LINE_CROP, st);
+            k::crop_lines(d_pages, d_hw, d_descs, d_poly, (int)descs.size(), (int)rec_h, d_all, st);
+        }
+        ws.sync();  // descs/poly are host temporaries
+        for (Chunk& ch : chunks) ch.ptr = d_all + ch.off;
+    }
+    auto chunk_ptr = [](const Chunk& ch) { return ch.ptr; };
 
-            // ---- model (recognition.rs:341-360, :485-493)
-            int Tn = 0, C = 0;
-            int32_t* d_labels = nullptr;
-            if (callback) {
-                const auto* cb = static_cast<const CallbackModel*>(recognition);
-                std::vector<float> hin(nb * rec_h * gw), hout;
-                OCRS_HIP(hipMemcpyAsync(hin.data(), d_batch, hin.size() * sizeof(float), hipMemcpyDeviceToHost, st));
-                ws.sync();
-                const int64_t ishape[4] = {(int64_t)nb, 1, rec_h, gw};
-                int64_t oshape[4];
-                int ond = 0;
-                cb->run(hin.data(), ishape, hout, oshape, &ond);
-                if (ond != 3)
-                    fail(OCRS_ERR_WRONG_OUTPUT,
-                         "model output had unexpected type or shape: expected recognition output to have 3 dims but it has %d", ond);
-                if ((size_t)oshape[1] != nb)
-                    fail(OCRS_ERR_WRONG_OUTPUT, "model output had unexpected type or shape: batch size %lld != %zu",
-                         (long long)oshape[1], nb);
-                Tn = (int)oshape[0];
-                C = (int)oshape[2];
-                if (alphabet_len + 1 != (size_t)C)
-                    fail(OCRS_ERR_WRONG_OUTPUT,
-                         "model output had unexpected type or shape: output column count (%d) does not match alphabet size (%zu)",
-                         C, alphabet_len + 1);
-                float* d_logp = ws.alloc_n<float>(hout.size());
-                OCRS_HIP(hipMemcpyAsync(d_logp, hout.data(), hout.size() * sizeof(float), hipMemcpyHostToDevice, st));
-                d_labels = ws.alloc_n<int32_t>((size_t)Tn * nb);
-                {
-                    StageScope sc(T, ST_CTC, st);
-                    k::argmax_rows(d_logp, (int64_t)Tn * nb, C, d_excl, d_labels, st);
-                }
-                ws.sync();
-            } else {
-                const auto* hm = static_cast<const HipModel*>(recognition);
-                TensorShape os = hm->infer((int)nb, (int)rec_h, (int)gw);
-                if (!os.seq)
-                    fail(OCRS_ERR_WRONG_OUTPUT,
-                         "model output had unexpected type or shape: expected recognition output to have 3 dims but it has 4");
-                Tn = os.n;
-                C = os.c;
-                if (alphabet_len + 1 != (size_t)C)
-                    fail(OCRS_ERR_WRONG_OUTPUT,
-                         "model output had unexpected type or shape: output column count (%d) does not match alphabet size (%zu)",
-                         C, alphabet_len + 1);
-                d_labels = ws.alloc_n<int32_t>((size_t)Tn * nb);
-                hm->run_device(ws, d_batch, (int)nb, (int)rec_h, (int)gw, nullptr, T, d_excl, d_labels, false, false);
-            }
-
-            // ---- greedy CTC (recognition.rs:511)
+    if (callback) {
+        // ---- `trait Model` implemented by the caller: one run per <=20-line chunk (recognition.rs:485)
+        const auto* cb = static_cast<const CallbackModel*>(recognition);
+        for (const Chunk& ch : chunks) {
+            const size_t nb = ch.members.size();
+            const uint32_t gw = ch.gw;
+            std::vector<float> hin(nb * rec_h * gw), hout;
+            OCRS_HIP(hipMemcpyAsync(hin.data(), chunk_ptr(ch), hin.size() * sizeof(float), hipMemcpyDeviceToHost, st));
+            ws.sync();
+            const int64_t ishape[4] = {(int64_t)nb, 1, rec_h, gw};
+            int64_t oshape[4];
+            int ond = 0;
+            cb->run(hin.data(), ishape, hout, oshape, &ond);
+            if (ond != 3)
+                fail(OCRS_ERR_WRONG_OUTPUT,
+                     "model output had unexpected type or shape: expected recognition output to have 3 dims but it has %d", ond);
+            if ((size_t)oshape[1] != nb)
+                fail(OCRS_ERR_WRONG_OUTPUT, "model output had unexpected type or shape: batch size %lld != %zu",
+                     (long long)oshape[1], nb);
+            const int Tn = (int)oshape[0], C = (int)oshape[2];
+            if (alphabet_len + 1 != (size_t)C)
+                fail(OCRS_ERR_WRONG_OUTPUT,
+                     "model output had unexpected type or shape: output column count (%d) does not match alphabet size (%zu)",
+                     C, alphabet_len + 1);
+            float* d_logp = ws.alloc_n<float>(hout.size());
+            OCRS_HIP(hipMemcpyAsync(d_logp, hout.data(), hout.size() * sizeof(float), hipMemcpyHostToDevice, st));
+            int32_t* d_labels = ws.alloc_n<int32_t>((size_t)Tn * nb);
             uint32_t* d_ol = ws.alloc_n<uint32_t>((size_t)nb * Tn);
             uint32_t* d_op = ws.alloc_n<uint32_t>((size_t)nb * Tn);
             int32_t* d_cnt = ws.alloc_n<int32_t>(nb);
             {
-                StageScope sc(T, ST_CTC, st);
-                k::ctc_collapse(d_labels, Tn, (int)nb, d_ol, d_op, d_cnt, st);
+                StageScope sc(T, ST_CTC, st, 2);
+                k::argmax_rows(d_logp, (int64_t)Tn * nb, C, d_excl, d_labels, st);
+                k::ctc_collapse(d_labels, Tn, (int)nb, d_ol, d_op, d_cnt, st);  // recognition.rs:511
             }
             std::vector<uint32_t> hl((size_t)nb * Tn), hpz((size_t)nb * Tn);
             std::vector<int32_t> hc(nb);
@@ -375,11 +375,99 @@ void ocrs_engine::recognize(const ocrs_page* const* pages, size_t n_pages,
             OCRS_HIP(hipMemcpyAsync(hc.data(), d_cnt, nb * 4, hipMemcpyDeviceToHost, st));
             ws.sync();
             for (size_t j = 0; j < nb; j++) {
-                const size_t li = members[c0 + j];
-                auto& s = (*steps_out)[li];
-                s.resize(hc[j]);
-                for (int q = 0; q < hc[j]; q++) s[q] = CtcStep{hl[j * Tn + q], hpz[j * Tn + q]};
+                const size_t li = ch.members[j];
+                auto& sv = (*steps_out)[li];
+                sv.resize(hc[j]);
+                for (int q = 0; q < hc[j]; q++) sv[q] = CtcStep{hl[j * Tn + q], hpz[j * Tn + q]};
                 (*ctc_len_out)[li] = (uint32_t)Tn;
+            }
+        }
+    } else {
+        // ---- fixed-graph HIP executor: all width groups in ONE ragged batch.  Each line keeps the
+        // padded width (hence sequence length) the reference gives it (recognition.rs:437), lines are
+        // sorted by length so that step t of the recurrence works on a dense prefix of rows.
+        const auto* hm = static_cast<const HipModel*>(recognition);
+        if (hm->packed_split() < 0)
+            fail(OCRS_ERR_WRONG_OUTPUT,
+                 "model output had unexpected type or shape: expected recognition output to have 3 dims but it has 4");
+        std::vector<int> chunk_T(chunks.size());
+        int C = 0;
+        for (size_t c = 0; c < chunks.size(); c++) {
+            TensorShape os = hm->infer(1, (int)rec_h, (int)chunks[c].gw);
+            if (!os.seq)
+                fail(OCRS_ERR_WRONG_OUTPUT,
+                     "model output had unexpected type or shape: expected recognition output to have 3 dims but it has 4");
+            chunk_T[c] = os.n;
+            C = os.c;
+        }
+        if (alphabet_len + 1 != (size_t)C)  // recognition.rs:487-493
+            fail(OCRS_ERR_WRONG_OUTPUT,
+                 "model output had unexpected type or shape: output column count (%d) does not match alphabet size (%zu)", C,
+                 alphabet_len + 1);
+        struct Slot { int T; size_t line; size_t chunk, j; };
+        std::vector<Slot> slots;
+        for (size_t c = 0; c < chunks.size(); c++)
+            for (size_t j = 0; j < chunks[c].members.size(); j++)
+                if (chunk_T[c] > 0) slots.push_back(Slot{chunk_T[c], chunks[c].members[j], c, j});
+        std::stable_sort(slots.begin(), slots.end(), [](const Slot& a, const Slot& b) { return a.T > b.T; });
+        const int M = (int)slots.size();
+        if (M > 0) {
+            HipModel::PackedPlan plan;
+            plan.M = M;
+            plan.Tmax = slots[0].T;
+            plan.active.assign(plan.Tmax, 0);
+            std::vector<int32_t> hTm(M), hoff(plan.Tmax + 1, 0);
+            std::vector<std::vector<int32_t>> hpos(chunks.size());
+            for (size_t c = 0; c < chunks.size(); c++) hpos[c].assign(chunks[c].members.size(), 0);
+            for (int m = 0; m < M; m++) {
+                hTm[m] = slots[m].T;
+                hpos[slots[m].chunk][slots[m].j] = m;
+                for (int t = 0; t < slots[m].T; t++) plan.active[t]++;
+            }
+            for (int t = 0; t < plan.Tmax; t++) hoff[t + 1] = hoff[t] + plan.active[t];
+            plan.R = hoff[plan.Tmax];
+            // one upload: Tm | off | pos of every chunk
+            std::vector<int32_t> meta;
+            meta.insert(meta.end(), hTm.begin(), hTm.end());
+            meta.insert(meta.end(), hoff.begin(), hoff.end());
+            std::vector<size_t> pos_at(chunks.size());
+            for (size_t c = 0; c < chunks.size(); c++) {
+                pos_at[c] = meta.size();
+                meta.insert(meta.end(), hpos[c].begin(), hpos[c].end());
+            }
+            int32_t* d_meta = ws.alloc_n<int32_t>(meta.size());
+            OCRS_HIP(hipMemcpyAsync(d_meta, meta.data(), meta.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+            plan.d_Tm = d_meta;
+            plan.d_off = d_meta + M;
+            std::vector<HipModel::PackedGroup> pg;
+            for (size_t c = 0; c < chunks.size(); c++)
+                if (chunk_T[c] > 0)
+                    pg.push_back(HipModel::PackedGroup{chunk_ptr(chunks[c]), (int)chunks[c].members.size(), (int)chunks[c].gw,
+                                                       d_meta + pos_at[c]});
+            int32_t* d_labels = ws.alloc_n<int32_t>((size_t)plan.R);
+            hm->run_recognition_packed(ws, pg, plan, (int)rec_h, T, d_excl, d_labels);
+
+            // ---- greedy CTC (recognition.rs:511)
+            const int Tmax = plan.Tmax;
+            uint32_t* d_ol = ws.alloc_n<uint32_t>((size_t)M * Tmax);
+            uint32_t* d_op = ws.alloc_n<uint32_t>((size_t)M * Tmax);
+            int32_t* d_cnt = ws.alloc_n<int32_t>(M);
+            {
+                StageScope sc(T, ST_CTC, st);
+                k::ctc_collapse_packed(d_labels, plan.d_Tm, plan.d_off, M, Tmax, d_ol, d_op, d_cnt, st);
+            }
+            std::vector<uint32_t> hl((size_t)M * Tmax), hpz((size_t)M * Tmax);
+            std::vector<int32_t> hc(M);
+            OCRS_HIP(hipMemcpyAsync(hl.data(), d_ol, hl.size() * 4, hipMemcpyDeviceToHost, st));
+            OCRS_HIP(hipMemcpyAsync(hpz.data(), d_op, hpz.size() * 4, hipMemcpyDeviceToHost, st));
+            OCRS_HIP(hipMemcpyAsync(hc.data(), d_cnt, (size_t)M * 4, hipMemcpyDeviceToHost, st));
+            ws.sync();
+            for (int m = 0; m < M; m++) {
+                const size_t li = slots[m].line;
+                auto& sv = (*steps_out)[li];
+                sv.resize(hc[m]);
+                for (int q = 0; q < hc[m]; q++) sv[q] = CtcStep{hl[(size_t)m * Tmax + q], hpz[(size_t)m * Tmax + q]};
+                (*ctc_len_out)[li] = (uint32_t)slots[m].T;
             }
         }
     }

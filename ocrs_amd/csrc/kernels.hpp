@@ -87,6 +87,18 @@ void gru_gates(const float* gx, const float* gh, float* h, float* y, int T, int 
 // logits/logp: [rows][C]; labels: [rows] (first max).  logp may be null.
 void log_softmax_argmax(const float* logits, int64_t rows, int c, const uint8_t* d_excluded /*[C] or null*/,
                         float* logp, int32_t* labels, hipStream_t s);
+// Ragged sequence batch (lines sorted by length, rows off[t] + m); see kernels_nn.hip.
+void to_seq_packed(const float* x, int n, int T, int c, const int32_t* d_pos, const int32_t* d_off, float* y,
+                   hipStream_t s);
+void gru_gates_packed(const float* gx, const float* gh, float* h, float* y, const int32_t* d_Tm, const int32_t* d_off,
+                      int64_t R, int Mcap, int active, int H, int step, hipStream_t s);
+// Fused recurrent step (hidden GEMM on 16x16x4 fp32 MFMA + gates), both directions.
+// hT_in/hT_out: [2][H][Mcap] transposed state (Mcap % 4 == 0), ping-ponged by the caller.
+bool gru_step_fused(const float* gx, const float* wh, const float* bh, const float* hT_in, float* hT_out, float* y,
+                    const int32_t* d_Tm, const int32_t* d_off, int64_t R, int Mcap, int active, int H, int step,
+                    hipStream_t s);
+void ctc_collapse_packed(const int32_t* labels, const int32_t* d_Tm, const int32_t* d_off, int M, int Tmax,
+                         uint32_t* out_labels, uint32_t* out_pos, int32_t* out_count, hipStream_t s);
 void argmax_rows(const float* x, int64_t rows, int c, const uint8_t* d_excluded, int32_t* labels, hipStream_t s);
 // Greedy CTC collapse (rten decode_greedy): labels [T][N] -> per line (label,pos) lists.
 void ctc_collapse(const int32_t* labels, int T, int N, uint32_t* out_labels, uint32_t* out_pos, int32_t* out_count,
@@ -99,12 +111,13 @@ struct LineDesc {      // one text line to crop (recognition.rs:91-126)
     int32_t poly_n;    // vertex count
     int32_t top, left, bh, bw;  // polygon bounding rect (exclusive bottom/right)
     int32_t resized_w;
-    int32_t out_row;   // row (line slot) in the batch tensor
+    int32_t out_w;     // padded width of this line's batch (its width group)
+    int64_t out_off;   // float offset of this line's [out_h, out_w] image in the output buffer
 };
-// Fill + gather + bilinear resize + pad into batch [n_lines, out_h, out_w] (pre-filled here with -0.5).
+// Fill + gather + bilinear resize + right-pad with -0.5; every line writes its own
+// [out_h, out_w] image at d_out + out_off (lines of different width groups in one launch).
 void crop_lines(const float* const* d_pages, const int32_t* d_page_hw /*[pages][2]*/, const LineDesc* d_lines,
-                const int32_t* d_poly /*(y,x) pairs*/, int n_lines, int out_h, int out_w, float* d_batch,
-                hipStream_t s);
+                const int32_t* d_poly /*(y,x) pairs*/, int n_lines, int out_h, float* d_out, hipStream_t s);
 
 }  // namespace k
 }  // namespace ocrs

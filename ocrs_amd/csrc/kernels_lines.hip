@@ -36,13 +36,14 @@ __device__ __forceinline__ int edge_x_at(int xa, int ya, int xb, int yb, int y) 
 
 __global__ void __launch_bounds__(256)
 crop_lines_kernel(const float* const* __restrict__ pages, const int32_t* __restrict__ page_hw,
-                  const LineDesc* __restrict__ lines, const int32_t* __restrict__ poly, int out_h, int out_w,
+                  const LineDesc* __restrict__ lines, const int32_t* __restrict__ poly, int out_h,
                   float* __restrict__ batch) {
     __shared__ int xs[2][MAX_LDS_EDGES];
     __shared__ int cnt[2];
     const LineDesc ln = lines[blockIdx.y];
     const int oy = blockIdx.x;
-    float* __restrict__ dst = batch + ((int64_t)ln.out_row * out_h + oy) * out_w;
+    const int out_w = ln.out_w;
+    float* __restrict__ dst = batch + ln.out_off + (int64_t)oy * out_w;
     const float fill = -0.5f;
     if (ln.bh <= 0 || ln.bw <= 0 || ln.poly_n > MAX_LDS_EDGES) {
         for (int ox = threadIdx.x; ox < out_w; ox += blockDim.x) dst[ox] = fill;
@@ -101,10 +102,10 @@ crop_lines_kernel(const float* const* __restrict__ pages, const int32_t* __restr
 }
 
 void crop_lines(const float* const* d_pages, const int32_t* d_page_hw, const LineDesc* d_lines, const int32_t* d_poly,
-                int n_lines, int out_h, int out_w, float* d_batch, hipStream_t s) {
+                int n_lines, int out_h, float* d_out, hipStream_t s) {
     if (n_lines <= 0) return;
     hipLaunchKernelGGL(crop_lines_kernel, dim3(out_h, n_lines), dim3(256), 0, s, d_pages, d_page_hw, d_lines, d_poly,
-                       out_h, out_w, d_batch);
+                       out_h, d_out);
 }
 
 }  // namespace k

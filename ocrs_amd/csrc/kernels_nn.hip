@@ -567,6 +567,213 @@ void log_softmax_argmax(const float* logits, int64_t rows, int c, const uint8_t*
                        labels);
 }
 
+// ---------------------------------------------------------------------------
+// Ragged ("packed") sequence batch.  Lines of every width group are sorted by
+// sequence length T descending; at time t the active lines are the prefix
+// m < active(t), stored at rows off[t] + m.  No padding rows exist, so GEMMs,
+// the recurrence and the head touch exactly sum_m T_m rows.
+// ---------------------------------------------------------------------------
+// features [n, 1, T, C] of one width group -> packed rows
+__global__ void __launch_bounds__(256)
+to_seq_packed_kernel(const float* __restrict__ x, int n, int T, int c, const int32_t* __restrict__ pos,
+                     const int32_t* __restrict__ off, float* __restrict__ y) {
+    const int64_t total = (int64_t)n * T * c;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % c);
+        const int64_t r = i / c;  // = line * T + t
+        const int t = (int)(r % T);
+        const int line = (int)(r / T);
+        y[((int64_t)off[t] + pos[line]) * c + ch] = x[i];
+    }
+}
+
+void to_seq_packed(const float* x, int n, int T, int c, const int32_t* d_pos, const int32_t* d_off, float* y,
+                   hipStream_t s) {
+    int64_t total = (int64_t)n * T * c;
+    if (total <= 0) return;
+    int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipLaunchKernelGGL(to_seq_packed_kernel, dim3(grid), dim3(256), 0, s, x, n, T, c, d_pos, d_off, y);
+}
+
+// GRU gates on the packed layout, both directions (blockIdx.y).  At step s the
+// forward direction is at t = s, the reverse one at t = T_m - 1 - s (per line).
+// gx: [2][R][3H]; gh: [2][Mcap][3H]; h: [2][Mcap][H]; y: [R][2H].
+__global__ void __launch_bounds__(256)
+gru_gates_packed_kernel(const float* __restrict__ gx, const float* __restrict__ gh, float* __restrict__ h,
+                        float* __restrict__ y, const int32_t* __restrict__ Tm, const int32_t* __restrict__ off,
+                        int64_t R, int Mcap, int active, int H, int step) {
+    const int dir = blockIdx.y;
+    const int64_t total = (int64_t)active * H;
+    const float* gxd = gx + (int64_t)dir * R * 3 * H;
+    const float* ghd = gh + (int64_t)dir * Mcap * 3 * H;
+    float* hd = h + (int64_t)dir * Mcap * H;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int j = (int)(i % H);
+        const int m = (int)(i / H);
+        const int t = dir ? Tm[m] - 1 - step : step;
+        const int64_t row = (int64_t)off[t] + m;
+        const float* gxr = gxd + row * 3 * H;
+        const float* ghr = ghd + (int64_t)m * 3 * H;
+        float r = spec_sigmoidf(gxr[j] + ghr[j]);
+        float z = spec_sigmoidf(gxr[H + j] + ghr[H + j]);
+        float nn = spec_tanhf(fmaf(r, ghr[2 * H + j], gxr[2 * H + j]));
+        float hprev = hd[i];
+        float hn = fmaf(z, hprev - nn, nn);
+        hd[i] = hn;
+        y[row * 2 * H + (int64_t)dir * H + j] = hn;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Fused GRU step on the packed layout:  gh = hT . Wh + bh  (fp32 MFMA, k ascending),
+// then the gates, for BOTH directions, in one launch per time step.
+//
+// Latency is what matters here (T up to 600 dependent steps), so the work is cut
+// into many short MFMA chains: one wave = 16 batch rows x 16 hidden units x 3
+// gates on v_mfma_f32_16x16x4_f32 (192 MFMAs of 32 cycles, three independent
+// accumulators so the 40-cycle dependent latency is covered).  A block = 4 waves
+// (64 rows) sharing one 16-unit slice of Wh (H x 48 floats) staged in LDS.
+// The state is kept TRANSPOSED, hT[k][m], so that the A operand (lane l needs
+// h[row l&15][k = 4s + (l>>4)]) is a coalesced 64-byte read per 16 lanes, and
+// the epilogue (each lane owns 4 consecutive rows of one unit) writes the new
+// state as one float4.  State is ping-ponged: other blocks still read step s's
+// state while this one writes step s+1's.
+// ---------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int H>
+__global__ void __launch_bounds__(256)
+gru_step_fused_kernel(const float* __restrict__ gx, const float* __restrict__ wh, const float* __restrict__ bh,
+                      const float* __restrict__ hT_in, float* __restrict__ hT_out, float* __restrict__ y,
+                      const int32_t* __restrict__ Tm, const int32_t* __restrict__ off, int64_t R, int Mcap, int active,
+                      int step) {
+    extern __shared__ __attribute__((aligned(16))) float lds_w[];  // [H][48]: k-major, (gate, unit) columns
+    const int dir = blockIdx.z;
+    const int j0 = blockIdx.y * 16;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int row0 = blockIdx.x * 64 + wave * 16;
+    const float* __restrict__ whd = wh + (int64_t)dir * H * 3 * H;
+    const float* __restrict__ bhd = bh + (int64_t)dir * 3 * H;
+    const float* __restrict__ hin = hT_in + (int64_t)dir * H * Mcap;
+    float* __restrict__ hout = hT_out + (int64_t)dir * H * Mcap;
+    const float* __restrict__ gxd = gx + (int64_t)dir * R * 3 * H;
+
+    // stage Wh[:, g*H + j0 .. +16) for g = r,z,n
+    for (int i = tid; i < H * 12; i += 256) {  // 12 float4 per k-row
+        const int k = i / 12, q = i - k * 12;
+        const int g = q >> 2, c4 = (q & 3) * 4;
+        const float4 v = *reinterpret_cast<const float4*>(whd + (int64_t)k * 3 * H + g * H + j0 + c4);
+        *reinterpret_cast<float4*>(&lds_w[k * 48 + g * 16 + c4]) = v;
+    }
+    __syncthreads();
+    if (row0 >= active) return;
+
+    const int i16 = lane & 15, kq = lane >> 4;
+    const int arow = min(row0 + i16, Mcap - 1);
+    f32x4 acc_r, acc_z, acc_n;
+    {
+        const float br = bhd[j0 + i16], bz = bhd[H + j0 + i16], bn = bhd[2 * H + j0 + i16];
+        for (int r = 0; r < 4; r++) { acc_r[r] = br; acc_z[r] = bz; acc_n[r] = bn; }
+    }
+    const float* ap = hin + (int64_t)kq * Mcap + arow;
+    const float* bp = &lds_w[kq * 48 + i16];
+#pragma unroll 8
+    for (int s4 = 0; s4 < H / 4; s4++) {
+        const float a = ap[(int64_t)s4 * 4 * Mcap];
+        const float* b = bp + s4 * 4 * 48;
+        acc_r = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[0], acc_r, 0, 0, 0);
+        acc_z = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[16], acc_z, 0, 0, 0);
+        acc_n = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[32], acc_n, 0, 0, 0);
+    }
+    // C/D layout 16x16: col = lane & 15 (hidden unit), row = (lane >> 4) * 4 + reg (batch row)
+    const int j = j0 + i16;
+    const int mbase = row0 + kq * 4;
+    float hnew[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int m = mbase + r;
+        float hn = 0.0f;
+        if (m < active) {
+            const int t = dir ? Tm[m] - 1 - step : step;
+            const int64_t row = (int64_t)off[t] + m;
+            const float* gxr = gxd + row * 3 * H;
+            const float rg = spec_sigmoidf(gxr[j] + acc_r[r]);
+            const float zg = spec_sigmoidf(gxr[H + j] + acc_z[r]);
+            const float ng = spec_tanhf(fmaf(rg, acc_n[r], gxr[2 * H + j]));
+            const float hprev = hin[(int64_t)j * Mcap + m];
+            hn = fmaf(zg, hprev - ng, ng);
+            y[row * 2 * H + (int64_t)dir * H + j] = hn;
+        }
+        hnew[r] = hn;
+    }
+    float* hp = hout + (int64_t)j * Mcap + mbase;
+    if (mbase + 3 < Mcap) {
+        *reinterpret_cast<float4*>(hp) = make_float4(hnew[0], hnew[1], hnew[2], hnew[3]);
+    } else {
+        for (int r = 0; r < 4 && mbase + r < Mcap; r++) hp[r] = hnew[r];
+    }
+}
+
+// hT buffers: [2 dirs][H][Mcap] with Mcap a multiple of 4.  Returns false if H is unsupported.
+bool gru_step_fused(const float* gx, const float* wh, const float* bh, const float* hT_in, float* hT_out, float* y,
+                    const int32_t* d_Tm, const int32_t* d_off, int64_t R, int Mcap, int active, int H, int step,
+                    hipStream_t s) {
+    if (active <= 0) return true;
+    dim3 grid((active + 63) / 64, H / 16, 2);
+    size_t lds = (size_t)H * 48 * sizeof(float);
+    if (H == 256)
+        hipLaunchKernelGGL((gru_step_fused_kernel<256>), grid, dim3(256), lds, s, gx, wh, bh, hT_in, hT_out, y, d_Tm, d_off,
+                           R, Mcap, active, step);
+    else if (H == 128)
+        hipLaunchKernelGGL((gru_step_fused_kernel<128>), grid, dim3(256), lds, s, gx, wh, bh, hT_in, hT_out, y, d_Tm, d_off,
+                           R, Mcap, active, step);
+    else if (H == 64)
+        hipLaunchKernelGGL((gru_step_fused_kernel<64>), grid, dim3(256), lds, s, gx, wh, bh, hT_in, hT_out, y, d_Tm, d_off, R,
+                           Mcap, active, step);
+    else
+        return false;
+    return true;
+}
+
+void gru_gates_packed(const float* gx, const float* gh, float* h, float* y, const int32_t* d_Tm, const int32_t* d_off,
+                      int64_t R, int Mcap, int active, int H, int step, hipStream_t s) {
+    int64_t total = (int64_t)active * H;
+    if (total <= 0) return;
+    int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(gru_gates_packed_kernel, dim3(grid, 2), dim3(256), 0, s, gx, gh, h, y, d_Tm, d_off, R, Mcap, active,
+                       H, step);
+}
+
+// Greedy CTC collapse over the packed layout: one lane per line.
+__global__ void __launch_bounds__(64)
+ctc_collapse_packed_kernel(const int32_t* __restrict__ labels, const int32_t* __restrict__ Tm,
+                           const int32_t* __restrict__ off, int M, int Tmax, uint32_t* __restrict__ out_labels,
+                           uint32_t* __restrict__ out_pos, int32_t* __restrict__ out_count) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    const int T = Tm[m];
+    int last = 0, cnt = 0;
+    for (int t = 0; t < T; t++) {
+        int l = labels[(int64_t)off[t] + m];
+        if (l == last) continue;
+        last = l;
+        if (l > 0) {
+            out_labels[(int64_t)m * Tmax + cnt] = (uint32_t)l;
+            out_pos[(int64_t)m * Tmax + cnt] = (uint32_t)t;
+            cnt++;
+        }
+    }
+    out_count[m] = cnt;
+}
+
+void ctc_collapse_packed(const int32_t* labels, const int32_t* d_Tm, const int32_t* d_off, int M, int Tmax,
+                         uint32_t* out_labels, uint32_t* out_pos, int32_t* out_count, hipStream_t s) {
+    if (M <= 0) return;
+    hipLaunchKernelGGL(ctc_collapse_packed_kernel, dim3((M + 63) / 64), dim3(64), 0, s, labels, d_Tm, d_off, M, Tmax,
+                       out_labels, out_pos, out_count);
+}
+
 // Arg-max only (for caller-implemented models whose output is already
 // [T,N,C]); excluded labels read as -inf (recognition.rs:547-561).  First maximum.
 __global__ void __launch_bounds__(256)

@@ -3,6 +3,7 @@
 // ocrs/src/layout_analysis.rs:19-233 and layout_analysis/empty_rects.rs:47-229.
 #include <cmath>
 #include <functional>
+#include <memory>
 
 #include "geometry.hpp"
 
@@ -14,88 +15,121 @@ namespace {
 // std::collections::BinaryHeap<Partition> with Rust's exact sift order, so that
 // partitions with equal scores pop in the same order as in the reference
 // (empty_rects.rs:20-24 compares scores only; ties are decided by heap mechanics).
+//
+// A partition's obstacle list (empty_rects.rs:118-122) is a pure function of its
+// boundary and its parent's list, and only the score takes part in the ordering,
+// so the list is materialised lazily when the partition is popped: most pushed
+// partitions are never popped once the 80 separators are found.
 struct Partition {
-    float score;
     Rect boundary;
-    std::vector<Rect> obstacles;
+    std::shared_ptr<const std::vector<uint32_t>> parent_obstacles;  // indices into the sorted obstacle array
+};
+
+// Heap entries are (score, payload id): sifting moves 8 bytes instead of the payload.
+struct HeapEntry {
+    float score;
+    uint32_t id;
 };
 
 class RustBinaryHeap {
   public:
-    void push(Partition&& p) {
-        data_.push_back(std::move(p));
+    void push(HeapEntry e) {
+        data_.push_back(e);
         sift_up(0, data_.size() - 1);
     }
-    bool pop(Partition& out) {
+    bool pop(HeapEntry& out) {
         if (data_.empty()) return false;
-        Partition item = std::move(data_.back());
+        HeapEntry item = data_.back();
         data_.pop_back();
         if (!data_.empty()) {
             std::swap(item, data_[0]);
             sift_down_to_bottom(0);
         }
-        out = std::move(item);
+        out = item;
         return true;
     }
 
   private:
     // f32::total_cmp on scores that are never NaN here
-    static bool le(const Partition& a, const Partition& b) { return a.score <= b.score; }
+    static bool le(const HeapEntry& a, const HeapEntry& b) { return a.score <= b.score; }
     size_t sift_up(size_t start, size_t pos) {
-        Partition elt = std::move(data_[pos]);
+        HeapEntry elt = data_[pos];
         while (pos > start) {
             size_t parent = (pos - 1) / 2;
             if (le(elt, data_[parent])) break;
-            data_[pos] = std::move(data_[parent]);
+            data_[pos] = data_[parent];
             pos = parent;
         }
-        data_[pos] = std::move(elt);
+        data_[pos] = elt;
         return pos;
     }
     void sift_down_to_bottom(size_t pos) {
         const size_t end = data_.size();
         const size_t start = pos;
-        Partition elt = std::move(data_[pos]);
+        HeapEntry elt = data_[pos];
         size_t child = 2 * pos + 1;
         while (end >= 2 && child <= end - 2) {
             if (le(data_[child], data_[child + 1])) child += 1;
-            data_[pos] = std::move(data_[child]);
+            data_[pos] = data_[child];
             pos = child;
             child = 2 * pos + 1;
         }
         if (child == end - 1) {
-            data_[pos] = std::move(data_[child]);
+            data_[pos] = data_[child];
             pos = child;
         }
-        data_[pos] = std::move(elt);
+        data_[pos] = elt;
         sift_up(start, pos);
     }
-    std::vector<Partition> data_;
+    std::vector<HeapEntry> data_;
 };
 
 // empty_rects.rs:80-138 + FilterRectIter (:184-221) + take(n)
-std::vector<Rect> max_empty_rects_filtered(const std::vector<Rect>& obstacles_in, Rect boundary,
-                                           const std::function<float(const Rect&)>& score, uint32_t min_width,
-                                           uint32_t min_height, float iou_threshold, size_t take) {
+template <class Score>
+std::vector<Rect> max_empty_rects_filtered(const std::vector<Rect>& obstacles_in, Rect boundary, Score&& score,
+                                           uint32_t min_width, uint32_t min_height, float iou_threshold, size_t take) {
     std::vector<Rect> obstacles = obstacles_in;
     std::stable_sort(obstacles.begin(), obstacles.end(), [](const Rect& a, const Rect& b) {
         PointI ca = a.center(), cb = b.center();
         return ca.x != cb.x ? ca.x < cb.x : ca.y < cb.y;
     });
+    auto all = std::make_shared<std::vector<uint32_t>>(obstacles.size());
+    for (size_t i = 0; i < obstacles.size(); i++) (*all)[i] = (uint32_t)i;
     RustBinaryHeap queue;
-    if (!boundary.is_empty()) queue.push(Partition{score(boundary), boundary, obstacles});
+    std::vector<Partition> store;  // payloads; a popped slot is released but never reused (ids stay unique)
+    auto push = [&](const Rect& r, const std::shared_ptr<const std::vector<uint32_t>>& obs) {
+        store.push_back(Partition{r, obs});
+        queue.push(HeapEntry{score(r), (uint32_t)(store.size() - 1)});
+    };
+    if (!boundary.is_empty()) push(boundary, all);
     std::vector<Rect> found;
-    Partition part;
-    while (found.size() < take && queue.pop(part)) {
+    HeapEntry he;
+    while (found.size() < take && queue.pop(he)) {
+        Partition part = std::move(store[he.id]);
         const Rect b = part.boundary;
-        if (part.obstacles.empty()) {
+        // materialise this partition's obstacle list (the root keeps every obstacle, as in the reference)
+        std::shared_ptr<const std::vector<uint32_t>> mine;
+        if (part.parent_obstacles == all && b == boundary) {
+            mine = all;
+        } else {
+            auto v = std::make_shared<std::vector<uint32_t>>();
+            v->reserve(part.parent_obstacles->size());
+            for (uint32_t idx : *part.parent_obstacles)
+                if (obstacles[idx].intersects(b)) v->push_back(idx);
+            mine = std::move(v);
+        }
+        if (mine->empty()) {
             bool overlaps = false;
-            for (const Rect& f : found)
+            for (const Rect& f : found) {
+                // disjoint rects have iou == 0 < threshold: skip the float division
+                if (!(f.left < b.right && f.right > b.left && f.top < b.bottom && f.bottom > b.top) && iou_threshold > 0.0f)
+                    continue;
                 if (f.iou(b) >= iou_threshold) { overlaps = true; break; }
+            }
             if (!overlaps) found.push_back(b);
             continue;
         }
-        const Rect pivot = part.obstacles[part.obstacles.size() / 2];
+        const Rect pivot = obstacles[(*mine)[mine->size() / 2]];
         const Rect right_rect = Rect::from_tlbr(b.top, pivot.right, b.bottom, b.right);
         const Rect left_rect = Rect::from_tlbr(b.top, b.left, b.bottom, pivot.left);
         const Rect top_rect = Rect::from_tlbr(b.top, b.left, pivot.top, b.right);
@@ -105,10 +139,7 @@ std::vector<Rect> max_empty_rects_filtered(const std::vector<Rect>& obstacles_in
             if ((uint32_t)std::max(sr.width(), 0) < min_width || (uint32_t)std::max(sr.height(), 0) < min_height ||
                 sr.is_empty())
                 continue;
-            std::vector<Rect> sub_obs;
-            for (const Rect& o : part.obstacles)
-                if (o.intersects(sr)) sub_obs.push_back(o);
-            queue.push(Partition{score(sr), sr, std::move(sub_obs)});
+            push(sr, mine);
         }
     }
     return found;
@@ -117,8 +148,8 @@ std::vector<Rect> max_empty_rects_filtered(const std::vector<Rect>& obstacles_in
 struct WordInfo {  // cached per-word quantities for group_into_lines
     RotatedRect rect;
     int32_t left_i;
-    LineF ledge, redge;
     float ledge_cx, redge_cx;
+    float ledge_y0, ledge_y1, redge_y0, redge_y1;  // y-extent of the downwards() edges
     int32_t cx_i;
 };
 
@@ -131,10 +162,11 @@ std::vector<std::vector<RotatedRect>> group_into_lines(const std::vector<Rotated
         WordInfo w;
         w.rect = r;
         w.left_i = as_i32(r.bounding_rect().left);
-        w.ledge = leftmost_edge(r);
-        w.redge = rightmost_edge(r);
-        w.ledge_cx = w.ledge.center().x;
-        w.redge_cx = w.redge.center().x;
+        const LineF le = leftmost_edge(r).downwards(), re = rightmost_edge(r).downwards();
+        w.ledge_cx = le.center().x;
+        w.redge_cx = re.center().x;
+        w.ledge_y0 = le.start.y; w.ledge_y1 = le.end.y;
+        w.redge_y0 = re.start.y; w.redge_y1 = re.end.y;
         w.cx_i = as_i32(r.cx);
         ws.push_back(w);
     }
@@ -161,7 +193,8 @@ std::vector<std::vector<RotatedRect>> group_into_lines(const std::vector<Rotated
                 const WordInfo& w = ws[i];
                 if (!(w.rect.cx > last.rect.cx)) continue;
                 if (!(w.ledge_cx - last.redge_cx >= -max_h_overlap)) continue;
-                if (!(last.redge.vertical_overlap(w.ledge) >= overlap_threshold)) continue;
+                // last_edge.vertical_overlap(edge) (Line::vertical_overlap on the downwards() edges)
+                if (!(overlap(last.redge_y0, last.redge_y1, w.ledge_y0, w.ledge_y1) >= overlap_threshold)) continue;
                 if (!separators.empty()) {
                     LineF a_to_b{last.rect.center(), w.rect.center()};
                     bool sep = false;

@@ -182,9 +182,12 @@ double HipModel::flops(int n, int h, int w) const {
 
 float* HipModel::run_device(Workspace& ws, const float* d_in, int n, int h, int w, TensorShape* out_shape,
                             StageTimers* timers, const uint8_t* d_excluded, int32_t* d_labels, bool want_logp,
-                            bool print_timing) const {
+                            bool print_timing, int stop_before) const {
     std::vector<TensorShape> shp;
-    const TensorShape out = infer(n, h, w, &shp);
+    TensorShape out = infer(n, h, w, &shp);
+    const size_t n_run = stop_before >= 0 ? (size_t)stop_before : ops.size();
+    const uint32_t ret_slot = stop_before >= 0 ? (uint32_t)ops[stop_before].in0 : out_slot;
+    if (stop_before >= 0) out = shp[ret_slot];
     if (out_shape) *out_shape = out;
     hipStream_t st = ws.s();
 
@@ -195,6 +198,7 @@ float* HipModel::run_device(Workspace& ws, const float* d_in, int n, int h, int 
         if (ops[i].in1 >= 0) last_use[ops[i].in1] = (int)i;
     }
     last_use[out_slot] = (int)ops.size() + 1;
+    last_use[ret_slot] = (int)ops.size() + 1;
     std::vector<float*> ptr(n_slots, nullptr);
     std::vector<size_t> cap(n_slots, 0);
     std::multimap<size_t, float*> free_local;
@@ -227,8 +231,15 @@ float* HipModel::run_device(Workspace& ws, const float* d_in, int n, int h, int 
         cur_stage = stage;
     };
     bool seen_seq = false;
+    // per-launch kernel timing (only when the engine asked for it)
+    auto timed = [&](int cls, double flops, double bytes, auto&& launch) {
+        int tok = timers ? timers->kbegin(cls, st, flops, bytes) : -1;
+        launch();
+        if (tok >= 0) timers->end(tok, st);
+    };
+    auto wbytes = [](const GraphOp& o, int j) { return (double)o.wcount[j] * 4.0; };
 
-    for (size_t i = 0; i < ops.size(); i++) {
+    for (size_t i = 0; i < n_run; i++) {
         const GraphOp& op = ops[i];
         const TensorShape a = shp[op.in0];
         const TensorShape o = shp[op.out];
@@ -257,47 +268,61 @@ float* HipModel::run_device(Workspace& ws, const float* d_in, int n, int h, int 
             case OP_CONV: {
                 const int64_t px = (int64_t)a.n * a.h * a.w;
                 const bool next_sigmoid = i + 1 < ops.size() && ops[i + 1].fused_into_prev;
+                const double cflops = 2.0 * px * op.cout * op.cin * op.kh * op.kw;
+                const double cbytes = 4.0 * (double)px * (op.cin + op.cout) + wbytes(op, 0);
                 if (op.kh == 1 && op.kw == 1 && op.cout == 1) {
-                    k::conv1x1_cout1(x, px, op.cin, op.w[0], op.w[1], next_sigmoid ? 1 : 0, y, st);
+                    timed(KC_CONV1X1_SIGMOID, cflops, cbytes,
+                          [&] { k::conv1x1_cout1(x, px, op.cin, op.w[0], op.w[1], next_sigmoid ? 1 : 0, y, st); });
                 } else if (op.kh == 1 && op.kw == 1 && (op.cin % 4) == 0) {
                     k::GemmDesc d{};
                     d.A = x; d.lda = op.cin; d.B = op.w[0]; d.ldb = op.cout; d.bias = op.w[1];
                     d.C = y; d.ldc = op.cout; d.M = (int)px; d.N = op.cout; d.K = op.cin; d.relu = op.relu;
-                    k::gemm(d, st);
+                    timed(KC_GEMM_POINTWISE, cflops, cbytes, [&] { k::gemm(d, st); });
                 } else if (op.kh == 3 && op.kw == 3 && (op.cin % 32) == 0) {
                     k::GemmDesc d{};
                     d.A = x; d.B = op.w[0]; d.ldb = op.cout; d.bias = op.w[1];
                     d.C = y; d.ldc = op.cout; d.M = (int)px; d.N = op.cout; d.K = 9 * op.cin; d.relu = op.relu;
                     d.im2col = 1; d.H = a.h; d.W = a.w; d.Cin = op.cin;
-                    k::gemm(d, st);
+                    timed(KC_GEMM_CONV3X3, cflops, cbytes, [&] { k::gemm(d, st); });
                 } else if ((op.cout % 4) == 0) {
-                    k::conv_direct(x, a.n, a.h, a.w, op.cin, op.w[0], op.w[1], op.kh, op.kw, op.cout, op.relu, y, st);
+                    timed(KC_CONV_DIRECT, cflops, cbytes, [&] {
+                        k::conv_direct(x, a.n, a.h, a.w, op.cin, op.w[0], op.w[1], op.kh, op.kw, op.cout, op.relu, y, st);
+                    });
                 } else {
                     fail(OCRS_ERR_RUN_FAILED, "model run failed: unsupported conv shape %dx%d %d->%d", op.kh, op.kw,
                          op.cin, op.cout);
                 }
                 break;
             }
-            case OP_DWCONV3: k::dwconv3x3(x, a.n, a.h, a.w, a.c, op.w[0], op.w[1], op.relu, y, st); break;
-            case OP_MAXPOOL: k::maxpool(x, a.n, a.h, a.w, a.c, op.kh, op.kw, y, st); break;
-            case OP_AVGPOOL: k::avgpool(x, a.n, a.h, a.w, a.c, op.kh, op.kw, y, st); break;
+            case OP_DWCONV3:
+                timed(KC_DWCONV3X3, 18.0 * a.count(), 8.0 * a.count(),
+                      [&] { k::dwconv3x3(x, a.n, a.h, a.w, a.c, op.w[0], op.w[1], op.relu, y, st); });
+                break;
+            case OP_MAXPOOL:
+                timed(KC_POOL, 0, 4.0 * (a.count() + o.count()), [&] { k::maxpool(x, a.n, a.h, a.w, a.c, op.kh, op.kw, y, st); });
+                break;
+            case OP_AVGPOOL:
+                timed(KC_POOL, 0, 4.0 * (a.count() + o.count()), [&] { k::avgpool(x, a.n, a.h, a.w, a.c, op.kh, op.kw, y, st); });
+                break;
             case OP_CONVT2: {
                 k::GemmDesc d{};
                 d.A = x; d.lda = op.cin; d.B = op.aux0; d.ldb = 4 * op.cout; d.bias = op.aux1;
                 d.C = y; d.M = (int)((int64_t)a.n * a.h * a.w); d.N = 4 * op.cout; d.K = op.cin;
                 d.convt = 1; d.H = a.h; d.W = a.w; d.Cout = op.cout;
-                k::gemm(d, st);
+                timed(KC_GEMM_CONVT, 2.0 * d.M * op.cin * op.cout * 4, 4.0 * (a.count() + o.count()) + wbytes(op, 0),
+                      [&] { k::gemm(d, st); });
                 break;
             }
             case OP_PADCAT: {
                 const TensorShape b = shp[op.in1];
-                k::padcat(x, a.n, a.h, a.w, a.c, ptr[op.in1], b.h, b.w, b.c, y, st);
+                timed(KC_PADCAT, 0, 8.0 * o.count(),
+                      [&] { k::padcat(x, a.n, a.h, a.w, a.c, ptr[op.in1], b.h, b.w, b.c, y, st); });
                 break;
             }
-            case OP_SIGMOID: k::sigmoid(x, y, a.count(), st); break;
+            case OP_SIGMOID: timed(KC_OTHER, 0, 8.0 * a.count(), [&] { k::sigmoid(x, y, a.count(), st); }); break;
             case OP_TOSEQ:
                 if (a.h != 1) fail(OCRS_ERR_RUN_FAILED, "model run failed: TOSEQ expects height 1, got %d", a.h);
-                k::to_seq(x, a.n, a.w, a.c, y, st);
+                timed(KC_OTHER, 0, 8.0 * a.count(), [&] { k::to_seq(x, a.n, a.w, a.c, y, st); });
                 break;
             case OP_GRU: {
                 const int T = a.n, N = a.h, I = a.c, H = op.hidden;
@@ -309,14 +334,17 @@ float* HipModel::run_device(Workspace& ws, const float* d_in, int n, int h, int 
                 d.A = x; d.lda = I; d.B = op.aux0; d.ldb = 3 * H; d.bias = op.aux1; d.C = gx.first; d.ldc = 3 * H;
                 d.M = T * N; d.N = 3 * H; d.K = I; d.batch = 2;
                 d.strideA = 0; d.strideB = (int64_t)I * 3 * H; d.strideBias = 3 * H; d.strideC = (int64_t)T * N * 3 * H;
-                k::gemm(d, st);
+                timed(KC_GEMM_GRU_INPUT, 2.0 * 2 * d.M * (double)d.N * d.K,
+                      4.0 * ((double)a.count() + 2.0 * d.M * d.N + 2.0 * d.K * d.N), [&] { k::gemm(d, st); });
                 k::GemmDesc r{};
                 r.A = hs.first; r.lda = H; r.B = op.aux2; r.ldb = 3 * H; r.bias = op.aux3; r.C = gh.first; r.ldc = 3 * H;
                 r.M = N; r.N = 3 * H; r.K = H; r.batch = 2;
                 r.strideA = (int64_t)N * H; r.strideB = (int64_t)H * 3 * H; r.strideBias = 3 * H; r.strideC = (int64_t)N * 3 * H;
                 for (int step = 0; step < T; step++) {
-                    k::gemm(r, st);
-                    k::gru_gates(gx.first, gh.first, hs.first, y, T, N, H, step, st);
+                    timed(KC_GEMM_GRU_HIDDEN, 2.0 * 2 * r.M * (double)r.N * r.K,
+                          4.0 * 2 * ((double)r.M * r.K + (double)r.M * r.N + (double)r.K * r.N), [&] { k::gemm(r, st); });
+                    timed(KC_GRU_GATES, 0, 4.0 * 2 * N * (double)H * 9,
+                          [&] { k::gru_gates(gx.first, gh.first, hs.first, y, T, N, H, step, st); });
                 }
                 free_local.emplace(gx.second, gx.first);
                 free_local.emplace(gh.second, gh.first);
@@ -328,12 +356,15 @@ float* HipModel::run_device(Workspace& ws, const float* d_in, int n, int h, int 
                 d.A = x; d.lda = op.cin; d.B = op.w[0]; d.ldb = op.cout; d.bias = op.w[1];
                 d.C = y; d.ldc = op.cout; d.M = (int)((int64_t)a.n * a.h * a.w); d.N = op.cout; d.K = op.cin;
                 d.relu = op.relu;
-                k::gemm(d, st);
+                timed(KC_GEMM_LINEAR, 2.0 * d.M * (double)d.N * d.K, 4.0 * ((double)a.count() + o.count()) + wbytes(op, 0),
+                      [&] { k::gemm(d, st); });
                 break;
             }
             case OP_LOGSOFTMAX:
-                k::log_softmax_argmax(x, (int64_t)a.n * a.h * a.w, a.c, is_final_logsoftmax ? d_excluded : nullptr, y,
-                                      is_final_logsoftmax ? d_labels : nullptr, st);
+                timed(KC_LOGSOFTMAX_ARGMAX, 0, 4.0 * a.count() * (y ? 2.0 : 1.0), [&] {
+                    k::log_softmax_argmax(x, (int64_t)a.n * a.h * a.w, a.c, is_final_logsoftmax ? d_excluded : nullptr, y,
+                                          is_final_logsoftmax ? d_labels : nullptr, st);
+                });
                 break;
             default: fail(OCRS_ERR_RUN_FAILED, "model run failed: bad op");
         }
@@ -354,7 +385,7 @@ float* HipModel::run_device(Workspace& ws, const float* d_in, int n, int h, int 
     if (print_timing) {
         OCRS_HIP(hipStreamSynchronize(st));
         float total = 0.f;
-        for (size_t i = 0; i < ops.size(); i++) {
+        for (size_t i = 0; i < n_run; i++) {
             float ms = 0.f;
             (void)hipEventElapsedTime(&ms, ev[i], ev[i + 1]);
             total += ms;
@@ -364,7 +395,141 @@ float* HipModel::run_device(Workspace& ws, const float* d_in, int n, int h, int 
         printf("total %.3fms\n", total);
         for (auto& e : ev) (void)hipEventDestroy(e);
     }
-    return ptr[out_slot];
+    return ptr[ret_slot];
+}
+
+// ---------------------------------------------------------------------------
+// Ragged recognition batch
+// ---------------------------------------------------------------------------
+int HipModel::packed_split() const {
+    int ts = -1;
+    for (size_t i = 0; i < ops.size(); i++)
+        if (ops[i].type == OP_TOSEQ) { ts = (int)i; break; }
+    if (ts < 0 || (size_t)ts + 3 > ops.size()) return -1;
+    int prev_out = ops[ts].out;
+    for (size_t i = ts + 1; i < ops.size(); i++) {
+        const GraphOp& op = ops[i];
+        const bool last = i + 1 == ops.size(), second_last = i + 2 == ops.size();
+        if (op.in0 != prev_out) return -1;
+        if (last) { if (op.type != OP_LOGSOFTMAX || (uint32_t)op.out != out_slot) return -1; }
+        else if (second_last) { if (op.type != OP_LINEAR) return -1; }
+        else if (op.type != OP_GRU) return -1;
+        prev_out = op.out;
+    }
+    for (int i = 0; i < ts; i++)
+        if (ops[i].type == OP_GRU || ops[i].type == OP_LINEAR || ops[i].type == OP_LOGSOFTMAX || ops[i].type == OP_TOSEQ)
+            return -1;
+    return ts;
+}
+
+int HipModel::run_recognition_packed(Workspace& ws, const std::vector<PackedGroup>& groups, const PackedPlan& plan, int h,
+                                     StageTimers* timers, const uint8_t* d_excluded, int32_t* d_labels) const {
+    const int ts = packed_split();
+    if (ts < 0) fail(OCRS_ERR_RUN_FAILED, "model run failed: graph is not <conv stack> TOSEQ GRU* LINEAR LOGSOFTMAX");
+    hipStream_t st = ws.s();
+    auto timed = [&](int cls, double flops, double bytes, auto&& launch) {
+        int tok = timers ? timers->kbegin(cls, st, flops, bytes) : -1;
+        launch();
+        if (tok >= 0) timers->end(tok, st);
+    };
+    const int64_t R = plan.R;
+    const int M = plan.M;
+
+    // ---- conv stack per width group -> packed feature rows
+    float* X = nullptr;
+    int C0 = 0;
+    for (const PackedGroup& g : groups) {
+        TensorShape fs;
+        float* feat = run_device(ws, g.d_batch, g.n, h, g.w, &fs, timers, nullptr, nullptr, true, false, ts);
+        if (fs.h != 1) fail(OCRS_ERR_RUN_FAILED, "model run failed: TOSEQ expects height 1, got %d", fs.h);
+        if (!X) {
+            C0 = fs.c;
+            X = ws.alloc_n<float>((size_t)R * C0);
+        }
+        int tok = timers ? timers->begin(ST_REC_CONV, st, 0) : -1;
+        timed(KC_OTHER, 0, 8.0 * fs.count(), [&] { k::to_seq_packed(feat, g.n, fs.w, fs.c, g.d_pos, plan.d_off, X, st); });
+        if (tok >= 0) timers->end(tok, st);
+    }
+    if (!X) return 0;
+
+    const float* cur = X;
+    int curC = C0;
+    int classes = 0;
+    for (size_t i = ts + 1; i < ops.size(); i++) {
+        const GraphOp& op = ops[i];
+        if (op.type == OP_GRU) {
+            const int H = op.hidden, I = op.cin;
+            if (I != curC) fail(OCRS_ERR_RUN_FAILED, "model run failed: GRU input size %d != %d", I, curC);
+            int tok = timers ? timers->begin(ST_REC_GRU, st, 0) : -1;
+            float* gx = ws.alloc_n<float>((size_t)2 * R * 3 * H);
+            float* y = ws.alloc_n<float>((size_t)R * 2 * H);
+            k::GemmDesc d{};
+            d.A = cur; d.lda = I; d.B = op.aux0; d.ldb = 3 * H; d.bias = op.aux1; d.C = gx; d.ldc = 3 * H;
+            d.M = (int)R; d.N = 3 * H; d.K = I; d.batch = 2;
+            d.strideA = 0; d.strideB = (int64_t)I * 3 * H; d.strideBias = 3 * H; d.strideC = R * 3 * H;
+            timed(KC_GEMM_GRU_INPUT, 2.0 * 2 * R * (double)d.N * d.K, 4.0 * ((double)R * I + 2.0 * R * d.N + 2.0 * d.K * d.N),
+                  [&] { k::gemm(d, st); });
+            const bool fused = (H == 256 || H == 128 || H == 64);
+            if (fused) {
+                // transposed, ping-ponged state hT[2 dirs][H][Mcap]
+                const int Mcap = (M + 3) & ~3;
+                float* hT0 = ws.alloc_n<float>((size_t)2 * H * Mcap);
+                float* hT1 = ws.alloc_n<float>((size_t)2 * H * Mcap);
+                OCRS_HIP(hipMemsetAsync(hT0, 0, (size_t)2 * H * Mcap * sizeof(float), st));
+                for (int step = 0; step < plan.Tmax; step++) {
+                    const int act = plan.active[step];
+                    if (act <= 0) break;
+                    const float* hin = (step & 1) ? hT1 : hT0;
+                    float* hout = (step & 1) ? hT0 : hT1;
+                    timed(KC_GEMM_GRU_HIDDEN, 2.0 * 2 * act * 3.0 * H * H,
+                          4.0 * 2 * ((double)act * H * 2 + (double)act * 3 * H + 3.0 * H * H + (double)act * H), [&] {
+                              k::gru_step_fused(gx, op.aux2, op.aux3, hin, hout, y, plan.d_Tm, plan.d_off, R, Mcap, act, H, step, st);
+                          });
+                }
+            } else {
+                float* gh = ws.alloc_n<float>((size_t)2 * M * 3 * H);
+                float* hs = ws.alloc_n<float>((size_t)2 * M * H);
+                OCRS_HIP(hipMemsetAsync(hs, 0, (size_t)2 * M * H * sizeof(float), st));
+                k::GemmDesc r{};
+                r.A = hs; r.lda = H; r.B = op.aux2; r.ldb = 3 * H; r.bias = op.aux3; r.C = gh; r.ldc = 3 * H;
+                r.N = 3 * H; r.K = H; r.batch = 2;
+                r.strideA = (int64_t)M * H; r.strideB = (int64_t)H * 3 * H; r.strideBias = 3 * H; r.strideC = (int64_t)M * 3 * H;
+                for (int step = 0; step < plan.Tmax; step++) {
+                    const int act = plan.active[step];
+                    if (act <= 0) break;
+                    r.M = act;
+                    timed(KC_GEMM_GRU_HIDDEN, 2.0 * 2 * act * (double)r.N * r.K,
+                          4.0 * 2 * ((double)act * r.K + (double)act * r.N + (double)r.K * r.N), [&] { k::gemm(r, st); });
+                    timed(KC_GRU_GATES, 0, 4.0 * 2 * act * (double)H * 9, [&] {
+                        k::gru_gates_packed(gx, gh, hs, y, plan.d_Tm, plan.d_off, R, M, act, H, step, st);
+                    });
+                }
+            }
+            if (tok >= 0) timers->end(tok, st);
+            cur = y;
+            curC = 2 * H;
+        } else if (op.type == OP_LINEAR) {
+            if (op.cin != curC) fail(OCRS_ERR_RUN_FAILED, "model run failed: Linear input size %d != %d", op.cin, curC);
+            int tok = timers ? timers->begin(ST_REC_HEAD, st, 0) : -1;
+            float* y = ws.alloc_n<float>((size_t)R * op.cout);
+            k::GemmDesc d{};
+            d.A = cur; d.lda = op.cin; d.B = op.w[0]; d.ldb = op.cout; d.bias = op.w[1];
+            d.C = y; d.ldc = op.cout; d.M = (int)R; d.N = op.cout; d.K = op.cin; d.relu = op.relu;
+            timed(KC_GEMM_LINEAR, 2.0 * R * (double)d.N * d.K, 4.0 * ((double)R * (op.cin + op.cout)) + 4.0 * op.wcount[0],
+                  [&] { k::gemm(d, st); });
+            if (tok >= 0) timers->end(tok, st);
+            cur = y;
+            curC = op.cout;
+        } else {  // LOGSOFTMAX (+ arg-max)
+            int tok = timers ? timers->begin(ST_REC_HEAD, st, 0) : -1;
+            timed(KC_LOGSOFTMAX_ARGMAX, 0, 4.0 * R * curC,
+                  [&] { k::log_softmax_argmax(cur, R, curC, d_excluded, nullptr, d_labels, st); });
+            if (tok >= 0) timers->end(tok, st);
+            classes = curC;
+        }
+    }
+    OCRS_HIP(hipGetLastError());
+    return classes;
 }
 
 }  // namespace ocrs

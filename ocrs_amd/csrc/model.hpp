@@ -68,9 +68,30 @@ struct HipModel : ModelBase {
     // `ws` (detection: [n,H,W,1] probabilities; recognition: [T,n,C] log-probs or, when
     // want_logp is false, nothing but the arg-max labels).  Recognition extras:
     //   d_excluded: [C] bytes or null; d_labels: [T*n] arg-max labels or null.
+    // stop_before >= 0: execute only ops [0, stop_before) and return that op's input tensor.
     float* run_device(Workspace& ws, const float* d_in, int n, int h, int w, TensorShape* out_shape,
                       StageTimers* timers, const uint8_t* d_excluded = nullptr, int32_t* d_labels = nullptr,
-                      bool want_logp = true, bool print_timing = false) const;
+                      bool want_logp = true, bool print_timing = false, int stop_before = -1) const;
+
+    // ---- ragged recognition batch (all width groups of a request at once) ----
+    // The graph must be: <conv stack> TOSEQ GRU* LINEAR LOGSOFTMAX.  Returns the index
+    // of the TOSEQ op, or -1 if the graph has another shape.
+    int packed_split() const;
+    struct PackedGroup {      // one width group: batch [n, h, w] and, per line, its row slot m
+        const float* d_batch;
+        int n, w;
+        const int32_t* d_pos;  // [n] device
+    };
+    struct PackedPlan {       // lines sorted by T descending; rows off[t] + m
+        int M = 0, Tmax = 0;
+        int64_t R = 0;
+        const int32_t* d_Tm = nullptr;   // [M]
+        const int32_t* d_off = nullptr;  // [Tmax + 1]
+        std::vector<int> active;         // [Tmax] host
+    };
+    // Writes arg-max labels of every packed row to d_labels [R]; returns class count.
+    int run_recognition_packed(Workspace& ws, const std::vector<PackedGroup>& groups, const PackedPlan& plan, int h,
+                               StageTimers* timers, const uint8_t* d_excluded, int32_t* d_labels) const;
 };
 
 }  // namespace ocrs
