@@ -204,6 +204,173 @@ __global__ void __launch_bounds__(256) gemm_mfma_kernel(GemmDesc d) {
     }
 }
 
+// ---------------------------------------------------------------------------
+// Tiled variant for the compute-bound shapes (3x3 convs of the CRNN, GRU input
+// projection, Linear): 128 x BN block tile, BK = 32, both operands staged in LDS
+// (k-major, so every MFMA operand is one conflict-free ds_read_b32), 4 waves as
+// 2 x 2, each owning 64 x BN/2 (2 x BN/64 tiles of 32x32).  The next chunk's
+// global loads are issued into registers before the current chunk's MFMAs and
+// written to the other LDS buffer afterwards: one barrier per chunk, global
+// latency hidden behind 64-128 MFMAs per wave.  K order per accumulator is
+// still strictly ascending, so results stay bit-identical.
+// Requires K % 32 == 0 (im2col: Cin % 32 == 0).
+// ---------------------------------------------------------------------------
+constexpr int TG_BM = 128, TG_BK = 32, TG_LDA = TG_BM + 1;
+
+template <int BN, bool IM2COL>
+__global__ void __launch_bounds__(256) gemm_tiled_kernel(GemmDesc d) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int NTW = BN / 64;  // 32-col tiles per wave
+    float* As = lds;                        // [2][TG_BK][TG_LDA]
+    float* Bs = lds + 2 * TG_BK * TG_LDA;   // [2][TG_BK][BN]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int z = blockIdx.z;
+    const float* __restrict__ A = d.A + (int64_t)z * d.strideA;
+    const float* __restrict__ B = d.B + (int64_t)z * d.strideB;
+    const float* __restrict__ bias = d.bias ? d.bias + (int64_t)z * d.strideBias : nullptr;
+    float* __restrict__ C = d.C + (int64_t)z * d.strideC;
+    const int64_t m0 = (int64_t)blockIdx.x * TG_BM;
+    const int n0 = blockIdx.y * BN;
+
+    // ---- per-thread load assignments
+    // A: 128 rows x 8 float4 per chunk -> 4 per thread; thread handles rows ar + 32*j, float4 column akq
+    const int ar = tid >> 3, akq = tid & 7;
+    const float* arow_ptr[4];
+    int apy[4], apx[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        int64_t row = m0 + ar + 32 * j;
+        if (row >= d.M) row = d.M - 1;
+        if (IM2COL) {
+            const int64_t hw = (int64_t)d.H * d.W;
+            const int64_t img = row / hw;
+            const int rem = (int)(row - img * hw);
+            apy[j] = rem / d.W;
+            apx[j] = rem - apy[j] * d.W;
+            arow_ptr[j] = A + img * hw * d.Cin;
+        } else {
+            apy[j] = apx[j] = 0;
+            arow_ptr[j] = A + row * d.lda;
+        }
+    }
+    // B: TG_BK x BN floats per chunk -> BN/32 float4 per thread
+    constexpr int BV = BN / 32;
+    const bool b_vec = ((d.ldb & 3) == 0) && (((uintptr_t)B & 15) == 0);
+
+    float4 pa[4], pb[BV];
+    auto prefetch = [&](int k0) {
+        if (IM2COL) {
+            const int tap = k0 / d.Cin;
+            const int ci0 = k0 - tap * d.Cin;
+            const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int iy = apy[j] + ky - 1, ix = apx[j] + kx - 1;
+                const bool ok = (unsigned)iy < (unsigned)d.H && (unsigned)ix < (unsigned)d.W;
+                pa[j] = ok ? *reinterpret_cast<const float4*>(arow_ptr[j] + ((int64_t)iy * d.W + ix) * d.Cin + ci0 + akq * 4)
+                           : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++) pa[j] = *reinterpret_cast<const float4*>(arow_ptr[j] + k0 + akq * 4);
+        }
+#pragma unroll
+        for (int j = 0; j < BV; j++) {
+            const int idx = tid + 256 * j;
+            const int kk = idx / (BN / 4), nn = (idx % (BN / 4)) * 4;
+            const float* src = B + (int64_t)(k0 + kk) * d.ldb + n0 + nn;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (b_vec && n0 + nn + 3 < d.N) {
+                v = *reinterpret_cast<const float4*>(src);
+            } else {
+                if (n0 + nn + 0 < d.N) v.x = src[0];
+                if (n0 + nn + 1 < d.N) v.y = src[1];
+                if (n0 + nn + 2 < d.N) v.z = src[2];
+                if (n0 + nn + 3 < d.N) v.w = src[3];
+            }
+            pb[j] = v;
+        }
+    };
+    auto commit = [&](int buf) {
+        float* a = As + buf * TG_BK * TG_LDA;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int r = ar + 32 * j;
+            a[(akq * 4 + 0) * TG_LDA + r] = pa[j].x;
+            a[(akq * 4 + 1) * TG_LDA + r] = pa[j].y;
+            a[(akq * 4 + 2) * TG_LDA + r] = pa[j].z;
+            a[(akq * 4 + 3) * TG_LDA + r] = pa[j].w;
+        }
+        float* b = Bs + buf * TG_BK * BN;
+#pragma unroll
+        for (int j = 0; j < BV; j++) {
+            const int idx = tid + 256 * j;
+            const int kk = idx / (BN / 4), nn = (idx % (BN / 4)) * 4;
+            *reinterpret_cast<float4*>(&b[kk * BN + nn]) = pb[j];
+        }
+    };
+
+    f32x16 acc[2][NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; t++) {
+        const int col = n0 + wn * (BN / 2) + t * 32 + l31;
+        const float bv = (bias && col < d.N) ? bias[col] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) { acc[0][t][r] = bv; acc[1][t][r] = bv; }
+    }
+
+    const int nchunks = d.K / TG_BK;
+    prefetch(0);
+    commit(0);
+    __syncthreads();
+    for (int c = 0; c < nchunks; c++) {
+        const int buf = c & 1;
+        if (c + 1 < nchunks) prefetch((c + 1) * TG_BK);
+        const float* a = As + buf * TG_BK * TG_LDA + wm * 64 + l31;
+        const float* b = Bs + buf * TG_BK * BN + wn * (BN / 2) + l31;
+#pragma unroll
+        for (int kp = 0; kp < TG_BK / 2; kp++) {
+            const int kr = 2 * kp + half;
+            const float a0 = a[kr * TG_LDA], a1 = a[kr * TG_LDA + 32];
+#pragma unroll
+            for (int t = 0; t < NTW; t++) {
+                const float bt = b[kr * BN + t * 32];
+                acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bt, acc[0][t], 0, 0, 0);
+                acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bt, acc[1][t], 0, 0, 0);
+            }
+        }
+        if (c + 1 < nchunks) commit(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue (32x32 C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5))
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int t = 0; t < NTW; t++) {
+            const int col = n0 + wn * (BN / 2) + t * 32 + l31;
+            if (col >= d.N) continue;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int64_t rr = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (rr >= d.M) continue;
+                float v = acc[i][t][r];
+                if (d.relu) v = v > 0.0f ? v : 0.0f;
+                C[rr * d.ldc + col] = v;
+            }
+        }
+}
+
+template <int BN>
+static void launch_gemm_tiled(const GemmDesc& d, hipStream_t s) {
+    dim3 grid((unsigned)((d.M + TG_BM - 1) / TG_BM), (unsigned)((d.N + BN - 1) / BN), (unsigned)(d.batch > 0 ? d.batch : 1));
+    size_t lds = (size_t)(2 * TG_BK * TG_LDA + 2 * TG_BK * BN) * sizeof(float);
+    if (d.im2col) hipLaunchKernelGGL((gemm_tiled_kernel<BN, true>), grid, dim3(256), lds, s, d);
+    else hipLaunchKernelGGL((gemm_tiled_kernel<BN, false>), grid, dim3(256), lds, s, d);
+}
+
 template <int NT>
 static void launch_gemm(const GemmDesc& d, hipStream_t s) {
     dim3 grid((unsigned)((d.M + 127) / 128), (unsigned)((d.N + 32 * NT - 1) / (32 * NT)), (unsigned)(d.batch > 0 ? d.batch : 1));
@@ -218,6 +385,13 @@ static void launch_gemm(const GemmDesc& d, hipStream_t s) {
 
 void gemm(const GemmDesc& d, hipStream_t s) {
     if (d.M <= 0 || d.N <= 0) return;
+    const bool tiled_ok = !d.convt && d.N >= 64 && (d.K % TG_BK) == 0 && d.M >= 256 &&
+                          (d.im2col ? (d.Cin % TG_BK) == 0 : ((d.lda & 3) == 0 && ((uintptr_t)d.A & 15) == 0));
+    if (tiled_ok) {
+        if (d.N <= 64) launch_gemm_tiled<64>(d, s);
+        else launch_gemm_tiled<128>(d, s);
+        return;
+    }
     if (d.N <= 32) launch_gemm<1>(d, s);
     else if (d.N <= 64) launch_gemm<2>(d, s);
     else launch_gemm<4>(d, s);
@@ -659,7 +833,42 @@ gru_step_fused_kernel(const float* __restrict__ gx, const float* __restrict__ wh
     float* __restrict__ hout = hT_out + (int64_t)dir * H * Mcap;
     const float* __restrict__ gxd = gx + (int64_t)dir * R * 3 * H;
 
-    // stage Wh[:, g*H + j0 .. +16) for g = r,z,n
+    const int i16 = lane & 15, kq = lane >> 4;
+    const bool wave_active = row0 < active;  // wave-uniform
+
+    // ---- issue every global load this wave needs up front (one memory latency, not 64):
+    // (1) the A fragment: lane (i16, kq) feeds h[row0 + i16][k = 4*s + kq] for s = 0..H/4
+    float areg[H / 4];
+    const int arow = min(row0 + i16, Mcap - 1);
+    if (wave_active) {
+        const float* ap = hin + (int64_t)kq * Mcap + arow;
+#pragma unroll
+        for (int s4 = 0; s4 < H / 4; s4++) areg[s4] = ap[(int64_t)s4 * 4 * Mcap];
+    }
+    // (2) the epilogue operands of this lane's 4 rows of hidden unit j
+    const int j = j0 + i16;
+    const int mbase = row0 + kq * 4;
+    float gxr_[4], gxz_[4], gxn_[4], hprev_[4];
+    int64_t yrow[4];
+    bool rok[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int m = mbase + r;
+        rok[r] = wave_active && m < active;
+        gxr_[r] = gxz_[r] = gxn_[r] = hprev_[r] = 0.0f;
+        yrow[r] = 0;
+        if (rok[r]) {
+            const int t = dir ? Tm[m] - 1 - step : step;
+            const int64_t row = (int64_t)off[t] + m;
+            const float* g = gxd + row * 3 * H;
+            gxr_[r] = g[j];
+            gxz_[r] = g[H + j];
+            gxn_[r] = g[2 * H + j];
+            hprev_[r] = hin[(int64_t)j * Mcap + m];
+            yrow[r] = row;
+        }
+    }
+    // (3) the Wh slice [:, g*H + j0 .. +16) for g = r,z,n -> LDS
     for (int i = tid; i < H * 12; i += 256) {  // 12 float4 per k-row
         const int k = i / 12, q = i - k * 12;
         const int g = q >> 2, c4 = (q & 3) * 4;
@@ -667,43 +876,33 @@ gru_step_fused_kernel(const float* __restrict__ gx, const float* __restrict__ wh
         *reinterpret_cast<float4*>(&lds_w[k * 48 + g * 16 + c4]) = v;
     }
     __syncthreads();
-    if (row0 >= active) return;
+    if (!wave_active) return;
 
-    const int i16 = lane & 15, kq = lane >> 4;
-    const int arow = min(row0 + i16, Mcap - 1);
     f32x4 acc_r, acc_z, acc_n;
     {
         const float br = bhd[j0 + i16], bz = bhd[H + j0 + i16], bn = bhd[2 * H + j0 + i16];
         for (int r = 0; r < 4; r++) { acc_r[r] = br; acc_z[r] = bz; acc_n[r] = bn; }
     }
-    const float* ap = hin + (int64_t)kq * Mcap + arow;
     const float* bp = &lds_w[kq * 48 + i16];
-#pragma unroll 8
+#pragma unroll
     for (int s4 = 0; s4 < H / 4; s4++) {
-        const float a = ap[(int64_t)s4 * 4 * Mcap];
+        const float a = areg[s4];
         const float* b = bp + s4 * 4 * 48;
         acc_r = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[0], acc_r, 0, 0, 0);
         acc_z = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[16], acc_z, 0, 0, 0);
         acc_n = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[32], acc_n, 0, 0, 0);
     }
     // C/D layout 16x16: col = lane & 15 (hidden unit), row = (lane >> 4) * 4 + reg (batch row)
-    const int j = j0 + i16;
-    const int mbase = row0 + kq * 4;
     float hnew[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-        const int m = mbase + r;
         float hn = 0.0f;
-        if (m < active) {
-            const int t = dir ? Tm[m] - 1 - step : step;
-            const int64_t row = (int64_t)off[t] + m;
-            const float* gxr = gxd + row * 3 * H;
-            const float rg = spec_sigmoidf(gxr[j] + acc_r[r]);
-            const float zg = spec_sigmoidf(gxr[H + j] + acc_z[r]);
-            const float ng = spec_tanhf(fmaf(rg, acc_n[r], gxr[2 * H + j]));
-            const float hprev = hin[(int64_t)j * Mcap + m];
-            hn = fmaf(zg, hprev - ng, ng);
-            y[row * 2 * H + (int64_t)dir * H + j] = hn;
+        if (rok[r]) {
+            const float rg = spec_sigmoidf(gxr_[r] + acc_r[r]);
+            const float zg = spec_sigmoidf(gxz_[r] + acc_z[r]);
+            const float ng = spec_tanhf(fmaf(rg, acc_n[r], gxn_[r]));
+            hn = fmaf(zg, hprev_[r] - ng, ng);
+            y[yrow[r] * 2 * H + (int64_t)dir * H + j] = hn;
         }
         hnew[r] = hn;
     }

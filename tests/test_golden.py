@@ -1,0 +1,84 @@
+"""Committed golden fixtures (tests/golden/, made by tests/golden/make_golden.py
+with the CPU oracle).  CPU: the oracle still reproduces them (drift guard).
+GPU: the HIP path reproduces them through the C ABI."""
+import os
+
+import numpy as np
+import pytest
+
+import models_util as M
+from oracle import pipeline as OP
+from oracle.nn import OracleGraph, OracleModel
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+DET_HW, DET_DEPTHS = (160, 128), (8, 16, 32, 32)
+
+
+def _bits_sum(a):
+    return int(np.frombuffer(np.ascontiguousarray(a).tobytes(), np.uint32).sum(dtype=np.uint64))
+
+
+def _load():
+    g = np.load(os.path.join(G, "pipeline_small.npz"))
+    dbuf, rbuf = M.detection_model_bytes(DET_HW, DET_DEPTHS), M.recognition_model_bytes()
+    assert [M.digest(dbuf), M.digest(rbuf)] == list(g["model_digests"]), "synthetic model files changed: regenerate goldens"
+    px = np.repeat(g["page"][:, :, None], 3, axis=2)
+    return g, dbuf, rbuf, np.ascontiguousarray(px)
+
+
+def test_oracle_reproduces_pipeline_golden():
+    g, dbuf, rbuf, px = _load()
+    ora = OP.OcrEngine(detection_model=OracleModel(OracleGraph(dbuf), "exact"),
+                       recognition_model=OracleModel(OracleGraph(rbuf), "exact"))
+    inp = ora.prepare_input(OP.ImageSource.from_tensor(px, "hwc"))
+    assert _bits_sum(inp) == int(g["grey_crc"][0])
+    prob = ora.detect_text_pixels(inp)
+    assert _bits_sum(prob) == int(g["prob_bits_sum"][0])
+    assert np.array_equal(np.packbits(prob > np.float32(0.2)), g["mask"])
+    words = ora.detect_words(inp)
+    assert np.array_equal(np.array([w.to_array() for w in words], np.float32).reshape(-1, 6), g["word_rects"])
+    lines = ora.find_text_lines(inp, words)
+    assert np.array_equal(np.cumsum([0] + [len(l) for l in lines]), g["line_offsets"])
+    assert np.array_equal(np.array([w.to_array() for l in lines for w in l], np.float32).reshape(-1, 6), g["line_rects"])
+    assert ora.get_text(inp) == str(g["text"][0])
+
+
+def test_oracle_reproduces_recognition_golden():
+    g = np.load(os.path.join(G, "recognition_small.npz"))
+    x = np.full((3, 1, 64, 100), -0.5, np.float32)
+    x[:, 0, :, :96] = g["crops"].astype(np.float32)
+    lp = OracleGraph(M.recognition_model_bytes()).run_exact(x)
+    assert np.array_equal(lp.argmax(-1).astype(np.uint8), g["argmax"])
+    assert _bits_sum(lp) == int(g["logp_bits_sum"][0])
+
+
+@pytest.mark.gpu
+def test_gpu_reproduces_pipeline_golden():
+    from ocrs_amd import DimOrder, ImageSource, Model, OcrEngine
+    g, dbuf, rbuf, px = _load()
+    eng = OcrEngine(detection_model=Model.load_bytes(dbuf), recognition_model=Model.load_bytes(rbuf))
+    inp = eng.prepare_input(ImageSource.from_tensor(px, DimOrder.Hwc))
+    assert _bits_sum(inp.image()) == int(g["grey_crc"][0])
+    prob = eng.detect_text_pixels(inp)
+    assert _bits_sum(prob) == int(g["prob_bits_sum"][0])
+    words = eng.detect_words(inp)
+    assert np.array_equal(words, g["word_rects"])
+    lines = eng.find_text_lines(inp, words)
+    assert np.array_equal(np.cumsum([0] + [len(l) for l in lines]), g["line_offsets"])
+    assert np.array_equal(np.concatenate(lines), g["line_rects"])
+    toks = eng.recognize_tokens(inp, lines)
+    flat = np.array([t for ts in toks for t in ts], np.int32).reshape(-1, 2)
+    assert np.array_equal(flat, g["tokens"])
+    assert np.array_equal(np.cumsum([0] + [len(t) for t in toks]), g["token_offsets"])
+    assert eng.get_text(inp) == str(g["text"][0])
+
+
+@pytest.mark.gpu
+def test_gpu_reproduces_recognition_golden():
+    from ocrs_amd import Model
+    g = np.load(os.path.join(G, "recognition_small.npz"))
+    x = np.full((3, 1, 64, 100), -0.5, np.float32)
+    x[:, 0, :, :96] = g["crops"].astype(np.float32)
+    lp = Model.load_bytes(M.recognition_model_bytes()).run(x)
+    assert np.array_equal(lp.argmax(-1).astype(np.uint8), g["argmax"])
+    assert _bits_sum(lp) == int(g["logp_bits_sum"][0])
