@@ -59,7 +59,7 @@ def main():
         line_rects=np.array([w.to_array() for l in lines for w in l], np.float32).reshape(-1, 6),
         line_offsets=line_off, tokens=tok_flat, token_offsets=tok_off, text=np.array([text]))
     # a recognition-only fixture: 3 crops -> log-prob arg-max path
-    crops = synth.synthetic_line_crops(21, n=3, width=96)
+    crops = synth.synthetic_line_crops(21, n=3, width=96).astype(np.float16).astype(np.float32)  # stored as f16
     x = np.full((3, 1, 64, 100), -0.5, np.float32)
     x[:, 0, :, :96] = crops
     lp = OracleGraph(rbuf).run_exact(x)
