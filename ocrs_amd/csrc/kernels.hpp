@@ -104,6 +104,30 @@ void argmax_rows(const float* x, int64_t rows, int c, const uint8_t* d_excluded,
 void ctc_collapse(const int32_t* labels, int T, int N, uint32_t* out_labels, uint32_t* out_pos, int32_t* out_count,
                   hipStream_t s);
 
+// ---- kernels_rec.hip: ragged batch of the recognition conv stack -----------
+// All width groups of one request in one NHWC buffer: group-major, then image, y, x.
+struct RaggedView {          // device pointers live in one metadata upload; passed by value
+    int G;                   // groups
+    int H;                   // image height at this layer (same for every group)
+    const int32_t* W;        // [G] image width at this layer
+    const int32_t* n;        // [G] images per group
+    const int64_t* poff;     // [G+1] pixel offset of each group in the buffer
+    const int32_t* toff128;  // [G+1] cumulative 128-pixel tile counts
+    const int32_t* toff256;  // [G+1] cumulative 256-pixel tile counts
+    const int32_t* loff;     // [G+1] cumulative image (line) counts
+    int ntiles128, ntiles256;
+    int64_t pixels;          // total pixels (host)
+};
+void conv1_relu_pool_ragged(const float* x, const RaggedView& in, const float* wt, const float* bias, int cout,
+                            float* y, const RaggedView& out, hipStream_t s);
+void pool_ragged(const float* x, const RaggedView& in, int c, int kh, int kw, bool avg, float* y, const RaggedView& out,
+                 hipStream_t s);
+void to_seq_packed_ragged(const float* x, const RaggedView& in, int c, const int32_t* d_pos, const int32_t* d_off,
+                          float* y, hipStream_t s);
+// returns false if the shape is not supported (caller falls back to the per-group path)
+bool conv3x3_ragged(const float* x, const RaggedView& rv, int cin, const float* wt, const float* bias, int cout, int relu,
+                    float* y, hipStream_t s);
+
 // ---- kernels_lines.hip ----------------------------------------------------
 struct LineDesc {      // one text line to crop (recognition.rs:91-126)
     int32_t page;      // index into page pointer table

@@ -1,0 +1,324 @@
+// Ragged-batch kernels for the recognition conv stack.
+//
+// The reference pads every text line to its own width group (recognition.rs:437),
+// so one request holds ~30 groups of images with different widths.  Launching each
+// layer once per group gives ~30 small grids per layer that cannot fill 256 CUs.
+// Here all groups live in ONE buffer (group-major, then image, y, x; NHWC) and every
+// layer is ONE launch: a block owns a tile of rows (pixels) inside a single group and
+// finds its group by binary search in a cumulative tile table.  Per-pixel arithmetic
+// is exactly that of the per-group kernels (same fmaf chains, same order), so results
+// are bit-identical.
+#include "kernels.hpp"
+
+namespace ocrs {
+namespace k {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ int find_group(const int32_t* __restrict__ toff, int G, int tile) {
+    int lo = 0, hi = G;  // largest g with toff[g] <= tile
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (toff[mid] <= tile) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// ---------------------------------------------------------------------------
+// conv 3x3 (Cin = 1) + bias + ReLU + MaxPool 2x2, fused.  One thread = one POOLED
+// pixel x 4 output channels: four conv outputs (9 fmaf each per channel, taps
+// (ky,kx) ascending from acc = bias, out-of-image taps fmaf(0,w,acc)), ReLU, then
+// m = v0; m = v > m ? v : m over (py,px) ascending — the spec order of the unfused ops.
+// HBM: reads 4 B per input pixel (L1/L2 serve the tap re-use), writes 4*Cout B per
+// pooled pixel; the full-resolution conv output is never materialised.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+conv1_relu_pool_ragged_kernel(const float* __restrict__ x, RaggedView in, const float* __restrict__ wt,
+                              const float* __restrict__ bias, int cout, float* __restrict__ y, RaggedView out) {
+    __shared__ float sw[9 * 64 + 64];
+    for (int i = threadIdx.x; i < 9 * cout; i += 256) sw[i] = wt[i];
+    for (int i = threadIdx.x; i < cout; i += 256) sw[9 * 64 + i] = bias[i];
+    __syncthreads();
+    const int g = find_group(out.toff256, out.G, blockIdx.x);
+    const int tile = blockIdx.x - out.toff256[g];
+    const int ow = out.W[g], oh = out.H, iw = in.W[g], ih = in.H;
+    const int64_t rows = (int64_t)out.n[g] * oh * ow;
+    const float* __restrict__ xg = x + in.poff[g];
+    float* __restrict__ yg = y + out.poff[g] * cout;
+    const int cq = cout >> 2;
+    for (int i = threadIdx.x; i < 256 * cq; i += 256) {
+        const int64_t r = (int64_t)tile * 256 + i / cq;
+        if (r >= rows) break;
+        const int q = i % cq;
+        const int ox = (int)(r % ow);
+        const int oy = (int)((r / ow) % oh);
+        const int64_t img = r / ((int64_t)ow * oh);
+        const float* xi = xg + img * ih * iw;
+        // 4x4 input patch around the 2x2 conv outputs
+        float p[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const int iy = 2 * oy - 1 + a, ix = 2 * ox - 1 + b;
+                p[a][b] = ((unsigned)iy < (unsigned)ih && (unsigned)ix < (unsigned)iw) ? xi[(int64_t)iy * iw + ix] : 0.0f;
+            }
+        float m[4];
+#pragma unroll
+        for (int py = 0; py < 2; py++)
+#pragma unroll
+            for (int px = 0; px < 2; px++) {
+                float acc[4];
+#pragma unroll
+                for (int c = 0; c < 4; c++) acc[c] = sw[9 * 64 + 4 * q + c];
+#pragma unroll
+                for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+                    for (int kx = 0; kx < 3; kx++) {
+                        const float xv = p[py + ky][px + kx];
+                        const float* w = &sw[(ky * 3 + kx) * cout + 4 * q];
+#pragma unroll
+                        for (int c = 0; c < 4; c++) acc[c] = fmaf(xv, w[c], acc[c]);
+                    }
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    float v = acc[c] > 0.0f ? acc[c] : 0.0f;
+                    if (py == 0 && px == 0) m[c] = v;
+                    else m[c] = v > m[c] ? v : m[c];
+                }
+            }
+        *reinterpret_cast<float4*>(yg + r * cout + 4 * q) = make_float4(m[0], m[1], m[2], m[3]);
+    }
+}
+
+void conv1_relu_pool_ragged(const float* x, const RaggedView& in, const float* wt, const float* bias, int cout,
+                            float* y, const RaggedView& out, hipStream_t s) {
+    if (out.ntiles256 <= 0) return;
+    hipLaunchKernelGGL(conv1_relu_pool_ragged_kernel, dim3(out.ntiles256), dim3(256), 0, s, x, in, wt, bias, cout, y, out);
+}
+
+// ---------------------------------------------------------------------------
+// Pools on the ragged batch (kernel = stride = (kh, kw), floor).  HBM-bound.
+// ---------------------------------------------------------------------------
+template <bool AVG>
+__global__ void __launch_bounds__(256)
+pool_ragged_kernel(const float* __restrict__ x, RaggedView in, int c, int kh, int kw, float* __restrict__ y,
+                   RaggedView out) {
+    const int g = find_group(out.toff256, out.G, blockIdx.x);
+    const int tile = blockIdx.x - out.toff256[g];
+    const int ow = out.W[g], oh = out.H, iw = in.W[g], ih = in.H;
+    const int64_t rows = (int64_t)out.n[g] * oh * ow;
+    const float* __restrict__ xg = x + in.poff[g] * c;
+    float* __restrict__ yg = y + out.poff[g] * c;
+    const int cq = c >> 2;
+    const float inv = 1.0f / (float)(kh * kw);
+    for (int i = threadIdx.x; i < 256 * cq; i += 256) {
+        const int64_t r = (int64_t)tile * 256 + i / cq;
+        if (r >= rows) break;
+        const int q = i % cq;
+        const int ox = (int)(r % ow);
+        const int oy = (int)((r / ow) % oh);
+        const int64_t img = r / ((int64_t)ow * oh);
+        const float* xp = xg + ((img * ih + (int64_t)oy * kh) * iw + (int64_t)ox * kw) * c + 4 * q;
+        float4 acc = AVG ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(xp);
+        for (int ky = 0; ky < kh; ky++)
+            for (int kx = 0; kx < kw; kx++) {
+                const float4 v = *reinterpret_cast<const float4*>(xp + ((int64_t)ky * iw + kx) * c);
+                if (AVG) { acc.x = acc.x + v.x; acc.y = acc.y + v.y; acc.z = acc.z + v.z; acc.w = acc.w + v.w; }
+                else {
+                    acc.x = v.x > acc.x ? v.x : acc.x; acc.y = v.y > acc.y ? v.y : acc.y;
+                    acc.z = v.z > acc.z ? v.z : acc.z; acc.w = v.w > acc.w ? v.w : acc.w;
+                }
+            }
+        if (AVG) { acc.x = acc.x * inv; acc.y = acc.y * inv; acc.z = acc.z * inv; acc.w = acc.w * inv; }
+        *reinterpret_cast<float4*>(yg + r * c + 4 * q) = acc;
+    }
+}
+
+void pool_ragged(const float* x, const RaggedView& in, int c, int kh, int kw, bool avg, float* y, const RaggedView& out,
+                 hipStream_t s) {
+    if (out.ntiles256 <= 0) return;
+    if (avg) hipLaunchKernelGGL((pool_ragged_kernel<true>), dim3(out.ntiles256), dim3(256), 0, s, x, in, c, kh, kw, y, out);
+    else hipLaunchKernelGGL((pool_ragged_kernel<false>), dim3(out.ntiles256), dim3(256), 0, s, x, in, c, kh, kw, y, out);
+}
+
+// ---------------------------------------------------------------------------
+// [group][n][1][T][C] features -> packed sequence rows off[t] + pos[line].
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+to_seq_packed_ragged_kernel(const float* __restrict__ x, RaggedView in, int c, const int32_t* __restrict__ pos,
+                            const int32_t* __restrict__ off, float* __restrict__ y) {
+    const int g = find_group(in.toff256, in.G, blockIdx.x);
+    const int tile = blockIdx.x - in.toff256[g];
+    const int T = in.W[g];
+    const int64_t rows = (int64_t)in.n[g] * T;  // H == 1
+    const float* __restrict__ xg = x + in.poff[g] * c;
+    const int32_t* __restrict__ posg = pos + in.loff[g];
+    const int cq = c >> 2;
+    for (int i = threadIdx.x; i < 256 * cq; i += 256) {
+        const int64_t r = (int64_t)tile * 256 + i / cq;
+        if (r >= rows) break;
+        const int q = i % cq;
+        const int t = (int)(r % T);
+        const int line = (int)(r / T);
+        const float4 v = *reinterpret_cast<const float4*>(xg + r * c + 4 * q);
+        *reinterpret_cast<float4*>(y + ((int64_t)off[t] + posg[line]) * c + 4 * q) = v;
+    }
+}
+
+void to_seq_packed_ragged(const float* x, const RaggedView& in, int c, const int32_t* d_pos, const int32_t* d_off,
+                          float* y, hipStream_t s) {
+    if (in.ntiles256 <= 0) return;
+    hipLaunchKernelGGL(to_seq_packed_ragged_kernel, dim3(in.ntiles256), dim3(256), 0, s, x, in, c, d_pos, d_off, y);
+}
+
+// ---------------------------------------------------------------------------
+// 3x3 / pad 1 convolution on the ragged batch as an implicit GEMM on the fp32 matrix
+// cores.  Same tile structure as gemm_tiled_kernel (128 x BN x 32, LDS-staged k-major
+// operands, double buffer, register prefetch, 2x2 waves of 64 x BN/2, k strictly
+// ascending per accumulator); a block's 128 rows are pixels of ONE group.
+// ---------------------------------------------------------------------------
+constexpr int RG_BM = 128, RG_BK = 32, RG_LDA = RG_BM + 1;
+
+template <int BN>
+__global__ void __launch_bounds__(256)
+conv3x3_ragged_kernel(const float* __restrict__ X, RaggedView rv, int cin, const float* __restrict__ Bw,
+                      const float* __restrict__ bias, int cout, int relu, float* __restrict__ Y) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int NTW = BN / 64;
+    float* As = lds;
+    float* Bs = lds + 2 * RG_BK * RG_LDA;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int g = find_group(rv.toff128, rv.G, blockIdx.x);
+    const int tile = blockIdx.x - rv.toff128[g];
+    const int H = rv.H, W = rv.W[g];
+    const int64_t rows = (int64_t)rv.n[g] * H * W;
+    const int64_t m0 = (int64_t)tile * RG_BM;
+    const int n0 = blockIdx.y * BN;
+    const float* __restrict__ A = X + rv.poff[g] * cin;
+    float* __restrict__ C = Y + rv.poff[g] * cout;
+    const int K = 9 * cin;
+
+    const int ar = tid >> 3, akq = tid & 7;
+    const float* aimg[4];
+    int apy[4], apx[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        int64_t row = m0 + ar + 32 * j;
+        if (row >= rows) row = rows - 1;
+        const int64_t hw = (int64_t)H * W;
+        const int64_t img = row / hw;
+        const int rem = (int)(row - img * hw);
+        apy[j] = rem / W;
+        apx[j] = rem - apy[j] * W;
+        aimg[j] = A + img * hw * cin;
+    }
+    constexpr int BV = BN / 32;
+    float4 pa[4], pb[BV];
+    auto prefetch = [&](int k0) {
+        const int tap = k0 / cin;
+        const int ci0 = k0 - tap * cin;
+        const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int iy = apy[j] + ky - 1, ix = apx[j] + kx - 1;
+            const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+            pa[j] = ok ? *reinterpret_cast<const float4*>(aimg[j] + ((int64_t)iy * W + ix) * cin + ci0 + akq * 4)
+                       : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int j = 0; j < BV; j++) {
+            const int idx = tid + 256 * j;
+            const int kk = idx / (BN / 4), nn = (idx % (BN / 4)) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (n0 + nn + 3 < cout) v = *reinterpret_cast<const float4*>(Bw + (int64_t)(k0 + kk) * cout + n0 + nn);
+            pb[j] = v;
+        }
+    };
+    auto commit = [&](int buf) {
+        float* a = As + buf * RG_BK * RG_LDA;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int r = ar + 32 * j;
+            a[(akq * 4 + 0) * RG_LDA + r] = pa[j].x;
+            a[(akq * 4 + 1) * RG_LDA + r] = pa[j].y;
+            a[(akq * 4 + 2) * RG_LDA + r] = pa[j].z;
+            a[(akq * 4 + 3) * RG_LDA + r] = pa[j].w;
+        }
+        float* b = Bs + buf * RG_BK * BN;
+#pragma unroll
+        for (int j = 0; j < BV; j++) {
+            const int idx = tid + 256 * j;
+            const int kk = idx / (BN / 4), nn = (idx % (BN / 4)) * 4;
+            *reinterpret_cast<float4*>(&b[kk * BN + nn]) = pb[j];
+        }
+    };
+
+    f32x16 acc[2][NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; t++) {
+        const int col = n0 + wn * (BN / 2) + t * 32 + l31;
+        const float bv = col < cout ? bias[col] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) { acc[0][t][r] = bv; acc[1][t][r] = bv; }
+    }
+    const int nchunks = K / RG_BK;
+    prefetch(0);
+    commit(0);
+    __syncthreads();
+    for (int c = 0; c < nchunks; c++) {
+        const int buf = c & 1;
+        if (c + 1 < nchunks) prefetch((c + 1) * RG_BK);
+        const float* a = As + buf * RG_BK * RG_LDA + wm * 64 + l31;
+        const float* b = Bs + buf * RG_BK * BN + wn * (BN / 2) + l31;
+#pragma unroll
+        for (int kp = 0; kp < RG_BK / 2; kp++) {
+            const int kr = 2 * kp + half;
+            const float a0 = a[kr * RG_LDA], a1 = a[kr * RG_LDA + 32];
+#pragma unroll
+            for (int t = 0; t < NTW; t++) {
+                const float bt = b[kr * BN + t * 32];
+                acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bt, acc[0][t], 0, 0, 0);
+                acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bt, acc[1][t], 0, 0, 0);
+            }
+        }
+        if (c + 1 < nchunks) commit(buf ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int t = 0; t < NTW; t++) {
+            const int col = n0 + wn * (BN / 2) + t * 32 + l31;
+            if (col >= cout) continue;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int64_t rr = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (rr >= rows) continue;
+                float v = acc[i][t][r];
+                if (relu) v = v > 0.0f ? v : 0.0f;
+                C[rr * cout + col] = v;
+            }
+        }
+}
+
+bool conv3x3_ragged(const float* x, const RaggedView& rv, int cin, const float* wt, const float* bias, int cout, int relu,
+                    float* y, hipStream_t s) {
+    if ((cin % RG_BK) != 0 || (cout % 4) != 0 || cout < 64) return false;
+    if (rv.ntiles128 <= 0) return true;
+    if (cout <= 64) {
+        size_t lds = (size_t)(2 * RG_BK * RG_LDA + 2 * RG_BK * 64) * sizeof(float);
+        hipLaunchKernelGGL((conv3x3_ragged_kernel<64>), dim3(rv.ntiles128, (cout + 63) / 64), dim3(256), lds, s, x, rv, cin, wt,
+                           bias, cout, relu, y);
+    } else {
+        size_t lds = (size_t)(2 * RG_BK * RG_LDA + 2 * RG_BK * 128) * sizeof(float);
+        hipLaunchKernelGGL((conv3x3_ragged_kernel<128>), dim3(rv.ntiles128, (cout + 127) / 128), dim3(256), lds, s, x, rv, cin,
+                           wt, bias, cout, relu, y);
+    }
+    return true;
+}
+
+}  // namespace k
+}  // namespace ocrs

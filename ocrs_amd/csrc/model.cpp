@@ -401,6 +401,158 @@ float* HipModel::run_device(Workspace& ws, const float* d_in, int n, int h, int 
 // ---------------------------------------------------------------------------
 // Ragged recognition batch
 // ---------------------------------------------------------------------------
+float* HipModel::run_prefix_ragged(Workspace& ws, const std::vector<PackedGroup>& groups, const PackedPlan& plan, int h,
+                                   int ts, StageTimers* timers, int* feat_c) const {
+    // supported stack: CONV 3x3 (Cin == 1 directly followed by MAXPOOL 2x2, or Cin % 32 == 0), MAXPOOL, AVGPOOL,
+    // each consuming the previous op's output
+    const int G = (int)groups.size();
+    if (G == 0 || ts <= 0) return nullptr;
+    for (int i = 0; i < ts; i++) {
+        const GraphOp& op = ops[i];
+        if (op.in0 != (i == 0 ? 0 : ops[i - 1].out)) return nullptr;
+        if (op.type == OP_CONV) {
+            if (op.kh != 3 || op.kw != 3 || !op.relu) return nullptr;
+            if (op.cin == 1) {
+                if (i + 1 >= ts || ops[i + 1].type != OP_MAXPOOL || ops[i + 1].kh != 2 || ops[i + 1].kw != 2) return nullptr;
+                if (op.cout > 64 || (op.cout % 4) != 0) return nullptr;
+            } else if ((op.cin % 32) != 0 || op.cout < 64 || (op.cout % 4) != 0) {
+                return nullptr;
+            }
+        } else if (op.type != OP_MAXPOOL && op.type != OP_AVGPOOL) {
+            return nullptr;
+        }
+    }
+    for (int g = 0; g + 1 < G; g++)  // groups must be contiguous in memory
+        if (groups[g].d_batch + (size_t)groups[g].n * h * groups[g].w != groups[g + 1].d_batch) return nullptr;
+
+    hipStream_t st = ws.s();
+    auto timed = [&](int cls, double flops, double bytes, auto&& launch) {
+        int tok = timers ? timers->kbegin(cls, st, flops, bytes) : -1;
+        launch();
+        if (tok >= 0) timers->end(tok, st);
+    };
+    // ---- per-layer geometry on the host, one metadata upload
+    struct Geo { int H; std::vector<int32_t> W; };
+    std::vector<Geo> geos;  // geos[0] = input; geos[i+1] = output of op i
+    geos.push_back(Geo{h, {}});
+    for (const PackedGroup& g : groups) geos[0].W.push_back(g.w);
+    for (int i = 0; i < ts; i++) {
+        Geo o = geos.back();
+        if (ops[i].type == OP_MAXPOOL || ops[i].type == OP_AVGPOOL) {
+            o.H /= ops[i].kh;
+            for (auto& w : o.W) w /= ops[i].kw;
+        }
+        geos.push_back(std::move(o));
+    }
+    std::vector<int32_t> nvec;
+    for (const PackedGroup& g : groups) nvec.push_back(g.n);
+    // layout of the metadata blob per geometry: W[G] | toff128[G+1] | toff256[G+1] | poff[G+1] (int64)
+    std::vector<int32_t> meta32;
+    std::vector<int64_t> meta64;
+    struct GeoOff { size_t w, t128, t256, p; int nt128, nt256; int64_t pixels; };
+    std::vector<GeoOff> goff;
+    const size_t n_at = 0;
+    meta32.insert(meta32.end(), nvec.begin(), nvec.end());
+    const size_t loff_at = meta32.size();
+    {
+        int32_t acc = 0;
+        meta32.push_back(0);
+        for (int g = 0; g < G; g++) { acc += nvec[g]; meta32.push_back(acc); }
+    }
+    for (const Geo& ge : geos) {
+        GeoOff o{};
+        o.w = meta32.size();
+        meta32.insert(meta32.end(), ge.W.begin(), ge.W.end());
+        o.t128 = meta32.size();
+        int32_t a128 = 0, a256 = 0;
+        int64_t px = 0;
+        std::vector<int32_t> t256{0};
+        std::vector<int64_t> pv{0};
+        meta32.push_back(0);
+        for (int g = 0; g < G; g++) {
+            const int64_t rows = (int64_t)nvec[g] * ge.H * ge.W[g];
+            a128 += (int32_t)((rows + 127) / 128);
+            a256 += (int32_t)((rows + 255) / 256);
+            px += rows;
+            meta32.push_back(a128);
+            t256.push_back(a256);
+            pv.push_back(px);
+        }
+        o.t256 = meta32.size();
+        meta32.insert(meta32.end(), t256.begin(), t256.end());
+        o.p = meta64.size();
+        meta64.insert(meta64.end(), pv.begin(), pv.end());
+        o.nt128 = a128; o.nt256 = a256; o.pixels = px;
+        goff.push_back(o);
+    }
+    int64_t* d64 = ws.alloc_n<int64_t>(meta64.size());
+    int32_t* d32 = ws.alloc_n<int32_t>(meta32.size());
+    OCRS_HIP(hipMemcpyAsync(d64, meta64.data(), meta64.size() * sizeof(int64_t), hipMemcpyHostToDevice, st));
+    OCRS_HIP(hipMemcpyAsync(d32, meta32.data(), meta32.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    OCRS_HIP(hipStreamSynchronize(st));  // meta32/meta64 are host temporaries
+    auto view = [&](size_t gi) {
+        k::RaggedView v{};
+        v.G = G; v.H = geos[gi].H;
+        v.W = d32 + goff[gi].w; v.n = d32 + n_at; v.poff = d64 + goff[gi].p;
+        v.toff128 = d32 + goff[gi].t128; v.toff256 = d32 + goff[gi].t256; v.loff = d32 + loff_at;
+        v.ntiles128 = goff[gi].nt128; v.ntiles256 = goff[gi].nt256; v.pixels = goff[gi].pixels;
+        return v;
+    };
+
+    int tok = timers ? timers->begin(ST_REC_CONV, st, 0) : -1;
+    const float* cur = groups[0].d_batch;
+    int curC = 1;
+    float* prev_buf = nullptr;  // buffer holding `cur` (nullptr: the caller's input)
+    std::vector<std::pair<float*, size_t>> spare;  // released buffers, reused by later layers
+    auto get = [&](size_t floats) -> float* {
+        const size_t bytes = floats * sizeof(float);
+        for (size_t i = 0; i < spare.size(); i++)
+            if (spare[i].second >= bytes) { float* p = spare[i].first; spare.erase(spare.begin() + i); return p; }
+        return static_cast<float*>(ws.alloc(bytes));
+    };
+    size_t prev_bytes = 0;
+    for (int i = 0; i < ts; i++) {
+        const GraphOp& op = ops[i];
+        const k::RaggedView vin = view(i);
+        float* y = nullptr;
+        size_t ybytes = 0;
+        if (op.type == OP_CONV && op.cin == 1) {
+            const k::RaggedView vout = view(i + 2);  // after the fused MaxPool 2x2
+            ybytes = (size_t)vout.pixels * op.cout * sizeof(float);
+            y = get((size_t)vout.pixels * op.cout);
+            timed(KC_CONV_DIRECT, 2.0 * vin.pixels * 9 * op.cout, 4.0 * vin.pixels + 4.0 * vout.pixels * op.cout,
+                  [&] { k::conv1_relu_pool_ragged(cur, vin, op.w[0], op.w[1], op.cout, y, vout, st); });
+            curC = op.cout;
+            i += 1;  // the pool is fused
+        } else if (op.type == OP_CONV) {
+            ybytes = (size_t)vin.pixels * op.cout * sizeof(float);
+            y = get((size_t)vin.pixels * op.cout);
+            timed(KC_GEMM_CONV3X3, 2.0 * vin.pixels * 9.0 * op.cin * op.cout,
+                  4.0 * vin.pixels * (op.cin + op.cout) + 4.0 * op.wcount[0],
+                  [&] { k::conv3x3_ragged(cur, vin, op.cin, op.w[0], op.w[1], op.cout, op.relu, y, st); });
+            curC = op.cout;
+        } else {
+            const k::RaggedView vout = view(i + 1);
+            ybytes = (size_t)vout.pixels * curC * sizeof(float);
+            y = get((size_t)vout.pixels * curC);
+            timed(KC_POOL, 0, 4.0 * curC * (vin.pixels + vout.pixels),
+                  [&] { k::pool_ragged(cur, vin, curC, op.kh, op.kw, op.type == OP_AVGPOOL, y, vout, st); });
+        }
+        if (prev_buf) spare.emplace_back(prev_buf, prev_bytes);
+        prev_buf = y;
+        prev_bytes = ybytes;
+        cur = y;
+    }
+    const k::RaggedView vf = view(ts);
+    if (vf.H != 1) fail(OCRS_ERR_RUN_FAILED, "model run failed: TOSEQ expects height 1, got %d", vf.H);
+    float* X = ws.alloc_n<float>((size_t)plan.R * curC);
+    timed(KC_OTHER, 0, 8.0 * vf.pixels * curC,
+          [&] { k::to_seq_packed_ragged(cur, vf, curC, groups[0].d_pos, plan.d_off, X, st); });
+    if (tok >= 0) timers->end(tok, st);
+    *feat_c = curC;
+    return X;
+}
+
 int HipModel::packed_split() const {
     int ts = -1;
     for (size_t i = 0; i < ops.size(); i++)
@@ -435,9 +587,12 @@ int HipModel::run_recognition_packed(Workspace& ws, const std::vector<PackedGrou
     const int64_t R = plan.R;
     const int M = plan.M;
 
-    // ---- conv stack per width group -> packed feature rows
+    // ---- conv stack -> packed feature rows: one launch per layer over all groups (ragged),
+    // or group by group if the stack has an op the ragged kernels do not cover
     float* X = nullptr;
     int C0 = 0;
+    X = run_prefix_ragged(ws, groups, plan, h, ts, timers, &C0);
+    if (!X)
     for (const PackedGroup& g : groups) {
         TensorShape fs;
         float* feat = run_device(ws, g.d_batch, g.n, h, g.w, &fs, timers, nullptr, nullptr, true, false, ts);

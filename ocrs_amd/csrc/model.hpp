@@ -78,9 +78,9 @@ struct HipModel : ModelBase {
     // of the TOSEQ op, or -1 if the graph has another shape.
     int packed_split() const;
     struct PackedGroup {      // one width group: batch [n, h, w] and, per line, its row slot m
-        const float* d_batch;
+        const float* d_batch;  // groups are contiguous in memory, in this order (ragged buffer)
         int n, w;
-        const int32_t* d_pos;  // [n] device
+        const int32_t* d_pos;  // [n] device; the pos arrays of consecutive groups are contiguous too
     };
     struct PackedPlan {       // lines sorted by T descending; rows off[t] + m
         int M = 0, Tmax = 0;
@@ -92,6 +92,10 @@ struct HipModel : ModelBase {
     // Writes arg-max labels of every packed row to d_labels [R]; returns class count.
     int run_recognition_packed(Workspace& ws, const std::vector<PackedGroup>& groups, const PackedPlan& plan, int h,
                                StageTimers* timers, const uint8_t* d_excluded, int32_t* d_labels) const;
+    // Conv stack (ops [0, ts)) over all groups at once; writes packed feature rows.  Returns
+    // nullptr if the stack has an op the ragged kernels do not cover.
+    float* run_prefix_ragged(Workspace& ws, const std::vector<PackedGroup>& groups, const PackedPlan& plan, int h, int ts,
+                             StageTimers* timers, int* feat_c) const;
 };
 
 }  // namespace ocrs
