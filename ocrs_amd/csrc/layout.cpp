@@ -22,7 +22,7 @@ namespace {
 // partitions are never popped once the 80 separators are found.
 struct Partition {
     Rect boundary;
-    std::shared_ptr<const std::vector<uint32_t>> parent_obstacles;  // indices into the sorted obstacle array
+    uint32_t obs_off, obs_len;  // the PARENT's obstacle list: a slice of the index arena
 };
 
 // Heap entries are (score, payload id): sifting moves 8 bytes instead of the payload.
@@ -93,32 +93,37 @@ std::vector<Rect> max_empty_rects_filtered(const std::vector<Rect>& obstacles_in
         PointI ca = a.center(), cb = b.center();
         return ca.x != cb.x ? ca.x < cb.x : ca.y < cb.y;
     });
-    auto all = std::make_shared<std::vector<uint32_t>>(obstacles.size());
-    for (size_t i = 0; i < obstacles.size(); i++) (*all)[i] = (uint32_t)i;
+    // index arena: every materialised obstacle list is appended here; partitions refer to slices
+    std::vector<uint32_t> arena(obstacles.size());
+    for (size_t i = 0; i < obstacles.size(); i++) arena[i] = (uint32_t)i;
+    arena.reserve(obstacles.size() * 64);
     RustBinaryHeap queue;
-    std::vector<Partition> store;  // payloads; a popped slot is released but never reused (ids stay unique)
-    auto push = [&](const Rect& r, const std::shared_ptr<const std::vector<uint32_t>>& obs) {
-        store.push_back(Partition{r, obs});
+    std::vector<Partition> store;  // payloads; ids stay unique
+    auto push = [&](const Rect& r, uint32_t off, uint32_t len) {
+        store.push_back(Partition{r, off, len});
         queue.push(HeapEntry{score(r), (uint32_t)(store.size() - 1)});
     };
-    if (!boundary.is_empty()) push(boundary, all);
+    const bool have_root = !boundary.is_empty();
+    if (have_root) push(boundary, 0, (uint32_t)obstacles.size());
     std::vector<Rect> found;
     HeapEntry he;
     while (found.size() < take && queue.pop(he)) {
-        Partition part = std::move(store[he.id]);
+        const Partition part = store[he.id];
         const Rect b = part.boundary;
         // materialise this partition's obstacle list (the root keeps every obstacle, as in the reference)
-        std::shared_ptr<const std::vector<uint32_t>> mine;
-        if (part.parent_obstacles == all && b == boundary) {
-            mine = all;
+        uint32_t my_off, my_len;
+        if (he.id == 0 && have_root) {
+            my_off = 0;
+            my_len = part.obs_len;
         } else {
-            auto v = std::make_shared<std::vector<uint32_t>>();
-            v->reserve(part.parent_obstacles->size());
-            for (uint32_t idx : *part.parent_obstacles)
-                if (obstacles[idx].intersects(b)) v->push_back(idx);
-            mine = std::move(v);
+            my_off = (uint32_t)arena.size();
+            for (uint32_t q = 0; q < part.obs_len; q++) {
+                const uint32_t idx = arena[part.obs_off + q];
+                if (obstacles[idx].intersects(b)) arena.push_back(idx);
+            }
+            my_len = (uint32_t)arena.size() - my_off;
         }
-        if (mine->empty()) {
+        if (my_len == 0) {
             bool overlaps = false;
             for (const Rect& f : found) {
                 // disjoint rects have iou == 0 < threshold: skip the float division
@@ -129,7 +134,7 @@ std::vector<Rect> max_empty_rects_filtered(const std::vector<Rect>& obstacles_in
             if (!overlaps) found.push_back(b);
             continue;
         }
-        const Rect pivot = obstacles[(*mine)[mine->size() / 2]];
+        const Rect pivot = obstacles[arena[my_off + my_len / 2]];
         const Rect right_rect = Rect::from_tlbr(b.top, pivot.right, b.bottom, b.right);
         const Rect left_rect = Rect::from_tlbr(b.top, b.left, b.bottom, pivot.left);
         const Rect top_rect = Rect::from_tlbr(b.top, b.left, pivot.top, b.right);
@@ -139,7 +144,7 @@ std::vector<Rect> max_empty_rects_filtered(const std::vector<Rect>& obstacles_in
             if ((uint32_t)std::max(sr.width(), 0) < min_width || (uint32_t)std::max(sr.height(), 0) < min_height ||
                 sr.is_empty())
                 continue;
-            push(sr, mine);
+            push(sr, my_off, my_len);
         }
     }
     return found;
@@ -253,10 +258,15 @@ std::vector<Rect> find_block_separators(const std::vector<RotatedRect>& words) {
     const int32_t median_height = (int32_t)rround(words[words.size() / 2].h);
 
     // Shafait/Keysers/Breuel score favouring tall rectangles (layout_analysis.rs:127-135).
+    // `aspect_ratio.log2().abs()` compared with 3 and 5: for a quotient of two integers below 2^17 the
+    // f32 log2 lands on the same side of 3 / 5 as the aspect ratio does of 8 / 32 (and 1/8, 1/32), so the
+    // logarithm is only evaluated where its value is used as the weight.
     auto score = [](const Rect& r) -> float {
-        float aspect = (float)r.height() / (float)r.width();
-        float lg = std::fabs((float)std::log2((double)aspect));
-        float wgt = lg < 3.0f ? 0.5f : (lg < 5.0f ? 1.5f : lg);
+        const float aspect = (float)r.height() / (float)r.width();
+        float wgt;
+        if (aspect > 0.125f && aspect < 8.0f) wgt = 0.5f;
+        else if (aspect > 0.03125f && aspect < 32.0f) wgt = 1.5f;
+        else wgt = std::fabs((float)std::log2((double)aspect));
         return std::sqrt((float)r.area() * wgt);
     };
 
