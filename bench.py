@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pages", type=int, default=3, help="pages in the bounded CPU-baseline sample")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--inflight", type=int, default=1,
+                    help="full steps kept in flight on separate host threads / HIP streams (default 1)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="run the stages of each step strictly one after another (default: 2-stage software "
                          "pipeline across steps: detect+layout of step i+1 overlap recognition of step i)")
@@ -114,6 +116,9 @@ def main():
     def run_steps(k):
         """k full steps.  Pipelined form: the library is thread-safe (one HIP stream per call), so
         stage A of step i+1 runs on a second host thread while this thread recognises step i."""
+        if args.inflight > 1 and k >= 2:
+            with ThreadPoolExecutor(max_workers=args.inflight) as ex:
+                return list(ex.map(lambda _: step(), range(k)))[-1]
         if args.no_pipeline or k < 2:
             out = None
             for _ in range(k):
@@ -136,6 +141,19 @@ def main():
 
     if args.warmup:
         run_steps(args.warmup)
+    # Calibration (untimed): one step with every kernel class timed picks the dominant class; during the
+    # timed region only that class carries per-launch HIP events (a handful of launches per step), so the
+    # live roofline figure does not slow the run down.  --profile-hint keeps all classes on.
+    dominant = None
+    if not args.no_kernel_timing:
+        engine.enable_timing(2)
+        engine.set_kernel_timing_classes(None)
+        engine.stage_times(reset=True)
+        step()
+        cal = {k: v for k, v in engine.kernel_stats(reset=True).items() if v["launches"] > 0}
+        if cal:
+            dominant = max(cal.items(), key=lambda kv: kv[1]["ms"])[0]
+        engine.set_kernel_timing_classes(None if args.profile_hint or dominant is None else [dominant])
     engine.enable_timing(0 if args.no_kernel_timing else 2)
     engine.stage_times(reset=True)
     sync_all()
@@ -214,7 +232,8 @@ def main():
     result["stages_ms_per_step"] = {k: round(v[0] / args.steps, 4) for k, v in stages.items() if v[0] > 0}
     kt = {k: v for k, v in kstats.items() if v["launches"] > 0}
     if kt:
-        dom_name, dom = max(kt.items(), key=lambda kv: kv[1]["ms"])
+        dom_name = dominant if dominant in kt else max(kt.items(), key=lambda kv: kv[1]["ms"])[0]
+        dom = kt[dom_name]
         is_mfma = dom_name.startswith("gemm_") and dom_name not in ("gemm_pointwise_mfma", "gemm_convt_mfma")
         avg_ms = dom["ms"] / dom["launches"]
         if is_mfma:
@@ -227,7 +246,8 @@ def main():
                     "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBS, 4)}
         roof["avg_launch_ms"] = round(avg_ms, 5)
         roof["launches_per_step"] = round(dom["launches"] / args.steps, 2)
-        roof["share_of_gpu_time"] = round(dom["ms"] / max(1e-9, sum(v["ms"] for v in kt.values())), 3)
+        roof["share_of_gpu_kernel_time_in_calibration_step"] = round(
+            cal[dom_name]["ms"] / max(1e-9, sum(v["ms"] for v in cal.values())), 3) if dom_name in cal else None
         roof["traffic"] = None  # HBM bytes from PMC counters: profiles/ (separate rocprofv3 --pmc pass)
         result["roofline"] = roof
         result["kernels_ms_per_step"] = {k: round(v["ms"] / args.steps, 4) for k, v in sorted(kt.items(), key=lambda kv: -kv[1]["ms"])}

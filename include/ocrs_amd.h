@@ -241,6 +241,8 @@ OCRS_API ocrs_status ocrs_engine_stage_times(ocrs_engine* e, double* ms, uint64_
 /* Kernel-class timers of the model executor (enable_timing(e, 2)): every launch
  * is bracketed by HIP events on its stream; flops/bytes are the ALGORITHMIC
  * figures of DESIGN.md §6 summed over the launches. */
+/* Restrict per-launch kernel timing to the classes whose bit is set (default: all). */
+OCRS_API ocrs_status ocrs_engine_set_kernel_timing_mask(ocrs_engine* e, uint32_t mask);
 OCRS_API int ocrs_kernel_class_count(void);
 OCRS_API const char* ocrs_kernel_class_name(int cls);
 OCRS_API ocrs_status ocrs_engine_kernel_stats(ocrs_engine* e, double* ms, uint64_t* launches, double* flops,

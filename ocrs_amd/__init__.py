@@ -463,6 +463,13 @@ class OcrEngine:
         """0 off, 1 per-stage HIP-event timers, 2 also per-launch kernel-class timers."""
         check(lib().ocrs_engine_enable_timing(self._h, int(level)))
 
+    def set_kernel_timing_classes(self, names=None):
+        """Restrict per-launch kernel timing to the named classes (None = all)."""
+        n = lib().ocrs_kernel_class_count()
+        all_names = [lib().ocrs_kernel_class_name(i).decode() for i in range(n)]
+        mask = 0xFFFFFFFF if names is None else sum(1 << all_names.index(x) for x in names)
+        check(lib().ocrs_engine_set_kernel_timing_mask(self._h, C.c_uint32(mask)))
+
     def kernel_stats(self, reset=True):
         n = lib().ocrs_kernel_class_count()
         ms = (C.c_double * n)()

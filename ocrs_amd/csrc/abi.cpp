@@ -565,6 +565,12 @@ ocrs_status ocrs_engine_enable_timing(ocrs_engine* e, int enable) {
         e->timers.kernels_enabled = enable >= 2;
     });
 }
+ocrs_status ocrs_engine_set_kernel_timing_mask(ocrs_engine* e, uint32_t mask) {
+    return guarded([&] {
+        if (!e) fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
+        e->timers.kernel_mask = mask;
+    });
+}
 int ocrs_kernel_class_count(void) { return KC_COUNT; }
 const char* ocrs_kernel_class_name(int cls) { return cls >= 0 && cls < KC_COUNT ? kKernelClassNames[cls] : ""; }
 ocrs_status ocrs_engine_kernel_stats(ocrs_engine* e, double* ms, uint64_t* launches, double* flops, double* bytes,

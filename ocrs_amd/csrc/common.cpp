@@ -97,10 +97,20 @@ StreamLease::~StreamLease() {
 }
 
 // ---------------------------------------------------------------- timers
+std::vector<StageTimers::Pending>& StageTimers::pending() {
+    static thread_local std::vector<Pending> p;
+    return p;
+}
+std::vector<hipEvent_t>& StageTimers::free_events() {
+    static thread_local std::vector<hipEvent_t> f;
+    return f;
+}
+
 hipEvent_t StageTimers::get_event() {
-    if (!free_events_.empty()) {
-        hipEvent_t e = free_events_.back();
-        free_events_.pop_back();
+    auto& fe = free_events();
+    if (!fe.empty()) {
+        hipEvent_t e = fe.back();
+        fe.pop_back();
         return e;
     }
     hipEvent_t e;
@@ -110,48 +120,44 @@ hipEvent_t StageTimers::get_event() {
 
 int StageTimers::begin(int stage, hipStream_t s, uint64_t n_launches) {
     if (!enabled) return -1;
-    std::lock_guard<std::mutex> g(mu);
     Pending p{stage, get_event(), get_event(), n_launches, false, 0.0, 0.0};
     OCRS_HIP(hipEventRecord(p.a, s));
-    pending.push_back(p);
-    return (int)pending.size() - 1;
+    pending().push_back(p);
+    return (int)pending().size() - 1;
 }
 
 int StageTimers::kbegin(int cls, hipStream_t s, double flops, double bytes) {
-    if (!enabled || !kernels_enabled) return -1;
-    std::lock_guard<std::mutex> g(mu);
+    if (!enabled || !kernels_enabled || !((kernel_mask >> cls) & 1u)) return -1;
     Pending p{cls, get_event(), get_event(), 1, true, flops, bytes};
     OCRS_HIP(hipEventRecord(p.a, s));
-    pending.push_back(p);
-    return (int)pending.size() - 1;
+    pending().push_back(p);
+    return (int)pending().size() - 1;
 }
 
 void StageTimers::end(int token, hipStream_t s) {
-    if (!enabled || token < 0) return;
-    std::lock_guard<std::mutex> g(mu);
-    if ((size_t)token < pending.size()) (void)hipEventRecord(pending[token].b, s);
+    if (token < 0) return;
+    auto& pd = pending();
+    if ((size_t)token < pd.size()) (void)hipEventRecord(pd[token].b, s);
 }
 
 void StageTimers::collect() {
-    if (!enabled) return;
-    std::lock_guard<std::mutex> g(mu);
-    for (auto& p : pending) {
+    auto& pd = pending();
+    if (pd.empty()) return;
+    double lms[ST_COUNT] = {0}, lkms[KC_COUNT] = {0}, lkf[KC_COUNT] = {0}, lkb[KC_COUNT] = {0};
+    uint64_t ln[ST_COUNT] = {0}, lkn[KC_COUNT] = {0};
+    for (auto& p : pd) {
         float t = 0.f;
         if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&t, p.a, p.b) == hipSuccess) {
-            if (p.kernel) {
-                kms[p.stage] += t;
-                klaunches[p.stage] += 1;
-                kflops[p.stage] += p.flops;
-                kbytes[p.stage] += p.bytes;
-            } else {
-                ms[p.stage] += t;
-                launches[p.stage] += p.n;
-            }
+            if (p.kernel) { lkms[p.stage] += t; lkn[p.stage] += 1; lkf[p.stage] += p.flops; lkb[p.stage] += p.bytes; }
+            else { lms[p.stage] += t; ln[p.stage] += p.n; }
         }
-        free_events_.push_back(p.a);
-        free_events_.push_back(p.b);
+        free_events().push_back(p.a);
+        free_events().push_back(p.b);
     }
-    pending.clear();
+    pd.clear();
+    std::lock_guard<std::mutex> g(mu);
+    for (int i = 0; i < ST_COUNT; i++) { ms[i] += lms[i]; launches[i] += ln[i]; }
+    for (int i = 0; i < KC_COUNT; i++) { kms[i] += lkms[i]; klaunches[i] += lkn[i]; kflops[i] += lkf[i]; kbytes[i] += lkb[i]; }
 }
 
 void StageTimers::reset() {

@@ -133,6 +133,7 @@ extern const char* const kKernelClassNames[KC_COUNT];
 struct StageTimers {
     bool enabled = false;
     bool kernels_enabled = false;
+    uint32_t kernel_mask = 0xffffffffu;  // which KernelClass values get per-launch events
     std::mutex mu;
     double ms[ST_COUNT] = {0};
     uint64_t launches[ST_COUNT] = {0};
@@ -141,14 +142,16 @@ struct StageTimers {
     double kflops[KC_COUNT] = {0};
     double kbytes[KC_COUNT] = {0};
     struct Pending { int stage; hipEvent_t a, b; uint64_t n; bool kernel; double flops, bytes; };
-    std::vector<Pending> pending;
+    // Pending events are per host thread (an API call runs on one thread and collects its own
+    // events after draining its stream), so concurrent calls never wait on each other's events.
+    static std::vector<Pending>& pending();
     int begin(int stage, hipStream_t s, uint64_t n_launches);  // returns token (-1 when disabled)
     int kbegin(int cls, hipStream_t s, double flops, double bytes);
     void end(int token, hipStream_t s);
     void collect();  // after a stream sync
     void reset();
   private:
-    std::vector<hipEvent_t> free_events_;
+    static std::vector<hipEvent_t>& free_events();
     hipEvent_t get_event();
 };
 
