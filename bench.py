@@ -54,6 +54,8 @@ def parse():
                     help="run the stages of each step strictly one after another (default: 2-stage software "
                          "pipeline across steps: detect+layout of step i+1 overlap recognition of step i)")
     ap.add_argument("--profile-hint", action="store_true", help="print per-stage and per-kernel tables to stderr")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the detection-only (configs[1]) and recognition-only (configs[2]) legs")
     return ap.parse_args()
 
 
@@ -248,7 +250,7 @@ def main():
         roof["launches_per_step"] = round(dom["launches"] / args.steps, 2)
         roof["share_of_gpu_kernel_time_in_calibration_step"] = round(
             cal[dom_name]["ms"] / max(1e-9, sum(v["ms"] for v in cal.values())), 3) if dom_name in cal else None
-        roof["traffic"] = None  # HBM bytes from PMC counters: profiles/ (separate rocprofv3 --pmc pass)
+        roof["traffic"] = pmc_traffic(dom_name)  # HBM bytes/launch from the rocprofv3 --pmc passes in profiles/
         result["roofline"] = roof
         result["kernels_ms_per_step"] = {k: round(v["ms"] / args.steps, 4) for k, v in sorted(kt.items(), key=lambda kv: -kv[1]["ms"])}
         if args.profile_hint:
@@ -260,12 +262,75 @@ def main():
             for k, v in stages.items():
                 print("stage %-18s %8.3f ms/step" % (k, v[0] / args.steps), file=sys.stderr)
 
+    # ---- extra legs named by BASELINE.json (rank 0, N=1 only; not part of `value`)
+    if world == 1 and not args.no_extras:
+        result["extras"] = extra_legs(engine, dptrs, H, W, synth, np, DimOrder, sync_all)
+
     # ---- CPU baseline: the oracle on the host cores, bounded sample (rank 0, N=1 only)
     if world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(host_pages[: args.cpu_pages], engine)
     print(json.dumps(result), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def pmc_traffic(kernel_class):
+    """HBM bytes per launch of the dominant kernel class from the committed PMC summary
+    (tools/profile.sh -> tools/pmc_summary.py -> profiles/*_pmc.json: separate FETCH_SIZE / WRITE_SIZE passes,
+    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  None if no summary covers the class."""
+    import glob
+    match = {"gemm_conv3x3_mfma": "conv3x3_ragged_kernel", "gemm_gru_hidden_mfma": "gru_step_fused_kernel",
+             "gemm_gru_input_mfma": "gemm_tiled_kernelILi128ELb0", "dwconv3x3": "dwconv3x3_kernel"}.get(kernel_class)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")))
+    if not match or not files:
+        return None
+    rows = [r for k, r in json.load(open(files[-1])).items() if match in k]
+    n = sum(r["launches"] for r in rows)
+    if not n:
+        return None
+    return {"hbm_bytes_per_launch": round(sum(r["hbm_bytes_per_launch"] * r["launches"] for r in rows) / n),
+            "source": os.path.relpath(files[-1], ROOT)}
+
+
+def extra_legs(engine, dptrs, H, W, synth, np, DimOrder, sync_all):
+    out = {}
+    # configs[1]: detection only — 8 synthetic 1024x1024 pages, CNN forward + threshold + components -> rects
+    inputs = [engine.prepare_input_device(p.value, np.uint8, DimOrder.Hwc, H, W, 3) for p in dptrs]
+    engine.detect_words_batch(inputs)
+    sync_all()
+    t0 = time.perf_counter()
+    reps = 10
+    for _ in range(reps):
+        engine.detect_words_batch(inputs)
+    sync_all()
+    dt = time.perf_counter() - t0
+    out["detection_only_pages_per_s"] = round(reps * len(inputs) / dt, 1)
+    # configs[2]: recognition only — 2048 line crops of 64x256 (padded to 300 by the engine exactly as
+    # recognition.rs:437 does), CRNN forward + greedy CTC, batched.  The crops are stacked into one tall
+    # grey page so that every line's crop+resize is the identity.
+    from ocrs_amd import ImageSource
+    n = 2048
+    crops = synth.synthetic_line_crops(1000, n=n)
+    page = (crops.reshape(1, n * 64, 256) + 0.5).astype(np.float32)  # [0,1]; prepare_input subtracts 0.5
+    inp = engine.prepare_input(ImageSource.from_tensor(page, DimOrder.Chw))
+    rects = np.zeros((n, 6), np.float32)
+    rects[:, 0] = 128.0
+    rects[:, 1] = np.arange(n) * 64.0 + 32.0
+    rects[:, 2], rects[:, 3] = 0.0, 1.0
+    rects[:, 4], rects[:, 5] = 256.0, 64.0
+    loffs = np.arange(n + 1, dtype=np.uintp)
+    poffs = np.array([0, n], dtype=np.uintp)
+    engine.recognize_text_batch_raw([inp], rects, loffs, poffs)
+    sync_all()
+    t0 = time.perf_counter()
+    reps = 3
+    for _ in range(reps):
+        chars, coffs = engine.recognize_text_batch_raw([inp], rects, loffs, poffs)
+    sync_all()
+    dt = time.perf_counter() - t0
+    out["recognition_only_lines_per_s"] = round(reps * n / dt, 1)
+    out["recognition_only_config"] = "2048 crops 64x256 -> width group 300 (T=75), crop+CRNN+greedy CTC, %d chars decoded" % len(chars)
+    return out
 
 
 def cpu_baseline(pages, engine):

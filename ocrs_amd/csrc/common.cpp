@@ -76,24 +76,31 @@ DevicePool& pool() {
 // ---------------------------------------------------------------- streams
 namespace {
 std::mutex g_stream_mu;
-std::vector<hipStream_t> g_streams;
+std::vector<hipStream_t> g_streams[2];  // [0] default priority, [1] highest priority
 }  // namespace
 
-StreamLease::StreamLease() {
+StreamLease::StreamLease(bool high_priority) : high_(high_priority) {
     {
         std::lock_guard<std::mutex> g(g_stream_mu);
-        if (!g_streams.empty()) {
-            s_ = g_streams.back();
-            g_streams.pop_back();
+        auto& v = g_streams[high_ ? 1 : 0];
+        if (!v.empty()) {
+            s_ = v.back();
+            v.pop_back();
             return;
         }
     }
-    OCRS_HIP(hipStreamCreateWithFlags(&s_, hipStreamNonBlocking));
+    if (high_) {
+        int least = 0, greatest = 0;
+        OCRS_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        OCRS_HIP(hipStreamCreateWithPriority(&s_, hipStreamNonBlocking, greatest));
+    } else {
+        OCRS_HIP(hipStreamCreateWithFlags(&s_, hipStreamNonBlocking));
+    }
 }
 
 StreamLease::~StreamLease() {
     std::lock_guard<std::mutex> g(g_stream_mu);
-    g_streams.push_back(s_);
+    g_streams[high_ ? 1 : 0].push_back(s_);
 }
 
 // ---------------------------------------------------------------- timers

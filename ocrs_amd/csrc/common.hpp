@@ -95,13 +95,14 @@ struct PinnedBuf {
 // recognition.rs:465-485).
 class StreamLease {
   public:
-    StreamLease();
+    explicit StreamLease(bool high_priority = false);
     ~StreamLease();
     hipStream_t get() const { return s_; }
     void sync() const { OCRS_HIP(hipStreamSynchronize(s_)); }
 
   private:
     hipStream_t s_;
+    bool high_;
 };
 
 // Stage timers (HIP events on the launching stream).
@@ -170,6 +171,14 @@ struct StageScope {
 struct Workspace {
     StreamLease stream;
     std::vector<DevBuf> bufs;
+    std::vector<std::vector<char>> host_keep;  // host staging that must outlive async uploads
+    Workspace() = default;
+    explicit Workspace(bool high_priority) : stream(high_priority) {}
+    // copy `bytes` from a host temporary to the device without a sync: the bytes are parked in the workspace
+    void upload(void* d_dst, const void* h_src, size_t bytes) {
+        host_keep.emplace_back((const char*)h_src, (const char*)h_src + bytes);
+        OCRS_HIP(hipMemcpyAsync(d_dst, host_keep.back().data(), bytes, hipMemcpyHostToDevice, stream.get()));
+    }
     hipStream_t s() const { return stream.get(); }
     void* alloc(size_t bytes) { bufs.emplace_back(bytes ? bytes : 4); return bufs.back().p; }
     template <class T> T* alloc_n(size_t n) { return static_cast<T*>(alloc(n * sizeof(T))); }

@@ -404,71 +404,106 @@ void ocrs_engine::recognize(const ocrs_page* const* pages, size_t n_pages,
             fail(OCRS_ERR_WRONG_OUTPUT,
                  "model output had unexpected type or shape: output column count (%d) does not match alphabet size (%zu)", C,
                  alphabet_len + 1);
+        // Two ragged batches when the request mixes long and short lines: the recurrence is a chain
+        // of up to 600 dependent, latency-bound steps whose tail only involves the few longest lines.
+        // The long groups run first on a high-priority stream; their recurrence then overlaps the
+        // conv stack of the short groups (the bulk of the FLOPs) on this call's main stream.
         struct Slot { int T; size_t line; size_t chunk, j; };
-        std::vector<Slot> slots;
+        struct Sub {
+            std::vector<Slot> slots;
+            std::vector<uint32_t> hl, hp;
+            std::vector<int32_t> hc;
+            int Tmax = 0;
+        };
+        const int T_SPLIT = 160;
+        size_t first_long = chunks.size();
         for (size_t c = 0; c < chunks.size(); c++)
-            for (size_t j = 0; j < chunks[c].members.size(); j++)
-                if (chunk_T[c] > 0) slots.push_back(Slot{chunk_T[c], chunks[c].members[j], c, j});
-        std::stable_sort(slots.begin(), slots.end(), [](const Slot& a, const Slot& b) { return a.T > b.T; });
-        const int M = (int)slots.size();
-        if (M > 0) {
+            if (chunk_T[c] > T_SPLIT) { first_long = c; break; }
+        size_t n_long_lines = 0, n_short_lines = 0;
+        for (size_t c = 0; c < chunks.size(); c++) (c >= first_long ? n_long_lines : n_short_lines) += chunks[c].members.size();
+        const bool split = n_long_lines > 0 && n_short_lines >= 64;
+        Workspace ws_long(true);  // high-priority stream (idle if unused)
+
+        auto launch = [&](size_t c0, size_t c1, Workspace& w, Sub& sub) {
+            hipStream_t sst = w.s();
+            for (size_t c = c0; c < c1; c++)
+                for (size_t j = 0; j < chunks[c].members.size(); j++)
+                    if (chunk_T[c] > 0) sub.slots.push_back(Slot{chunk_T[c], chunks[c].members[j], c, j});
+            std::stable_sort(sub.slots.begin(), sub.slots.end(), [](const Slot& x, const Slot& y) { return x.T > y.T; });
+            const int M = (int)sub.slots.size();
+            if (M == 0) return;
             HipModel::PackedPlan plan;
             plan.M = M;
-            plan.Tmax = slots[0].T;
+            plan.Tmax = sub.slots[0].T;
             plan.active.assign(plan.Tmax, 0);
             std::vector<int32_t> hTm(M), hoff(plan.Tmax + 1, 0);
-            std::vector<std::vector<int32_t>> hpos(chunks.size());
-            for (size_t c = 0; c < chunks.size(); c++) hpos[c].assign(chunks[c].members.size(), 0);
+            std::vector<std::vector<int32_t>> hpos(c1 - c0);
+            for (size_t c = c0; c < c1; c++) hpos[c - c0].assign(chunks[c].members.size(), 0);
             for (int m = 0; m < M; m++) {
-                hTm[m] = slots[m].T;
-                hpos[slots[m].chunk][slots[m].j] = m;
-                for (int t = 0; t < slots[m].T; t++) plan.active[t]++;
+                hTm[m] = sub.slots[m].T;
+                hpos[sub.slots[m].chunk - c0][sub.slots[m].j] = m;
+                for (int t = 0; t < sub.slots[m].T; t++) plan.active[t]++;
             }
             for (int t = 0; t < plan.Tmax; t++) hoff[t + 1] = hoff[t] + plan.active[t];
             plan.R = hoff[plan.Tmax];
-            // one upload: Tm | off | pos of every chunk
-            std::vector<int32_t> meta;
+            std::vector<int32_t> meta;  // Tm | off | pos of every chunk (contiguous, chunk order)
             meta.insert(meta.end(), hTm.begin(), hTm.end());
             meta.insert(meta.end(), hoff.begin(), hoff.end());
-            std::vector<size_t> pos_at(chunks.size());
-            for (size_t c = 0; c < chunks.size(); c++) {
-                pos_at[c] = meta.size();
-                meta.insert(meta.end(), hpos[c].begin(), hpos[c].end());
+            std::vector<size_t> pos_at(c1 - c0);
+            for (size_t c = c0; c < c1; c++) {
+                pos_at[c - c0] = meta.size();
+                meta.insert(meta.end(), hpos[c - c0].begin(), hpos[c - c0].end());
             }
-            int32_t* d_meta = ws.alloc_n<int32_t>(meta.size());
-            OCRS_HIP(hipMemcpyAsync(d_meta, meta.data(), meta.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+            int32_t* d_meta = w.alloc_n<int32_t>(meta.size());
+            w.upload(d_meta, meta.data(), meta.size() * sizeof(int32_t));
             plan.d_Tm = d_meta;
             plan.d_off = d_meta + M;
             std::vector<HipModel::PackedGroup> pg;
-            for (size_t c = 0; c < chunks.size(); c++)
+            for (size_t c = c0; c < c1; c++)
                 if (chunk_T[c] > 0)
                     pg.push_back(HipModel::PackedGroup{chunk_ptr(chunks[c]), (int)chunks[c].members.size(), (int)chunks[c].gw,
-                                                       d_meta + pos_at[c]});
-            int32_t* d_labels = ws.alloc_n<int32_t>((size_t)plan.R);
-            hm->run_recognition_packed(ws, pg, plan, (int)rec_h, T, d_excl, d_labels);
-
-            // ---- greedy CTC (recognition.rs:511)
+                                                       d_meta + pos_at[c - c0]});
+            int32_t* d_labels = w.alloc_n<int32_t>((size_t)plan.R);
+            hm->run_recognition_packed(w, pg, plan, (int)rec_h, T, d_excl, d_labels);
+            // greedy CTC (recognition.rs:511)
             const int Tmax = plan.Tmax;
-            uint32_t* d_ol = ws.alloc_n<uint32_t>((size_t)M * Tmax);
-            uint32_t* d_op = ws.alloc_n<uint32_t>((size_t)M * Tmax);
-            int32_t* d_cnt = ws.alloc_n<int32_t>(M);
+            sub.Tmax = Tmax;
+            uint32_t* d_ol = w.alloc_n<uint32_t>((size_t)M * Tmax);
+            uint32_t* d_op = w.alloc_n<uint32_t>((size_t)M * Tmax);
+            int32_t* d_cnt = w.alloc_n<int32_t>(M);
             {
-                StageScope sc(T, ST_CTC, st);
-                k::ctc_collapse_packed(d_labels, plan.d_Tm, plan.d_off, M, Tmax, d_ol, d_op, d_cnt, st);
+                StageScope sc(T, ST_CTC, sst);
+                k::ctc_collapse_packed(d_labels, plan.d_Tm, plan.d_off, M, Tmax, d_ol, d_op, d_cnt, sst);
             }
-            std::vector<uint32_t> hl((size_t)M * Tmax), hpz((size_t)M * Tmax);
-            std::vector<int32_t> hc(M);
-            OCRS_HIP(hipMemcpyAsync(hl.data(), d_ol, hl.size() * 4, hipMemcpyDeviceToHost, st));
-            OCRS_HIP(hipMemcpyAsync(hpz.data(), d_op, hpz.size() * 4, hipMemcpyDeviceToHost, st));
-            OCRS_HIP(hipMemcpyAsync(hc.data(), d_cnt, (size_t)M * 4, hipMemcpyDeviceToHost, st));
-            ws.sync();
-            for (int m = 0; m < M; m++) {
-                const size_t li = slots[m].line;
+            sub.hl.resize((size_t)M * Tmax);
+            sub.hp.resize((size_t)M * Tmax);
+            sub.hc.resize(M);
+            OCRS_HIP(hipMemcpyAsync(sub.hl.data(), d_ol, sub.hl.size() * 4, hipMemcpyDeviceToHost, sst));
+            OCRS_HIP(hipMemcpyAsync(sub.hp.data(), d_op, sub.hp.size() * 4, hipMemcpyDeviceToHost, sst));
+            OCRS_HIP(hipMemcpyAsync(sub.hc.data(), d_cnt, (size_t)M * 4, hipMemcpyDeviceToHost, sst));
+        };
+        auto unpack = [&](const Sub& sub) {
+            for (size_t m = 0; m < sub.slots.size(); m++) {
+                const size_t li = sub.slots[m].line;
                 auto& sv = (*steps_out)[li];
-                sv.resize(hc[m]);
-                for (int q = 0; q < hc[m]; q++) sv[q] = CtcStep{hl[(size_t)m * Tmax + q], hpz[(size_t)m * Tmax + q]};
-                (*ctc_len_out)[li] = (uint32_t)slots[m].T;
+                sv.resize(sub.hc[m]);
+                for (int q = 0; q < sub.hc[m]; q++)
+                    sv[q] = CtcStep{sub.hl[m * sub.Tmax + q], sub.hp[m * sub.Tmax + q]};
+                (*ctc_len_out)[li] = (uint32_t)sub.slots[m].T;
             }
+        };
+        Sub sub_long, sub_short;
+        if (split) {
+            launch(first_long, chunks.size(), ws_long, sub_long);  // the crops were produced on `st` and are already synced
+            launch(0, first_long, ws, sub_short);
+            ws_long.sync();
+            ws.sync();
+            unpack(sub_long);
+            unpack(sub_short);
+        } else {
+            launch(0, chunks.size(), ws, sub_short);
+            ws.sync();
+            unpack(sub_short);
         }
     }
     if (T) T->collect();

@@ -231,7 +231,10 @@ __global__ void __launch_bounds__(256) gemm_tiled_kernel(GemmDesc d) {
     const float* __restrict__ B = d.B + (int64_t)z * d.strideB;
     const float* __restrict__ bias = d.bias ? d.bias + (int64_t)z * d.strideBias : nullptr;
     float* __restrict__ C = d.C + (int64_t)z * d.strideC;
-    const int64_t m0 = (int64_t)blockIdx.x * TG_BM;
+    // XCD-aware row-block order (see kernels_rec.hip): consecutive row blocks share im2col rows / A panels
+    const int nwg = gridDim.x, xcd = blockIdx.x & 7, xq = nwg >> 3, xr = nwg & 7;
+    const int mblk = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (blockIdx.x >> 3);
+    const int64_t m0 = (int64_t)mblk * TG_BM;
     const int n0 = blockIdx.y * BN;
 
     // ---- per-thread load assignments

@@ -15,6 +15,14 @@ namespace k {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// Workgroup b runs on XCD b % 8 (observed; used for speed only).  Neighbouring tiles share
+// im2col rows, so give each XCD a contiguous range of tiles: their re-reads then hit that
+// XCD's L2 instead of going to HBM once per XCD.  Bijective for any grid size.
+__device__ __forceinline__ int xcd_remap(int b, int nwg) {
+    const int xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+}
+
 __device__ __forceinline__ int find_group(const int32_t* __restrict__ toff, int G, int tile) {
     int lo = 0, hi = G;  // largest g with toff[g] <= tile
     while (hi - lo > 1) {
@@ -191,8 +199,9 @@ conv3x3_ragged_kernel(const float* __restrict__ X, RaggedView rv, int cin, const
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
     const int wm = wave >> 1, wn = wave & 1;
-    const int g = find_group(rv.toff128, rv.G, blockIdx.x);
-    const int tile = blockIdx.x - rv.toff128[g];
+    const int gtile = xcd_remap(blockIdx.x, gridDim.x);
+    const int g = find_group(rv.toff128, rv.G, gtile);
+    const int tile = gtile - rv.toff128[g];
     const int H = rv.H, W = rv.W[g];
     const int64_t rows = (int64_t)rv.n[g] * H * W;
     const int64_t m0 = (int64_t)tile * RG_BM;

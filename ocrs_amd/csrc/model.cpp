@@ -487,9 +487,8 @@ float* HipModel::run_prefix_ragged(Workspace& ws, const std::vector<PackedGroup>
     }
     int64_t* d64 = ws.alloc_n<int64_t>(meta64.size());
     int32_t* d32 = ws.alloc_n<int32_t>(meta32.size());
-    OCRS_HIP(hipMemcpyAsync(d64, meta64.data(), meta64.size() * sizeof(int64_t), hipMemcpyHostToDevice, st));
-    OCRS_HIP(hipMemcpyAsync(d32, meta32.data(), meta32.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
-    OCRS_HIP(hipStreamSynchronize(st));  // meta32/meta64 are host temporaries
+    ws.upload(d64, meta64.data(), meta64.size() * sizeof(int64_t));
+    ws.upload(d32, meta32.data(), meta32.size() * sizeof(int32_t));
     auto view = [&](size_t gi) {
         k::RaggedView v{};
         v.G = G; v.H = geos[gi].H;

@@ -1,0 +1,15 @@
+#!/bin/bash
+# rocprofv3 passes behind profiles/: kernel trace, then HBM traffic counters in separate
+# --pmc passes (FETCH_SIZE and WRITE_SIZE do not fit one pass: MI355X_MICROARCH.md "rocprofv3 PMC slots").
+# Usage (on the GPU box, from the repo root): tools/profile.sh <tag>
+set -u
+TAG=${1:-r1}
+OUT=$PWD/gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+BENCH="python $OLDPWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-pipeline"
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT -o trace -- $BENCH > $OUT/trace.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT -o fetch -- $BENCH > $OUT/fetch.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT -o write -- $BENCH > $OUT/write.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES -d $OUT -o mfma -- $BENCH > $OUT/mfma.log 2>&1
+ls -la $OUT
