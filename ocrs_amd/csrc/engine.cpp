@@ -1,7 +1,9 @@
 #include "engine.hpp"
 
 #include <algorithm>
+#include <limits>
 #include <map>
+#include <thread>
 
 #include "kernels.hpp"
 
@@ -235,8 +237,7 @@ void ocrs_engine::recognize(const ocrs_page* const* pages, size_t n_pages,
                             std::vector<std::vector<CtcStep>>* steps_out, std::vector<RecLine>* rec_lines_out,
                             std::vector<uint32_t>* ctc_len_out) const {
     if (!recognition) fail(OCRS_ERR_MODEL_NOT_LOADED, "Recognition model not loaded");
-    if (decode_method == OCRS_DECODE_BEAM_SEARCH)
-        fail(OCRS_ERR_INVALID_ARGUMENT, "beam search decoding is not available in this build (SURVEY.md §8 f3)");
+    const bool beam = decode_method == OCRS_DECODE_BEAM_SEARCH;
     const uint32_t rec_h = rec_input_height();
     const size_t alphabet_len = alphabet.size();
 
@@ -357,6 +358,21 @@ void ocrs_engine::recognize(const ocrs_page* const* pages, size_t n_pages,
                 fail(OCRS_ERR_WRONG_OUTPUT,
                      "model output had unexpected type or shape: output column count (%d) does not match alphabet size (%zu)",
                      C, alphabet_len + 1);
+            if (beam) {  // decode_beam on the model output, masked as recognition.rs:547-561 does
+                std::vector<float> seq((size_t)Tn * C);
+                for (size_t j = 0; j < nb; j++) {
+                    for (int t = 0; t < Tn; t++)
+                        for (int c = 0; c < C; c++) {
+                            float v = hout[((size_t)t * nb + j) * C + c];
+                            if (has_excluded && excluded[c]) v = -std::numeric_limits<float>::infinity();
+                            seq[(size_t)t * C + c] = v;
+                        }
+                    const size_t li = ch.members[j];
+                    (*steps_out)[li] = ctc_beam_search(seq.data(), Tn, C, C, beam_width);
+                    (*ctc_len_out)[li] = (uint32_t)Tn;
+                }
+                continue;
+            }
             float* d_logp = ws.alloc_n<float>(hout.size());
             OCRS_HIP(hipMemcpyAsync(d_logp, hout.data(), hout.size() * sizeof(float), hipMemcpyHostToDevice, st));
             int32_t* d_labels = ws.alloc_n<int32_t>((size_t)Tn * nb);
@@ -414,6 +430,8 @@ void ocrs_engine::recognize(const ocrs_page* const* pages, size_t n_pages,
             std::vector<uint32_t> hl, hp;
             std::vector<int32_t> hc;
             int Tmax = 0;
+            std::vector<float> logp;      // beam search only: packed [R][C]
+            std::vector<int32_t> off;     // beam search only
         };
         const int T_SPLIT = 160;
         size_t first_long = chunks.size();
@@ -464,7 +482,15 @@ void ocrs_engine::recognize(const ocrs_page* const* pages, size_t n_pages,
                     pg.push_back(HipModel::PackedGroup{chunk_ptr(chunks[c]), (int)chunks[c].members.size(), (int)chunks[c].gw,
                                                        d_meta + pos_at[c - c0]});
             int32_t* d_labels = w.alloc_n<int32_t>((size_t)plan.R);
-            hm->run_recognition_packed(w, pg, plan, (int)rec_h, T, d_excl, d_labels);
+            float* d_logp = nullptr;
+            hm->run_recognition_packed(w, pg, plan, (int)rec_h, T, d_excl, d_labels, beam ? &d_logp : nullptr);
+            if (beam) {
+                sub.logp.resize((size_t)plan.R * C);
+                sub.off = hoff;
+                sub.Tmax = plan.Tmax;
+                OCRS_HIP(hipMemcpyAsync(sub.logp.data(), d_logp, sub.logp.size() * sizeof(float), hipMemcpyDeviceToHost, sst));
+                return;
+            }
             // greedy CTC (recognition.rs:511)
             const int Tmax = plan.Tmax;
             sub.Tmax = Tmax;
@@ -483,6 +509,29 @@ void ocrs_engine::recognize(const ocrs_page* const* pages, size_t n_pages,
             OCRS_HIP(hipMemcpyAsync(sub.hc.data(), d_cnt, (size_t)M * 4, hipMemcpyDeviceToHost, sst));
         };
         auto unpack = [&](const Sub& sub) {
+            if (beam) {  // rten decode_beam (recognition.rs:512-514), host side, one thread per slice of lines
+                const size_t M = sub.slots.size();
+                const unsigned nth = (unsigned)std::max<size_t>(1, std::min<size_t>({(size_t)std::thread::hardware_concurrency(), (size_t)32, M}));
+                std::vector<std::thread> th;
+                for (unsigned w0 = 0; w0 < nth; w0++)
+                    th.emplace_back([&, w0] {
+                        std::vector<float> seq;
+                        for (size_t m = w0; m < M; m += nth) {
+                            const int Tm = sub.slots[m].T;
+                            seq.resize((size_t)Tm * C);
+                            for (int t = 0; t < Tm; t++) {
+                                const float* src = &sub.logp[((size_t)sub.off[t] + m) * C];
+                                for (int c = 0; c < C; c++)
+                                    seq[(size_t)t * C + c] = (has_excluded && excluded[c]) ? -std::numeric_limits<float>::infinity() : src[c];
+                            }
+                            const size_t li = sub.slots[m].line;
+                            (*steps_out)[li] = ctc_beam_search(seq.data(), Tm, C, C, beam_width);
+                            (*ctc_len_out)[li] = (uint32_t)Tm;
+                        }
+                    });
+                for (auto& t : th) t.join();
+                return;
+            }
             for (size_t m = 0; m < sub.slots.size(); m++) {
                 const size_t li = sub.slots[m].line;
                 auto& sv = (*steps_out)[li];

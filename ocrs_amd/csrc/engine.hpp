@@ -17,6 +17,9 @@ namespace ocrs {
 
 struct CtcStep { uint32_t label, pos; };
 
+// ctc_beam.cpp — rten decode_beam (recognition.rs:512-514)
+std::vector<CtcStep> ctc_beam_search(const float* logp, int T, int C, int row_stride, uint32_t width);
+
 struct TextChar {  // text_items.rs:48-54
     uint32_t ch;
     geom::Rect rect;

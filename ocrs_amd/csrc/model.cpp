@@ -574,7 +574,8 @@ int HipModel::packed_split() const {
 }
 
 int HipModel::run_recognition_packed(Workspace& ws, const std::vector<PackedGroup>& groups, const PackedPlan& plan, int h,
-                                     StageTimers* timers, const uint8_t* d_excluded, int32_t* d_labels) const {
+                                     StageTimers* timers, const uint8_t* d_excluded, int32_t* d_labels,
+                                     float** d_logp) const {
     const int ts = packed_split();
     if (ts < 0) fail(OCRS_ERR_RUN_FAILED, "model run failed: graph is not <conv stack> TOSEQ GRU* LINEAR LOGSOFTMAX");
     hipStream_t st = ws.s();
@@ -676,8 +677,13 @@ int HipModel::run_recognition_packed(Workspace& ws, const std::vector<PackedGrou
             curC = op.cout;
         } else {  // LOGSOFTMAX (+ arg-max)
             int tok = timers ? timers->begin(ST_REC_HEAD, st, 0) : -1;
-            timed(KC_LOGSOFTMAX_ARGMAX, 0, 4.0 * R * curC,
-                  [&] { k::log_softmax_argmax(cur, R, curC, d_excluded, nullptr, d_labels, st); });
+            float* lp = nullptr;
+            if (d_logp) {
+                lp = ws.alloc_n<float>((size_t)R * curC);
+                *d_logp = lp;
+            }
+            timed(KC_LOGSOFTMAX_ARGMAX, 0, 4.0 * R * curC * (lp ? 2.0 : 1.0),
+                  [&] { k::log_softmax_argmax(cur, R, curC, d_excluded, lp, d_labels, st); });
             if (tok >= 0) timers->end(tok, st);
             classes = curC;
         }

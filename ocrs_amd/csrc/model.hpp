@@ -90,8 +90,10 @@ struct HipModel : ModelBase {
         std::vector<int> active;         // [Tmax] host
     };
     // Writes arg-max labels of every packed row to d_labels [R]; returns class count.
+    // d_logp (optional): receives the packed log-probabilities [R][classes] (model output, unmasked).
     int run_recognition_packed(Workspace& ws, const std::vector<PackedGroup>& groups, const PackedPlan& plan, int h,
-                               StageTimers* timers, const uint8_t* d_excluded, int32_t* d_labels) const;
+                               StageTimers* timers, const uint8_t* d_excluded, int32_t* d_labels,
+                               float** d_logp = nullptr) const;
     // Conv stack (ops [0, ts)) over all groups at once; writes packed feature rows.  Returns
     // nullptr if the stack has an op the ragged kernels do not cover.
     float* run_prefix_ragged(Workspace& ws, const std::vector<PackedGroup>& groups, const PackedPlan& plan, int h, int ts,

@@ -186,12 +186,23 @@ class TextLine:
 
 
 def ctc_beam_search(seq_tc, width):
-    """rten::ctc::CtcDecoder::decode_beam (recognition.rs:512-514): CTC prefix
-    beam search over log-probabilities.  Returns list of (label, pos) for the
-    best prefix; pos = time step at which the label was first appended.
-    [Published algorithm (Hannun et al. 2014, "First-Pass Large Vocabulary
-    Continuous Speech Recognition using Bi-Directional Recurrent DNNs",
-    Alg. 1) — rten's tie handling is unpinned.]"""
+    """rten::ctc::CtcDecoder::decode_beam (recognition.rs:512-514): CTC prefix beam
+    search over log-probabilities [T, C] (blank = 0).  Returns [(label, pos)] of the
+    best prefix, pos = time step at which each label was appended.
+
+    rten's source is not vendored; this restates the published algorithm (Hannun et
+    al. 2014, "First-Pass Large Vocabulary Continuous Speech Recognition using
+    Bi-Directional Recurrent DNNs", Alg. 1) with every choice spelled out so that the
+    HIP engine's host implementation can match it exactly — parity with rten itself
+    is UNPINNED:
+      * scores are float64 log-probabilities, log-sum-exp via m + log(exp(a-m)+exp(b-m));
+      * candidates of a step are kept in first-insertion order, keyed by label sequence;
+        the positions of a prefix are those of its first insertion;
+      * beams are expanded in their current order, blank first, then labels 1..C-1
+        ascending, skipping labels whose log-prob is -inf;
+      * pruning keeps the `width` best by total score, stable (ties keep insertion order);
+      * the answer is the first beam with the maximal total score.
+    """
     T, C = seq_tc.shape
     NEG = -math.inf
 
@@ -200,45 +211,47 @@ def ctc_beam_search(seq_tc, width):
             return b
         if b == NEG:
             return a
-        m = max(a, b)
+        m = a if a > b else b
         return m + math.log(math.exp(a - m) + math.exp(b - m))
 
-    # prefix (tuple of (label,pos)) -> (p_blank, p_nonblank)
-    beams = {(): (0.0, NEG)}
+    beams = [((), (), 0.0, NEG)]  # (labels, positions, p_blank, p_nonblank)
     for t in range(T):
-        row = seq_tc[t]
-        nxt = {}
+        row = [float(v) for v in seq_tc[t]]
+        order = []
+        cand = {}
 
-        def add(prefix, pb, pnb):
-            opb, opnb = nxt.get(prefix, (NEG, NEG))
-            nxt[prefix] = (lse(opb, pb), lse(opnb, pnb))
+        def add(labels, positions, pb, pnb):
+            e = cand.get(labels)
+            if e is None:
+                cand[labels] = [positions, pb, pnb]
+                order.append(labels)
+            else:
+                e[1] = lse(e[1], pb)
+                e[2] = lse(e[2], pnb)
 
-        for prefix, (pb, pnb) in beams.items():
+        for labels, positions, pb, pnb in beams:
             total = lse(pb, pnb)
-            add(prefix, total + float(row[0]), NEG)
-            last = prefix[-1][0] if prefix else None
+            add(labels, positions, total + row[0], NEG)
+            last = labels[-1] if labels else -1
             for c in range(1, C):
-                lp = float(row[c])
+                lp = row[c]
                 if lp == NEG:
                     continue
                 if c == last:
-                    add(prefix, NEG, pnb + lp)
-                    add(prefix + ((c, t),), NEG, pb + lp)
+                    add(labels, positions, NEG, pnb + lp)
+                    add(labels + (c,), positions + (t,), NEG, pb + lp)
                 else:
-                    add(prefix + ((c, t),), NEG, total + lp)
-        # merge prefixes with identical label sequences (keep earliest positions)
-        merged = {}
-        for prefix, (pb, pnb) in nxt.items():
-            key = tuple(l for l, _ in prefix)
-            if key in merged:
-                opfx, opb, opnb = merged[key]
-                merged[key] = (min(opfx, prefix), lse(opb, pb), lse(opnb, pnb))
-            else:
-                merged[key] = (prefix, pb, pnb)
-        items = sorted(merged.values(), key=lambda v: -lse(v[1], v[2]))[:width]
-        beams = {pfx: (pb, pnb) for pfx, pb, pnb in items}
-    best = max(beams.items(), key=lambda kv: lse(kv[1][0], kv[1][1]))[0]
-    return [(l, p) for l, p in best]
+                    add(labels + (c,), positions + (t,), NEG, total + lp)
+        scored = [(lse(cand[k][1], cand[k][2]), i, k) for i, k in enumerate(order)]
+        scored.sort(key=lambda x: (-x[0], x[1]))
+        beams = [(k, cand[k][0], cand[k][1], cand[k][2]) for _, _, k in scored[:width]]
+    best = beams[0]
+    best_score = lse(best[2], best[3])
+    for b in beams[1:]:
+        sc = lse(b[2], b[3])
+        if sc > best_score:
+            best, best_score = b, sc
+    return list(zip(best[0], best[1]))
 
 
 class TextRecognizer:

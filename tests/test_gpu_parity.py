@@ -326,3 +326,52 @@ def test_full_pipeline_tokens_boxes_and_text_identical():
     ed = ora_d.recognize_text(oin, olines[:6])
     assert [str(x) if x else None for x in gd] == [str(x) if x else None for x in ed]
     assert all(ch in "0123456789" for x in gd if x for ch in str(x))
+
+
+# ------------------------------------------------------------------ DecodeMethod::BeamSearch (recognition.rs:198-205,512-514)
+def test_beam_search_tokens_match_oracle():
+    rbuf = M.recognition_model_bytes()
+    from ocrs_amd import DecodeMethod
+    px = synth.synthetic_page(6, 160, 420, lines=5, columns=1)
+    words = []
+    for i in range(5):  # five short lines: [y, x, h, w]
+        words.append([RotatedRect.new((np.float32(40 + 70 * i + 35), np.float32(20 + 28 * i)), (np.float32(0.0), np.float32(1.0)),
+                                      np.float32(70.0), np.float32(18.0))])
+    lines = [rects_of(w) for w in words]
+    for width in (1, 7):
+        gpu = OcrEngine(recognition_model=Model.load_bytes(rbuf), decode_method=DecodeMethod.BeamSearch(width))
+        ora = OP.OcrEngine(recognition_model=OracleModel(OracleGraph(rbuf), "exact"), decode_method=("beam", width))
+        inp = gpu.prepare_input(ImageSource.from_tensor(px, DimOrder.Hwc))
+        oin = ora.prepare_input(OP.ImageSource.from_tensor(px, "hwc"))
+        got = gpu.recognize_text(inp, lines)
+        exp = ora.recognize_text(oin, words)
+        assert [str(x) if x else None for x in got] == [str(x) if x else None for x in exp], width
+        for g, e in zip(got, exp):
+            if g is not None:
+                assert [c.rect for c in g.chars()] == [c.rect.tlbr() for c in e.chars]
+    # masked beam search
+    gpu = OcrEngine(recognition_model=Model.load_bytes(rbuf), decode_method=DecodeMethod.BeamSearch(4), allowed_chars="abcdefghij")
+    ora = OP.OcrEngine(recognition_model=OracleModel(OracleGraph(rbuf), "exact"), decode_method=("beam", 4), allowed_chars="abcdefghij")
+    got = gpu.recognize_text(gpu.prepare_input(ImageSource.from_tensor(px, DimOrder.Hwc)), lines)
+    exp = ora.recognize_text(ora.prepare_input(OP.ImageSource.from_tensor(px, "hwc")), words)
+    assert [str(x) if x else None for x in got] == [str(x) if x else None for x in exp]
+
+
+def test_beam_search_with_callback_model():
+    rec = Model.from_callable(K.FAKE_RECOGNITION_SHAPE, K.fake_recognition_run)
+    from ocrs_amd import DecodeMethod
+    image = np.zeros((1, 64, 32), np.float32)
+    image[:, 2, :] = 1.0
+    got = _recognize(OcrEngine(recognition_model=rec, alphabet=K.make_alphabet(), decode_method=DecodeMethod.BeamSearch(10)), image)
+
+    class FakeRec:
+        def input_shape(self):
+            return K.FAKE_RECOGNITION_SHAPE
+
+        def run(self, x):
+            return K.fake_recognition_run(x)
+
+    ora = OP.OcrEngine(recognition_model=FakeRec(), alphabet=K.make_alphabet(), decode_method=("beam", 10))
+    oin = ora.prepare_input(OP.ImageSource.from_tensor(image, "chw"))
+    exp = ora.recognize_text(oin, [[RotatedRect.from_rect(Rect.from_tlhw(0, 0, 64, 32))]])
+    assert got == str(exp[0])
