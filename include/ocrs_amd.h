@@ -211,6 +211,13 @@ OCRS_API ocrs_status ocrs_engine_recognize_tokens(const ocrs_engine* e, const oc
                                          const size_t* line_offsets, size_t n_lines, uint32_t** labels,
                                          uint32_t** positions, size_t** token_offsets);
 
+/* TextItem::rotated_rect (text_items.rs:18-30) for a TextLine / TextWord given its characters'
+ * rects (n x {top,left,bottom,right}): minimum-area rectangle of the box corners, oriented
+ * towards "up" (y = -1).  out6 = (center.x, center.y, up.x, up.y, width, height).  Host side. */
+OCRS_API ocrs_status ocrs_text_item_rotated_rect(const int32_t* rects_tlbr, size_t n_chars, float out6[6]);
+/* RotatedRect::corners (order pinned by text_items.rs:156-166): out8 = 4 x (x, y). */
+OCRS_API ocrs_status ocrs_rotated_rect_corners(const float rect6[6], float out8[8]);
+
 /* OcrEngine::prepare_recognition_input (lib.rs:268-278 -> recognition.rs:366-392):
  * *out receives a [height, width] f32 line image. */
 OCRS_API ocrs_status ocrs_engine_prepare_recognition_input(const ocrs_engine* e, const ocrs_page* page, const float* line,

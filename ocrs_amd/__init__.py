@@ -213,8 +213,23 @@ class _TextItem:
         a = np.array([c.rect for c in self._chars])
         return (int(a[:, 0].min()), int(a[:, 1].min()), int(a[:, 2].max()), int(a[:, 3].max()))
 
+    def rotated_rect(self):
+        """text_items.rs:18-30 -> (center.x, center.y, up.x, up.y, width, height)."""
+        a = np.ascontiguousarray(np.array([c.rect for c in self._chars], np.int32).reshape(-1, 4))
+        out = (C.c_float * 6)()
+        check(lib().ocrs_text_item_rotated_rect(a.ctypes.data_as(C.POINTER(C.c_int32)), C.c_size_t(len(a)), out))
+        return np.array(list(out), np.float32)
+
     def __str__(self):
         return "".join(c.char for c in self._chars)
+
+
+def rotated_rect_corners(rect6):
+    """RotatedRect::corners -> [[x, y] x 4] floats."""
+    r = (C.c_float * 6)(*[float(v) for v in rect6])
+    out = (C.c_float * 8)()
+    check(lib().ocrs_rotated_rect_corners(r, out))
+    return [[out[2 * i], out[2 * i + 1]] for i in range(4)]
 
 
 class TextWord(_TextItem):  # text_items.rs:92-107

@@ -476,6 +476,23 @@ ocrs_status ocrs_engine_recognize_tokens(const ocrs_engine* e, const ocrs_page* 
     });
 }
 
+ocrs_status ocrs_text_item_rotated_rect(const int32_t* rects_tlbr, size_t n_chars, float out6[6]) {
+    return guarded([&] {
+        if (!rects_tlbr || !out6 || n_chars == 0) fail(OCRS_ERR_INVALID_ARGUMENT, "expected valid rect");
+        RotatedRect rr;
+        if (!text_item_rotated_rect(rects_tlbr, n_chars, &rr)) fail(OCRS_ERR_INVALID_ARGUMENT, "expected valid rect");
+        rr.to_array(out6);
+    });
+}
+
+ocrs_status ocrs_rotated_rect_corners(const float rect6[6], float out8[8]) {
+    return guarded([&] {
+        if (!rect6 || !out8) fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
+        auto c = RotatedRect::from_array(rect6).corners();
+        for (int i = 0; i < 4; i++) { out8[2 * i] = c[i].x; out8[2 * i + 1] = c[i].y; }
+    });
+}
+
 ocrs_status ocrs_engine_prepare_recognition_input(const ocrs_engine* e, const ocrs_page* page, const float* line,
                                                   size_t n_words, float** out, int* height, int* width) {
     return guarded([&] {

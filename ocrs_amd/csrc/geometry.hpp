@@ -146,6 +146,9 @@ inline LineF downwards_line(const LineF& l) { return l.start.y <= l.end.y ? l : 
 
 }  // namespace geom
 
+// text_items.cpp — text_items.rs:18-30
+bool text_item_rotated_rect(const int32_t* tlbr, size_t n_chars, geom::RotatedRect* out);
+
 // layout.cpp — layout_analysis.rs:158-233
 std::vector<std::vector<geom::RotatedRect>> find_text_lines(const std::vector<geom::RotatedRect>& words);
 std::vector<geom::Rect> find_block_separators(const std::vector<geom::RotatedRect>& words);
