@@ -15,6 +15,7 @@ namespace {
 template <class F>
 ocrs_status guarded(F&& f) {
     try {
+        bind_thread_to_device();
         f();
         set_last_error("");
         return OCRS_OK;
@@ -118,7 +119,7 @@ ocrs_status ocrs_device_count(int* n) {
 }
 
 ocrs_status ocrs_set_device(int device) {
-    return guarded([&] { OCRS_HIP(hipSetDevice(device)); });
+    return guarded([&] { select_device(device); });
 }
 
 // ------------------------------------------------------------------ models

@@ -1,11 +1,32 @@
 #include "common.hpp"
 
+#include <atomic>
+
 namespace ocrs {
 
 static thread_local std::string g_last_error;
 
 void set_last_error(const std::string& msg) { g_last_error = msg; }
 const std::string& last_error() { return g_last_error; }
+
+namespace {
+std::atomic<int> g_device{-1};
+thread_local int t_bound_device = -1;
+}  // namespace
+
+void select_device(int device) {
+    OCRS_HIP(hipSetDevice(device));
+    g_device.store(device);
+    t_bound_device = device;
+}
+
+void bind_thread_to_device() {
+    const int d = g_device.load();
+    if (d >= 0 && t_bound_device != d) {
+        OCRS_HIP(hipSetDevice(d));
+        t_bound_device = d;
+    }
+}
 
 const char* const kStageNames[ST_COUNT] = {
     "prepare_image", "resize_to_model", "detection_cnn", "resize_threshold", "ccl",      "contour_rects",

@@ -43,6 +43,11 @@ struct Error : std::runtime_error {
 
 void set_last_error(const std::string& msg);
 
+// The device chosen with ocrs_set_device() is process-wide (one process per GPU); HIP's current
+// device is per host thread, so every API entry binds the calling thread to it.
+void select_device(int device);
+void bind_thread_to_device();
+
 // Size-bucketed caching allocator: hipMalloc is far too slow to sit on the
 // per-page path, and stages need scratch whose size depends on the page.
 class DevicePool {

@@ -256,3 +256,22 @@ def test_find_text_lines():
             br = r.bounding_rect() if br is None else br.union(r.bounding_rect())
         assert abs(float(br.height()) - 5) <= 1.0
         assert abs(float(br.width()) - (5 * (5 + 2) - 2)) <= 1.0
+
+
+# ---------------------------------------------------------------- BASELINE.json configs[0]: CPU plumbing baseline
+def test_config0_single_800x600_image_cpu_path():
+    """One 600w x 800h page through all four OcrEngine calls on the CPU path
+    (oracle with torch-CPU networks, synthetic weights): plumbing check, no GPU."""
+    import models_util as M
+    from ocrs_amd import synth
+    from oracle.nn import OracleGraph, OracleModel
+    px = synth.synthetic_page(0, 800, 600, lines=30, columns=1)
+    eng = OcrEngine(detection_model=OracleModel(OracleGraph(M.detection_model_bytes()), "torch"),
+                    recognition_model=OracleModel(OracleGraph(M.recognition_model_bytes()), "torch"))
+    inp = eng.prepare_input(ImageSource.from_tensor(px, "hwc"))
+    assert inp.shape == (1, 800, 600)
+    words = eng.detect_words(inp)
+    lines = eng.find_text_lines(inp, words)
+    texts = eng.recognize_text(inp, lines[:4])
+    assert len(words) > 100 and len(lines) >= 25
+    assert sum(1 for t in texts if t is not None) >= 3
