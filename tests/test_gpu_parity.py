@@ -375,3 +375,54 @@ def test_beam_search_with_callback_model():
     oin = ora.prepare_input(OP.ImageSource.from_tensor(image, "chw"))
     exp = ora.recognize_text(oin, [[RotatedRect.from_rect(Rect.from_tlhw(0, 0, 64, 32))]])
     assert got == str(exp[0])
+
+
+# ------------------------------------------------------------------ edge cases
+def test_edge_pages_match_oracle():
+    dbuf, rbuf = M.detection_model_bytes((160, 128), (8, 16, 32, 32)), M.recognition_model_bytes()
+    gpu = OcrEngine(detection_model=Model.load_bytes(dbuf), recognition_model=Model.load_bytes(rbuf))
+    ora = OP.OcrEngine(detection_model=OracleModel(OracleGraph(dbuf), "exact"),
+                       recognition_model=OracleModel(OracleGraph(rbuf), "exact"))
+    cases = {
+        "blank": np.full((90, 130, 3), 255, np.uint8),
+        "black": np.zeros((90, 130, 3), np.uint8),
+        "tiny": np.full((7, 9, 1), 128, np.uint8),
+        "one_word": np.full((60, 200, 4), 255, np.uint8),
+        "tall": np.full((400, 40, 3), 255, np.uint8),
+    }
+    cases["one_word"][20:38, 30:120, :3] = 10
+    cases["tall"][50:350:30, 5:35] = 0
+    for name, px in cases.items():
+        inp = gpu.prepare_input(ImageSource.from_tensor(px, DimOrder.Hwc))
+        oin = ora.prepare_input(OP.ImageSource.from_tensor(px, "hwc"))
+        assert np.array_equal(gpu.detect_text_pixels(inp), ora.detect_text_pixels(oin)), name
+        words = gpu.detect_words(inp)
+        owords = ora.detect_words(oin)
+        assert np.array_equal(words, rects_of(owords)), name
+        lines = gpu.find_text_lines(inp, words)
+        olines = ora.find_text_lines(oin, owords)
+        assert len(lines) == len(olines), name
+        got = gpu.recognize_text(inp, lines)
+        exp = ora.recognize_text(oin, olines)
+        assert [str(x) if x else None for x in got] == [str(x) if x else None for x in exp], name
+        assert gpu.get_text(inp) == ora.get_text(oin), name
+    # empty inputs
+    inp = gpu.prepare_input(ImageSource.from_tensor(cases["blank"], DimOrder.Hwc))
+    assert gpu.recognize_text(inp, []) == []
+    assert gpu.find_text_lines(inp, np.zeros((0, 6), np.float32)) == []
+    assert gpu.detect_words_batch([]) == []
+
+
+def test_thread_safety_concurrent_calls():
+    """Model::run is called from several threads at once in the reference (recognition.rs:465-485)."""
+    from concurrent.futures import ThreadPoolExecutor
+    dbuf = M.detection_model_bytes((160, 128), (8, 16, 32, 32))
+    gpu = OcrEngine(detection_model=Model.load_bytes(dbuf))
+    pages = [synth.synthetic_page(s, 150, 220, lines=6, columns=1) for s in range(6)]
+    inps = [gpu.prepare_input(ImageSource.from_tensor(p, DimOrder.Hwc)) for p in pages]
+    ref = [gpu.detect_words(i) for i in inps]
+    with ThreadPoolExecutor(6) as ex:
+        for _ in range(3):
+            got = list(ex.map(gpu.detect_words, inps))
+            for a, b in zip(got, ref):
+                assert np.array_equal(a, b)
