@@ -215,10 +215,10 @@ __global__ void __launch_bounds__(256) gemm_mfma_kernel(GemmDesc d) {
 // still strictly ascending, so results stay bit-identical.
 // Requires K % 32 == 0 (im2col: Cin % 32 == 0).
 // ---------------------------------------------------------------------------
-constexpr int TG_BM = 128, TG_BK = 32, TG_LDA = TG_BM + 1;
+constexpr int TG_BM = 128, TG_BK = 16, TG_LDA = TG_BM + 1;
 
 template <int BN, bool IM2COL>
-__global__ void __launch_bounds__(256) gemm_tiled_kernel(GemmDesc d) {
+__global__ void __launch_bounds__(256, 3) gemm_tiled_kernel(GemmDesc d) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NTW = BN / 64;  // 32-col tiles per wave
     float* As = lds;                        // [2][TG_BK][TG_LDA]
@@ -238,13 +238,14 @@ __global__ void __launch_bounds__(256) gemm_tiled_kernel(GemmDesc d) {
     const int n0 = blockIdx.y * BN;
 
     // ---- per-thread load assignments
-    // A: 128 rows x 8 float4 per chunk -> 4 per thread; thread handles rows ar + 32*j, float4 column akq
-    const int ar = tid >> 3, akq = tid & 7;
-    const float* arow_ptr[4];
-    int apy[4], apx[4];
+    // A: 128 rows x TG_BK/4 float4 per chunk; thread handles rows ar + AROWS*j, float4 column akq
+    constexpr int AQ = TG_BK / 4, AROWS = 256 / AQ, AV = TG_BM / AROWS;
+    const int ar = tid / AQ, akq = tid % AQ;
+    const float* arow_ptr[AV];
+    int apy[AV], apx[AV];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        int64_t row = m0 + ar + 32 * j;
+    for (int j = 0; j < AV; j++) {
+        int64_t row = m0 + ar + AROWS * j;
         if (row >= d.M) row = d.M - 1;
         if (IM2COL) {
             const int64_t hw = (int64_t)d.H * d.W;
@@ -258,18 +259,18 @@ __global__ void __launch_bounds__(256) gemm_tiled_kernel(GemmDesc d) {
             arow_ptr[j] = A + row * d.lda;
         }
     }
-    // B: TG_BK x BN floats per chunk -> BN/32 float4 per thread
-    constexpr int BV = BN / 32;
+    // B: TG_BK x BN floats per chunk
+    constexpr int BV = TG_BK * BN / 4 / 256;
     const bool b_vec = ((d.ldb & 3) == 0) && (((uintptr_t)B & 15) == 0);
 
-    float4 pa[4], pb[BV];
+    float4 pa[AV], pb[BV];
     auto prefetch = [&](int k0) {
         if (IM2COL) {
             const int tap = k0 / d.Cin;
             const int ci0 = k0 - tap * d.Cin;
             const int ky = tap / 3, kx = tap - ky * 3;
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
+            for (int j = 0; j < AV; j++) {
                 const int iy = apy[j] + ky - 1, ix = apx[j] + kx - 1;
                 const bool ok = (unsigned)iy < (unsigned)d.H && (unsigned)ix < (unsigned)d.W;
                 pa[j] = ok ? *reinterpret_cast<const float4*>(arow_ptr[j] + ((int64_t)iy * d.W + ix) * d.Cin + ci0 + akq * 4)
@@ -277,7 +278,7 @@ __global__ void __launch_bounds__(256) gemm_tiled_kernel(GemmDesc d) {
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < 4; j++) pa[j] = *reinterpret_cast<const float4*>(arow_ptr[j] + k0 + akq * 4);
+            for (int j = 0; j < AV; j++) pa[j] = *reinterpret_cast<const float4*>(arow_ptr[j] + k0 + akq * 4);
         }
 #pragma unroll
         for (int j = 0; j < BV; j++) {
@@ -299,8 +300,8 @@ __global__ void __launch_bounds__(256) gemm_tiled_kernel(GemmDesc d) {
     auto commit = [&](int buf) {
         float* a = As + buf * TG_BK * TG_LDA;
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int r = ar + 32 * j;
+        for (int j = 0; j < AV; j++) {
+            const int r = ar + AROWS * j;
             a[(akq * 4 + 0) * TG_LDA + r] = pa[j].x;
             a[(akq * 4 + 1) * TG_LDA + r] = pa[j].y;
             a[(akq * 4 + 2) * TG_LDA + r] = pa[j].z;

@@ -182,14 +182,26 @@ void to_seq_packed_ragged(const float* x, const RaggedView& in, int c, const int
 
 // ---------------------------------------------------------------------------
 // 3x3 / pad 1 convolution on the ragged batch as an implicit GEMM on the fp32 matrix
-// cores.  Same tile structure as gemm_tiled_kernel (128 x BN x 32, LDS-staged k-major
+// cores.  Same tile structure as gemm_tiled_kernel (128 x BN x BK, LDS-staged k-major
 // operands, double buffer, register prefetch, 2x2 waves of 64 x BN/2, k strictly
 // ascending per accumulator); a block's 128 rows are pixels of ONE group.
+// BK = 16 keeps LDS at 33 KB/block so that three blocks (3 waves/SIMD) share a CU and
+// cover each other's barrier / LDS-fill phases: 108 TFLOP/s vs 102 at BK = 32 with two
+// blocks per CU; s_setprio around the MFMA cluster measured -1 % (tools/conv_variants.sh).
 // ---------------------------------------------------------------------------
-constexpr int RG_BM = 128, RG_BK = 32, RG_LDA = RG_BM + 1;
+#ifndef OCRS_CONV_BK
+#define OCRS_CONV_BK 16
+#endif
+constexpr int RG_BM = 128, RG_BK = OCRS_CONV_BK, RG_LDA = RG_BM + 1;
 
+#ifndef OCRS_CONV_WAVES
+#define OCRS_CONV_WAVES 3
+#endif
+#ifndef OCRS_CONV_SETPRIO
+#define OCRS_CONV_SETPRIO 0
+#endif
 template <int BN>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, OCRS_CONV_WAVES)
 conv3x3_ragged_kernel(const float* __restrict__ X, RaggedView rv, int cin, const float* __restrict__ Bw,
                       const float* __restrict__ bias, int cout, int relu, float* __restrict__ Y) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -210,12 +222,15 @@ conv3x3_ragged_kernel(const float* __restrict__ X, RaggedView rv, int cin, const
     float* __restrict__ C = Y + rv.poff[g] * cout;
     const int K = 9 * cin;
 
-    const int ar = tid >> 3, akq = tid & 7;
-    const float* aimg[4];
-    int apy[4], apx[4];
+    constexpr int AQ = RG_BK / 4;          // float4 per row per chunk
+    constexpr int AROWS = 256 / AQ;        // rows covered by one pass of the block
+    constexpr int AV = RG_BM / AROWS;      // passes (float4 per thread)
+    const int ar = tid / AQ, akq = tid % AQ;
+    const float* aimg[AV];
+    int apy[AV], apx[AV];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        int64_t row = m0 + ar + 32 * j;
+    for (int j = 0; j < AV; j++) {
+        int64_t row = m0 + ar + AROWS * j;
         if (row >= rows) row = rows - 1;
         const int64_t hw = (int64_t)H * W;
         const int64_t img = row / hw;
@@ -224,14 +239,14 @@ conv3x3_ragged_kernel(const float* __restrict__ X, RaggedView rv, int cin, const
         apx[j] = rem - apy[j] * W;
         aimg[j] = A + img * hw * cin;
     }
-    constexpr int BV = BN / 32;
-    float4 pa[4], pb[BV];
+    constexpr int BV = RG_BK * BN / 4 / 256;
+    float4 pa[AV], pb[BV];
     auto prefetch = [&](int k0) {
         const int tap = k0 / cin;
         const int ci0 = k0 - tap * cin;
         const int ky = tap / 3, kx = tap - ky * 3;
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
+        for (int j = 0; j < AV; j++) {
             const int iy = apy[j] + ky - 1, ix = apx[j] + kx - 1;
             const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
             pa[j] = ok ? *reinterpret_cast<const float4*>(aimg[j] + ((int64_t)iy * W + ix) * cin + ci0 + akq * 4)
@@ -249,8 +264,8 @@ conv3x3_ragged_kernel(const float* __restrict__ X, RaggedView rv, int cin, const
     auto commit = [&](int buf) {
         float* a = As + buf * RG_BK * RG_LDA;
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int r = ar + 32 * j;
+        for (int j = 0; j < AV; j++) {
+            const int r = ar + AROWS * j;
             a[(akq * 4 + 0) * RG_LDA + r] = pa[j].x;
             a[(akq * 4 + 1) * RG_LDA + r] = pa[j].y;
             a[(akq * 4 + 2) * RG_LDA + r] = pa[j].z;
@@ -282,6 +297,9 @@ conv3x3_ragged_kernel(const float* __restrict__ X, RaggedView rv, int cin, const
         if (c + 1 < nchunks) prefetch((c + 1) * RG_BK);
         const float* a = As + buf * RG_BK * RG_LDA + wm * 64 + l31;
         const float* b = Bs + buf * RG_BK * BN + wn * (BN / 2) + l31;
+#if OCRS_CONV_SETPRIO
+        __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
         for (int kp = 0; kp < RG_BK / 2; kp++) {
             const int kr = 2 * kp + half;
@@ -293,6 +311,9 @@ conv3x3_ragged_kernel(const float* __restrict__ X, RaggedView rv, int cin, const
                 acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bt, acc[1][t], 0, 0, 0);
             }
         }
+#if OCRS_CONV_SETPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         if (c + 1 < nchunks) commit(buf ^ 1);
         __syncthreads();
     }
