@@ -41,15 +41,16 @@ PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md "HBM3E peak BW" (spec)
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=6)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--pages", type=int, default=8, help="pages per step per GPU")
     ap.add_argument("--lines", type=int, default=80, help="text lines per synthetic page")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pages", type=int, default=3, help="pages in the bounded CPU-baseline sample")
     ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--inflight", type=int, default=1,
-                    help="full steps kept in flight on separate host threads / HIP streams (default 1)")
+    ap.add_argument("--inflight", type=int, default=4,
+                    help="full steps kept in flight on separate host threads / HIP streams (default 4; 1 = the "
+                         "2-stage pipeline or, with --no-pipeline, strictly sequential steps)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="run the stages of each step strictly one after another (default: 2-stage software "
                          "pipeline across steps: detect+layout of step i+1 overlap recognition of step i)")
@@ -221,9 +222,12 @@ def main():
             "words_per_page": round(n_words / B, 1),
             "weights": "seeded synthetic weights on the SURVEY.md §2.4 architectures (real ocrs weights unobtainable offline)",
             "parallelism": "page-sharded, %d process(es) x 1 GPU, no data-path collective" % world,
-            "step_overlap": "none (stages strictly sequential)" if args.no_pipeline else
-                            "2-stage software pipeline across steps: detect+layout of step i+1 (2nd host thread, own HIP "
-                            "stream) overlap recognition of step i; every step still does all of its work",
+            "step_overlap": ("%d whole steps in flight (one host thread + HIP stream each); the conv stacks of all "
+                             "requests run FIFO on one shared stream, the latency-bound GRU chains and the host layout "
+                             "overlap them; every step still does all of its work" % args.inflight) if args.inflight > 1 else
+                            ("none (stages strictly sequential)" if args.no_pipeline else
+                             "2-stage software pipeline across steps: detect+layout of step i+1 (2nd host thread, own HIP "
+                             "stream) overlap recognition of step i; every step still does all of its work"),
         },
         "lines_per_s": round(n_lines_all * args.steps / elapsed, 1),
         "chars_last_step": n_chars,

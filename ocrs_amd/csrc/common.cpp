@@ -94,6 +94,15 @@ DevicePool& pool() {
     return *p;
 }
 
+hipStream_t heavy_stream() {
+    static hipStream_t s = [] {
+        hipStream_t h;
+        OCRS_HIP(hipStreamCreateWithFlags(&h, hipStreamNonBlocking));
+        return h;
+    }();
+    return s;
+}
+
 // ---------------------------------------------------------------- streams
 namespace {
 std::mutex g_stream_mu;

@@ -65,6 +65,9 @@ class DevicePool {
 
 DevicePool& pool();
 
+// One process-wide stream for the throughput-bound conv stacks of all in-flight requests (model.cpp).
+hipStream_t heavy_stream();
+
 // RAII device buffer from the pool.
 struct DevBuf {
     void* p = nullptr;
@@ -177,6 +180,13 @@ struct Workspace {
     StreamLease stream;
     std::vector<DevBuf> bufs;
     std::vector<std::vector<char>> host_keep;  // host staging that must outlive async uploads
+    std::vector<hipEvent_t> events;            // cross-stream dependencies created by this call
+    hipEvent_t make_event() {
+        hipEvent_t e;
+        OCRS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        events.push_back(e);
+        return e;
+    }
     Workspace() = default;
     explicit Workspace(bool high_priority) : stream(high_priority) {}
     // copy `bytes` from a host temporary to the device without a sync: the bytes are parked in the workspace
@@ -188,7 +198,10 @@ struct Workspace {
     void* alloc(size_t bytes) { bufs.emplace_back(bytes ? bytes : 4); return bufs.back().p; }
     template <class T> T* alloc_n(size_t n) { return static_cast<T*>(alloc(n * sizeof(T))); }
     void sync() { stream.sync(); }
-    ~Workspace() { (void)hipStreamSynchronize(stream.get()); }
+    ~Workspace() {
+        (void)hipStreamSynchronize(stream.get());
+        for (hipEvent_t e : events) (void)hipEventDestroy(e);
+    }
 };
 
 const std::string& last_error();

@@ -401,8 +401,8 @@ float* HipModel::run_device(Workspace& ws, const float* d_in, int n, int h, int 
 // ---------------------------------------------------------------------------
 // Ragged recognition batch
 // ---------------------------------------------------------------------------
-float* HipModel::run_prefix_ragged(Workspace& ws, const std::vector<PackedGroup>& groups, const PackedPlan& plan, int h,
-                                   int ts, StageTimers* timers, int* feat_c) const {
+float* HipModel::run_prefix_ragged(Workspace& ws, hipStream_t exec, const std::vector<PackedGroup>& groups,
+                                   const PackedPlan& plan, int h, int ts, StageTimers* timers, int* feat_c) const {
     // supported stack: CONV 3x3 (Cin == 1 directly followed by MAXPOOL 2x2, or Cin % 32 == 0), MAXPOOL, AVGPOOL,
     // each consuming the previous op's output
     const int G = (int)groups.size();
@@ -425,7 +425,7 @@ float* HipModel::run_prefix_ragged(Workspace& ws, const std::vector<PackedGroup>
     for (int g = 0; g + 1 < G; g++)  // groups must be contiguous in memory
         if (groups[g].d_batch + (size_t)groups[g].n * h * groups[g].w != groups[g + 1].d_batch) return nullptr;
 
-    hipStream_t st = ws.s();
+    hipStream_t st = exec;
     auto timed = [&](int cls, double flops, double bytes, auto&& launch) {
         int tok = timers ? timers->kbegin(cls, st, flops, bytes) : -1;
         launch();
@@ -489,6 +489,11 @@ float* HipModel::run_prefix_ragged(Workspace& ws, const std::vector<PackedGroup>
     int32_t* d32 = ws.alloc_n<int32_t>(meta32.size());
     ws.upload(d64, meta64.data(), meta64.size() * sizeof(int64_t));
     ws.upload(d32, meta32.data(), meta32.size() * sizeof(int32_t));
+    if (exec != ws.s()) {  // inputs (crops, plan, metadata) were produced on the request's stream
+        hipEvent_t ready = ws.make_event();
+        OCRS_HIP(hipEventRecord(ready, ws.s()));
+        OCRS_HIP(hipStreamWaitEvent(exec, ready, 0));
+    }
     auto view = [&](size_t gi) {
         k::RaggedView v{};
         v.G = G; v.H = geos[gi].H;
@@ -548,6 +553,11 @@ float* HipModel::run_prefix_ragged(Workspace& ws, const std::vector<PackedGroup>
     timed(KC_OTHER, 0, 8.0 * vf.pixels * curC,
           [&] { k::to_seq_packed_ragged(cur, vf, curC, groups[0].d_pos, plan.d_off, X, st); });
     if (tok >= 0) timers->end(tok, st);
+    if (exec != ws.s()) {  // the request's stream continues once the conv stack has drained
+        hipEvent_t done = ws.make_event();
+        OCRS_HIP(hipEventRecord(done, exec));
+        OCRS_HIP(hipStreamWaitEvent(ws.s(), done, 0));
+    }
     *feat_c = curC;
     return X;
 }
@@ -588,10 +598,20 @@ int HipModel::run_recognition_packed(Workspace& ws, const std::vector<PackedGrou
     const int M = plan.M;
 
     // ---- conv stack -> packed feature rows: one launch per layer over all groups (ragged),
-    // or group by group if the stack has an op the ragged kernels do not cover
+    // or group by group if the stack has an op the ragged kernels do not cover.
+    // The conv stack saturates the GPU; the recurrence that follows is a chain of small,
+    // latency-bound launches.  When several requests are in flight (host threads / streams),
+    // two conv stacks at once gain nothing, but a conv stack next to other requests' GRU chains
+    // does: so every request's conv stack is enqueued on one shared stream (FIFO on the GPU, linked
+    // to the request's own stream by events) and everything after it overlaps freely.
     float* X = nullptr;
     int C0 = 0;
-    X = run_prefix_ragged(ws, groups, plan, h, ts, timers, &C0);
+    static std::mutex heavy_phase;
+    {
+        // all conv stacks go through ONE stream, in request order, without host waits
+        std::lock_guard<std::mutex> heavy(heavy_phase);
+        X = run_prefix_ragged(ws, heavy_stream(), groups, plan, h, ts, timers, &C0);
+    }
     if (!X)
     for (const PackedGroup& g : groups) {
         TensorShape fs;

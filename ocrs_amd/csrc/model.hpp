@@ -96,8 +96,9 @@ struct HipModel : ModelBase {
                                float** d_logp = nullptr) const;
     // Conv stack (ops [0, ts)) over all groups at once; writes packed feature rows.  Returns
     // nullptr if the stack has an op the ragged kernels do not cover.
-    float* run_prefix_ragged(Workspace& ws, const std::vector<PackedGroup>& groups, const PackedPlan& plan, int h, int ts,
-                             StageTimers* timers, int* feat_c) const;
+    // Kernels are launched on `exec` (which may differ from ws.s(); the caller links the two with events).
+    float* run_prefix_ragged(Workspace& ws, hipStream_t exec, const std::vector<PackedGroup>& groups,
+                             const PackedPlan& plan, int h, int ts, StageTimers* timers, int* feat_c) const;
 };
 
 }  // namespace ocrs
