@@ -112,7 +112,6 @@ void ocrs_engine::detect(const ocrs_page* const* pages, size_t n, std::vector<st
     b.pts = ws.alloc_n<uint32_t>((size_t)N * arena);
     b.tmp = ws.alloc_n<uint32_t>((size_t)N * arena * 4);
     b.keep = ws.alloc_n<uint8_t>((size_t)N * arena);
-    b.stack = nullptr;
     b.rects = ws.alloc_n<float>((size_t)N * max_comp * 6);
     b.valid = ws.alloc_n<uint8_t>((size_t)N * max_comp);
     OCRS_HIP(hipMemsetAsync(b.overflow, 0, N * sizeof(int32_t), st));
@@ -299,6 +298,11 @@ void ocrs_engine::recognize(const ocrs_page* const* pages, size_t n_pages,
                 chunks.push_back(std::move(ch));
             }
         }
+        // activations of the conv stack scale with the input (~100 B per input pixel): refuse requests
+        // that cannot fit one device instead of failing inside an allocation
+        if ((double)off * 100.0 > 200e9)
+            fail(OCRS_ERR_CAPACITY, "recognition request too large (%lld input pixels): split the lines over several calls",
+                 (long long)off);
         std::vector<k::LineDesc> descs;
         std::vector<int32_t> poly;
         for (const Chunk& ch : chunks)

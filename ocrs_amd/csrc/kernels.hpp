@@ -34,13 +34,11 @@ struct CclBuffers {
     int32_t* offsets;     // [n, max_comp]  arena offsets (exclusive scan of lengths)
     int32_t* overflow;    // [n]  set if a capacity was exceeded
     uint32_t* pts;        // [n, arena]  packed (y << 16 | x) contour points
-    uint32_t* tmp;        // [n, arena]  simplified / sorted / hull scratch (3 regions of arena/1)
+    uint32_t* tmp;        // [n, 4 * arena]  per component: simplified | sorted | hull (2x) scratch
     uint8_t* keep;        // [n, arena]
-    int32_t* stack;       // [n, arena * 2 + 4]
     float* rects;         // [n, max_comp, 6]
     uint8_t* valid;       // [n, max_comp]
 };
-size_t ccl_workspace_bytes(int n, int h, int w, int max_comp, int64_t arena);
 // mask [n,h,w] -> per page: raster-ordered external components -> rects
 // (find_contours(External) -> simplify_polygon(2) -> min_area_rect -> resize(+2*expand)
 //  -> area >= min_area; detection.rs:41-62).

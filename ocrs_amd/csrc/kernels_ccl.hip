@@ -491,12 +491,6 @@ contour_rect_kernel(const uint8_t* __restrict__ mask, int h, int w, const int32_
     }
 }
 
-size_t ccl_workspace_bytes(int n, int h, int w, int max_comp, int64_t arena) {
-    size_t px = (size_t)n * h * w;
-    return px * 4 + (size_t)n * h * 8 + (size_t)n * 8 + (size_t)n * max_comp * (4 * 3 + 24 + 1) +
-           (size_t)n * arena * (4 + 16 + 1) + 4096;
-}
-
 void contour_rects(const uint8_t* d_mask, int n, int h, int w, const CclBuffers& b, int max_comp, int64_t arena,
                    float expand, float min_area, float eps, hipStream_t s) {
     hipLaunchKernelGGL(trace_count_kernel, dim3(64, n), dim3(64), 0, s, d_mask, h, w, b.n_roots, b.roots, b.lengths,

@@ -240,8 +240,14 @@ conv3x3_ragged_kernel(const float* __restrict__ X, RaggedView rv, int cin, const
         aimg[j] = A + img * hw * cin;
     }
     constexpr int BV = RG_BK * BN / 4 / 256;
-    float4 pa[AV], pb[BV];
-    auto prefetch = [&](int k0) {
+    // A is fetched from global memory a full 128-byte line (32 channels) per pixel at a time — two
+    // consecutive 16-wide K chunks — while LDS staging stays 16-wide: half the A load instructions
+    // and 28 fewer VGPRs than fetching per chunk (+3.5 %).  (It does NOT change FETCH_SIZE: the
+    // L2-miss traffic of this kernel — 3.1 GB/launch — is a capacity effect of three resident blocks
+    // per CU streaming ~6 MB of distinct A lines per XCD between tap re-uses; the kernel moves
+    // ~1.5 TB/s and stays MFMA-bound.  DESIGN.md §6.)
+    float4 pa0[AV], pa1[AV], pb[BV];
+    auto load_a_pair = [&](int k0) {  // chunks k0 and k0 + RG_BK (same tap: cin % (2*RG_BK) == 0)
         const int tap = k0 / cin;
         const int ci0 = k0 - tap * cin;
         const int ky = tap / 3, kx = tap - ky * 3;
@@ -249,9 +255,12 @@ conv3x3_ragged_kernel(const float* __restrict__ X, RaggedView rv, int cin, const
         for (int j = 0; j < AV; j++) {
             const int iy = apy[j] + ky - 1, ix = apx[j] + kx - 1;
             const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-            pa[j] = ok ? *reinterpret_cast<const float4*>(aimg[j] + ((int64_t)iy * W + ix) * cin + ci0 + akq * 4)
-                       : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float* src = aimg[j] + ((int64_t)(ok ? iy : 0) * W + (ok ? ix : 0)) * cin + ci0 + akq * 4;
+            pa0[j] = ok ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
+            pa1[j] = ok ? *reinterpret_cast<const float4*>(src + RG_BK) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
+    };
+    auto load_b = [&](int k0) {
 #pragma unroll
         for (int j = 0; j < BV; j++) {
             const int idx = tid + 256 * j;
@@ -261,7 +270,7 @@ conv3x3_ragged_kernel(const float* __restrict__ X, RaggedView rv, int cin, const
             pb[j] = v;
         }
     };
-    auto commit = [&](int buf) {
+    auto commit = [&](int buf, const float4* pa) {
         float* a = As + buf * RG_BK * RG_LDA;
 #pragma unroll
         for (int j = 0; j < AV; j++) {
@@ -288,18 +297,9 @@ conv3x3_ragged_kernel(const float* __restrict__ X, RaggedView rv, int cin, const
 #pragma unroll
         for (int r = 0; r < 16; r++) { acc[0][t][r] = bv; acc[1][t][r] = bv; }
     }
-    const int nchunks = K / RG_BK;
-    prefetch(0);
-    commit(0);
-    __syncthreads();
-    for (int c = 0; c < nchunks; c++) {
-        const int buf = c & 1;
-        if (c + 1 < nchunks) prefetch((c + 1) * RG_BK);
+    auto compute = [&](int buf) {
         const float* a = As + buf * RG_BK * RG_LDA + wm * 64 + l31;
         const float* b = Bs + buf * RG_BK * BN + wn * (BN / 2) + l31;
-#if OCRS_CONV_SETPRIO
-        __builtin_amdgcn_s_setprio(1);
-#endif
 #pragma unroll
         for (int kp = 0; kp < RG_BK / 2; kp++) {
             const int kr = 2 * kp + half;
@@ -311,10 +311,26 @@ conv3x3_ragged_kernel(const float* __restrict__ X, RaggedView rv, int cin, const
                 acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bt, acc[1][t], 0, 0, 0);
             }
         }
-#if OCRS_CONV_SETPRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
-        if (c + 1 < nchunks) commit(buf ^ 1);
+    };
+    const int nchunks = K / RG_BK;  // even: cin % (2*RG_BK) == 0
+    load_a_pair(0);
+    load_b(0);
+    commit(0, pa0);
+    __syncthreads();
+    for (int c = 0; c < nchunks; c += 2) {
+        // even chunk c in buffer 0; chunk c+1's A half is already in registers
+        load_b((c + 1) * RG_BK);
+        compute(0);
+        commit(1, pa1);
+        __syncthreads();
+        // odd chunk c+1 in buffer 1; fetch the next pair
+        const bool more = c + 2 < nchunks;
+        if (more) {
+            load_a_pair((c + 2) * RG_BK);
+            load_b((c + 2) * RG_BK);
+        }
+        compute(1);
+        if (more) commit(0, pa0);
         __syncthreads();
     }
 #pragma unroll
@@ -336,7 +352,7 @@ conv3x3_ragged_kernel(const float* __restrict__ X, RaggedView rv, int cin, const
 
 bool conv3x3_ragged(const float* x, const RaggedView& rv, int cin, const float* wt, const float* bias, int cout, int relu,
                     float* y, hipStream_t s) {
-    if ((cin % RG_BK) != 0 || (cout % 4) != 0 || cout < 64) return false;
+    if ((cin % (2 * RG_BK)) != 0 || (cout % 4) != 0 || cout < 64) return false;
     if (rv.ntiles128 <= 0) return true;
     if (cout <= 64) {
         size_t lds = (size_t)(2 * RG_BK * RG_LDA + 2 * RG_BK * 64) * sizeof(float);
