@@ -334,6 +334,11 @@ def extra_legs(engine, dptrs, H, W, synth, np, DimOrder, sync_all):
     dt = time.perf_counter() - t0
     out["recognition_only_lines_per_s"] = round(reps * n / dt, 1)
     out["recognition_only_config"] = "2048 crops 64x256 -> width group 300 (T=75), crop+CRNN+greedy CTC, %d chars decoded" % len(chars)
+    # what this box sustains, next to the nominal peaks the roofline divides by
+    from ocrs_amd._lib import measure_peaks
+    tf, gbps = measure_peaks()
+    out["measured_device_rates"] = {"mfma_f32_tflops": round(tf, 1), "hbm_copy_gbps": round(gbps, 0),
+                                    "how": "register-only 32x32x2 fp32 MFMA loop, 2 waves/SIMD; 2 GiB float4 copy, read+write"}
     return out
 
 

@@ -235,6 +235,9 @@ OCRS_API ocrs_status ocrs_device_malloc(size_t bytes, void** d_ptr);
 OCRS_API ocrs_status ocrs_device_free(void* d_ptr);
 OCRS_API ocrs_status ocrs_device_upload(void* d_dst, const void* h_src, size_t bytes);
 OCRS_API ocrs_status ocrs_device_synchronize(void);
+/* Rates this device sustains: register-only fp32 MFMA loop (TFLOP/s) and a large float4 copy
+ * (GB/s, read + write).  Reported by bench.py beside the nominal peaks the roofline uses. */
+OCRS_API ocrs_status ocrs_device_measure_peaks(double* mfma_f32_tflops, double* hbm_copy_gbps);
 
 /* Per-stage timers: when enabled, every GPU stage is bracketed by HIP events
  * on the stream it is launched on; ocrs_engine_stage_times returns accumulated

@@ -52,7 +52,7 @@ DECLARED_SYMBOLS = [
     "ocrs_engine_find_text_lines_batch",
     "ocrs_engine_recognize_text", "ocrs_engine_recognize_text_batch", "ocrs_engine_recognize_tokens",
     "ocrs_engine_prepare_recognition_input", "ocrs_text_item_rotated_rect", "ocrs_rotated_rect_corners", "ocrs_engine_get_text", "ocrs_device_malloc", "ocrs_device_free",
-    "ocrs_device_upload", "ocrs_device_synchronize", "ocrs_engine_enable_timing", "ocrs_stage_count",
+    "ocrs_device_upload", "ocrs_device_synchronize", "ocrs_device_measure_peaks", "ocrs_engine_enable_timing", "ocrs_stage_count",
     "ocrs_stage_name", "ocrs_engine_stage_times", "ocrs_kernel_class_count", "ocrs_kernel_class_name",
     "ocrs_engine_kernel_stats", "ocrs_engine_set_kernel_timing_mask",
 ]
@@ -91,6 +91,13 @@ def device_count():
     n = C.c_int(0)
     check(lib().ocrs_device_count(C.byref(n)))
     return n.value
+
+
+def measure_peaks():
+    """(fp32 MFMA TFLOP/s, HBM copy GB/s) this device sustains (micro-benchmarks in kernels_peaks.hip)."""
+    a, b = C.c_double(0), C.c_double(0)
+    check(lib().ocrs_device_measure_peaks(C.byref(a), C.byref(b)))
+    return a.value, b.value
 
 
 def require_gpu():

@@ -576,6 +576,13 @@ ocrs_status ocrs_device_synchronize(void) {
     return guarded([&] { OCRS_HIP(hipDeviceSynchronize()); });
 }
 
+ocrs_status ocrs_device_measure_peaks(double* mfma_f32_tflops, double* hbm_copy_gbps) {
+    return guarded([&] {
+        if (!mfma_f32_tflops || !hbm_copy_gbps) fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
+        k::measure_peaks(mfma_f32_tflops, hbm_copy_gbps);
+    });
+}
+
 ocrs_status ocrs_engine_enable_timing(ocrs_engine* e, int enable) {
     return guarded([&] {
         if (!e) fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");

@@ -141,5 +141,8 @@ struct LineDesc {      // one text line to crop (recognition.rs:91-126)
 void crop_lines(const float* const* d_pages, const int32_t* d_page_hw /*[pages][2]*/, const LineDesc* d_lines,
                 const int32_t* d_poly /*(y,x) pairs*/, int n_lines, int out_h, float* d_out, hipStream_t s);
 
+// kernels_peaks.hip
+void measure_peaks(double* mfma_tflops, double* copy_gbps);
+
 }  // namespace k
 }  // namespace ocrs

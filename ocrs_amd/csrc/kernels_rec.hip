@@ -195,10 +195,10 @@ void to_seq_packed_ragged(const float* x, const RaggedView& in, int c, const int
 constexpr int RG_BM = 128, RG_BK = OCRS_CONV_BK, RG_LDA = RG_BM + 1;
 
 #ifndef OCRS_CONV_WAVES
-#define OCRS_CONV_WAVES 3
+#define OCRS_CONV_WAVES 4
 #endif
-#ifndef OCRS_CONV_SETPRIO
-#define OCRS_CONV_SETPRIO 0
+#ifndef OCRS_CONV_FRAGPIPE
+#define OCRS_CONV_FRAGPIPE 0
 #endif
 template <int BN>
 __global__ void __launch_bounds__(256, OCRS_CONV_WAVES)
@@ -300,16 +300,32 @@ conv3x3_ragged_kernel(const float* __restrict__ X, RaggedView rv, int cin, const
     auto compute = [&](int buf) {
         const float* a = As + buf * RG_BK * RG_LDA + wm * 64 + l31;
         const float* b = Bs + buf * RG_BK * BN + wn * (BN / 2) + l31;
+        // operand fragments double-buffered in registers: the LDS reads of k-pair kp+1 are issued
+        // before the MFMAs of kp, so a full group of MFMAs (not just the last one) covers their latency
+        float fa[2][2], fb[2][NTW];
+        auto fetch = [&](int kp, int s) {
+            const int kr = 2 * kp + half;
+            fa[s][0] = a[kr * RG_LDA];
+            fa[s][1] = a[kr * RG_LDA + 32];
+#pragma unroll
+            for (int t = 0; t < NTW; t++) fb[s][t] = b[kr * BN + t * 32];
+        };
+        fetch(0, 0);
 #pragma unroll
         for (int kp = 0; kp < RG_BK / 2; kp++) {
-            const int kr = 2 * kp + half;
-            const float a0 = a[kr * RG_LDA], a1 = a[kr * RG_LDA + 32];
+            const int s = kp & 1;
+            if (kp + 1 < RG_BK / 2) fetch(kp + 1, s ^ 1);
+#if OCRS_CONV_FRAGPIPE
+            __builtin_amdgcn_sched_barrier(0);  // keep the reads ahead of this group's MFMAs
+#endif
 #pragma unroll
             for (int t = 0; t < NTW; t++) {
-                const float bt = b[kr * BN + t * 32];
-                acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bt, acc[0][t], 0, 0, 0);
-                acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bt, acc[1][t], 0, 0, 0);
+                acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s][0], fb[s][t], acc[0][t], 0, 0, 0);
+                acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s][1], fb[s][t], acc[1][t], 0, 0, 0);
             }
+#if OCRS_CONV_FRAGPIPE
+            __builtin_amdgcn_sched_barrier(0);
+#endif
         }
     };
     const int nchunks = K / RG_BK;  // even: cin % (2*RG_BK) == 0
