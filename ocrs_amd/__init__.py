@@ -78,6 +78,11 @@ class Model:
 
     @staticmethod
     def load_file(path):
+        """`*.ocrsm` containers are read by the library; `*.onnx` files (the format the real
+        ocrs models are published in, README.md:96-102) are lowered by `onnx_import` first."""
+        if str(path).lower().endswith(".onnx"):
+            from .onnx_import import import_onnx
+            return Model.load_bytes(import_onnx(str(path)).to_bytes())
         h = C.c_void_p()
         check(lib().ocrs_model_load_file(str(path).encode(), C.byref(h)))
         return Model(h)

@@ -144,6 +144,20 @@ def test_detection_model_run_bit_exact(in_hw, n):
     assert np.abs(got - og.run_torch(x)).max() < 1e-4  # fp32 tolerance vs the ONNX-operator semantics
 
 
+def test_onnx_files_load_and_run_bit_exact(tmp_path):
+    """`.onnx` files go through ocrs_amd.onnx_import into the HIP executor."""
+    from ocrs_amd import modelfile as mf
+    from ocrs_amd.onnx_export import export_onnx
+    det = mf.build_detection(in_hw=(100, 76), depths=(8, 16, 16, 32), seed=5)
+    rec = mf.build_recognition(n_classes=31, in_h=64, seed=6, hidden=64, chans=(32, 32, 64, 64, 64, 64))
+    rng = np.random.default_rng(3)
+    for g, x in ((det, rng.uniform(-0.5, 0.5, (2, 1, 100, 76))), (rec, rng.uniform(-0.5, 0.5, (3, 1, 64, 120)))):
+        path = tmp_path / ("m%d.onnx" % g.kind)
+        path.write_bytes(export_onnx(g))
+        got = Model.load_file(str(path)).run(x.astype(np.float32))
+        assert np.array_equal(got, OracleGraph(g.to_bytes()).run_exact(x.astype(np.float32)))
+
+
 @pytest.mark.parametrize("n,width", [(3, 100), (5, 300), (1, 50)])
 def test_recognition_model_run_bit_exact(n, width):
     buf = M.recognition_model_bytes()
