@@ -114,6 +114,8 @@ struct RaggedView {          // device pointers live in one metadata upload; pas
     const int32_t* toff256;  // [G+1] cumulative 256-pixel tile counts
     const int32_t* loff;     // [G+1] cumulative image (line) counts
     int ntiles128, ntiles256;
+    const int32_t* toff2d;   // [G+1] cumulative TH x TW patch counts (conv3x3_ragged), TH = 128 / tw
+    int ntiles2d, tw;
     int64_t pixels;          // total pixels (host)
 };
 void conv1_relu_pool_ragged(const float* x, const RaggedView& in, const float* wt, const float* bias, int cout,
@@ -124,7 +126,7 @@ void to_seq_packed_ragged(const float* x, const RaggedView& in, int c, const int
                           float* y, hipStream_t s);
 // returns false if the shape is not supported (caller falls back to the per-group path)
 bool conv3x3_ragged(const float* x, const RaggedView& rv, int cin, const float* wt, const float* bias, int cout, int relu,
-                    float* y, hipStream_t s);
+                    int ph, int pw, float* y, const RaggedView& out, hipStream_t s);
 
 // ---- kernels_lines.hip ----------------------------------------------------
 struct LineDesc {      // one text line to crop (recognition.rs:91-126)

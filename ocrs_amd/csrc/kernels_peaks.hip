@@ -10,6 +10,7 @@ namespace ocrs {
 namespace k {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 __global__ void __launch_bounds__(256)
 peak_mfma_f32_kernel(float* __restrict__ out, int iters) {
@@ -27,9 +28,20 @@ peak_mfma_f32_kernel(float* __restrict__ out, int iters) {
 }
 
 __global__ void __launch_bounds__(256)
-peak_copy_kernel(const float4* __restrict__ src, float4* __restrict__ dst, int64_t n) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        dst[i] = src[i];
+peak_copy_kernel(const f32x4v* __restrict__ src, f32x4v* __restrict__ dst, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n; i += 4 * stride) {  // four independent 16-byte loads in flight per lane
+        const f32x4v a = __builtin_nontemporal_load(src + i);
+        const f32x4v b = __builtin_nontemporal_load(src + i + stride);
+        const f32x4v c = __builtin_nontemporal_load(src + i + 2 * stride);
+        const f32x4v d = __builtin_nontemporal_load(src + i + 3 * stride);
+        __builtin_nontemporal_store(a, dst + i);
+        __builtin_nontemporal_store(b, dst + i + stride);
+        __builtin_nontemporal_store(c, dst + i + 2 * stride);
+        __builtin_nontemporal_store(d, dst + i + 3 * stride);
+    }
+    for (; i < n; i += stride) dst[i] = src[i];
 }
 
 void measure_peaks(double* mfma_tflops, double* copy_gbps) {
@@ -60,12 +72,12 @@ void measure_peaks(double* mfma_tflops, double* copy_gbps) {
     }
     {
         const int64_t bytes = (int64_t)2 << 30;
-        float4 *a = nullptr, *b = nullptr;
+        f32x4v *a = nullptr, *b = nullptr;
         OCRS_HIP(hipMalloc(&a, bytes));
         OCRS_HIP(hipMalloc(&b, bytes));
         OCRS_HIP(hipMemsetAsync(a, 0, bytes, s));
         const int64_t n = bytes / 16;
-        const int blocks = prop.multiProcessorCount * 16;
+        const int blocks = prop.multiProcessorCount * 8;
         peak_copy_kernel<<<blocks, 256, 0, s>>>(a, b, n);
         OCRS_HIP(hipEventRecord(e0, s));
         const int reps = 8;

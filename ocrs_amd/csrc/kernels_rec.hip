@@ -181,13 +181,23 @@ void to_seq_packed_ragged(const float* x, const RaggedView& in, int c, const int
 }
 
 // ---------------------------------------------------------------------------
-// 3x3 / pad 1 convolution on the ragged batch as an implicit GEMM on the fp32 matrix
-// cores.  Same tile structure as gemm_tiled_kernel (128 x BN x BK, LDS-staged k-major
-// operands, double buffer, register prefetch, 2x2 waves of 64 x BN/2, k strictly
-// ascending per accumulator); a block's 128 rows are pixels of ONE group.
-// BK = 16 keeps LDS at 33 KB/block so that three blocks (3 waves/SIMD) share a CU and
-// cover each other's barrier / LDS-fill phases: 108 TFLOP/s vs 102 at BK = 32 with two
-// blocks per CU; s_setprio around the MFMA cluster measured -1 % (tools/conv_variants.sh).
+// 3x3 / pad 1 convolution (+ bias + ReLU [+ MaxPool 2x1 / 2x2]) on the ragged batch as an
+// implicit GEMM on the fp32 matrix cores.  Same GEMM structure as gemm_tiled_kernel
+// (128 x BN x BK, LDS-staged k-major operands, double buffer, register prefetch, 2x2 waves of
+// 64 x BN/2, k strictly ascending per accumulator).
+//
+// A block's 128 GEMM rows are a TH x TW patch (4 x 32 or 8 x 16 pixels) of ONE image:
+//   * the nine taps of a patch touch (TH+2)(TW+2) = 204 / 180 distinct pixels instead of the
+//     3 x 130 = 390 of a 1 x 128 row segment, so the L2 working set of the resident blocks and the
+//     re-read traffic roughly halve;
+//   * both pixels of a vertical pooling pair and of a horizontal one sit in the SAME lane's
+//     accumulator registers (32x32 MFMA C layout: row = (r & 3) + 8 (r >> 2) + 4 half), so the
+//     MaxPool that follows conv2 / conv4 / conv6 is a few v_max in the epilogue: the
+//     full-resolution activation is never written nor re-read, and the pool launches disappear.
+//     max(relu(a), relu(b)) over the window in (py, px) order is exactly MaxPool(ReLU(conv)).
+// BK = 16 keeps LDS at 33 KB/block and the kernel at 128 VGPRs, so four blocks (4 waves/SIMD)
+// share a CU and cover each other's barrier / LDS-fill phases (tools/conv_variants.sh: 113 TFLOP/s
+// vs 109 with three, 102 at BK = 32 with two; s_setprio around the MFMA cluster measured -1 %).
 // ---------------------------------------------------------------------------
 #ifndef OCRS_CONV_BK
 #define OCRS_CONV_BK 16
@@ -197,55 +207,49 @@ constexpr int RG_BM = 128, RG_BK = OCRS_CONV_BK, RG_LDA = RG_BM + 1;
 #ifndef OCRS_CONV_WAVES
 #define OCRS_CONV_WAVES 4
 #endif
-#ifndef OCRS_CONV_FRAGPIPE
-#define OCRS_CONV_FRAGPIPE 0
-#endif
-template <int BN>
+template <int BN, int TW, int PH, int PW>
 __global__ void __launch_bounds__(256, OCRS_CONV_WAVES)
 conv3x3_ragged_kernel(const float* __restrict__ X, RaggedView rv, int cin, const float* __restrict__ Bw,
-                      const float* __restrict__ bias, int cout, int relu, float* __restrict__ Y) {
+                      const float* __restrict__ bias, int cout, int relu, float* __restrict__ Y,
+                      const int64_t* __restrict__ out_poff) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NTW = BN / 64;
+    constexpr int TH = RG_BM / TW;
+    static_assert(TW == 32 || TW == 16, "patch width");
     float* As = lds;
     float* Bs = lds + 2 * RG_BK * RG_LDA;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
     const int wm = wave >> 1, wn = wave & 1;
     const int gtile = xcd_remap(blockIdx.x, gridDim.x);
-    const int g = find_group(rv.toff128, rv.G, gtile);
-    const int tile = gtile - rv.toff128[g];
+    const int g = find_group(rv.toff2d, rv.G, gtile);
+    const int tile = gtile - rv.toff2d[g];
     const int H = rv.H, W = rv.W[g];
-    const int64_t rows = (int64_t)rv.n[g] * H * W;
-    const int64_t m0 = (int64_t)tile * RG_BM;
+    const int tiles_w = (W + TW - 1) / TW, tiles_h = H / TH;
+    const int cb = tile % tiles_w;
+    const int t2 = tile / tiles_w;
+    const int rb = t2 % tiles_h, img = t2 / tiles_h;
+    const int y0 = rb * TH, x0 = cb * TW;
     const int n0 = blockIdx.y * BN;
-    const float* __restrict__ A = X + rv.poff[g] * cin;
-    float* __restrict__ C = Y + rv.poff[g] * cout;
+    const float* __restrict__ A = X + (rv.poff[g] + (int64_t)img * H * W) * cin;
     const int K = 9 * cin;
 
     constexpr int AQ = RG_BK / 4;          // float4 per row per chunk
     constexpr int AROWS = 256 / AQ;        // rows covered by one pass of the block
     constexpr int AV = RG_BM / AROWS;      // passes (float4 per thread)
     const int ar = tid / AQ, akq = tid % AQ;
-    const float* aimg[AV];
     int apy[AV], apx[AV];
 #pragma unroll
     for (int j = 0; j < AV; j++) {
-        int64_t row = m0 + ar + AROWS * j;
-        if (row >= rows) row = rows - 1;
-        const int64_t hw = (int64_t)H * W;
-        const int64_t img = row / hw;
-        const int rem = (int)(row - img * hw);
-        apy[j] = rem / W;
-        apx[j] = rem - apy[j] * W;
-        aimg[j] = A + img * hw * cin;
+        const int m = ar + AROWS * j;
+        apy[j] = y0 + m / TW;
+        apx[j] = x0 + m % TW;
+        if (apx[j] >= W) apy[j] = -(1 << 20);  // column past the image: every tap fails the bounds test
     }
     constexpr int BV = RG_BK * BN / 4 / 256;
     // A is fetched from global memory a full 128-byte line (32 channels) per pixel at a time — two
     // consecutive 16-wide K chunks — while LDS staging stays 16-wide: half the A load instructions
-    // and 28 fewer VGPRs than fetching per chunk (+3.5 %).  (It does NOT change FETCH_SIZE: the
-    // L2-miss traffic of this kernel — 3.1 GB/launch — is a capacity effect of three resident blocks
-    // per CU streaming ~6 MB of distinct A lines per XCD between tap re-uses; the kernel moves
-    // ~1.5 TB/s and stays MFMA-bound.  DESIGN.md §6.)
+    // and 28 fewer VGPRs than fetching per chunk (+3.5 %).
     float4 pa0[AV], pa1[AV], pb[BV];
     auto load_a_pair = [&](int k0) {  // chunks k0 and k0 + RG_BK (same tap: cin % (2*RG_BK) == 0)
         const int tap = k0 / cin;
@@ -255,7 +259,7 @@ conv3x3_ragged_kernel(const float* __restrict__ X, RaggedView rv, int cin, const
         for (int j = 0; j < AV; j++) {
             const int iy = apy[j] + ky - 1, ix = apx[j] + kx - 1;
             const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-            const float* src = aimg[j] + ((int64_t)(ok ? iy : 0) * W + (ok ? ix : 0)) * cin + ci0 + akq * 4;
+            const float* src = A + ((int64_t)(ok ? iy : 0) * W + (ok ? ix : 0)) * cin + ci0 + akq * 4;
             pa0[j] = ok ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
             pa1[j] = ok ? *reinterpret_cast<const float4*>(src + RG_BK) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
@@ -300,32 +304,16 @@ conv3x3_ragged_kernel(const float* __restrict__ X, RaggedView rv, int cin, const
     auto compute = [&](int buf) {
         const float* a = As + buf * RG_BK * RG_LDA + wm * 64 + l31;
         const float* b = Bs + buf * RG_BK * BN + wn * (BN / 2) + l31;
-        // operand fragments double-buffered in registers: the LDS reads of k-pair kp+1 are issued
-        // before the MFMAs of kp, so a full group of MFMAs (not just the last one) covers their latency
-        float fa[2][2], fb[2][NTW];
-        auto fetch = [&](int kp, int s) {
-            const int kr = 2 * kp + half;
-            fa[s][0] = a[kr * RG_LDA];
-            fa[s][1] = a[kr * RG_LDA + 32];
-#pragma unroll
-            for (int t = 0; t < NTW; t++) fb[s][t] = b[kr * BN + t * 32];
-        };
-        fetch(0, 0);
 #pragma unroll
         for (int kp = 0; kp < RG_BK / 2; kp++) {
-            const int s = kp & 1;
-            if (kp + 1 < RG_BK / 2) fetch(kp + 1, s ^ 1);
-#if OCRS_CONV_FRAGPIPE
-            __builtin_amdgcn_sched_barrier(0);  // keep the reads ahead of this group's MFMAs
-#endif
+            const int kr = 2 * kp + half;
+            const float a0 = a[kr * RG_LDA], a1 = a[kr * RG_LDA + 32];
 #pragma unroll
             for (int t = 0; t < NTW; t++) {
-                acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s][0], fb[s][t], acc[0][t], 0, 0, 0);
-                acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s][1], fb[s][t], acc[1][t], 0, 0, 0);
+                const float bt = b[kr * BN + t * 32];
+                acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bt, acc[0][t], 0, 0, 0);
+                acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bt, acc[1][t], 0, 0, 0);
             }
-#if OCRS_CONV_FRAGPIPE
-            __builtin_amdgcn_sched_barrier(0);
-#endif
         }
     };
     const int nchunks = K / RG_BK;  // even: cin % (2*RG_BK) == 0
@@ -349,36 +337,75 @@ conv3x3_ragged_kernel(const float* __restrict__ X, RaggedView rv, int cin, const
         if (more) commit(0, pa0);
         __syncthreads();
     }
+
+    // ---- epilogue: ReLU, optional in-register MaxPool, store.
+    // GEMM row m = wm*64 + i*32 + q, q = (r&3) + 8*(r>>2) + 4*half, is patch pixel (m / TW, m % TW):
+    //   TW = 32: ty = 2*wm + i,              tx = q            vertical partner: the other i, same r
+    //   TW = 16: ty = 4*wm + 2*i + (r >> 3), tx = q & 15       vertical partner: r + 8, same i
+    // horizontal partner (both): r + 1 (tx even <-> (r & 1) == 0).
+    const int Ho = H / PH, Wo = W / PW;
+    float* __restrict__ C = Y + (out_poff[g] + (int64_t)img * Ho * Wo) * cout;
+    auto act = [&](float v) { return relu ? (v > 0.0f ? v : 0.0f) : v; };
 #pragma unroll
-    for (int i = 0; i < 2; i++)
+    for (int t = 0; t < NTW; t++) {
+        const int col = n0 + wn * (BN / 2) + t * 32 + l31;
+        if (col >= cout) continue;
 #pragma unroll
-        for (int t = 0; t < NTW; t++) {
-            const int col = n0 + wn * (BN / 2) + t * 32 + l31;
-            if (col >= cout) continue;
+        for (int i = 0; i < 2; i++) {
+            if (PH == 2 && TW == 32 && i == 1) continue;
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                const int64_t rr = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (rr >= rows) continue;
-                float v = acc[i][t][r];
-                if (relu) v = v > 0.0f ? v : 0.0f;
-                C[rr * cout + col] = v;
+                if (PH == 2 && TW == 16 && (r & 8)) continue;
+                if (PW == 2 && (r & 1)) continue;
+                const int q = (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int ty = TW == 32 ? 2 * wm + i : 4 * wm + 2 * i + (r >> 3);
+                const int tx = TW == 32 ? q : (q & 15);
+                const int x = x0 + tx;
+                if (x + (PW - 1) >= W) continue;
+                constexpr int VI = (PH == 2 && TW == 32) ? 1 : 0;   // partner's i offset
+                constexpr int VR = (PH == 2 && TW == 16) ? 8 : 0;   // partner's r offset
+                float m = act(acc[i][t][r]);
+                if (PW == 2) { const float v = act(acc[i][t][(r + 1) & 15]); m = v > m ? v : m; }
+                if (PH == 2) {
+                    { const float v = act(acc[(i + VI) & 1][t][(r + VR) & 15]); m = v > m ? v : m; }
+                    if (PW == 2) { const float v = act(acc[(i + VI) & 1][t][(r + VR + 1) & 15]); m = v > m ? v : m; }
+                }
+                const int yo = (y0 + ty) / PH, xo = x / PW;
+                C[((int64_t)yo * Wo + xo) * cout + col] = m;
             }
         }
+    }
 }
 
+// rv carries the 2-D tiling of the INPUT geometry (toff2d / ntiles2d / tw); `out` is the geometry after the
+// fused pool (== rv when ph == pw == 1).  Returns false if the shape is not supported.
 bool conv3x3_ragged(const float* x, const RaggedView& rv, int cin, const float* wt, const float* bias, int cout, int relu,
-                    float* y, hipStream_t s) {
+                    int ph, int pw, float* y, const RaggedView& out, hipStream_t s) {
     if ((cin % (2 * RG_BK)) != 0 || (cout % 4) != 0 || cout < 64) return false;
-    if (rv.ntiles128 <= 0) return true;
-    if (cout <= 64) {
-        size_t lds = (size_t)(2 * RG_BK * RG_LDA + 2 * RG_BK * 64) * sizeof(float);
-        hipLaunchKernelGGL((conv3x3_ragged_kernel<64>), dim3(rv.ntiles128, (cout + 63) / 64), dim3(256), lds, s, x, rv, cin, wt,
-                           bias, cout, relu, y);
+    if (!((ph == 1 && pw == 1) || (ph == 2 && (pw == 1 || pw == 2)))) return false;
+    if ((ph == 2 || pw == 2) && !relu) return false;  // the fused pool assumes ReLU'd (non-negative, NaN-free order) inputs
+    if (rv.tw != 32 && rv.tw != 16) return false;
+    if (rv.H % (RG_BM / rv.tw) != 0) return false;
+    if (rv.ntiles2d <= 0) return true;
+    const bool n64 = cout <= 64;
+    const size_t lds = (size_t)(2 * RG_BK * RG_LDA + 2 * RG_BK * (n64 ? 64 : 128)) * sizeof(float);
+    const dim3 grid(rv.ntiles2d, (cout + (n64 ? 63 : 127)) / (n64 ? 64 : 128));
+#define OCRS_LAUNCH_CONV(BN_, TW_, PH_, PW_)                                                                        \
+    hipLaunchKernelGGL((conv3x3_ragged_kernel<BN_, TW_, PH_, PW_>), grid, dim3(256), lds, s, x, rv, cin, wt, bias, cout, \
+                       relu, y, out.poff)
+#define OCRS_DISPATCH_POOL(BN_, TW_)                                   \
+    do {                                                               \
+        if (ph == 1) OCRS_LAUNCH_CONV(BN_, TW_, 1, 1);                 \
+        else if (pw == 1) OCRS_LAUNCH_CONV(BN_, TW_, 2, 1);            \
+        else OCRS_LAUNCH_CONV(BN_, TW_, 2, 2);                         \
+    } while (0)
+    if (n64) {
+        if (rv.tw == 32) OCRS_DISPATCH_POOL(64, 32); else OCRS_DISPATCH_POOL(64, 16);
     } else {
-        size_t lds = (size_t)(2 * RG_BK * RG_LDA + 2 * RG_BK * 128) * sizeof(float);
-        hipLaunchKernelGGL((conv3x3_ragged_kernel<128>), dim3(rv.ntiles128, (cout + 127) / 128), dim3(256), lds, s, x, rv, cin,
-                           wt, bias, cout, relu, y);
+        if (rv.tw == 32) OCRS_DISPATCH_POOL(128, 32); else OCRS_DISPATCH_POOL(128, 16);
     }
+#undef OCRS_DISPATCH_POOL
+#undef OCRS_LAUNCH_CONV
     return true;
 }
 

@@ -422,6 +422,13 @@ float* HipModel::run_prefix_ragged(Workspace& ws, hipStream_t exec, const std::v
             return nullptr;
         }
     }
+    {  // the patch-tiled conv needs H % 4 == 0 at every Cin > 1 conv
+        int hh = h;
+        for (int i = 0; i < ts; i++) {
+            if (ops[i].type == OP_CONV && ops[i].cin != 1 && (hh % 4) != 0) return nullptr;
+            if (ops[i].type == OP_MAXPOOL || ops[i].type == OP_AVGPOOL) hh /= ops[i].kh;
+        }
+    }
     for (int g = 0; g + 1 < G; g++)  // groups must be contiguous in memory
         if (groups[g].d_batch + (size_t)groups[g].n * h * groups[g].w != groups[g + 1].d_batch) return nullptr;
 
@@ -449,7 +456,7 @@ float* HipModel::run_prefix_ragged(Workspace& ws, hipStream_t exec, const std::v
     // layout of the metadata blob per geometry: W[G] | toff128[G+1] | toff256[G+1] | poff[G+1] (int64)
     std::vector<int32_t> meta32;
     std::vector<int64_t> meta64;
-    struct GeoOff { size_t w, t128, t256, p; int nt128, nt256; int64_t pixels; };
+    struct GeoOff { size_t w, t128, t256, t32, t16, p; int nt128, nt256, nt32, nt16; int64_t pixels; };
     std::vector<GeoOff> goff;
     const size_t n_at = 0;
     meta32.insert(meta32.end(), nvec.begin(), nvec.end());
@@ -464,22 +471,31 @@ float* HipModel::run_prefix_ragged(Workspace& ws, hipStream_t exec, const std::v
         o.w = meta32.size();
         meta32.insert(meta32.end(), ge.W.begin(), ge.W.end());
         o.t128 = meta32.size();
-        int32_t a128 = 0, a256 = 0;
+        int32_t a128 = 0, a256 = 0, a32 = 0, a16 = 0;
         int64_t px = 0;
-        std::vector<int32_t> t256{0};
+        std::vector<int32_t> t256{0}, t32{0}, t16{0};  // t32 / t16: 4 x 32 and 8 x 16 pixel patches (conv3x3_ragged)
         std::vector<int64_t> pv{0};
         meta32.push_back(0);
         for (int g = 0; g < G; g++) {
             const int64_t rows = (int64_t)nvec[g] * ge.H * ge.W[g];
             a128 += (int32_t)((rows + 127) / 128);
             a256 += (int32_t)((rows + 255) / 256);
+            a32 += nvec[g] * (ge.H / 4) * ((ge.W[g] + 31) / 32);
+            a16 += nvec[g] * (ge.H / 8) * ((ge.W[g] + 15) / 16);
             px += rows;
             meta32.push_back(a128);
             t256.push_back(a256);
+            t32.push_back(a32);
+            t16.push_back(a16);
             pv.push_back(px);
         }
         o.t256 = meta32.size();
         meta32.insert(meta32.end(), t256.begin(), t256.end());
+        o.t32 = meta32.size();
+        meta32.insert(meta32.end(), t32.begin(), t32.end());
+        o.t16 = meta32.size();
+        meta32.insert(meta32.end(), t16.begin(), t16.end());
+        o.nt32 = a32; o.nt16 = a16;
         o.p = meta64.size();
         meta64.insert(meta64.end(), pv.begin(), pv.end());
         o.nt128 = a128; o.nt256 = a256; o.pixels = px;
@@ -500,6 +516,11 @@ float* HipModel::run_prefix_ragged(Workspace& ws, hipStream_t exec, const std::v
         v.W = d32 + goff[gi].w; v.n = d32 + n_at; v.poff = d64 + goff[gi].p;
         v.toff128 = d32 + goff[gi].t128; v.toff256 = d32 + goff[gi].t256; v.loff = d32 + loff_at;
         v.ntiles128 = goff[gi].nt128; v.ntiles256 = goff[gi].nt256; v.pixels = goff[gi].pixels;
+        // patch shape for the 3x3 convs: the one that wastes fewer lanes on ragged right edges
+        const bool use16 = geos[gi].H % 8 == 0 && (geos[gi].H % 4 != 0 || goff[gi].nt16 < goff[gi].nt32);
+        v.tw = use16 ? 16 : 32;
+        v.toff2d = d32 + (use16 ? goff[gi].t16 : goff[gi].t32);
+        v.ntiles2d = use16 ? goff[gi].nt16 : goff[gi].nt32;
         return v;
     };
 
@@ -529,12 +550,20 @@ float* HipModel::run_prefix_ragged(Workspace& ws, hipStream_t exec, const std::v
             curC = op.cout;
             i += 1;  // the pool is fused
         } else if (op.type == OP_CONV) {
-            ybytes = (size_t)vin.pixels * op.cout * sizeof(float);
-            y = get((size_t)vin.pixels * op.cout);
+            // a MaxPool 2x1 / 2x2 that consumes this conv is folded into its epilogue
+            const bool fuse = i + 1 < ts && ops[i + 1].type == OP_MAXPOOL && ops[i + 1].kh == 2 &&
+                              (ops[i + 1].kw == 1 || ops[i + 1].kw == 2) && vin.H % 2 == 0;
+            const int ph = fuse ? 2 : 1, pw = fuse ? ops[i + 1].kw : 1;
+            const k::RaggedView vout = view(fuse ? i + 2 : i + 1);
+            ybytes = (size_t)vout.pixels * op.cout * sizeof(float);
+            y = get((size_t)vout.pixels * op.cout);
+            bool ok = false;
             timed(KC_GEMM_CONV3X3, 2.0 * vin.pixels * 9.0 * op.cin * op.cout,
-                  4.0 * vin.pixels * (op.cin + op.cout) + 4.0 * op.wcount[0],
-                  [&] { k::conv3x3_ragged(cur, vin, op.cin, op.w[0], op.w[1], op.cout, op.relu, y, st); });
+                  4.0 * (vin.pixels * op.cin + vout.pixels * op.cout) + 4.0 * op.wcount[0],
+                  [&] { ok = k::conv3x3_ragged(cur, vin, op.cin, op.w[0], op.w[1], op.cout, op.relu, ph, pw, y, vout, st); });
+            if (!ok) fail(OCRS_ERR_RUN_FAILED, "model run failed: ragged conv %d->%d at height %d not supported", op.cin, op.cout, vin.H);
             curC = op.cout;
+            if (fuse) i += 1;
         } else {
             const k::RaggedView vout = view(i + 1);
             ybytes = (size_t)vout.pixels * curC * sizeof(float);
