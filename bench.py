@@ -254,7 +254,11 @@ def main():
         roof["launches_per_step"] = round(dom["launches"] / args.steps, 2)
         roof["share_of_gpu_kernel_time_in_calibration_step"] = round(
             cal[dom_name]["ms"] / max(1e-9, sum(v["ms"] for v in cal.values())), 3) if dom_name in cal else None
-        roof["traffic"] = pmc_traffic(dom_name)  # HBM bytes/launch from the rocprofv3 --pmc passes in profiles/
+        tr = pmc_traffic(dom_name)  # L2-miss (HBM + Infinity Cache) bytes/launch from the rocprofv3 --pmc passes in profiles/
+        roof["traffic"] = tr["hbm_bytes_per_launch"] if tr else None
+        roof["traffic_unit"] = "bytes/launch"
+        roof["traffic_source"] = tr["source"] if tr else None
+        roof["algorithmic_bytes_per_launch"] = round(dom["bytes"] / max(dom["launches"], 1))
         result["roofline"] = roof
         result["kernels_ms_per_step"] = {k: round(v["ms"] / args.steps, 4) for k, v in sorted(kt.items(), key=lambda kv: -kv[1]["ms"])}
         if args.profile_hint:
