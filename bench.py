@@ -41,14 +41,14 @@ PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md "HBM3E peak BW" (spec)
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=16)
-    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=24)
+    ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--pages", type=int, default=8, help="pages per step per GPU")
     ap.add_argument("--lines", type=int, default=80, help="text lines per synthetic page")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pages", type=int, default=3, help="pages in the bounded CPU-baseline sample")
     ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--inflight", type=int, default=4,
+    ap.add_argument("--inflight", type=int, default=6,
                     help="full steps kept in flight on separate host threads / HIP streams (default 4; 1 = the "
                          "2-stage pipeline or, with --no-pipeline, strictly sequential steps)")
     ap.add_argument("--no-pipeline", action="store_true",
