@@ -49,7 +49,7 @@ def parse():
     ap.add_argument("--cpu-pages", type=int, default=3, help="pages in the bounded CPU-baseline sample")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--inflight", type=int, default=6,
-                    help="full steps kept in flight on separate host threads / HIP streams (default 4; 1 = the "
+                    help="full steps kept in flight on separate host threads / HIP streams (default 6; 1 = the "
                          "2-stage pipeline or, with --no-pipeline, strictly sequential steps)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="run the stages of each step strictly one after another (default: 2-stage software "
