@@ -304,6 +304,44 @@ def test_prepare_recognition_input_bit_exact():
     assert np.array_equal(gpu.prepare_recognition_input(inp, rects_of(edge)), ora.prepare_recognition_input(oin, edge))
 
 
+@pytest.mark.parametrize("in_h,chans", [(32, (32, 64, 64, 64, 64, 64)), (16, (32, 64, 64, 64, 64, 64)),
+                                         (64, (32, 64, 128, 128, 128, 128))])
+def test_recognition_other_input_heights_and_ragged_widths(in_h, chans):
+    """The engine's ragged recognition path on models of other input heights: 64 -> 8x16 patches at
+    H = 32/16/8, 32 -> 4x32 patches at H = 4, 16 -> H = 2 is not patch-tileable and takes the per-group
+    path.  Lines of many different widths (one width group each), tokens and boxes identical."""
+    from ocrs_amd import modelfile as mf
+    g = mf.build_recognition(n_classes=97, in_h=in_h, seed=21, hidden=64, chans=chans)
+    cal = synth.synthetic_line_crops(9, n=8)[:, ::64 // in_h, ::64 // in_h]
+    xp = np.full((8, 1, in_h, 300), -0.5, np.float32)
+    xp[:, 0, :, :cal.shape[2]] = cal
+    g = mf.calibrate_recognition_head(g, lambda buf, x: OracleGraph(buf).run_torch(x), xp)
+    rbuf = g.to_bytes()
+    gpu = OcrEngine(recognition_model=Model.load_bytes(rbuf))
+    ora = OP.OcrEngine(recognition_model=OracleModel(OracleGraph(rbuf), "exact"))
+    px = synth.synthetic_page(31, 700, 900, lines=20)
+    inp = gpu.prepare_input(ImageSource.from_tensor(px, DimOrder.Hwc))
+    oin = ora.prepare_input(OP.ImageSource.from_tensor(px, "hwc"))
+    rng = np.random.default_rng(in_h)
+    lines = []
+    for i in range(26):  # widths 30 .. 880 px at heights 12 .. 30 -> resized widths across many groups
+        ww, hh = 30 + 34 * i, int(rng.integers(12, 31))
+        y = 20 + 25 * i
+        lines.append([RotatedRect.new((np.float32(10 + ww / 2), np.float32(y)), (np.float32(0.0), np.float32(1.0)),
+                                      np.float32(ww), np.float32(hh))])
+    got = gpu.recognize_text(inp, [rects_of(l) for l in lines])
+    exp = ora.recognize_text(oin, lines)
+    assert len(got) == len(exp) == 26
+    n_chars = 0
+    for a, b in zip(got, exp):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert str(a) == str(b)
+            assert [c.rect for c in a.chars()] == [c.rect.tlbr() for c in b.chars]
+            n_chars += len(b.chars)
+    assert n_chars > 20
+
+
 def test_full_pipeline_tokens_boxes_and_text_identical():
     dbuf, rbuf = M.detection_model_bytes(), M.recognition_model_bytes()
     gpu = OcrEngine(detection_model=Model.load_bytes(dbuf), recognition_model=Model.load_bytes(rbuf))
