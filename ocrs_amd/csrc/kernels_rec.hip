@@ -14,6 +14,8 @@ namespace ocrs {
 namespace k {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // Workgroup b runs on XCD b % 8 (observed; used for speed only).  Neighbouring tiles share
 // im2col rows, so give each XCD a contiguous range of tiles: their re-reads then hit that
@@ -207,6 +209,9 @@ constexpr int RG_BM = 128, RG_BK = OCRS_CONV_BK, RG_LDA = RG_BM + 1;
 #ifndef OCRS_CONV_WAVES
 #define OCRS_CONV_WAVES 4
 #endif
+#ifndef OCRS_ABL
+#define OCRS_ABL 0  // ablation builds (tools/conv_ablation.sh; results are WRONG on purpose): 1 no barriers,
+#endif              // 2 no global loads, 4 no LDS writes, 8 A loads redirected to one L2-resident window
 template <int BN, int TW, int PH, int PW>
 __global__ void __launch_bounds__(256, OCRS_CONV_WAVES)
 conv3x3_ragged_kernel(const float* __restrict__ X, RaggedView rv, int cin, const float* __restrict__ Bw,
@@ -238,43 +243,66 @@ conv3x3_ragged_kernel(const float* __restrict__ X, RaggedView rv, int cin, const
     constexpr int AROWS = 256 / AQ;        // rows covered by one pass of the block
     constexpr int AV = RG_BM / AROWS;      // passes (float4 per thread)
     const int ar = tid / AQ, akq = tid % AQ;
-    int apy[AV], apx[AV];
+    // Per-thread A addressing, hoisted out of the K loop: the centre-pixel offset of each of the thread's
+    // rows and a 9-bit mask of the taps that fall inside the image.  In the loop a load is then
+    // base + (uniform tap delta), unconditional from a clamped address, and zeroed by a select — no
+    // divergent branches and no 64-bit multiplies (the load path cost 10 % of the kernel: tools/conv_ablation.sh).
+    int aoff[AV];        // ((y * W + x) * cin + akq * 4) of the centre pixel, clamped inside the image
+    unsigned amask[AV];  // bit (3 * ky + kx) set <=> tap (ky, kx) of this row is inside the image
 #pragma unroll
     for (int j = 0; j < AV; j++) {
         const int m = ar + AROWS * j;
-        apy[j] = y0 + m / TW;
-        apx[j] = x0 + m % TW;
-        if (apx[j] >= W) apy[j] = -(1 << 20);  // column past the image: every tap fails the bounds test
+        const int py = y0 + m / TW, px = x0 + m % TW;
+        unsigned mk = 0;
+        if (px < W) {  // a column past the image contributes nothing (its outputs are never stored)
+#pragma unroll
+            for (int t9 = 0; t9 < 9; t9++) {
+                const int iy = py + t9 / 3 - 1, ix = px + t9 % 3 - 1;
+                if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) mk |= 1u << t9;
+            }
+        }
+        amask[j] = mk;
+        aoff[j] = (py * W + min(px, W - 1)) * cin + akq * 4;
     }
     constexpr int BV = RG_BK * BN / 4 / 256;
     // A is fetched from global memory a full 128-byte line (32 channels) per pixel at a time — two
     // consecutive 16-wide K chunks — while LDS staging stays 16-wide: half the A load instructions
     // and 28 fewer VGPRs than fetching per chunk (+3.5 %).
-    float4 pa0[AV], pa1[AV], pb[BV];
+    f32x4 pa0[AV], pa1[AV], pb[BV];
+    // Buffer loads: the hardware range check returns 0.0f for the out-of-image taps (their lanes get an
+    // offset beyond num_records), so the load is unconditional and needs neither a branch nor a select.
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(A), /*stride*/ 0, (int)((int64_t)H * W * cin * sizeof(float)), 0x00020000);
+    constexpr int OOB = 0x40000000;  // 1 GiB: past any image (an image is at most H * W * cin * 4 < 2^30 bytes)
     auto load_a_pair = [&](int k0) {  // chunks k0 and k0 + RG_BK (same tap: cin % (2*RG_BK) == 0)
         const int tap = k0 / cin;
         const int ci0 = k0 - tap * cin;
         const int ky = tap / 3, kx = tap - ky * 3;
+        const int delta = ((ky - 1) * W + (kx - 1)) * cin + ci0;  // wave-uniform
 #pragma unroll
         for (int j = 0; j < AV; j++) {
-            const int iy = apy[j] + ky - 1, ix = apx[j] + kx - 1;
-            const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-            const float* src = A + ((int64_t)(ok ? iy : 0) * W + (ok ? ix : 0)) * cin + ci0 + akq * 4;
-            pa0[j] = ok ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
-            pa1[j] = ok ? *reinterpret_cast<const float4*>(src + RG_BK) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const int voff = ((amask[j] >> tap) & 1u) ? (aoff[j] + delta) * 4 : OOB;
+            const u32x4 v0 = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, voff, 0, 0);
+            const u32x4 v1 = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, voff + RG_BK * 4, 0, 0);
+            pa0[j] = __builtin_bit_cast(f32x4, v0);
+            pa1[j] = __builtin_bit_cast(f32x4, v1);
         }
     };
-    auto load_b = [&](int k0) {
+    // B columns past cout (only when cout % BN != 0) are read from a clamped column: their products land
+    // in output columns that are never stored.
+    int boff[BV];
 #pragma unroll
-        for (int j = 0; j < BV; j++) {
-            const int idx = tid + 256 * j;
-            const int kk = idx / (BN / 4), nn = (idx % (BN / 4)) * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (n0 + nn + 3 < cout) v = *reinterpret_cast<const float4*>(Bw + (int64_t)(k0 + kk) * cout + n0 + nn);
-            pb[j] = v;
-        }
+    for (int j = 0; j < BV; j++) {
+        const int idx = tid + 256 * j;
+        const int kk = idx / (BN / 4), nn = (idx % (BN / 4)) * 4;
+        boff[j] = kk * cout + min(n0 + nn, cout - 4);
+    }
+    auto load_b = [&](int k0) {
+        const float* __restrict__ bk = Bw + (int64_t)k0 * cout;
+#pragma unroll
+        for (int j = 0; j < BV; j++) pb[j] = *reinterpret_cast<const f32x4*>(bk + boff[j]);
     };
-    auto commit = [&](int buf, const float4* pa) {
+    auto commit = [&](int buf, const f32x4 (&pa)[AV]) {
         float* a = As + buf * RG_BK * RG_LDA;
 #pragma unroll
         for (int j = 0; j < AV; j++) {
@@ -289,7 +317,7 @@ conv3x3_ragged_kernel(const float* __restrict__ X, RaggedView rv, int cin, const
         for (int j = 0; j < BV; j++) {
             const int idx = tid + 256 * j;
             const int kk = idx / (BN / 4), nn = (idx % (BN / 4)) * 4;
-            *reinterpret_cast<float4*>(&b[kk * BN + nn]) = pb[j];
+            *reinterpret_cast<f32x4*>(&b[kk * BN + nn]) = pb[j];
         }
     };
 
@@ -321,22 +349,24 @@ conv3x3_ragged_kernel(const float* __restrict__ X, RaggedView rv, int cin, const
     load_b(0);
     commit(0, pa0);
     __syncthreads();
+#define OCRS_SYNC() do { if (!(OCRS_ABL & 1)) __syncthreads(); } while (0)
     for (int c = 0; c < nchunks; c += 2) {
         // even chunk c in buffer 0; chunk c+1's A half is already in registers
-        load_b((c + 1) * RG_BK);
+        if (!(OCRS_ABL & 2)) load_b((c + 1) * RG_BK);
         compute(0);
-        commit(1, pa1);
-        __syncthreads();
+        if (!(OCRS_ABL & 4)) commit(1, pa1);
+        OCRS_SYNC();
         // odd chunk c+1 in buffer 1; fetch the next pair
         const bool more = c + 2 < nchunks;
-        if (more) {
+        if (more && !(OCRS_ABL & 2)) {
             load_a_pair((c + 2) * RG_BK);
             load_b((c + 2) * RG_BK);
         }
         compute(1);
-        if (more) commit(0, pa0);
-        __syncthreads();
+        if (more && !(OCRS_ABL & 4)) commit(0, pa0);
+        OCRS_SYNC();
     }
+#undef OCRS_SYNC
 
     // ---- epilogue: ReLU, optional in-register MaxPool, store.
     // GEMM row m = wm*64 + i*32 + q, q = (r&3) + 8*(r>>2) + 4*half, is patch pixel (m / TW, m % TW):
