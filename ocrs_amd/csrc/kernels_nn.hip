@@ -217,8 +217,10 @@ __global__ void __launch_bounds__(256) gemm_mfma_kernel(GemmDesc d) {
 // ---------------------------------------------------------------------------
 constexpr int TG_BM = 128, TG_BK = 16, TG_LDA = TG_BM + 1;
 
-template <int BN, bool IM2COL>
-__global__ void __launch_bounds__(256, 3) gemm_tiled_kernel(GemmDesc d) {
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+template <int BN, bool IM2COL, bool PAIR>
+__global__ void __launch_bounds__(256, 4) gemm_tiled_kernel(GemmDesc d) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NTW = BN / 64;  // 32-col tiles per wave
     float* As = lds;                        // [2][TG_BK][TG_LDA]
@@ -263,7 +265,29 @@ __global__ void __launch_bounds__(256, 3) gemm_tiled_kernel(GemmDesc d) {
     constexpr int BV = TG_BK * BN / 4 / 256;
     const bool b_vec = ((d.ldb & 3) == 0) && (((uintptr_t)B & 15) == 0);
 
-    float4 pa[AV], pb[BV];
+    // dense B with 16-byte rows and N % 4 == 0: unconditional float4 loads from a clamped column (columns past N
+    // only feed output columns that are never stored) — no divergent branches in the K loop
+    int boff[BV];
+#pragma unroll
+    for (int j = 0; j < BV; j++) {
+        const int idx = tid + 256 * j;
+        const int kk = idx / (BN / 4), nn = (idx % (BN / 4)) * 4;
+        boff[j] = kk * d.ldb + min(n0 + nn, d.N - 4);
+    }
+    f32x4v pa[AV], pa2[AV], pb[BV];
+    auto prefetch_b_fast = [&](int k0) {
+        const float* __restrict__ bk = B + (int64_t)k0 * d.ldb;
+#pragma unroll
+        for (int j = 0; j < BV; j++) pb[j] = *reinterpret_cast<const f32x4v*>(bk + boff[j]);
+    };
+    auto prefetch_a_pair = [&](int k0) {  // dense A, chunks k0 and k0 + TG_BK: one full 128-byte line per row
+#pragma unroll
+        for (int j = 0; j < AV; j++) {
+            const float* src = arow_ptr[j] + k0 + akq * 4;
+            pa[j] = *reinterpret_cast<const f32x4v*>(src);
+            pa2[j] = *reinterpret_cast<const f32x4v*>(src + TG_BK);
+        }
+    };
     auto prefetch = [&](int k0) {
         if (IM2COL) {
             const int tap = k0 / d.Cin;
@@ -273,21 +297,21 @@ __global__ void __launch_bounds__(256, 3) gemm_tiled_kernel(GemmDesc d) {
             for (int j = 0; j < AV; j++) {
                 const int iy = apy[j] + ky - 1, ix = apx[j] + kx - 1;
                 const bool ok = (unsigned)iy < (unsigned)d.H && (unsigned)ix < (unsigned)d.W;
-                pa[j] = ok ? *reinterpret_cast<const float4*>(arow_ptr[j] + ((int64_t)iy * d.W + ix) * d.Cin + ci0 + akq * 4)
-                           : make_float4(0.f, 0.f, 0.f, 0.f);
+                pa[j] = ok ? *reinterpret_cast<const f32x4v*>(arow_ptr[j] + ((int64_t)iy * d.W + ix) * d.Cin + ci0 + akq * 4)
+                           : f32x4v{0.f, 0.f, 0.f, 0.f};
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < AV; j++) pa[j] = *reinterpret_cast<const float4*>(arow_ptr[j] + k0 + akq * 4);
+            for (int j = 0; j < AV; j++) pa[j] = *reinterpret_cast<const f32x4v*>(arow_ptr[j] + k0 + akq * 4);
         }
 #pragma unroll
         for (int j = 0; j < BV; j++) {
             const int idx = tid + 256 * j;
             const int kk = idx / (BN / 4), nn = (idx % (BN / 4)) * 4;
             const float* src = B + (int64_t)(k0 + kk) * d.ldb + n0 + nn;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            f32x4v v = {0.f, 0.f, 0.f, 0.f};
             if (b_vec && n0 + nn + 3 < d.N) {
-                v = *reinterpret_cast<const float4*>(src);
+                v = *reinterpret_cast<const f32x4v*>(src);
             } else {
                 if (n0 + nn + 0 < d.N) v.x = src[0];
                 if (n0 + nn + 1 < d.N) v.y = src[1];
@@ -297,24 +321,25 @@ __global__ void __launch_bounds__(256, 3) gemm_tiled_kernel(GemmDesc d) {
             pb[j] = v;
         }
     };
-    auto commit = [&](int buf) {
+    auto commit_from = [&](int buf, const f32x4v (&src)[AV]) {
         float* a = As + buf * TG_BK * TG_LDA;
 #pragma unroll
         for (int j = 0; j < AV; j++) {
             const int r = ar + AROWS * j;
-            a[(akq * 4 + 0) * TG_LDA + r] = pa[j].x;
-            a[(akq * 4 + 1) * TG_LDA + r] = pa[j].y;
-            a[(akq * 4 + 2) * TG_LDA + r] = pa[j].z;
-            a[(akq * 4 + 3) * TG_LDA + r] = pa[j].w;
+            a[(akq * 4 + 0) * TG_LDA + r] = src[j].x;
+            a[(akq * 4 + 1) * TG_LDA + r] = src[j].y;
+            a[(akq * 4 + 2) * TG_LDA + r] = src[j].z;
+            a[(akq * 4 + 3) * TG_LDA + r] = src[j].w;
         }
         float* b = Bs + buf * TG_BK * BN;
 #pragma unroll
         for (int j = 0; j < BV; j++) {
             const int idx = tid + 256 * j;
             const int kk = idx / (BN / 4), nn = (idx % (BN / 4)) * 4;
-            *reinterpret_cast<float4*>(&b[kk * BN + nn]) = pb[j];
+            *reinterpret_cast<f32x4v*>(&b[kk * BN + nn]) = pb[j];
         }
     };
+    auto commit = [&](int buf) { commit_from(buf, pa); };
 
     f32x16 acc[2][NTW];
 #pragma unroll
@@ -326,12 +351,7 @@ __global__ void __launch_bounds__(256, 3) gemm_tiled_kernel(GemmDesc d) {
     }
 
     const int nchunks = d.K / TG_BK;
-    prefetch(0);
-    commit(0);
-    __syncthreads();
-    for (int c = 0; c < nchunks; c++) {
-        const int buf = c & 1;
-        if (c + 1 < nchunks) prefetch((c + 1) * TG_BK);
+    auto compute = [&](int buf) {
         const float* a = As + buf * TG_BK * TG_LDA + wm * 64 + l31;
         const float* b = Bs + buf * TG_BK * BN + wn * (BN / 2) + l31;
 #pragma unroll
@@ -345,8 +365,38 @@ __global__ void __launch_bounds__(256, 3) gemm_tiled_kernel(GemmDesc d) {
                 acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bt, acc[1][t], 0, 0, 0);
             }
         }
-        if (c + 1 < nchunks) commit(buf ^ 1);
+    };
+    if (PAIR) {
+        // dense A, K % (2 * TG_BK) == 0, fast B: the chunk-pair loop of conv3x3_ragged_kernel
+        prefetch_a_pair(0);
+        prefetch_b_fast(0);
+        commit_from(0, pa);
         __syncthreads();
+        for (int c = 0; c < nchunks; c += 2) {
+            prefetch_b_fast((c + 1) * TG_BK);
+            compute(0);
+            commit_from(1, pa2);
+            __syncthreads();
+            const bool more = c + 2 < nchunks;
+            if (more) {
+                prefetch_a_pair((c + 2) * TG_BK);
+                prefetch_b_fast((c + 2) * TG_BK);
+            }
+            compute(1);
+            if (more) commit_from(0, pa);
+            __syncthreads();
+        }
+    } else {
+        prefetch(0);
+        commit(0);
+        __syncthreads();
+        for (int c = 0; c < nchunks; c++) {
+            const int buf = c & 1;
+            if (c + 1 < nchunks) prefetch((c + 1) * TG_BK);
+            compute(buf);
+            if (c + 1 < nchunks) commit(buf ^ 1);
+            __syncthreads();
+        }
     }
 
     // ---- epilogue (32x32 C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5))
@@ -371,8 +421,11 @@ template <int BN>
 static void launch_gemm_tiled(const GemmDesc& d, hipStream_t s) {
     dim3 grid((unsigned)((d.M + TG_BM - 1) / TG_BM), (unsigned)((d.N + BN - 1) / BN), (unsigned)(d.batch > 0 ? d.batch : 1));
     size_t lds = (size_t)(2 * TG_BK * TG_LDA + 2 * TG_BK * BN) * sizeof(float);
-    if (d.im2col) hipLaunchKernelGGL((gemm_tiled_kernel<BN, true>), grid, dim3(256), lds, s, d);
-    else hipLaunchKernelGGL((gemm_tiled_kernel<BN, false>), grid, dim3(256), lds, s, d);
+    const bool pair = !d.im2col && (d.K % (2 * TG_BK)) == 0 && (d.ldb & 3) == 0 && (((uintptr_t)d.B) & 15) == 0 &&
+                      (d.strideB & 3) == 0 && (d.N & 3) == 0 && d.N >= 4;
+    if (d.im2col) hipLaunchKernelGGL((gemm_tiled_kernel<BN, true, false>), grid, dim3(256), lds, s, d);
+    else if (pair) hipLaunchKernelGGL((gemm_tiled_kernel<BN, false, true>), grid, dim3(256), lds, s, d);
+    else hipLaunchKernelGGL((gemm_tiled_kernel<BN, false, false>), grid, dim3(256), lds, s, d);
 }
 
 template <int NT>
