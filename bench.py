@@ -41,9 +41,9 @@ PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md "HBM3E peak BW" (spec)
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=24)
+    ap.add_argument("--steps", type=int, default=18)
     ap.add_argument("--warmup", type=int, default=6)
-    ap.add_argument("--pages", type=int, default=8, help="pages per step per GPU")
+    ap.add_argument("--pages", type=int, default=16, help="pages per step per GPU")
     ap.add_argument("--lines", type=int, default=80, help="text lines per synthetic page")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pages", type=int, default=3, help="pages in the bounded CPU-baseline sample")
@@ -303,7 +303,7 @@ def pmc_traffic(kernel_class):
 def extra_legs(engine, dptrs, H, W, synth, np, DimOrder, sync_all):
     out = {}
     # configs[1]: detection only — 8 synthetic 1024x1024 pages, CNN forward + threshold + components -> rects
-    inputs = [engine.prepare_input_device(p.value, np.uint8, DimOrder.Hwc, H, W, 3) for p in dptrs]
+    inputs = [engine.prepare_input_device(p.value, np.uint8, DimOrder.Hwc, H, W, 3) for p in dptrs[:8]]
     engine.detect_words_batch(inputs)
     sync_all()
     t0 = time.perf_counter()
