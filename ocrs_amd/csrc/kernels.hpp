@@ -117,6 +117,7 @@ struct RaggedView {          // device pointers live in one metadata upload; pas
     const int32_t* toff2d;   // [G+1] cumulative TH x TW patch counts (conv3x3_ragged), TH = 128 / tw
     int ntiles2d, tw;
     int64_t pixels;          // total pixels (host)
+    int max_w;               // widest image at this layer (host)
 };
 void conv1_relu_pool_ragged(const float* x, const RaggedView& in, const float* wt, const float* bias, int cout,
                             float* y, const RaggedView& out, hipStream_t s);

@@ -416,6 +416,8 @@ bool conv3x3_ragged(const float* x, const RaggedView& rv, int cin, const float* 
     if ((ph == 2 || pw == 2) && !relu) return false;  // the fused pool assumes ReLU'd (non-negative, NaN-free order) inputs
     if (rv.tw != 32 && rv.tw != 16) return false;
     if (rv.H % (RG_BM / rv.tw) != 0) return false;
+    // A is addressed through a buffer descriptor per image with 32-bit byte offsets (OOB marker at 1 GiB)
+    if ((int64_t)rv.H * rv.max_w * cin * (int64_t)sizeof(float) >= (int64_t)1 << 30) return false;
     if (rv.ntiles2d <= 0) return true;
     const bool n64 = cout <= 64;
     const size_t lds = (size_t)(2 * RG_BK * RG_LDA + 2 * RG_BK * (n64 ? 64 : 128)) * sizeof(float);

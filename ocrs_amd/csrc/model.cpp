@@ -516,6 +516,8 @@ float* HipModel::run_prefix_ragged(Workspace& ws, hipStream_t exec, const std::v
         v.W = d32 + goff[gi].w; v.n = d32 + n_at; v.poff = d64 + goff[gi].p;
         v.toff128 = d32 + goff[gi].t128; v.toff256 = d32 + goff[gi].t256; v.loff = d32 + loff_at;
         v.ntiles128 = goff[gi].nt128; v.ntiles256 = goff[gi].nt256; v.pixels = goff[gi].pixels;
+        v.max_w = 0;
+        for (int32_t w : geos[gi].W) v.max_w = std::max(v.max_w, (int)w);
         // patch shape for the 3x3 convs: the one that wastes fewer lanes on ragged right edges
         const bool use16 = geos[gi].H % 8 == 0 && (geos[gi].H % 4 != 0 || goff[gi].nt16 < goff[gi].nt32);
         v.tw = use16 ? 16 : 32;
