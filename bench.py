@@ -260,6 +260,16 @@ def main():
         roof["traffic_source"] = tr["source"] if tr else None
         roof["algorithmic_bytes_per_launch"] = round(dom["bytes"] / max(dom["launches"], 1))
         result["roofline"] = roof
+        if not args.no_kernel_timing and cal:
+            # whole-pipeline view: algorithmic FLOPs of ONE step (every kernel class, from the untimed calibration
+            # step) over the measured step time — how much of the fp32 matrix peak the full job sustains
+            tfl = sum(v["flops"] for v in cal.values()) / 1e12
+            result["pipeline"] = {"algorithmic_tflop_per_step": round(tfl, 3),
+                                  "sustained_tflops": round(tfl / (elapsed / args.steps), 1),
+                                  "frac_of_fp32_mfma_peak": round(tfl / (elapsed / args.steps) / PEAK_FP32_MFMA_TFLOPS, 3),
+                                  "mfma_classes_tflop_per_step": {k: round(v["flops"] / 1e12, 3) for k, v in
+                                                                  sorted(cal.items(), key=lambda kv: -kv[1]["flops"])
+                                                                  if v["flops"] > 1e9}}
         result["kernels_ms_per_step"] = {k: round(v["ms"] / args.steps, 4) for k, v in sorted(kt.items(), key=lambda kv: -kv[1]["ms"])}
         if args.profile_hint:
             for k, v in sorted(kt.items(), key=lambda kv: -kv[1]["ms"]):
