@@ -160,10 +160,12 @@ def main():
     engine.enable_timing(0 if args.no_kernel_timing else 2)
     engine.stage_times(reset=True)
     sync_all()
+    cpu0 = time.process_time()
     t0 = time.perf_counter()
     out = run_steps(args.steps)
     sync_all()
     elapsed = time.perf_counter() - t0
+    host_cpu_s = time.process_time() - cpu0  # all host threads of this rank (layout analysis dominates)
     stages = engine.stage_times(reset=False)
     kstats = engine.kernel_stats(reset=True)
     engine.enable_timing(0)
@@ -230,6 +232,7 @@ def main():
                              "stream) overlap recognition of step i; every step still does all of its work"),
         },
         "lines_per_s": round(n_lines_all * args.steps / elapsed, 1),
+        "host_cpu_cores_busy_per_gpu": round(host_cpu_s / elapsed, 2),
         "chars_last_step": n_chars,
         "gathered_pages": sum(len(g) for g in gathered if g),
     }
