@@ -70,10 +70,15 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the ocrs_amd engine has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    # one rank per GPU; OCRS_DIST_BACKEND=gloo lets the multi-rank path be exercised on a box with fewer GPUs than
+    # ranks (ranks then share devices) — the driver's runs use the default, nccl = RCCL
+    backend = os.environ.get("OCRS_DIST_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    red_dev = "cuda" if backend == "nccl" else "cpu"
 
     import ocrs_amd
     from ocrs_amd import DimOrder, Model, OcrEngine, _lib, models, synth
@@ -83,7 +88,7 @@ def main():
         from ocrs_amd import build
         build.build()
     L = _lib.lib()
-    _lib.check(L.ocrs_set_device(local_rank))
+    _lib.check(L.ocrs_set_device(dev_index))
 
     det = Model.load_bytes(models.synthetic_detection_bytes())
     rec = Model.load_bytes(models.synthetic_recognition_bytes())
@@ -186,10 +191,10 @@ def main():
     gathered = D.gather_results(local_payload)
 
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        cnt = torch.tensor([n_lines, n_words, n_chars], dtype=torch.int64, device="cuda")
+        cnt = torch.tensor([n_lines, n_words, n_chars], dtype=torch.int64, device=red_dev)
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
         n_lines_all = int(cnt[0].item())
     else:
