@@ -211,7 +211,7 @@ constexpr int RG_BM = 128, RG_BK = OCRS_CONV_BK, RG_LDA = RG_BM + 1;
 #endif
 #ifndef OCRS_ABL
 #define OCRS_ABL 0  // ablation builds (tools/conv_ablation.sh; results are WRONG on purpose): 1 no barriers,
-#endif              // 2 no global loads, 4 no LDS writes, 8 A loads redirected to one L2-resident window
+#endif              // 2 no global loads, 4 no LDS writes
 template <int BN, int TW, int PH, int PW>
 __global__ void __launch_bounds__(256, OCRS_CONV_WAVES)
 conv3x3_ragged_kernel(const float* __restrict__ X, RaggedView rv, int cin, const float* __restrict__ Bw,
