@@ -47,16 +47,25 @@ def main(prefix, out_txt, out_json):
         mb = mfma.get(name, {})
         busy = mb.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)
         avg_us = dm.get(name, 0) / max(lm.get(name, 1), 1) / 1e3
+        # GRBM_GUI_ACTIVE is summed over the 8 XCDs; MFMA busy cycles over the 1024 SIMDs (256 CUs x 4)
+        gui = mb.get("GRBM_GUI_ACTIVE", 0.0) / 8.0
+        mfma_util = busy / (gui * 1024.0) if gui > 0 else None
+        clock_ghz = gui / max(dm.get(name, 0), 1) if gui > 0 else None  # cycles per ns
         rows.append(dict(kernel=name, launches=n, fetch_kib_per_launch=f_kib / n, write_kib_per_launch=w_kib / nw,
                          hbm_bytes_per_launch=hbm, avg_us_in_pmc_pass=avg_us,
-                         mfma_busy_cycles_per_launch=busy / max(lm.get(name, 1), 1)))
+                         mfma_busy_cycles_per_launch=busy / max(lm.get(name, 1), 1),
+                         mfma_insts_per_launch=mb.get("SQ_INSTS_MFMA", 0.0) / max(lm.get(name, 1), 1),
+                         mfma_pipe_util=mfma_util, shader_clock_ghz=clock_ghz))
     rows.sort(key=lambda r: -r["hbm_bytes_per_launch"] * r["launches"])
     lines = ["# HBM traffic per launch from rocprofv3 --pmc passes (FETCH_SIZE x2 correction for gfx950, see header of tools/pmc_summary.py)",
-             "%-62s %8s %14s %14s %14s %10s" % ("kernel", "launches", "fetch KiB/l", "write KiB/l", "HBM MB/launch", "avg us")]
+             "# mfma% = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 x 1024 SIMDs); GHz = GRBM_GUI_ACTIVE/8 / duration",
+             "%-62s %8s %14s %14s %14s %10s %7s %6s" % ("kernel", "launches", "fetch KiB/l", "write KiB/l", "HBM MB/launch", "avg us", "mfma%", "GHz")]
     for r in rows:
-        lines.append("%-62s %8d %14.1f %14.1f %14.2f %10.1f" % (r["kernel"][:62], r["launches"], r["fetch_kib_per_launch"],
-                                                                 r["write_kib_per_launch"], r["hbm_bytes_per_launch"] / 1e6,
-                                                                 r["avg_us_in_pmc_pass"]))
+        lines.append("%-62s %8d %14.1f %14.1f %14.2f %10.1f %7s %6s" % (
+            r["kernel"][:62], r["launches"], r["fetch_kib_per_launch"], r["write_kib_per_launch"],
+            r["hbm_bytes_per_launch"] / 1e6, r["avg_us_in_pmc_pass"],
+            "%.1f" % (100 * r["mfma_pipe_util"]) if r["mfma_pipe_util"] is not None else "-",
+            "%.2f" % r["shader_clock_ghz"] if r["shader_clock_ghz"] is not None else "-"))
     open(out_txt, "w").write("\n".join(lines) + "\n")
     json.dump({r["kernel"]: r for r in rows}, open(out_json, "w"), indent=1)
     print("\n".join(lines[:14]))

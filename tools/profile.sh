@@ -11,7 +11,7 @@ BENCH="python $OLDPWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT -o trace -- $BENCH > $OUT/trace.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT -o fetch -- $BENCH > $OUT/fetch.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT -o write -- $BENCH > $OUT/write.log 2>&1
-timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES -d $OUT -o mfma -- $BENCH > $OUT/mfma.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE -d $OUT -o mfma -- $BENCH > $OUT/mfma.log 2>&1
 # the default bench command (4 steps in flight) under the kernel trace, for the duration cross-check
 timeout 400 rocprofv3 --kernel-trace --stats -d $OUT -o default -- python $OLDPWD/bench.py --no-cpu-baseline --no-extras > $OUT/default.log 2>&1
 ls -la $OUT
