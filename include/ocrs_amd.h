@@ -56,8 +56,10 @@ OCRS_API const char* ocrs_last_error(void);
 /* Release any buffer handed out through a `T**` out-parameter. */
 OCRS_API void ocrs_buffer_free(void* p);
 
-/* Number of HIP devices visible; selects the device used by handles created
- * afterwards on this thread (one process per GPU uses device LOCAL_RANK). */
+/* Number of HIP devices visible; ocrs_set_device selects the device for the WHOLE PROCESS (every
+ * thread that enters the library is bound to it; stream and memory pools are per process).  The
+ * deployment model is one process per GPU: call it once, with LOCAL_RANK, before
+ * creating any handle.  Default: device 0. */
 OCRS_API ocrs_status ocrs_device_count(int* n);
 OCRS_API ocrs_status ocrs_set_device(int device);
 
