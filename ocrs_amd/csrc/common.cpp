@@ -115,7 +115,7 @@ hipStream_t heavy_stream() {
 // ---------------------------------------------------------------- streams
 namespace {
 std::mutex g_stream_mu;
-std::vector<hipStream_t> g_streams[2];  // [0] default priority, [1] highest priority
+std::vector<std::pair<hipStream_t, hipEvent_t>> g_streams[2];  // [0] default priority, [1] highest priority
 }  // namespace
 
 StreamLease::StreamLease(bool high_priority) : high_(high_priority) {
@@ -124,7 +124,8 @@ StreamLease::StreamLease(bool high_priority) : high_(high_priority) {
         std::lock_guard<std::mutex> g(g_stream_mu);
         auto& v = g_streams[high_ ? 1 : 0];
         if (!v.empty()) {
-            s_ = v.back();
+            s_ = v.back().first;
+            done_ = v.back().second;
             v.pop_back();
             return;
         }
@@ -136,11 +137,12 @@ StreamLease::StreamLease(bool high_priority) : high_(high_priority) {
     } else {
         OCRS_HIP(hipStreamCreateWithFlags(&s_, hipStreamNonBlocking));
     }
+    OCRS_HIP(hipEventCreateWithFlags(&done_, hipEventBlockingSync | hipEventDisableTiming));
 }
 
 StreamLease::~StreamLease() {
     std::lock_guard<std::mutex> g(g_stream_mu);
-    g_streams[high_ ? 1 : 0].push_back(s_);
+    g_streams[high_ ? 1 : 0].emplace_back(s_, done_);
 }
 
 // ---------------------------------------------------------------- timers

@@ -106,10 +106,21 @@ class StreamLease {
     explicit StreamLease(bool high_priority = false);
     ~StreamLease();
     hipStream_t get() const { return s_; }
-    void sync() const { OCRS_HIP(hipStreamSynchronize(s_)); }
+    // Host wait for everything enqueued so far.  A blocking-sync event: the waiting thread sleeps instead
+    // of spinning in hipStreamSynchronize — with several requests in flight per process and several
+    // processes per host, spinning waiters cost more cores than the layout analysis does.
+    void sync() const {
+        OCRS_HIP(hipEventRecord(done_, s_));
+        OCRS_HIP(hipEventSynchronize(done_));
+    }
+    hipError_t sync_noexcept() const noexcept {
+        hipError_t e = hipEventRecord(done_, s_);
+        return e == hipSuccess ? hipEventSynchronize(done_) : e;
+    }
 
   private:
     hipStream_t s_;
+    hipEvent_t done_;
     bool high_;
 };
 
@@ -199,7 +210,7 @@ struct Workspace {
     template <class T> T* alloc_n(size_t n) { return static_cast<T*>(alloc(n * sizeof(T))); }
     void sync() { stream.sync(); }
     ~Workspace() {
-        (void)hipStreamSynchronize(stream.get());
+        (void)stream.sync_noexcept();
         for (hipEvent_t e : events) (void)hipEventDestroy(e);
     }
 };
