@@ -6,8 +6,12 @@ find_text_lines -> recognize_text, print text or JSON.
 Differences that are forced by the environment: models are `.ocrsm` files
 (--detect-model / --rec-model; there is no network to download the default
 `.rten` files from, main.rs:305-309) — with neither flag the seeded synthetic
-models of ocrs_amd.models are used; PNG annotation output is not provided.
+models of ocrs_amd.models are used; the annotated-PNG output (-p) is not provided.
+The debug dumps (--text-map / --text-mask / --text-line-images, main.rs:422-444)
+write the same greyscale PNGs as the reference: (x.clamp(0,1) * 255) as u8
+(main.rs:44-51).
 """
+import os
 import argparse
 import sys
 
@@ -21,6 +25,14 @@ def load_image(path):
         return np.ascontiguousarray(np.asarray(im.convert("RGB"), dtype=np.uint8))
 
 
+def write_image(path, chw_or_hw):
+    """main.rs:21-51: float tensor in [0, 1] -> 8-bit greyscale PNG, `(x.clamp(0., 1.) * 255.0) as u8` (truncating)."""
+    from PIL import Image
+    a = np.asarray(chw_or_hw, np.float32)
+    a = a.reshape(a.shape[-2], a.shape[-1])
+    Image.fromarray((np.clip(a, np.float32(0.0), np.float32(1.0)) * np.float32(255.0)).astype(np.uint8), "L").save(path)
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(prog="ocrs_amd", description="Extract text from an image (MI355X engine).")
     ap.add_argument("image")
@@ -32,8 +44,10 @@ def main(argv=None):
     ap.add_argument("-j", "--json", action="store_true")
     ap.add_argument("-o", "--output")
     ap.add_argument("--debug", action="store_true")
-    ap.add_argument("--text-map", action="store_true", help="write text-map.npy (detect_text_pixels)")
-    ap.add_argument("--text-mask", action="store_true", help="write text-mask.npy")
+    ap.add_argument("--text-map", action="store_true", help="write text-map.png (detect_text_pixels)")
+    ap.add_argument("--text-mask", action="store_true", help="write text-mask.png (text map > detection threshold)")
+    ap.add_argument("--text-line-images", action="store_true",
+                    help="write lines/line-N.png: the pre-processed recognition input of every text line")
     args = ap.parse_args(argv)
 
     from . import DecodeMethod, DimOrder, ImageSource, Model, OcrEngine, models, output
@@ -47,11 +61,15 @@ def main(argv=None):
     if args.text_map or args.text_mask:
         tm = engine.detect_text_pixels(inp)
         if args.text_map:
-            np.save("text-map.npy", tm)
+            write_image("text-map.png", tm)
         if args.text_mask:
-            np.save("text-mask.npy", (tm > np.float32(engine.detection_threshold())).astype(np.uint8))
+            write_image("text-mask.png", (tm > np.float32(engine.detection_threshold())).astype(np.float32))
     words = engine.detect_words(inp)
     lines = engine.find_text_lines(inp, words)
+    if args.text_line_images:  # main.rs:66-86
+        os.makedirs("lines", exist_ok=True)
+        for i, line in enumerate(lines):
+            write_image("lines/line-%d.png" % i, engine.prepare_recognition_input(inp, line) + np.float32(0.5))
     texts = engine.recognize_text(inp, lines)
     if args.json:
         content = output.format_json_output(args.image, img.shape[:2], texts)

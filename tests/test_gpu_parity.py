@@ -478,3 +478,43 @@ def test_thread_safety_concurrent_calls():
             got = list(ex.map(gpu.detect_words, inps))
             for a, b in zip(got, ref):
                 assert np.array_equal(a, b)
+
+
+def test_cli_driver_text_json_and_debug_dumps(tmp_path, monkeypatch, capsys):
+    """BASELINE configs[0] plumbing (ocrs-cli/src/main.rs:366-497): image file -> text / JSON through the four API
+    calls, plus the --text-map / --text-mask / --text-line-images dumps; everything equals the oracle pipeline."""
+    import json
+    from PIL import Image
+    from ocrs_amd import cli, output
+    dbuf, rbuf = M.detection_model_bytes(), M.recognition_model_bytes()
+    (tmp_path / "det.ocrsm").write_bytes(dbuf)
+    (tmp_path / "rec.ocrsm").write_bytes(rbuf)
+    px = synth.synthetic_page(8, 600, 800, lines=16)   # 800 x 600 image as in configs[0]
+    Image.fromarray(px, "RGB").save(tmp_path / "page.png")
+    monkeypatch.chdir(tmp_path)
+    common = ["--detect-model", "det.ocrsm", "--rec-model", "rec.ocrsm"]
+
+    ora = OP.OcrEngine(detection_model=OracleModel(OracleGraph(dbuf), "exact"),
+                       recognition_model=OracleModel(OracleGraph(rbuf), "exact"))
+    oin = ora.prepare_input(OP.ImageSource.from_tensor(px, "hwc"))
+    owords = ora.detect_words(oin)
+    olines = ora.find_text_lines(oin, owords)
+    otexts = ora.recognize_text(oin, olines)
+
+    assert cli.main(["page.png", "--text-map", "--text-mask", "--text-line-images"] + common) == 0
+    text = capsys.readouterr().out
+    assert text.rstrip("\n") == "\n".join(str(t) for t in otexts if t is not None)  # output.rs:88-95
+    tm = ora.detect_text_pixels(oin)
+    exp_map = (np.clip(tm, 0, 1) * np.float32(255.0)).astype(np.uint8)
+    assert np.array_equal(np.asarray(Image.open("text-map.png")), exp_map)
+    assert np.array_equal(np.asarray(Image.open("text-mask.png")), (tm > np.float32(0.2)).astype(np.uint8) * 255)
+    assert len(list((tmp_path / "lines").glob("line-*.png"))) == len(olines) > 5
+    l0 = ora.prepare_recognition_input(oin, olines[0]) + np.float32(0.5)
+    assert np.array_equal(np.asarray(Image.open("lines/line-0.png")),
+                          (np.clip(l0, 0, 1) * np.float32(255.0)).astype(np.uint8).reshape(l0.shape[-2], l0.shape[-1]))
+
+    assert cli.main(["page.png", "--json", "-o", "out.json"] + common) == 0
+    doc = json.loads((tmp_path / "out.json").read_text())
+    assert doc["url"] == "page.png" and (doc["image_width"], doc["image_height"]) == (800, 600)
+    got_lines = [l["text"] for p in doc["paragraphs"] for l in p["lines"]]
+    assert got_lines == [str(t) for t in otexts if t is not None]
