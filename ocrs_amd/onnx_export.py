@@ -43,9 +43,11 @@ class _Emitter:
         return self.node("Constant", [], {"value": np.asarray(arr)}, hint="constant")
 
 
-def export_onnx(graph, in_hw=None, opset=17):
+def export_onnx(graph, in_hw=None, opset=17, toseq="reshape"):
     """Serialise `graph` to ONNX bytes.  `in_hw` fixes the spatial input size used for the static
-    U-Net pad amounts (defaults to the graph's own fixed dims; recognition graphs need none)."""
+    U-Net pad amounts (defaults to the graph's own fixed dims; recognition graphs need none).
+    `toseq`: how [N,C,1,W] becomes [W,N,C] — "reshape" (x.reshape(N,-1,W).permute(2,0,1), with the
+    Shape/Gather/Unsqueeze/Concat arithmetic torch emits) or "squeeze" (x.squeeze(2).permute(2,0,1))."""
     E = _Emitter()
     h0 = graph.input_shape[2] if graph.input_shape[2] > 0 else (in_hw or (0, 0))[0]
     w0 = graph.input_shape[3] if graph.input_shape[3] > 0 else (in_hw or (0, 0))[1]
@@ -97,6 +99,8 @@ def export_onnx(graph, in_hw=None, opset=17):
         elif t == mf.OP_SIGMOID:
             y = E.node("Sigmoid", [x])
             hw[op.out] = hw[op.in0]
+        elif t == mf.OP_TOSEQ and toseq == "squeeze":
+            y = E.node("Transpose", [E.node("Squeeze", [x, E.constant_node(np.array([2], np.int64))])], {"perm": [2, 0, 1]})
         elif t == mf.OP_TOSEQ:
             # x.reshape(N, -1, W).permute(2, 0, 1)
             shp = E.node("Shape", [x])

@@ -155,6 +155,12 @@ def test_import_of_export_is_identity(make):
     assert back.to_bytes() == g.to_bytes()
 
 
+def test_import_squeeze_idiom_and_evaluator_agree():
+    g = small_recognition()
+    data = export_onnx(g, toseq="squeeze")
+    assert import_onnx(data).to_bytes() == g.to_bytes()
+
+
 def test_imported_model_runs_in_oracle_executor():
     g = small_recognition()
     back = import_onnx(export_onnx(g))
