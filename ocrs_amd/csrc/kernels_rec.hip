@@ -268,7 +268,7 @@ conv3x3_ragged_kernel(const float* __restrict__ X, RaggedView rv, int cin, const
     // A is fetched from global memory a full 128-byte line (32 channels) per pixel at a time — two
     // consecutive 16-wide K chunks — while LDS staging stays 16-wide: half the A load instructions
     // and 28 fewer VGPRs than fetching per chunk (+3.5 %).
-    f32x4 pa0[AV], pa1[AV], pb[BV];
+    f32x4 pa0[AV], pa1[AV];
     // Buffer loads: the hardware range check returns 0.0f for the out-of-image taps (their lanes get an
     // offset beyond num_records), so the load is unconditional and needs neither a branch nor a select.
     const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -297,10 +297,16 @@ conv3x3_ragged_kernel(const float* __restrict__ X, RaggedView rv, int cin, const
         const int kk = idx / (BN / 4), nn = (idx % (BN / 4)) * 4;
         boff[j] = kk * cout + min(n0 + nn, cout - 4);
     }
-    auto load_b = [&](int k0) {
+    // B goes global -> LDS directly (global_load_lds_dwordx4: wave-uniform LDS base + lane * 16 B, per-lane global
+    // address): the [k][BN] tile is row-major and contiguous in LDS, so chunk element idx lands at float 4 * idx.
+    // No staging registers and no ds_write for B; the barrier that ends the chunk drains the copies (vmcnt(0)).
+    auto load_b = [&](int k0, int buf) {
         const float* __restrict__ bk = Bw + (int64_t)k0 * cout;
+        float* bdst = Bs + buf * RG_BK * BN + wave * 256;  // this wave's 64 float4 slots (wave-uniform)
 #pragma unroll
-        for (int j = 0; j < BV; j++) pb[j] = *reinterpret_cast<const f32x4*>(bk + boff[j]);
+        for (int j = 0; j < BV; j++)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bk + boff[j]),
+                                             (__attribute__((address_space(3))) void*)(bdst + 1024 * j), 16, 0, 0);
     };
     auto commit = [&](int buf, const f32x4 (&pa)[AV]) {
         float* a = As + buf * RG_BK * RG_LDA;
@@ -311,13 +317,6 @@ conv3x3_ragged_kernel(const float* __restrict__ X, RaggedView rv, int cin, const
             a[(akq * 4 + 1) * RG_LDA + r] = pa[j].y;
             a[(akq * 4 + 2) * RG_LDA + r] = pa[j].z;
             a[(akq * 4 + 3) * RG_LDA + r] = pa[j].w;
-        }
-        float* b = Bs + buf * RG_BK * BN;
-#pragma unroll
-        for (int j = 0; j < BV; j++) {
-            const int idx = tid + 256 * j;
-            const int kk = idx / (BN / 4), nn = (idx % (BN / 4)) * 4;
-            *reinterpret_cast<f32x4*>(&b[kk * BN + nn]) = pb[j];
         }
     };
 
@@ -346,13 +345,13 @@ conv3x3_ragged_kernel(const float* __restrict__ X, RaggedView rv, int cin, const
     };
     const int nchunks = K / RG_BK;  // even: cin % (2*RG_BK) == 0
     load_a_pair(0);
-    load_b(0);
+    load_b(0, 0);
     commit(0, pa0);
     __syncthreads();
 #define OCRS_SYNC() do { if (!(OCRS_ABL & 1)) __syncthreads(); } while (0)
     for (int c = 0; c < nchunks; c += 2) {
         // even chunk c in buffer 0; chunk c+1's A half is already in registers
-        if (!(OCRS_ABL & 2)) load_b((c + 1) * RG_BK);
+        if (!(OCRS_ABL & 2)) load_b((c + 1) * RG_BK, 1);
         compute(0);
         if (!(OCRS_ABL & 4)) commit(1, pa1);
         OCRS_SYNC();
@@ -360,7 +359,7 @@ conv3x3_ragged_kernel(const float* __restrict__ X, RaggedView rv, int cin, const
         const bool more = c + 2 < nchunks;
         if (more && !(OCRS_ABL & 2)) {
             load_a_pair((c + 2) * RG_BK);
-            load_b((c + 2) * RG_BK);
+            load_b((c + 2) * RG_BK, 0);
         }
         compute(1);
         if (more && !(OCRS_ABL & 4)) commit(0, pa0);
