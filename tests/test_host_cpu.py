@@ -148,3 +148,24 @@ def test_item_rotated_rect(lib):  # text_items.rs:148-166
     rr = word.rotated_rect()
     assert (rr[2], rr[3]) == (0.0, -1.0)  # up_axis() == Vec2::from_yx(-1., 0.)
     assert rotated_rect_corners(rr) == [[30.0, 25.0], [0.0, 25.0], [0.0, 0.0], [30.0, 0.0]]
+
+
+def test_committed_bench_line_keeps_the_driver_contract():
+    """profiles/r1_bench_default.json is the last `python bench.py` line measured on an MI355X; the keys the
+    driver and the judge read must be there with the right types (a schema check, not a performance check)."""
+    import json
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r1_bench_default.json")
+    d = json.load(open(path))
+    for k, t in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
+                 ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str),
+                 ("config", dict), ("roofline", dict), ("cpu_baseline", dict)):
+        assert isinstance(d[k], t), k
+    assert d["vs_baseline"] is None and d["scaling"] == "weak" and d["higher_is_better"] is True and d["n_gpus"] == 1
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["traffic"] is None or isinstance(r["traffic"], (int, float))
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and isinstance(c["sample"], str)
+    assert abs(d["value"] - d["config"]["pages_per_step_per_gpu"] * 1000.0 / d["ms_per_step"]) / d["value"] < 1e-3
