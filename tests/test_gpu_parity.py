@@ -518,3 +518,41 @@ def test_cli_driver_text_json_and_debug_dumps(tmp_path, monkeypatch, capsys):
     assert doc["url"] == "page.png" and (doc["image_width"], doc["image_height"]) == (800, 600)
     got_lines = [l["text"] for p in doc["paragraphs"] for l in p["lines"]]
     assert got_lines == [str(t) for t in otexts if t is not None]
+
+
+def test_recognition_long_short_split_path():
+    """A request mixing >= 64 short lines (T <= 160) with long ones is run as two ragged batches on two streams
+    (engine.cpp, T_SPLIT); tokens and boxes must not depend on that."""
+    from ocrs_amd import modelfile as mf
+    g = mf.build_recognition(n_classes=97, in_h=64, seed=23, hidden=64, chans=(32, 64, 64, 64, 64, 64))
+    cal = synth.synthetic_line_crops(9, n=8)
+    xp = np.full((8, 1, 64, 300), -0.5, np.float32)
+    xp[:, 0, :, :cal.shape[2]] = cal
+    g = mf.calibrate_recognition_head(g, lambda buf, x: OracleGraph(buf).run_torch(x), xp)
+    rbuf = g.to_bytes()
+    gpu = OcrEngine(recognition_model=Model.load_bytes(rbuf))
+    ora = OP.OcrEngine(recognition_model=OracleModel(OracleGraph(rbuf), "exact"))
+    px = synth.synthetic_page(41, 1000, 1000, lines=40)
+    inp = gpu.prepare_input(ImageSource.from_tensor(px, DimOrder.Hwc))
+    oin = ora.prepare_input(OP.ImageSource.from_tensor(px, "hwc"))
+    rng = np.random.default_rng(5)
+    lines = []
+    for i in range(72):   # short: 20..150 px wide at height ~20 -> resized width <= 480 -> T <= 120
+        ww, hh = int(rng.integers(20, 150)), int(rng.integers(16, 24))
+        lines.append([RotatedRect.new((np.float32(20 + (i % 6) * 160 + ww / 2), np.float32(12 + (i // 6) * 26)),
+                                      (np.float32(0.0), np.float32(1.0)), np.float32(ww), np.float32(hh))])
+    for i in range(5):    # long: 600..950 px wide at height 14 -> clamped towards 2400 -> T up to 600
+        ww = 600 + 80 * i
+        lines.append([RotatedRect.new((np.float32(20 + ww / 2), np.float32(400 + 30 * i)), (np.float32(0.0), np.float32(1.0)),
+                                      np.float32(ww), np.float32(14.0))])
+    got = gpu.recognize_text(inp, [rects_of(l) for l in lines])
+    exp = ora.recognize_text(oin, lines)
+    assert len(got) == len(exp) == 77
+    n_chars = 0
+    for a, b in zip(got, exp):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert str(a) == str(b)
+            assert [c.rect for c in a.chars()] == [c.rect.tlbr() for c in b.chars]
+            n_chars += len(b.chars)
+    assert n_chars > 100
