@@ -556,3 +556,66 @@ def test_recognition_long_short_split_path():
             assert [c.rect for c in a.chars()] == [c.rect.tlbr() for c in b.chars]
             n_chars += len(b.chars)
     assert n_chars > 100
+
+
+def test_bench_call_sequence_batch_apis_match_single_page_path_and_oracle():
+    """bench.py's sequence — pixels resident in HBM, prepare_input_device, detect_words_batch,
+    find_text_lines_batch_raw, recognize_text_batch_raw, several steps in flight — must give, page for page,
+    what the one-page API gives (itself oracle-checked above), and the oracle's text for the first page."""
+    import ctypes as C
+    from concurrent.futures import ThreadPoolExecutor
+    from ocrs_amd import _lib
+    L = _lib.lib()
+    dbuf, rbuf = M.detection_model_bytes(), M.recognition_model_bytes()
+    gpu = OcrEngine(detection_model=Model.load_bytes(dbuf), recognition_model=Model.load_bytes(rbuf))
+    pages = [synth.synthetic_page(60 + i, 512, 640, lines=12) for i in range(3)]
+    dptrs = []
+    for pg in pages:
+        p = C.c_void_p()
+        _lib.check(L.ocrs_device_malloc(C.c_size_t(pg.nbytes), C.byref(p)))
+        _lib.check(L.ocrs_device_upload(p, pg.ctypes.data_as(C.c_void_p), C.c_size_t(pg.nbytes)))
+        dptrs.append(p)
+
+    def step(_=None):
+        inputs = [gpu.prepare_input_device(p.value, np.uint8, DimOrder.Hwc, 512, 640, 3) for p in dptrs]
+        words = gpu.detect_words_batch(inputs)
+        rects, loffs, poffs = gpu.find_text_lines_batch_raw(words)
+        chars, coffs = gpu.recognize_text_batch_raw(inputs, rects, loffs, poffs)
+        return inputs, words, rects, loffs, poffs, chars, coffs
+
+    with ThreadPoolExecutor(max_workers=3) as ex:   # steps in flight, as the bench runs them
+        outs = list(ex.map(step, range(3)))
+    inputs, words, rects, loffs, poffs, chars, coffs = outs[0]
+    for o in outs[1:]:
+        assert np.array_equal(o[2], rects) and np.array_equal(o[5], chars) and np.array_equal(o[6], coffs)
+    assert inputs[0].shape == (1, 512, 640)
+    texts = []
+    for pi, pg in enumerate(pages):
+        inp = gpu.prepare_input(ImageSource.from_tensor(pg, DimOrder.Hwc))
+        assert np.array_equal(inp.image(), inputs[pi].image())
+        w1 = gpu.detect_words(inp)
+        assert np.array_equal(w1, words[pi])
+        l1 = gpu.find_text_lines(inp, w1)
+        lo, hi = int(poffs[pi]), int(poffs[pi + 1])
+        assert hi - lo == len(l1)
+        for k, line in enumerate(l1):
+            assert np.array_equal(line, rects[int(loffs[lo + k]):int(loffs[lo + k + 1])])
+        t1 = gpu.recognize_text(inp, l1)
+        page_text = []
+        for k, tl in enumerate(t1):
+            a, b = int(coffs[lo + k]), int(coffs[lo + k + 1])
+            got = "".join(chr(c) for c in chars["ch"][a:b])
+            assert got == ("" if tl is None else "".join(c.char for c in tl.chars()))
+            if tl is not None:
+                assert [tuple(int(v) for v in (chars["top"][i], chars["left"][i], chars["bottom"][i], chars["right"][i]))
+                        for i in range(a, b)] == [tuple(c.rect) for c in tl.chars()]
+            page_text.append(got)
+        texts.append(page_text)
+    ora = OP.OcrEngine(detection_model=OracleModel(OracleGraph(dbuf), "exact"),
+                       recognition_model=OracleModel(OracleGraph(rbuf), "exact"))
+    oin = ora.prepare_input(OP.ImageSource.from_tensor(pages[0], "hwc"))
+    olines = ora.recognize_text(oin, ora.find_text_lines(oin, ora.detect_words(oin)))
+    assert [t for t in texts[0] if t] == [str(t) for t in olines if t is not None and str(t)]
+    assert Model.load_bytes(rbuf).flops(1, 64, 300) > 1e8
+    for p in dptrs:
+        _lib.check(L.ocrs_device_free(p))
