@@ -69,5 +69,24 @@ def main():
     print("wrote golden fixtures:", len(words), "words,", len(lines), "lines,", len(text), "chars")
 
 
+def bench_page_words():
+    """tests/golden/bench_page_words_seed{0,1}.npy: the ~700 word boxes the detection stage finds on the bench's
+    1024x1024 synthetic pages (seeds 0 and 1, 80 lines) with the bench's detection model (ocrs_amd.modelfile
+    build_detection(seed=1), evaluated by the oracle's torch backend).  Input of the bench-scale layout test."""
+    from ocrs_amd import modelfile as mf
+    dbuf = mf.build_detection(in_hw=(800, 600), seed=1).to_bytes()
+    ora = OP.OcrEngine(detection_model=OracleModel(OracleGraph(dbuf), "torch"))
+    for seed in (0, 1):
+        px = synth.synthetic_page(seed, 1024, 1024, lines=80)
+        oin = ora.prepare_input(OP.ImageSource.from_tensor(px, "hwc"))
+        words = ora.detect_words(oin)
+        a = np.array([w.to_array() for w in words], np.float32).reshape(-1, 6)
+        np.save(os.path.join(HERE, "bench_page_words_seed%d.npy" % seed), a)
+        print("bench_page_words_seed%d.npy: %d words" % (seed, len(a)))
+
+
 if __name__ == "__main__":
+    if "--bench-page-words" in sys.argv:
+        bench_page_words()
+        sys.exit(0)
     main()

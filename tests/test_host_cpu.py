@@ -113,6 +113,20 @@ def test_find_text_lines_matches_oracle_on_random_layouts(lib, seed):
     _same_lines(_host_find_text_lines(lib, words), oracle_find_text_lines(words))
 
 
+@pytest.mark.parametrize("seed", [0, 1])
+def test_find_text_lines_matches_oracle_on_bench_scale_pages(lib, seed):
+    """~700 word boxes as the detection stage produces them for a 1024x1024 bench page (tests/golden/make_golden.py
+    documents how the fixture was made): the layout search pops ~48k heap entries here, with score ties, so this
+    is where an inexact emulation of Rust's BinaryHeap order would show."""
+    a = np.load(os.path.join(os.path.dirname(__file__), "golden", "bench_page_words_seed%d.npy" % seed))
+    words = [RotatedRect.from_array(r) for r in a]
+    assert len(words) > 600
+    got = _host_find_text_lines(lib, words)
+    exp = oracle_find_text_lines(words)
+    assert 70 <= len(exp) <= 90
+    _same_lines(got, exp)
+
+
 def test_find_text_lines_empty(lib):
     assert _host_find_text_lines(lib, []) == []
 
