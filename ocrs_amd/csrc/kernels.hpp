@@ -68,6 +68,9 @@ void conv_direct(const float* x, int n, int h, int w, int cin, const float* wt, 
                  int cout, int relu, float* y, hipStream_t s);
 void dwconv3x3(const float* x, int n, int h, int w, int c, const float* wt, const float* bias, int relu, float* y,
                hipStream_t s);
+// depthwise 3x3 over concat([skip, centred-pad(up)]) without building the concatenation; false if unsupported
+bool dwconv3x3_cat(const float* skip, int n, int h, int w, int cs, const float* up, int uh, int uw, int cu, const float* wt,
+                   const float* bias, int relu, float* y, hipStream_t s);
 void maxpool(const float* x, int n, int h, int w, int c, int kh, int kw, float* y, hipStream_t s);
 void avgpool(const float* x, int n, int h, int w, int c, int kh, int kw, float* y, hipStream_t s);
 void padcat(const float* skip, int n, int sh, int sw, int cs, const float* x, int h, int w, int cx, float* y,

@@ -555,6 +555,65 @@ dwconv3x3_kernel(const float* __restrict__ x, int n, int h, int w, int c, const 
     }
 }
 
+// Depthwise 3x3 over the channel concatenation [skip, pad(up)] WITHOUT materialising it (the U-Net's
+// Up block: PADCAT feeding the first depthwise conv of its DoubleConv).  Channel group g reads from `skip`
+// ([n,h,w,cs]) when g*4 < cs, otherwise from `up` ([n,uh,uw,cu]) shifted by the centred pad; positions outside
+// `up` and outside the image contribute fmaf(0, w, acc) exactly as the padded, concatenated tensor would.
+__global__ void __launch_bounds__(256)
+dwconv3x3_cat_kernel(const float* __restrict__ skip, int n, int h, int w, int cs, const float* __restrict__ up, int uh,
+                     int uw, int cu, const float* __restrict__ wt, const float* __restrict__ bias, int relu,
+                     float* __restrict__ y) {
+    const int c = cs + cu;
+    const int cq = c / 4;
+    const int py = (h - uh) / 2, px = (w - uw) / 2;
+    const int64_t total = (int64_t)n * h * w * cq;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int g = (int)(i % cq);
+        const int64_t pix = i / cq;
+        const int ox = (int)(pix % w);
+        const int oy = (int)((pix / w) % h);
+        const int64_t img = pix / ((int64_t)w * h);
+        const bool from_skip = g * 4 < cs;
+        float acc[4];
+#pragma unroll
+        for (int v = 0; v < 4; v++) acc[v] = bias[g * 4 + v];
+#pragma unroll
+        for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+            for (int kx = 0; kx < 3; kx++) {
+                const int iy = oy + ky - 1, ix = ox + kx - 1;
+                float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (from_skip) {
+                    if ((unsigned)iy < (unsigned)h && (unsigned)ix < (unsigned)w)
+                        xv = *reinterpret_cast<const float4*>(skip + ((img * h + iy) * w + ix) * cs + g * 4);
+                } else {
+                    const int uy = iy - py, ux = ix - px;
+                    if ((unsigned)uy < (unsigned)uh && (unsigned)ux < (unsigned)uw)
+                        xv = *reinterpret_cast<const float4*>(up + ((img * uh + uy) * uw + ux) * cu + (g * 4 - cs));
+                }
+                const float4 wv = *reinterpret_cast<const float4*>(wt + (ky * 3 + kx) * c + g * 4);
+                acc[0] = fmaf(xv.x, wv.x, acc[0]);
+                acc[1] = fmaf(xv.y, wv.y, acc[1]);
+                acc[2] = fmaf(xv.z, wv.z, acc[2]);
+                acc[3] = fmaf(xv.w, wv.w, acc[3]);
+            }
+#pragma unroll
+        for (int v = 0; v < 4; v++)
+            if (relu) acc[v] = acc[v] > 0.f ? acc[v] : 0.f;
+        *reinterpret_cast<float4*>(y + pix * c + g * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    }
+}
+
+bool dwconv3x3_cat(const float* skip, int n, int h, int w, int cs, const float* up, int uh, int uw, int cu, const float* wt,
+                   const float* bias, int relu, float* y, hipStream_t s) {
+    if ((cs % 4) != 0 || (cu % 4) != 0 || uh > h || uw > w) return false;
+    int64_t total = (int64_t)n * h * w * ((cs + cu) / 4);
+    int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(dwconv3x3_cat_kernel, dim3(grid), dim3(256), 0, s, skip, n, h, w, cs, up, uh, uw, cu, wt, bias, relu, y);
+    return true;
+}
+
 void dwconv3x3(const float* x, int n, int h, int w, int c, const float* wt, const float* bias, int relu, float* y,
                hipStream_t s) {
     const bool v4 = (c % 4) == 0;

@@ -131,6 +131,17 @@ std::unique_ptr<HipModel> HipModel::load(const void* data, size_t len) {
             if (!other_use && (uint32_t)a.out != m->out_slot) b.fused_into_prev = true;
         }
     }
+    // PADCAT consumed only by the depthwise conv that follows: that conv reads skip / up directly.
+    for (size_t i = 0; i + 1 < m->ops.size(); i++) {
+        GraphOp& a = m->ops[i];
+        GraphOp& b = m->ops[i + 1];
+        if (a.type == OP_PADCAT && b.type == OP_DWCONV3 && b.in0 == a.out && (uint32_t)a.out != m->out_slot) {
+            bool other_use = false;
+            for (size_t j = i + 2; j < m->ops.size(); j++)
+                if (m->ops[j].in0 == a.out || m->ops[j].in1 == a.out) other_use = true;
+            if (!other_use) { a.cat_into_next = true; b.reads_cat = true; }
+        }
+    }
     return m;
 }
 
@@ -199,6 +210,14 @@ float* HipModel::run_device(Workspace& ws, const float* d_in, int n, int h, int 
     }
     last_use[out_slot] = (int)ops.size() + 1;
     last_use[ret_slot] = (int)ops.size() + 1;
+    auto cat_fused = [&](size_t i) {  // PADCAT i is skipped and op i+1 reads its inputs (only inside this run's range)
+        return ops[i].cat_into_next && i + 1 < n_run && (int)ret_slot != ops[i].out;
+    };
+    for (size_t i = 0; i + 1 < ops.size(); i++)
+        if (cat_fused(i)) {
+            last_use[ops[i].in0] = std::max(last_use[ops[i].in0], (int)i + 1);
+            last_use[ops[i].in1] = std::max(last_use[ops[i].in1], (int)i + 1);
+        }
     std::vector<float*> ptr(n_slots, nullptr);
     std::vector<size_t> cap(n_slots, 0);
     std::multimap<size_t, float*> free_local;
@@ -257,6 +276,8 @@ float* HipModel::run_device(Workspace& ws, const float* d_in, int n, int h, int 
             cap[op.out] = cap[op.in0];
             cap[op.in0] = 0;
             ptr[op.in0] = nullptr;
+        } else if (op.type == OP_PADCAT && cat_fused(i)) {
+            // nothing to do: the depthwise conv that follows reads skip / up directly
         } else {
         if (!(is_final_logsoftmax && !want_logp)) {
             auto r = get((size_t)o.count());
@@ -295,6 +316,31 @@ float* HipModel::run_device(Workspace& ws, const float* d_in, int n, int h, int 
                 break;
             }
             case OP_DWCONV3:
+                if (op.reads_cat && i > 0 && cat_fused(i - 1)) {
+                    const GraphOp& cat = ops[i - 1];
+                    const TensorShape sk = shp[cat.in0], up = shp[cat.in1];
+                    if ((sk.c % 4) == 0 && (up.c % 4) == 0) {
+                        timed(KC_DWCONV3X3, 18.0 * a.count(), 8.0 * a.count(), [&] {
+                            k::dwconv3x3_cat(ptr[cat.in0], sk.n, sk.h, sk.w, sk.c, ptr[cat.in1], up.h, up.w, up.c, op.w[0],
+                                             op.w[1], op.relu, y, st);
+                        });
+                    } else {  // channel counts the vectorised kernel does not take: build the concatenation after all
+                        auto tmp = get((size_t)a.count());
+                        timed(KC_PADCAT, 0, 8.0 * a.count(), [&] {
+                            k::padcat(ptr[cat.in0], sk.n, sk.h, sk.w, sk.c, ptr[cat.in1], up.h, up.w, up.c, tmp.first, st);
+                        });
+                        timed(KC_DWCONV3X3, 18.0 * a.count(), 8.0 * a.count(),
+                              [&] { k::dwconv3x3(tmp.first, a.n, a.h, a.w, a.c, op.w[0], op.w[1], op.relu, y, st); });
+                        free_local.emplace(tmp.second, tmp.first);
+                    }
+                    for (int sl : {cat.in0, cat.in1})  // the skipped PADCAT's inputs: this was their last reader
+                        if (sl > 0 && last_use[sl] == (int)i && ptr[sl] && cap[sl]) {
+                            free_local.emplace(cap[sl], ptr[sl]);
+                            ptr[sl] = nullptr;
+                            cap[sl] = 0;
+                        }
+                    break;
+                }
                 timed(KC_DWCONV3X3, 18.0 * a.count(), 8.0 * a.count(),
                       [&] { k::dwconv3x3(x, a.n, a.h, a.w, a.c, op.w[0], op.w[1], op.relu, y, st); });
                 break;
