@@ -68,6 +68,10 @@ void conv_direct(const float* x, int n, int h, int w, int cin, const float* wt, 
                  int cout, int relu, float* y, hipStream_t s);
 void dwconv3x3(const float* x, int n, int h, int w, int c, const float* wt, const float* bias, int relu, float* y,
                hipStream_t s);
+// dw 3x3 + pw 1x1 in one pass (8 <= C <= 32); same arithmetic as the two separate kernels
+bool dwpw_fused_supported(int cin, int cout);
+void dwpw_fused(const float* x, int n, int h, int w, int cin, const float* wdw, const float* bdw, int relu_dw, int cout,
+                const float* wpw, const float* bpw, int relu_pw, float* y, hipStream_t s);
 // depthwise 3x3 over concat([skip, centred-pad(up)]) without building the concatenation; false if unsupported
 bool dwconv3x3_cat(const float* skip, int n, int h, int w, int cs, const float* up, int uh, int uw, int cu, const float* wt,
                    const float* bias, int relu, float* y, hipStream_t s);

@@ -614,6 +614,104 @@ bool dwconv3x3_cat(const float* skip, int n, int h, int w, int cs, const float* 
     return true;
 }
 
+// ---------------------------------------------------------------------------
+// Depthwise 3x3 + pointwise 1x1 in one pass (the DoubleConv halves of the detection U-Net at the levels
+// where C <= 32).  Same thread layout as dwconv3x3_kernel — one thread = one pixel x 4 channels, so the
+// loads stay coalesced — then the T = CIN/4 lanes of a pixel exchange their depthwise outputs with wave
+// shuffles and each computes COUT/T of the pointwise outputs.  The intermediate tensor never exists.
+// Arithmetic is exactly that of the two kernels: dw  acc = bias; (ky,kx) ascending fmaf, zero taps
+// included; [relu]; pw  acc = bias; ci ascending fmaf(dw[ci], W[ci][co], acc); [relu].
+// ---------------------------------------------------------------------------
+template <int CIN, int COUT>
+__global__ void __launch_bounds__(256)
+dwpw_fused_kernel(const float* __restrict__ x, int n, int h, int w, const float* __restrict__ wdw,
+                  const float* __restrict__ bdw, int relu_dw, const float* __restrict__ wpw,
+                  const float* __restrict__ bpw, int relu_pw, float* __restrict__ y) {
+    constexpr int T = CIN / 4;      // lanes per pixel
+    constexpr int OPT = COUT / T;   // pointwise outputs per lane
+    static_assert(CIN % 4 == 0 && COUT % T == 0 && (OPT == 2 || OPT % 4 == 0), "shape");
+    __shared__ float s_w[CIN * COUT];
+    for (int i = threadIdx.x; i < CIN * COUT; i += 256) s_w[i] = wpw[i];
+    __syncthreads();
+    const int64_t total = (int64_t)n * h * w * T;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;   // a multiple of 64, hence of T
+    const int lane = threadIdx.x & 63;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int g = (int)(i % T);
+        const int64_t pix = i / T;
+        const int ox = (int)(pix % w);
+        const int oy = (int)((pix / w) % h);
+        const int64_t img = pix / ((int64_t)w * h);
+        float acc[4];
+#pragma unroll
+        for (int v = 0; v < 4; v++) acc[v] = bdw[g * 4 + v];
+#pragma unroll
+        for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+            for (int kx = 0; kx < 3; kx++) {
+                const int iy = oy + ky - 1, ix = ox + kx - 1;
+                const bool inb = (unsigned)iy < (unsigned)h && (unsigned)ix < (unsigned)w;
+                const float* xp = x + ((img * h + (inb ? iy : 0)) * w + (inb ? ix : 0)) * CIN + g * 4;
+                const float4 xv = inb ? *reinterpret_cast<const float4*>(xp) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 wv = *reinterpret_cast<const float4*>(wdw + (ky * 3 + kx) * CIN + g * 4);
+                acc[0] = fmaf(xv.x, wv.x, acc[0]);
+                acc[1] = fmaf(xv.y, wv.y, acc[1]);
+                acc[2] = fmaf(xv.z, wv.z, acc[2]);
+                acc[3] = fmaf(xv.w, wv.w, acc[3]);
+            }
+        if (relu_dw) {
+#pragma unroll
+            for (int v = 0; v < 4; v++) acc[v] = acc[v] > 0.f ? acc[v] : 0.f;
+        }
+        // all CIN depthwise outputs of this pixel, from the T neighbouring lanes
+        float d[CIN];
+        const int base = lane & ~(T - 1);
+#pragma unroll
+        for (int gg = 0; gg < T; gg++)
+#pragma unroll
+            for (int v = 0; v < 4; v++) d[gg * 4 + v] = __shfl(acc[v], base + gg, 64);
+        float o[OPT];
+#pragma unroll
+        for (int q = 0; q < OPT; q++) o[q] = bpw[g * OPT + q];
+#pragma unroll
+        for (int ci = 0; ci < CIN; ci++)
+#pragma unroll
+            for (int q = 0; q < OPT; q++) o[q] = fmaf(d[ci], s_w[ci * COUT + g * OPT + q], o[q]);
+        if (relu_pw) {
+#pragma unroll
+            for (int q = 0; q < OPT; q++) o[q] = o[q] > 0.f ? o[q] : 0.f;
+        }
+        float* yp = y + pix * COUT + g * OPT;
+        if (OPT == 2) {
+            *reinterpret_cast<float2*>(yp) = make_float2(o[0], o[1 % OPT]);
+        } else {
+#pragma unroll
+            for (int q = 0; q < OPT; q += 4)
+                *reinterpret_cast<float4*>(yp + q) = make_float4(o[q], o[(q + 1) % OPT], o[(q + 2) % OPT], o[(q + 3) % OPT]);
+        }
+    }
+}
+
+bool dwpw_fused_supported(int cin, int cout) {
+    return (cin == 8 || cin == 16 || cin == 32) && (cout == 8 || cout == 16 || cout == 32);
+}
+
+void dwpw_fused(const float* x, int n, int h, int w, int cin, const float* wdw, const float* bdw, int relu_dw, int cout,
+                const float* wpw, const float* bpw, int relu_pw, float* y, hipStream_t s) {
+    const int64_t total = (int64_t)n * h * w * (cin / 4);
+    int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    if (grid < 1) grid = 1;
+#define OCRS_DWPW(CI, CO)                                                                                              \
+    if (cin == CI && cout == CO) {                                                                                     \
+        hipLaunchKernelGGL((dwpw_fused_kernel<CI, CO>), dim3(grid), dim3(256), 0, s, x, n, h, w, wdw, bdw, relu_dw, wpw, \
+                           bpw, relu_pw, y);                                                                           \
+        return;                                                                                                        \
+    }
+    OCRS_DWPW(8, 8) OCRS_DWPW(8, 16) OCRS_DWPW(8, 32) OCRS_DWPW(16, 8) OCRS_DWPW(16, 16) OCRS_DWPW(16, 32)
+    OCRS_DWPW(32, 16) OCRS_DWPW(32, 32)
+#undef OCRS_DWPW
+}
+
 void dwconv3x3(const float* x, int n, int h, int w, int c, const float* wt, const float* bias, int relu, float* y,
                hipStream_t s) {
     const bool v4 = (c % 4) == 0;

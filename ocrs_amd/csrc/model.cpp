@@ -131,6 +131,18 @@ std::unique_ptr<HipModel> HipModel::load(const void* data, size_t len) {
             if (!other_use && (uint32_t)a.out != m->out_slot) b.fused_into_prev = true;
         }
     }
+    // Depthwise 3x3 followed by its pointwise 1x1 (both 8 <= C <= 32) run as one kernel.
+    for (size_t i = 0; i + 1 < m->ops.size(); i++) {
+        GraphOp& a = m->ops[i];
+        GraphOp& b = m->ops[i + 1];
+        if (a.type == OP_DWCONV3 && b.type == OP_CONV && b.kh == 1 && b.kw == 1 && b.in0 == a.out && b.cin == a.cin &&
+            k::dwpw_fused_supported(a.cin, b.cout) && (uint32_t)a.out != m->out_slot) {
+            bool other_use = false;
+            for (size_t j = i + 2; j < m->ops.size(); j++)
+                if (m->ops[j].in0 == a.out || m->ops[j].in1 == a.out) other_use = true;
+            if (!other_use) { a.fuse_next_pw = true; b.done_by_prev = true; }
+        }
+    }
     // PADCAT consumed only by the depthwise conv that follows: that conv reads skip / up directly.
     for (size_t i = 0; i + 1 < m->ops.size(); i++) {
         GraphOp& a = m->ops[i];
@@ -278,6 +290,18 @@ float* HipModel::run_device(Workspace& ws, const float* d_in, int n, int h, int 
             ptr[op.in0] = nullptr;
         } else if (op.type == OP_PADCAT && cat_fused(i)) {
             // nothing to do: the depthwise conv that follows reads skip / up directly
+        } else if (op.done_by_prev && ptr[op.out]) {
+            // computed together with the preceding depthwise conv
+        } else if (op.fuse_next_pw && !op.reads_cat && i + 1 < n_run && (int)ret_slot != op.out) {
+            const GraphOp& pw = ops[i + 1];
+            const TensorShape po = shp[pw.out];
+            auto r = get((size_t)po.count());
+            ptr[pw.out] = r.first;
+            cap[pw.out] = r.second;
+            const double px = (double)a.n * a.h * a.w;
+            timed(KC_DWCONV3X3, 2.0 * px * (9.0 * op.cin + (double)op.cin * pw.cout), 4.0 * px * (op.cin + pw.cout), [&] {
+                k::dwpw_fused(x, a.n, a.h, a.w, op.cin, op.w[0], op.w[1], op.relu, pw.cout, pw.w[0], pw.w[1], pw.relu, r.first, st);
+            });
         } else {
         if (!(is_final_logsoftmax && !want_logp)) {
             auto r = get((size_t)o.count());

@@ -27,6 +27,8 @@ struct GraphOp {
     const float* aux2 = nullptr;  // GRU: Wh [2][H][3H]
     const float* aux3 = nullptr;  // GRU: bh [2][3H]
     bool fused_into_prev = false; // e.g. SIGMOID folded into the preceding Cout==1 conv
+    bool fuse_next_pw = false;    // DWCONV3 whose only consumer is the next op, a 1x1 CONV (8 <= C <= 32): one fused launch
+    bool done_by_prev = false;    // that 1x1 CONV
     bool cat_into_next = false;   // PADCAT whose only reader is the next op, a DWCONV3: the concatenation is never built
     bool reads_cat = false;       // that DWCONV3 (reads the two PADCAT inputs directly)
 };
