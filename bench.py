@@ -70,6 +70,10 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the ocrs_amd engine has no CPU fallback")
+    if args.gpus != world and rank == 0:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d: one process drives one GPU, launch N>1 with "
+              "`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`; measuring %d GPU(s)"
+              % (args.gpus, world, world), file=sys.stderr)
     # one rank per GPU; OCRS_DIST_BACKEND=gloo lets the multi-rank path be exercised on a box with fewer GPUs than
     # ranks (ranks then share devices) — the driver's runs use the default, nccl = RCCL
     backend = os.environ.get("OCRS_DIST_BACKEND", "nccl")
