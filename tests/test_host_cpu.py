@@ -183,3 +183,16 @@ def test_committed_bench_line_keeps_the_driver_contract():
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and isinstance(c["sample"], str)
     assert abs(d["value"] - d["config"]["pages_per_step_per_gpu"] * 1000.0 / d["ms_per_step"]) / d["value"] < 1e-3
+
+
+def test_no_gpu_means_a_loud_error_not_a_cpu_fallback(lib):
+    """The product has no CPU path: without a HIP device, loading a model (the first thing that needs HBM) must
+    raise, not quietly compute somewhere else."""
+    if _lib.device_count() > 0:
+        pytest.skip("a HIP device is visible")
+    from ocrs_amd import modelfile as mf
+    buf = mf.build_recognition(hidden=8, chans=(4, 8, 8, 8, 8, 8), n_classes=5, in_h=32).to_bytes()
+    with pytest.raises(ocrs_amd.OcrsError, match="(?i)device|hip"):
+        ocrs_amd.Model.load_bytes(buf)
+    with pytest.raises(ocrs_amd.OcrsError):
+        _lib.require_gpu()
