@@ -42,7 +42,7 @@ def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=18)
-    ap.add_argument("--warmup", type=int, default=12)
+    ap.add_argument("--warmup", type=int, default=36)
     ap.add_argument("--pages", type=int, default=16, help="pages per step per GPU")
     ap.add_argument("--lines", type=int, default=80, help="text lines per synthetic page")
     ap.add_argument("--no-cpu-baseline", action="store_true")
