@@ -43,6 +43,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=18)
     ap.add_argument("--warmup", type=int, default=36)
+    ap.add_argument("--settle-s", type=float, default=3.0,
+                    help="keep running untimed steps after the W warm-up steps until this many seconds have passed "
+                         "since warm-up began (0 = exactly W warm-up steps)")
     ap.add_argument("--pages", type=int, default=16, help="pages per step per GPU")
     ap.add_argument("--lines", type=int, default=80, help="text lines per synthetic page")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -151,8 +154,15 @@ def main():
         if world > 1:
             dist.barrier()
 
+    t_warm = time.perf_counter()
     if args.warmup:
         run_steps(args.warmup)
+    # settle: the first seconds after start-up (allocator growth, clocks after another process used the GPU) run a few
+    # per cent slower whatever W is; keep running untimed steps until 3 s have passed since warm-up began
+    settle_steps = 0
+    while args.settle_s > 0 and time.perf_counter() - t_warm < args.settle_s and settle_steps < 200:
+        run_steps(max(args.inflight, 1))
+        settle_steps += max(args.inflight, 1)
     # Calibration (untimed): one step with every kernel class timed picks the dominant class; during the
     # timed region only that class carries per-launch HIP events (a handful of launches per step), so the
     # live roofline figure does not slow the run down.  --profile-hint keeps all classes on.
@@ -218,6 +228,7 @@ def main():
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
+        "extra_untimed_settle_steps": settle_steps,
         "ms_per_step": round(1000.0 * elapsed / args.steps, 3),
         "higher_is_better": True,
         "scaling": "weak",

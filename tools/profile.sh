@@ -7,7 +7,7 @@ TAG=${1:-r1}
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $OLDPWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --no-kernel-timing --no-pipeline"
+BENCH="python $OLDPWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --no-kernel-timing --no-pipeline --settle-s 0"
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT -o trace -- $BENCH > $OUT/trace.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT -o fetch -- $BENCH > $OUT/fetch.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT -o write -- $BENCH > $OUT/write.log 2>&1
