@@ -41,7 +41,7 @@ PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md "HBM3E peak BW" (spec)
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=18)
+    ap.add_argument("--steps", type=int, default=36)
     ap.add_argument("--warmup", type=int, default=36)
     ap.add_argument("--settle-s", type=float, default=3.0,
                     help="keep running untimed steps after the W warm-up steps until this many seconds have passed "
