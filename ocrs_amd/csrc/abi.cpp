@@ -195,7 +195,7 @@ ocrs_status ocrs_model_run(const ocrs_model* m, const float* input, const int64_
         float* d_out = hm->run_device(ws, d_in, (int)n, (int)h, (int)w, &os, nullptr, nullptr, nullptr, true,
                                       opts && opts->timing);
         std::vector<float> host((size_t)os.count());
-        OCRS_HIP(hipMemcpyAsync(host.data(), d_out, host.size() * sizeof(float), hipMemcpyDeviceToHost, ws.s()));
+        ws.download(host.data(), d_out, host.size() * sizeof(float));
         ws.sync();
         if (os.seq) {  // [T, N, C]
             out_shape[0] = os.n; out_shape[1] = os.h; out_shape[2] = os.c; out_shape[3] = 1;
@@ -526,7 +526,7 @@ ocrs_status ocrs_engine_prepare_recognition_input(const ocrs_engine* e, const oc
         std::vector<float> host((size_t)rec_h * rw);
         if (rw > 0) {
             k::crop_lines(d_pages, d_hw, d_desc, d_poly, 1, rec_h, d_out, ws.s());
-            OCRS_HIP(hipMemcpyAsync(host.data(), d_out, host.size() * 4, hipMemcpyDeviceToHost, ws.s()));
+            ws.download(host.data(), d_out, host.size() * 4);
         }
         ws.sync();
         *out = dup_buffer(host);

@@ -97,6 +97,40 @@ DevicePool& pool() {
     return *p;
 }
 
+// ---------------------------------------------------------------- HostPool
+void* HostPool::alloc(size_t bytes) {
+    const size_t sz = round_size(bytes);
+    {
+        std::lock_guard<std::mutex> g(mu_);
+        auto it = free_.find(sz);
+        if (it != free_.end()) {
+            void* p = it->second;
+            free_.erase(it);
+            live_[p] = sz;
+            return p;
+        }
+    }
+    void* p = nullptr;
+    OCRS_HIP(hipHostMalloc(&p, sz, hipHostMallocDefault));
+    std::lock_guard<std::mutex> g(mu_);
+    live_[p] = sz;
+    return p;
+}
+
+void HostPool::release(void* p) {
+    if (!p) return;
+    std::lock_guard<std::mutex> g(mu_);
+    auto it = live_.find(p);
+    if (it == live_.end()) return;
+    free_.emplace(it->second, p);
+    live_.erase(it);
+}
+
+HostPool& host_pool() {
+    static HostPool* p = new HostPool();
+    return *p;
+}
+
 hipStream_t heavy_stream() {
     static hipStream_t s = [] {
         // Lowest queue priority: the conv stacks are long throughput-bound grids whose blocks live ~200 us;

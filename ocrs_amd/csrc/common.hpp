@@ -7,11 +7,13 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <map>
 #include <mutex>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/ocrs_amd.h"
@@ -65,6 +67,22 @@ class DevicePool {
 
 DevicePool& pool();
 
+// Pinned host staging (hipHostMalloc), cached by size.  Device-to-host results go through it: a
+// hipMemcpyAsync into PAGEABLE memory does not return until the stream has reached and finished the
+// copy, and the calling thread spins for all of that time — tens of milliseconds per request when
+// the copy is queued behind the request's own kernels.
+class HostPool {
+  public:
+    void* alloc(size_t bytes);
+    void release(void* p);
+
+  private:
+    std::mutex mu_;
+    std::multimap<size_t, void*> free_;
+    std::map<void*, size_t> live_;
+};
+HostPool& host_pool();
+
 // One process-wide stream for the throughput-bound conv stacks of all in-flight requests (model.cpp).
 hipStream_t heavy_stream();
 
@@ -106,17 +124,22 @@ class StreamLease {
     explicit StreamLease(bool high_priority = false);
     ~StreamLease();
     hipStream_t get() const { return s_; }
-    // Host wait for everything enqueued so far.  A blocking-sync event: the waiting thread sleeps instead
-    // of spinning in hipStreamSynchronize — with several requests in flight per process and several
-    // processes per host, spinning waiters cost more cores than the layout analysis does.
-    void sync() const {
-        OCRS_HIP(hipEventRecord(done_, s_));
-        OCRS_HIP(hipEventSynchronize(done_));
-    }
-    hipError_t sync_noexcept() const noexcept {
+    // Host wait for everything enqueued so far.  hipStreamSynchronize / hipEventSynchronize spin a core for the
+    // whole wait here (measured: every request thread at ~100 % CPU, also with hipEventBlockingSync), which with
+    // several requests in flight per process and several processes per host costs more cores than the layout
+    // analysis does.  So: record an event, poll it briefly, then sleep between polls (<= 0.1 ms added latency).
+    hipError_t wait_done() const noexcept {
         hipError_t e = hipEventRecord(done_, s_);
-        return e == hipSuccess ? hipEventSynchronize(done_) : e;
+        if (e != hipSuccess) return e;
+        for (int i = 0;; i++) {
+            e = hipEventQuery(done_);
+            if (e != hipErrorNotReady) return e;
+            if (i < 64) std::this_thread::yield();
+            else std::this_thread::sleep_for(std::chrono::microseconds(i < 256 ? 20 : 100));
+        }
     }
+    void sync() const { OCRS_HIP(wait_done()); }
+    hipError_t sync_noexcept() const noexcept { return wait_done(); }
 
   private:
     hipStream_t s_;
@@ -205,12 +228,33 @@ struct Workspace {
         host_keep.emplace_back((const char*)h_src, (const char*)h_src + bytes);
         OCRS_HIP(hipMemcpyAsync(d_dst, host_keep.back().data(), bytes, hipMemcpyHostToDevice, stream.get()));
     }
+    // device -> host without blocking the caller: staged in pinned memory on `st` (default: this workspace's
+    // stream) and handed to `h_dst` by the next sync() of this workspace — which must cover `st`
+    struct Download { void* pinned; void* dst; size_t bytes; };
+    std::vector<Download> downloads;
+    void download(void* h_dst, const void* d_src, size_t bytes, hipStream_t st = nullptr) {
+        if (!bytes) return;
+        void* pin = host_pool().alloc(bytes);
+        downloads.push_back(Download{pin, h_dst, bytes});
+        OCRS_HIP(hipMemcpyAsync(pin, d_src, bytes, hipMemcpyDeviceToHost, st ? st : stream.get()));
+    }
     hipStream_t s() const { return stream.get(); }
     void* alloc(size_t bytes) { bufs.emplace_back(bytes ? bytes : 4); return bufs.back().p; }
     template <class T> T* alloc_n(size_t n) { return static_cast<T*>(alloc(n * sizeof(T))); }
-    void sync() { stream.sync(); }
+    void finish_downloads(bool copy) {
+        for (const Download& d : downloads) {
+            if (copy) memcpy(d.dst, d.pinned, d.bytes);
+            host_pool().release(d.pinned);
+        }
+        downloads.clear();
+    }
+    void sync() {
+        stream.sync();
+        finish_downloads(true);
+    }
     ~Workspace() {
         (void)stream.sync_noexcept();
+        finish_downloads(false);
         for (hipEvent_t e : events) (void)hipEventDestroy(e);
     }
 };

@@ -56,8 +56,7 @@ void ocrs_engine::detect(const ocrs_page* const* pages, size_t n, std::vector<st
         std::vector<float> hin((size_t)in_h * in_w), hout;
         float* d_out = ws.alloc_n<float>((size_t)N * in_h * in_w);
         for (int i = 0; i < N; i++) {
-            OCRS_HIP(hipMemcpyAsync(hin.data(), d_in + (size_t)i * in_h * in_w, hin.size() * sizeof(float),
-                                    hipMemcpyDeviceToHost, st));
+            ws.download(hin.data(), d_in + (size_t)i * in_h * in_w, hin.size() * sizeof(float));
             ws.sync();
             const int64_t ishape[4] = {1, 1, in_h, in_w};
             int64_t oshape[4];
@@ -89,7 +88,7 @@ void ocrs_engine::detect(const ocrs_page* const* pages, size_t n, std::vector<st
         k::resize_threshold(d_prob, N, in_h, in_w, sh, sw, text_threshold, d_mask, d_map, h, w, st);
     }
     if (host_map)
-        OCRS_HIP(hipMemcpyAsync(host_map, d_map, (size_t)N * h * w * sizeof(float), hipMemcpyDeviceToHost, st));
+        ws.download(host_map, d_map, (size_t)N * h * w * sizeof(float));
     if (!rects_out) {
         ws.sync();
         if (T) T->collect();
@@ -124,28 +123,29 @@ void ocrs_engine::detect(const ocrs_page* const* pages, size_t n, std::vector<st
         k::contour_rects(d_mask, N, h, w, b, max_comp, arena, /*expand*/ 3.0f, min_area, /*eps*/ 2.0f, st);
     }
     std::vector<int32_t> counts(N), ovf(N);
-    OCRS_HIP(hipMemcpyAsync(counts.data(), b.n_roots, N * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    OCRS_HIP(hipMemcpyAsync(ovf.data(), b.overflow, N * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    ws.download(counts.data(), b.n_roots, N * sizeof(int32_t));
+    ws.download(ovf.data(), b.overflow, N * sizeof(int32_t));
     ws.sync();
     for (int i = 0; i < N; i++)
         if (ovf[i] || counts[i] > max_comp)
             fail(OCRS_ERR_CAPACITY, "text mask of page %d has too many components or border pixels (%d components)", i,
                  counts[i]);
     rects_out->assign(n, {});
-    std::vector<float> hr;
-    std::vector<uint8_t> hv;
-    for (int i = 0; i < N; i++) {
+    std::vector<std::vector<float>> hr(N);
+    std::vector<std::vector<uint8_t>> hv(N);
+    for (int i = 0; i < N; i++) {  // all pages' results in one round trip
         const int cnt = counts[i];
         if (cnt == 0) continue;
-        hr.resize((size_t)cnt * 6);
-        hv.resize(cnt);
-        OCRS_HIP(hipMemcpyAsync(hr.data(), b.rects + (size_t)i * max_comp * 6, hr.size() * sizeof(float),
-                                hipMemcpyDeviceToHost, st));
-        OCRS_HIP(hipMemcpyAsync(hv.data(), b.valid + (size_t)i * max_comp, cnt, hipMemcpyDeviceToHost, st));
-        ws.sync();
+        hr[i].resize((size_t)cnt * 6);
+        hv[i].resize(cnt);
+        ws.download(hr[i].data(), b.rects + (size_t)i * max_comp * 6, hr[i].size() * sizeof(float));
+        ws.download(hv[i].data(), b.valid + (size_t)i * max_comp, cnt);
+    }
+    ws.sync();
+    for (int i = 0; i < N; i++) {
         auto& out = (*rects_out)[i];
-        for (int c = 0; c < cnt; c++)
-            if (hv[c]) out.push_back(RotatedRect::from_array(&hr[(size_t)c * 6]));
+        for (int c = 0; c < counts[i]; c++)
+            if (hv[i][c]) out.push_back(RotatedRect::from_array(&hr[i][(size_t)c * 6]));
     }
     if (T) T->collect();
 }
@@ -345,7 +345,7 @@ void ocrs_engine::recognize(const ocrs_page* const* pages, size_t n_pages,
             const size_t nb = ch.members.size();
             const uint32_t gw = ch.gw;
             std::vector<float> hin(nb * rec_h * gw), hout;
-            OCRS_HIP(hipMemcpyAsync(hin.data(), chunk_ptr(ch), hin.size() * sizeof(float), hipMemcpyDeviceToHost, st));
+            ws.download(hin.data(), chunk_ptr(ch), hin.size() * sizeof(float));
             ws.sync();
             const int64_t ishape[4] = {(int64_t)nb, 1, rec_h, gw};
             int64_t oshape[4];
@@ -390,9 +390,9 @@ void ocrs_engine::recognize(const ocrs_page* const* pages, size_t n_pages,
             }
             std::vector<uint32_t> hl((size_t)nb * Tn), hpz((size_t)nb * Tn);
             std::vector<int32_t> hc(nb);
-            OCRS_HIP(hipMemcpyAsync(hl.data(), d_ol, hl.size() * 4, hipMemcpyDeviceToHost, st));
-            OCRS_HIP(hipMemcpyAsync(hpz.data(), d_op, hpz.size() * 4, hipMemcpyDeviceToHost, st));
-            OCRS_HIP(hipMemcpyAsync(hc.data(), d_cnt, nb * 4, hipMemcpyDeviceToHost, st));
+            ws.download(hl.data(), d_ol, hl.size() * 4);
+            ws.download(hpz.data(), d_op, hpz.size() * 4);
+            ws.download(hc.data(), d_cnt, nb * 4);
             ws.sync();
             for (size_t j = 0; j < nb; j++) {
                 const size_t li = ch.members[j];
@@ -492,7 +492,7 @@ void ocrs_engine::recognize(const ocrs_page* const* pages, size_t n_pages,
                 sub.logp.resize((size_t)plan.R * C);
                 sub.off = hoff;
                 sub.Tmax = plan.Tmax;
-                OCRS_HIP(hipMemcpyAsync(sub.logp.data(), d_logp, sub.logp.size() * sizeof(float), hipMemcpyDeviceToHost, sst));
+                w.download(sub.logp.data(), d_logp, sub.logp.size() * sizeof(float), sst);
                 return;
             }
             // greedy CTC (recognition.rs:511)
@@ -508,9 +508,9 @@ void ocrs_engine::recognize(const ocrs_page* const* pages, size_t n_pages,
             sub.hl.resize((size_t)M * Tmax);
             sub.hp.resize((size_t)M * Tmax);
             sub.hc.resize(M);
-            OCRS_HIP(hipMemcpyAsync(sub.hl.data(), d_ol, sub.hl.size() * 4, hipMemcpyDeviceToHost, sst));
-            OCRS_HIP(hipMemcpyAsync(sub.hp.data(), d_op, sub.hp.size() * 4, hipMemcpyDeviceToHost, sst));
-            OCRS_HIP(hipMemcpyAsync(sub.hc.data(), d_cnt, (size_t)M * 4, hipMemcpyDeviceToHost, sst));
+            w.download(sub.hl.data(), d_ol, sub.hl.size() * 4, sst);
+            w.download(sub.hp.data(), d_op, sub.hp.size() * 4, sst);
+            w.download(sub.hc.data(), d_cnt, (size_t)M * 4, sst);
         };
         auto unpack = [&](const Sub& sub) {
             if (beam) {  // rten decode_beam (recognition.rs:512-514), host side, one thread per slice of lines
