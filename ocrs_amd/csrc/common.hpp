@@ -213,7 +213,6 @@ struct StageScope {
 struct Workspace {
     StreamLease stream;
     std::vector<DevBuf> bufs;
-    std::vector<std::vector<char>> host_keep;  // host staging that must outlive async uploads
     std::vector<hipEvent_t> events;            // cross-stream dependencies created by this call
     hipEvent_t make_event() {
         hipEvent_t e;
@@ -223,10 +222,15 @@ struct Workspace {
     }
     Workspace() = default;
     explicit Workspace(bool high_priority) : stream(high_priority) {}
-    // copy `bytes` from a host temporary to the device without a sync: the bytes are parked in the workspace
+    // copy `bytes` from a host temporary to the device without a sync: the bytes are parked in pinned staging
+    // owned by the workspace (released once its stream has drained), so the copy is a real asynchronous DMA
+    std::vector<void*> upload_staging;
     void upload(void* d_dst, const void* h_src, size_t bytes) {
-        host_keep.emplace_back((const char*)h_src, (const char*)h_src + bytes);
-        OCRS_HIP(hipMemcpyAsync(d_dst, host_keep.back().data(), bytes, hipMemcpyHostToDevice, stream.get()));
+        if (!bytes) return;
+        void* pin = host_pool().alloc(bytes);
+        memcpy(pin, h_src, bytes);
+        upload_staging.push_back(pin);
+        OCRS_HIP(hipMemcpyAsync(d_dst, pin, bytes, hipMemcpyHostToDevice, stream.get()));
     }
     // device -> host without blocking the caller: staged in pinned memory on `st` (default: this workspace's
     // stream) and handed to `h_dst` by the next sync() of this workspace — which must cover `st`
@@ -241,12 +245,14 @@ struct Workspace {
     hipStream_t s() const { return stream.get(); }
     void* alloc(size_t bytes) { bufs.emplace_back(bytes ? bytes : 4); return bufs.back().p; }
     template <class T> T* alloc_n(size_t n) { return static_cast<T*>(alloc(n * sizeof(T))); }
-    void finish_downloads(bool copy) {
+    void finish_downloads(bool copy) {  // call only after the stream has drained
         for (const Download& d : downloads) {
             if (copy) memcpy(d.dst, d.pinned, d.bytes);
             host_pool().release(d.pinned);
         }
         downloads.clear();
+        for (void* p : upload_staging) host_pool().release(p);
+        upload_staging.clear();
     }
     void sync() {
         stream.sync();
