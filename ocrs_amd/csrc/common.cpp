@@ -1,5 +1,6 @@
 #include "common.hpp"
 
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 
@@ -63,10 +64,17 @@ void* DevicePool::alloc(size_t bytes) {
         }
     }
     void* p = nullptr;
+    static const bool trace = getenv("OCRS_POOL_TRACE") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
     hipError_t e = hipMalloc(&p, sz);
     if (e != hipSuccess) {
         trim();
         OCRS_HIP(hipMalloc(&p, sz));
+    }
+    if (trace) {
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        const double now = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+        fprintf(stderr, "[pool] t=%.3f hipMalloc %.1f MB took %.2f ms\n", now, sz / 1e6, ms);
     }
     std::lock_guard<std::mutex> g(mu_);
     live_[p] = sz;
