@@ -63,6 +63,14 @@ OCRS_API void ocrs_buffer_free(void* p);
 OCRS_API ocrs_status ocrs_device_count(int* n);
 OCRS_API ocrs_status ocrs_set_device(int device);
 
+/* Process-wide integer tuning options (no reference counterpart: RTen's equivalents are compile-time).
+ * Each also reads its initial value from the environment variable OCRS_<NAME IN CAPITALS>.
+ *   "gru_mode"        0 = one persistent kernel per GRU layer (default), 1 = one launch per time step
+ *   "det_fuse"        1 = fused / LDS-tiled detection kernels (default), 0 = the unfused ones
+ *   "layout_threads"  host threads ocrs_engine_find_text_lines_batch may use (0 = automatic)
+ * Results never depend on an option; OCRS_ERR_INVALID_ARGUMENT for an unknown name. */
+OCRS_API ocrs_status ocrs_set_option(const char* name, long value);
+
 /* ------------------------------------------------------------------------
  * L2 seam: `trait Model` (ocrs/src/model.rs:6-17) and its rten impl
  * (model.rs:19-41).  A Rust `impl Model for HipModel` binds these four calls

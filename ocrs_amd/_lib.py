@@ -43,7 +43,7 @@ class OcrsError(RuntimeError):
 
 # Every symbol include/ocrs_amd.h declares (tests check they are all exported).
 DECLARED_SYMBOLS = [
-    "ocrs_last_error", "ocrs_buffer_free", "ocrs_device_count", "ocrs_set_device", "ocrs_model_load_file",
+    "ocrs_last_error", "ocrs_buffer_free", "ocrs_device_count", "ocrs_set_device", "ocrs_set_option", "ocrs_model_load_file",
     "ocrs_model_load_bytes", "ocrs_model_from_callback", "ocrs_model_input_shape", "ocrs_model_run",
     "ocrs_model_flops", "ocrs_model_free", "ocrs_engine_new", "ocrs_engine_free", "ocrs_image_source_check_bytes",
     "ocrs_engine_prepare_input", "ocrs_engine_prepare_input_device", "ocrs_page_free", "ocrs_page_dims",
@@ -98,6 +98,11 @@ def measure_peaks():
     a, b = C.c_double(0), C.c_double(0)
     check(lib().ocrs_device_measure_peaks(C.byref(a), C.byref(b)))
     return a.value, b.value
+
+
+def set_option(name, value):
+    """ocrs_set_option: process-wide tuning knob (results never depend on it)."""
+    check(lib().ocrs_set_option(name.encode(), C.c_long(int(value))))
 
 
 def require_gpu():

@@ -122,6 +122,12 @@ ocrs_status ocrs_set_device(int device) {
     return guarded([&] { select_device(device); });
 }
 
+ocrs_status ocrs_set_option(const char* name, long value) {
+    return guarded([&] {
+        if (!set_option(name, value)) fail(OCRS_ERR_INVALID_ARGUMENT, "unknown option '%s'", name ? name : "(null)");
+    });
+}
+
 // ------------------------------------------------------------------ models
 ocrs_status ocrs_model_load_bytes(const void* data, size_t len, ocrs_model** out) {
     return guarded([&] {

@@ -51,15 +51,29 @@ static size_t round_size(size_t n) {
     return ((n + step - 1) / step) * step;
 }
 
+// Cached (free) bytes above this are returned to the driver on release, largest blocks first: scratch sizes follow
+// the pages, so an unbounded cache would only be trimmed by the first failing hipMalloc.  OCRS_POOL_CAP_GB overrides.
+static size_t pool_cap_bytes() {
+    static const size_t cap = [] {
+        const char* e = getenv("OCRS_POOL_CAP_GB");
+        const double gb = e && *e ? atof(e) : 96.0;
+        return (size_t)(gb * (double)(size_t(1) << 30));
+    }();
+    return cap;
+}
+
 void* DevicePool::alloc(size_t bytes) {
     size_t sz = round_size(bytes);
     {
+        // smallest cached block that fits, if it wastes at most a quarter of the request
         std::lock_guard<std::mutex> g(mu_);
-        auto it = free_.find(sz);
-        if (it != free_.end()) {
+        auto it = free_.lower_bound(sz);
+        if (it != free_.end() && it->first <= sz + sz / 4) {
             void* p = it->second;
+            const size_t got = it->first;
             free_.erase(it);
-            live_[p] = sz;
+            cached_ -= got;
+            live_[p] = got;
             return p;
         }
     }
@@ -68,6 +82,7 @@ void* DevicePool::alloc(size_t bytes) {
     const auto t0 = std::chrono::steady_clock::now();
     hipError_t e = hipMalloc(&p, sz);
     if (e != hipSuccess) {
+        (void)hipGetLastError();  // the retry below decides; do not leave a stale out-of-memory for later checks
         trim();
         OCRS_HIP(hipMalloc(&p, sz));
     }
@@ -87,13 +102,21 @@ void DevicePool::release(void* p) {
     auto it = live_.find(p);
     if (it == live_.end()) return;
     free_.emplace(it->second, p);
+    cached_ += it->second;
     live_.erase(it);
+    while (cached_ > pool_cap_bytes() && !free_.empty()) {  // rare: hipFree synchronises the device
+        auto big = std::prev(free_.end());
+        (void)hipFree(big->second);
+        cached_ -= big->first;
+        free_.erase(big);
+    }
 }
 
 void DevicePool::trim() {
     std::lock_guard<std::mutex> g(mu_);
     for (auto& kv : free_) (void)hipFree(kv.second);
     free_.clear();
+    cached_ = 0;
 }
 
 DevicePool::~DevicePool() {
@@ -152,6 +175,50 @@ hipStream_t heavy_stream() {
         return h;
     }();
     return s;
+}
+
+hipStream_t recurrent_stream() {
+    static hipStream_t s = [] {
+        hipStream_t h;
+        int least = 0, greatest = 0;
+        OCRS_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        OCRS_HIP(hipStreamCreateWithPriority(&h, hipStreamNonBlocking, greatest));
+        return h;
+    }();
+    return s;
+}
+
+// ---------------------------------------------------------------- options
+namespace {
+struct OptDef { const char* name; const char* env; long def; };
+const OptDef kOptDefs[OPT_COUNT] = {
+    {"gru_mode", "OCRS_GRU_MODE", GRU_PERSISTENT},      // 0 persistent recurrence kernel, 1 one launch per time step
+    {"det_fuse", "OCRS_DET_FUSE", 1},                   // 1 fused/LDS-tiled detection kernels, 0 the unfused ones
+    {"layout_threads", "OCRS_LAYOUT_THREADS", 0},       // host threads of find_text_lines_batch (0 = automatic)
+};
+std::atomic<long> g_opts[OPT_COUNT];
+std::once_flag g_opts_once;
+void init_options() {
+    for (int i = 0; i < OPT_COUNT; i++) {
+        const char* e = getenv(kOptDefs[i].env);
+        g_opts[i].store(e && *e ? strtol(e, nullptr, 10) : kOptDefs[i].def);
+    }
+}
+}  // namespace
+
+int option(Option o) {
+    std::call_once(g_opts_once, init_options);
+    return (int)g_opts[o].load(std::memory_order_relaxed);
+}
+
+bool set_option(const char* name, long value) {
+    std::call_once(g_opts_once, init_options);
+    for (int i = 0; i < OPT_COUNT; i++)
+        if (name && strcmp(name, kOptDefs[i].name) == 0) {
+            g_opts[i].store(value);
+            return true;
+        }
+    return false;
 }
 
 // ---------------------------------------------------------------- streams

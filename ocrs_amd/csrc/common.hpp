@@ -63,6 +63,7 @@ class DevicePool {
     std::mutex mu_;
     std::multimap<size_t, void*> free_;
     std::map<void*, size_t> live_;
+    size_t cached_ = 0;  // bytes in free_
 };
 
 DevicePool& pool();
@@ -85,6 +86,17 @@ HostPool& host_pool();
 
 // One process-wide stream for the throughput-bound conv stacks of all in-flight requests (model.cpp).
 hipStream_t heavy_stream();
+// One process-wide stream for the persistent GRU recurrences (kernels_gru.hip): their workgroups wait on each
+// other, so they are serialised on the device; highest queue priority.
+hipStream_t recurrent_stream();
+
+// Process-wide tuning options (ocrs_set_option; initial value from the environment variable OCRS_<NAME>).
+// Integer-valued, looked up by name; unknown names are rejected by the ABI.
+enum Option { OPT_GRU_MODE = 0, OPT_DET_FUSE, OPT_LAYOUT_THREADS, OPT_COUNT };
+enum { GRU_PERSISTENT = 0, GRU_STEP = 1 };
+int option(Option o);
+bool set_option(const char* name, long value);  // false: unknown name
+inline int gru_mode() { return option(OPT_GRU_MODE); }
 
 // RAII device buffer from the pool.
 struct DevBuf {

@@ -434,6 +434,7 @@ void ocrs_engine::recognize(const ocrs_page* const* pages, size_t n_pages,
             std::vector<uint32_t> hl, hp;
             std::vector<int32_t> hc;
             int Tmax = 0;
+            uint32_t gru_status[8] = {0};  // time-out words of the persistent GRU kernels (0 = fine)
             std::vector<float> logp;      // beam search only: packed [R][C]
             std::vector<int32_t> off;     // beam search only
         };
@@ -455,6 +456,7 @@ void ocrs_engine::recognize(const ocrs_page* const* pages, size_t n_pages,
             const int M = (int)sub.slots.size();
             if (M == 0) return;
             HipModel::PackedPlan plan;
+            plan.h_status = sub.gru_status;
             plan.M = M;
             plan.Tmax = sub.slots[0].T;
             plan.active.assign(plan.Tmax, 0);
@@ -513,6 +515,8 @@ void ocrs_engine::recognize(const ocrs_page* const* pages, size_t n_pages,
             w.download(sub.hc.data(), d_cnt, (size_t)M * 4, sst);
         };
         auto unpack = [&](const Sub& sub) {
+            for (uint32_t st8 : sub.gru_status)
+                if (st8) fail(OCRS_ERR_DEVICE, "GRU recurrence kernel timed out waiting for a peer workgroup");
             if (beam) {  // rten decode_beam (recognition.rs:512-514), host side, one thread per slice of lines
                 const size_t M = sub.slots.size();
                 const unsigned nth = (unsigned)std::max<size_t>(1, std::min<size_t>({(size_t)std::thread::hardware_concurrency(), (size_t)32, M}));

@@ -102,6 +102,12 @@ void gru_gates_packed(const float* gx, const float* gh, float* h, float* y, cons
 bool gru_step_fused(const float* gx, const float* wh, const float* bh, const float* hT_in, float* hT_out, float* y,
                     const int32_t* d_Tm, const int32_t* d_off, int64_t R, int Mcap, int active, int H, int step,
                     hipStream_t s);
+// ---- kernels_gru.hip: all time steps of one bidirectional GRU layer in ONE persistent launch.
+// d_sync: gru_persistent_sync_words(M) words of scratch (zeroed by the call); its last word is non-zero
+// afterwards if a wait inside the kernel timed out.  Returns false if H is unsupported.
+size_t gru_persistent_sync_words(int M);
+bool gru_persistent(const float* gx, const float* wh, const float* bh, float* y, const int32_t* d_Tm, const int32_t* d_off,
+                    int64_t R, int M, int H, uint32_t* d_sync, hipStream_t s);
 void ctc_collapse_packed(const int32_t* labels, const int32_t* d_Tm, const int32_t* d_off, int M, int Tmax,
                          uint32_t* out_labels, uint32_t* out_pos, int32_t* out_count, hipStream_t s);
 void argmax_rows(const float* x, int64_t rows, int c, const uint8_t* d_excluded, int32_t* labels, hipStream_t s);

@@ -1,0 +1,274 @@
+// Persistent bidirectional-GRU recurrence on the packed ("ragged") sequence batch
+// (the sequential part of TextRecognizer::run, ocrs/src/recognition.rs:341-360).
+//
+// ONE launch per GRU layer replaces the chain of Tmax dependent launches of gru_step_fused
+// (kernels_nn.hip).  Numerics are unchanged: per output
+//     gh = bh;  gh = fmaf(h[k], Wh[k][j], gh)  for k ascending  (v_mfma_f32_16x16x4_f32 chain)
+//     r = sigma(gx_r + gh_r), z = sigma(gx_z + gh_z), n = tanh(fmaf(r, gh_n, gx_n)), h' = fmaf(z, h - n, n).
+//
+// Decomposition.  Rows (text lines, sorted by sequence length descending) are cut into 16-row
+// tiles; the H hidden units into UB = H/16 slices.  A workgroup = 4 waves that share ONE 16-unit
+// slice of Wh (H x 48 floats, staged into LDS once for all T steps) and serve 4*RT row tiles
+// (wave w: tiles base + w, base + 4 + w, ...).  The UB workgroups that own the slices of the same
+// rows form a "cluster"; the only data they exchange is the new hidden state of their rows.
+//
+// Exchange = the layer's own output.  y[row(t, m)][dir*H + unit] has to be written anyway; a wave
+// writes its 16 rows x 16 units with 16-byte WRITE-THROUGH stores, drains them (s_waitcnt vmcnt(0))
+// and bumps the arrival counter of (dir, tile).  The UB waves that need the tile's full state for the
+// next step poll that one counter (relaxed, agent scope), then read the y rows of the previous step
+// with cache-bypassing loads (MI355X_MICROARCH.md "inter-workgroup visibility", form R1: write-through
+// payload + drained flag on the producer, relaxed poll + bypassing loads on the consumer).  No grid
+// barrier: tiles never wait for each other, and nothing depends on workgroup placement or order
+// (blocks of a cluster are merely steered to one XCD for speed).  Every wait is bounded: on a
+// time-out the kernel raises the error word and returns, the host reports OCRS_ERR_DEVICE.
+//
+// MFMA roles.  D = A.B with A = Wh^T (16 units x 4 k, from LDS) and B = h^T (4 k x 16 rows, from
+// registers), so a lane ends up with 4 CONSECUTIVE units of one row: the epilogue's gx reads and
+// the y store are one 16-byte access per gate / per lane in the natural layouts.  The B operand
+// wants lane (row, kq) to hold h[row][4*s + kq]; rows are fetched as 16-byte pieces and turned by a
+// 4x4 transpose across the four 16-lane groups (v_permlane16_swap / v_permlane32_swap).
+#include "kernels.hpp"
+#include "spec_math.hpp"
+
+namespace ocrs {
+namespace k {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+struct GruParams {
+    const float* gx;     // [2][R][3H] input projections (+ bi), natural column order (r | z | n)
+    const float* wh;     // [2][H][3H]
+    const float* bh;     // [2][3H]
+    float* y;            // [R][2H]
+    const int32_t* Tm;   // [M] sequence length of line m (descending)
+    const int32_t* off;  // [Tmax + 1] first packed row of time t
+    uint32_t* sync;      // [2 * ntiles] arrival counters, then [1] error word; zeroed before the launch
+    int64_t R;
+    int M, ntiles, RT, ncl;
+    uint32_t spin_limit;
+};
+
+// cache-bypassing 16-byte accesses (volatile => sc0 sc1 on gfx950: write-through store / L1-bypassing load)
+// Always GLOBAL (address_space(1)) instructions: a flat access would also tick lgkmcnt and take the slower path.
+typedef __attribute__((address_space(1))) f32x4 gf32x4;
+typedef __attribute__((address_space(1))) uint32_t gu32;
+__device__ __forceinline__ f32x4 load_bypass(const float* p) { return *(const volatile gf32x4*)p; }
+__device__ __forceinline__ void store_through(float* p, f32x4 v) { *(volatile gf32x4*)p = v; }
+
+// 4x4 transpose between (register e, 16-lane group g):  out[a] in group g  =  in[g] of group a
+__device__ __forceinline__ void transpose4(const f32x4& in, float* out) {
+    const unsigned v0 = __float_as_uint(in[0]), v1 = __float_as_uint(in[1]);
+    const unsigned v2 = __float_as_uint(in[2]), v3 = __float_as_uint(in[3]);
+    // permlane16_swap(a, b): a's odd 16-lane rows <-> b's even rows
+    const u32x2 p01 = __builtin_amdgcn_permlane16_swap(v0, v1, false, false);
+    const u32x2 p23 = __builtin_amdgcn_permlane16_swap(v2, v3, false, false);
+    // permlane32_swap(a, b): a's rows 2,3 <-> b's rows 0,1
+    const u32x2 q02 = __builtin_amdgcn_permlane32_swap(p01[0], p23[0], false, false);
+    const u32x2 q13 = __builtin_amdgcn_permlane32_swap(p01[1], p23[1], false, false);
+    out[0] = __uint_as_float(q02[0]);
+    out[1] = __uint_as_float(q13[0]);
+    out[2] = __uint_as_float(q02[1]);
+    out[3] = __uint_as_float(q13[1]);
+}
+
+template <int H>
+struct Loaded {             // everything one (tile, step) item reads from memory
+    f32x4 h[H / 16];        // lane (row, kq): pieces q = 4j + kq of the row's previous state
+    f32x4 hp;               // previous state of this lane's own 4 units
+    f32x4 gr, gz, gn;       // gx of this lane's 4 units
+    int64_t row;            // packed output row
+    bool active;
+};
+
+template <int H>
+__device__ __forceinline__ bool issue_loads(const GruParams& p, int dir, int ub, int tile, int s, int i16, int kq,
+                                            Loaded<H>& L) {
+    const int m = tile * 16 + i16;
+    const int tm = m < p.M ? p.Tm[m] : 0;
+    L.active = tm > s;
+    const int t = dir ? tm - 1 - s : s;
+    L.row = L.active ? (int64_t)p.off[t] + m : 0;
+    const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+    L.gr = L.gz = L.gn = zero;
+    if (L.active) {
+        const float* g = p.gx + ((int64_t)dir * p.R + L.row) * 3 * H + ub * 16 + kq * 4;
+        L.gr = *reinterpret_cast<const f32x4*>(g);
+        L.gz = *reinterpret_cast<const f32x4*>(g + H);
+        L.gn = *reinterpret_cast<const f32x4*>(g + 2 * H);
+    }
+    L.hp = zero;
+#pragma unroll
+    for (int j = 0; j < H / 16; j++) L.h[j] = zero;
+    if (s == 0) return true;  // h(-1) = 0
+    // every slice of this tile's previous step must have landed: UB arrivals per step
+    gu32* ctr = (gu32*)(p.sync + (size_t)dir * p.ntiles + tile);
+    const uint32_t target = (uint32_t)(H / 16) * (uint32_t)s;
+    for (uint32_t spins = 0;; spins++) {
+        const uint32_t v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        if (v >= target) break;
+        __builtin_amdgcn_s_sleep(1);
+        if ((spins & 1023u) == 1023u) {
+            gu32* err = (gu32*)(p.sync + (size_t)2 * p.ntiles);
+            const uint32_t e = __builtin_amdgcn_readfirstlane(__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            if (e != 0 || spins >= p.spin_limit) {
+                __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return false;
+            }
+        }
+    }
+    asm volatile("" ::: "memory");
+    if (L.active) {
+        const int tp = dir ? tm - s : s - 1;
+        const float* yp = p.y + ((int64_t)p.off[tp] + m) * 2 * H + dir * H;
+#pragma unroll
+        for (int j = 0; j < H / 16; j++) L.h[j] = load_bypass(yp + 16 * j + 4 * kq);
+        L.hp = load_bypass(yp + ub * 16 + kq * 4);
+    }
+    return true;
+}
+
+template <int H>
+__device__ __forceinline__ void compute_item(const GruParams& p, int dir, int ub, int tile, int i16, int kq, int lane,
+                                             const Loaded<H>& L, const float (&w)[H / 4], const float* lds_w,
+                                             const f32x4& br, const f32x4& bz, const f32x4& bn) {
+    f32x4 acc_r = br, acc_z = bz, acc_n = bn;
+    // A operand: lane (unit c = i16, kq) feeds Wh[4*s4 + kq][g*H + 16ub + c].  LDS holds, per (gate, block of 4
+    // steps), one 16-byte piece per lane (lds_slot()): a conflict-free ds_read_b128 fetches 4 steps of one gate.
+    // Reads run one block ahead of the MFMAs that consume them.
+    const f32x4* ap = reinterpret_cast<const f32x4*>(lds_w) + lane;
+    f32x4 ar = ap[0], az = ap[(H / 16) * 64], an = ap[2 * (H / 16) * 64];
+#pragma unroll
+    for (int blk = 0; blk < H / 16; blk++) {
+        f32x4 nr = ar, nz = az, nn = an;
+        if (blk + 1 < H / 16) {
+            nr = ap[(blk + 1) * 64];
+            nz = ap[((H / 16) + blk + 1) * 64];
+            nn = ap[(2 * (H / 16) + blk + 1) * 64];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const float b = w[4 * blk + e];
+            acc_r = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[e], b, acc_r, 0, 0, 0);
+            acc_z = __builtin_amdgcn_mfma_f32_16x16x4f32(az[e], b, acc_z, 0, 0, 0);
+            acc_n = __builtin_amdgcn_mfma_f32_16x16x4f32(an[e], b, acc_n, 0, 0, 0);
+        }
+        ar = nr; az = nz; an = nn;
+    }
+    // D layout 16x16: lane holds D[i = 4*kq + r][j = i16] = unit 16ub + 4kq + r of row i16
+    if (L.active) {
+        f32x4 hn;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const float rg = spec_sigmoidf(L.gr[r] + acc_r[r]);
+            const float zg = spec_sigmoidf(L.gz[r] + acc_z[r]);
+            const float ng = spec_tanhf(fmaf(rg, acc_n[r], L.gn[r]));
+            hn[r] = fmaf(zg, L.hp[r] - ng, ng);
+        }
+        store_through(p.y + L.row * 2 * H + dir * H + ub * 16 + kq * 4, hn);
+    }
+    // publish: every byte this wave stored has left the CU before the counter moves
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0)
+        __hip_atomic_fetch_add((gu32*)(p.sync + (size_t)dir * p.ntiles + tile), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int H>
+__global__ void __launch_bounds__(256)
+gru_persistent_kernel(GruParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds_w[];  // H*48 floats, layout below
+    constexpr int UB = H / 16;
+    // blocks of one cluster share blockIdx % 8 (observed: block b runs on XCD b % 8 — speed only)
+    const int b = blockIdx.x;
+    const int q = b >> 3;
+    const int ub = q % UB;
+    const int cid = (q / UB) * 8 + (b & 7);
+    if (cid >= 2 * p.ncl) return;
+    const int dir = cid & 1, cl = cid >> 1;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i16 = lane & 15, kq = lane >> 4;
+    const float* __restrict__ whd = p.wh + (int64_t)dir * H * 3 * H;
+    const float* __restrict__ bhd = p.bh + (int64_t)dir * 3 * H;
+    const int j0 = ub * 16;
+    // the Wh slice [:, g*H + j0 .. +16) for g = r,z,n -> LDS, once: element (k = 16*blk + 4*e + kq, gate g, unit c)
+    // sits at float ((g*(H/16) + blk)*64 + kq*16 + c)*4 + e
+    for (int i = tid; i < H * 12; i += 256) {
+        const int k = i / 12, qq = i - k * 12;
+        const int g = qq >> 2, c4 = (qq & 3) * 4;
+        const float4 v = *reinterpret_cast<const float4*>(whd + (int64_t)k * 3 * H + g * H + j0 + c4);
+        const int blk = k >> 4, e = (k >> 2) & 3, kk = k & 3;
+        float* dst = &lds_w[(((g * (H / 16) + blk) * 64) + kk * 16 + c4) * 4 + e];
+        dst[0] = v.x; dst[4] = v.y; dst[8] = v.z; dst[12] = v.w;
+    }
+    const f32x4 br = *reinterpret_cast<const f32x4*>(bhd + j0 + kq * 4);
+    const f32x4 bz = *reinterpret_cast<const f32x4*>(bhd + H + j0 + kq * 4);
+    const f32x4 bn = *reinterpret_cast<const f32x4*>(bhd + 2 * H + j0 + kq * 4);
+    __syncthreads();
+    __builtin_amdgcn_s_setprio(3);  // a short dependent chain: outrank co-resident throughput kernels at issue
+
+    const int base = cl * 4 * p.RT + wave;  // this wave's tiles: base, base + 4, ...
+    auto tile_T = [&](int i) -> int {       // steps of the wave's i-th tile (its first row is its longest)
+        const int tile = base + 4 * i;
+        return (i < p.RT && tile < p.ntiles) ? p.Tm[tile * 16] : 0;
+    };
+    if (tile_T(0) <= 0) return;
+    // items in (step, tile) order; the loads of the NEXT item are issued before the current one is
+    // computed whenever it belongs to another tile (its inputs cannot depend on the current item)
+    int s = 0, i = 0;
+    Loaded<H> cur, nxt;
+    if (!issue_loads<H>(p, dir, ub, base, 0, i16, kq, cur)) return;
+    for (;;) {
+        int ns = s, ni = i + 1;
+        if (tile_T(ni) <= s) { ns = s + 1; ni = 0; }
+        const bool have_next = tile_T(ni) > ns;
+        const bool early = have_next && ni != i;
+        // B operand: lane (row, kq) feeds h[row][4*s4 + kq].  Turned BEFORE the next item's loads are issued so
+        // that those can land in the registers the pieces leave behind.
+        float w[H / 4];
+#pragma unroll
+        for (int j = 0; j < H / 16; j++) transpose4(cur.h[j], &w[4 * j]);
+        if (early && !issue_loads<H>(p, dir, ub, base + 4 * ni, ns, i16, kq, nxt)) return;
+        compute_item<H>(p, dir, ub, base + 4 * i, i16, kq, lane, cur, w, lds_w, br, bz, bn);
+        if (!have_next) break;
+        if (!early && !issue_loads<H>(p, dir, ub, base + 4 * ni, ns, i16, kq, nxt)) return;
+        cur = nxt;
+        s = ns;
+        i = ni;
+    }
+}
+
+}  // namespace
+
+size_t gru_persistent_sync_words(int M) { return (size_t)2 * ((M + 15) / 16) + 1; }
+
+bool gru_persistent(const float* gx, const float* wh, const float* bh, float* y, const int32_t* d_Tm, const int32_t* d_off,
+                    int64_t R, int M, int H, uint32_t* d_sync, hipStream_t s) {
+    if (M <= 0) return true;
+    if (H != 256 && H != 128 && H != 64) return false;
+    GruParams p{};
+    p.gx = gx; p.wh = wh; p.bh = bh; p.y = y; p.Tm = d_Tm; p.off = d_off; p.sync = d_sync;
+    p.R = R; p.M = M;
+    p.ntiles = (M + 15) / 16;
+    const int UB = H / 16;
+    // at most ~256 workgroups (one per CU: every workgroup of a cluster must be resident at once)
+    const int max_cids = 256 / UB >= 2 ? 256 / UB : 2;          // clusters x directions
+    const int max_ncl = max_cids / 2;
+    p.RT = (p.ntiles + 4 * max_ncl - 1) / (4 * max_ncl);
+    p.ncl = (p.ntiles + 4 * p.RT - 1) / (4 * p.RT);
+    p.spin_limit = 4u << 20;  // polls of >= ~0.5 us each: seconds, far beyond any legitimate wait
+    const int groups = (2 * p.ncl + 7) / 8;
+    const dim3 grid(8 * UB * groups);
+    const size_t lds = (size_t)H * 48 * sizeof(float);
+    (void)hipMemsetAsync(d_sync, 0, gru_persistent_sync_words(M) * sizeof(uint32_t), s);
+    if (H == 256) hipLaunchKernelGGL((gru_persistent_kernel<256>), grid, dim3(256), lds, s, p);
+    else if (H == 128) hipLaunchKernelGGL((gru_persistent_kernel<128>), grid, dim3(256), lds, s, p);
+    else hipLaunchKernelGGL((gru_persistent_kernel<64>), grid, dim3(256), lds, s, p);
+    return true;
+}
+
+}  // namespace k
+}  // namespace ocrs

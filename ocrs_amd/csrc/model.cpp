@@ -2,6 +2,7 @@
 
 #include <cstdio>
 #include <map>
+#include <mutex>
 
 #include "kernels.hpp"
 
@@ -711,7 +712,22 @@ int HipModel::run_recognition_packed(Workspace& ws, const std::vector<PackedGrou
     {
         // all conv stacks go through ONE stream, in request order, without host waits
         std::lock_guard<std::mutex> heavy(heavy_phase);
-        X = run_prefix_ragged(ws, heavy_stream(), groups, plan, h, ts, timers, &C0);
+        try {
+            X = run_prefix_ragged(ws, heavy_stream(), groups, plan, h, ts, timers, &C0);
+        } catch (...) {
+            // Kernels of this request may already be queued on the shared stream, reading and writing scratch
+            // that ~Workspace hands back to the pool after draining only the request's OWN stream: make that
+            // stream wait for them first (best effort, no throw on the error path).
+            hipEvent_t e = nullptr;
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess) {
+                ws.events.push_back(e);
+                if (hipEventRecord(e, heavy_stream()) != hipSuccess || hipStreamWaitEvent(ws.s(), e, 0) != hipSuccess)
+                    (void)hipStreamSynchronize(heavy_stream());
+            } else {
+                (void)hipStreamSynchronize(heavy_stream());
+            }
+            throw;
+        }
     }
     if (!X)
     for (const PackedGroup& g : groups) {
@@ -731,6 +747,7 @@ int HipModel::run_recognition_packed(Workspace& ws, const std::vector<PackedGrou
     const float* cur = X;
     int curC = C0;
     int classes = 0;
+    int gru_layer = 0;
     for (size_t i = ts + 1; i < ops.size(); i++) {
         const GraphOp& op = ops[i];
         if (op.type == OP_GRU) {
@@ -746,23 +763,29 @@ int HipModel::run_recognition_packed(Workspace& ws, const std::vector<PackedGrou
             timed(KC_GEMM_GRU_INPUT, 2.0 * 2 * R * (double)d.N * d.K, 4.0 * ((double)R * I + 2.0 * R * d.N + 2.0 * d.K * d.N),
                   [&] { k::gemm(d, st); });
             const bool fused = (H == 256 || H == 128 || H == 64);
-            if (fused) {
-                // transposed, ping-ponged state hT[2 dirs][H][Mcap]
-                const int Mcap = (M + 3) & ~3;
-                float* hT0 = ws.alloc_n<float>((size_t)2 * H * Mcap);
-                float* hT1 = ws.alloc_n<float>((size_t)2 * H * Mcap);
-                OCRS_HIP(hipMemsetAsync(hT0, 0, (size_t)2 * H * Mcap * sizeof(float), st));
-                for (int step = 0; step < plan.Tmax; step++) {
-                    const int act = plan.active[step];
-                    if (act <= 0) break;
-                    const float* hin = (step & 1) ? hT1 : hT0;
-                    float* hout = (step & 1) ? hT0 : hT1;
-                    timed(KC_GEMM_GRU_HIDDEN, 2.0 * 2 * act * 3.0 * H * H,
-                          4.0 * 2 * ((double)act * H * 2 + (double)act * 3 * H + 3.0 * H * H + (double)act * H), [&] {
-                              k::gru_step_fused(gx, op.aux2, op.aux3, hin, hout, y, plan.d_Tm, plan.d_off, R, Mcap, act, H, step, st);
-                          });
+            if (fused && gru_mode() == GRU_PERSISTENT) {
+                // ONE launch for all Tmax steps of both directions (kernels_gru.hip).  Its workgroups wait on
+                // each other, so two such kernels must never be half-resident at the same time: every request's
+                // recurrences go through one process-wide stream (FIFO on the GPU, linked by events, no host wait).
+                uint32_t* d_sync = ws.alloc_n<uint32_t>(k::gru_persistent_sync_words(M));
+                double fl = 0.0;
+                for (int step = 0; step < plan.Tmax; step++) fl += 2.0 * 2 * plan.active[step] * 3.0 * H * H;
+                {
+                    static std::mutex rec_phase;
+                    std::lock_guard<std::mutex> g(rec_phase);
+                    hipStream_t rs = recurrent_stream();
+                    hipEvent_t ready = ws.make_event(), done = ws.make_event();
+                    OCRS_HIP(hipEventRecord(ready, st));
+                    OCRS_HIP(hipStreamWaitEvent(rs, ready, 0));
+                    int ktok = timers ? timers->kbegin(KC_GEMM_GRU_HIDDEN, rs, fl, 4.0 * ((double)R * (2.0 * 3 * H + 2.0 * 2 * H) + 2.0 * 3 * H * H)) : -1;
+                    k::gru_persistent(gx, op.aux2, op.aux3, y, plan.d_Tm, plan.d_off, R, M, H, d_sync, rs);
+                    if (ktok >= 0) timers->end(ktok, rs);
+                    if (plan.h_status && gru_layer < 8) ws.download(plan.h_status + gru_layer, d_sync + k::gru_persistent_sync_words(M) - 1, sizeof(uint32_t), rs);
+                    OCRS_HIP(hipEventRecord(done, rs));
+                    OCRS_HIP(hipStreamWaitEvent(st, done, 0));
                 }
-            } else {
+            } else if (fused) {
+                // one launch per time step: transposed, ping-ponged state            } else {
                 float* gh = ws.alloc_n<float>((size_t)2 * M * 3 * H);
                 float* hs = ws.alloc_n<float>((size_t)2 * M * H);
                 OCRS_HIP(hipMemsetAsync(hs, 0, (size_t)2 * M * H * sizeof(float), st));
@@ -782,6 +805,7 @@ int HipModel::run_recognition_packed(Workspace& ws, const std::vector<PackedGrou
                 }
             }
             if (tok >= 0) timers->end(tok, st);
+            gru_layer++;
             cur = y;
             curC = 2 * H;
         } else if (op.type == OP_LINEAR) {

@@ -92,6 +92,8 @@ struct HipModel : ModelBase {
         const int32_t* d_Tm = nullptr;   // [M]
         const int32_t* d_off = nullptr;  // [Tmax + 1]
         std::vector<int> active;         // [Tmax] host
+        uint32_t* h_status = nullptr;    // host [8]: slot i receives the time-out word of the i-th GRU layer's
+                                         // persistent kernel after the workspace's next sync (0 = fine)
     };
     // Writes arg-max labels of every packed row to d_labels [R]; returns class count.
     // d_logp (optional): receives the packed log-probabilities [R][classes] (model output, unmasked).

@@ -82,3 +82,49 @@ def test_gpu_reproduces_recognition_golden():
     lp = Model.load_bytes(M.recognition_model_bytes()).run(x)
     assert np.array_equal(lp.argmax(-1).astype(np.uint8), g["argmax"])
     assert _bits_sum(lp) == int(g["logp_bits_sum"][0])
+
+
+# ---- bench-scale fixtures (tests/golden/make_golden_bench.py): CPU drift guards --------------------------------
+def test_oracle_and_host_layout_reproduce_bench_page_golden():
+    """Seed-0 bench page (1024x1024, 80 lines): the oracle's exact detection still gives the golden word rects, and
+    the PRODUCT's host layout analysis (layout.cpp through the C ABI, no GPU work) groups them into the golden lines
+    (layout_analysis.rs:19-233 at the bench's ~700 words/page)."""
+    from ocrs_amd import OcrEngine, synth
+    g = np.load(os.path.join(G, "bench_page_seed0.npz"))
+    dbuf, rbuf = M.detection_model_bytes(), M.recognition_model_bytes()
+    assert [M.digest(dbuf), M.digest(rbuf)] == list(g["model_digests"]), "synthetic model files changed: regenerate goldens"
+    ora = OP.OcrEngine(detection_model=OracleModel(OracleGraph(dbuf), "exact"))
+    px = synth.synthetic_page(0, 1024, 1024, lines=80)
+    words = ora.detect_words(ora.prepare_input(OP.ImageSource.from_tensor(px, "hwc")))
+    assert np.array_equal(np.array([w.to_array() for w in words], np.float32).reshape(-1, 6), g["word_rects"])
+    lines = OcrEngine().find_text_lines(None, g["word_rects"])
+    assert np.array_equal(np.cumsum([0] + [len(l) for l in lines]), g["line_offsets"])
+    assert np.array_equal(np.concatenate(lines), g["line_rects"])
+
+
+def test_oracle_reproduces_bench_crops_golden_sample():
+    """configs[2] fixture: the first 40 of the 2048 crops through the oracle (crop -> width group 300 -> CRNN -> CTC)."""
+    from ocrs_amd import synth
+    from oracle import clib
+    from oracle.geometry import RotatedRect
+    g = np.load(os.path.join(G, "bench_crops_2048.npz"))
+    rbuf = M.recognition_model_bytes()
+    assert [M.digest(rbuf)] == list(g["model_digests"])
+    n = 40
+    crops = synth.synthetic_line_crops(1000, n=2048)[:n]
+    page = (crops.reshape(1, n * 64, 256) + 0.5).astype(np.float32)
+    ora = OP.OcrEngine(recognition_model=OracleModel(OracleGraph(rbuf), "exact"))
+    inp = ora.prepare_input(OP.ImageSource.from_tensor(page, "chw"))
+    rec = ora.recognizer
+    to = g["token_offsets"]
+    for c0 in range(0, n, 20):
+        batch = np.full((20, 1, 64, 300), -0.5, np.float32)
+        for i in range(20):
+            line = [RotatedRect.from_array(np.array([128.0, (c0 + i) * 64.0 + 32.0, 0.0, 1.0, 256.0, 64.0], np.float32))]
+            poly, rw = rec._line_geometry(line)
+            assert rw == 256
+            clib.prepare_text_line_into(inp[0], [(p[1], p[0]) for p in poly], rw, 64, batch[i, 0])
+        out = rec.run(batch)
+        for i in range(20):
+            steps = np.array(clib.ctc_greedy(out[i]), np.int32).reshape(-1, 2)
+            assert np.array_equal(steps, g["tokens"][to[c0 + i]:to[c0 + i + 1]])

@@ -1,0 +1,173 @@
+"""GPU parity at the BENCHMARKED configurations (BASELINE.json configs[2] and configs[3]), against golden
+fixtures the CPU oracle produced in `exact` mode (tests/golden/make_golden_bench.py; the oracle needs ~16 s of CPU
+per page, the fixtures make the comparison free on the GPU box).
+
+  * configs[3]: bench.py's exact call sequence — 16 pages of 1024x1024 (seeds 0..15, 80 lines) resident in HBM,
+    prepare_input_device -> detect_words_batch -> find_text_lines_batch_raw -> recognize_text_batch_raw, 6 whole
+    steps in flight on 6 host threads — every page's word rects, line grouping, char boxes and text equal to
+    the oracle's; the CTC steps (label, pos) of every line through ocrs_engine_recognize_tokens.
+  * configs[2]: 2048 crops 64x256 -> width group 300 (T = 75): CTC steps and char boxes of all 2048 lines.
+  * both GRU execution modes (persistent kernel / one launch per step) give the same bits.
+
+Bit-exact: integer / index results with ==, float rects with array_equal (ocrs/src/lib.rs:466-488-style exactness).
+"""
+import ctypes as C
+import os
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+import models_util as M
+from ocrs_amd import DimOrder, ImageSource, Model, OcrEngine, _lib, synth
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+N_PAGES = 16
+
+
+@pytest.fixture(scope="module")
+def engine():
+    _lib.require_gpu()
+    dbuf, rbuf = M.detection_model_bytes(), M.recognition_model_bytes()
+    eng = OcrEngine(detection_model=Model.load_bytes(dbuf), recognition_model=Model.load_bytes(rbuf))
+    eng._digests = (M.digest(dbuf), M.digest(rbuf))
+    return eng
+
+
+def _golden_page(seed, digests):
+    path = os.path.join(GOLD, "bench_page_seed%d.npz" % seed)
+    if not os.path.exists(path):
+        return None
+    g = np.load(path)
+    assert tuple(g["model_digests"]) == digests, "fixture was made with other model files: re-run make_golden_bench.py"
+    return g
+
+
+def _upload(pages):
+    L = _lib.lib()
+    dptrs = []
+    for pg in pages:
+        p = C.c_void_p()
+        _lib.check(L.ocrs_device_malloc(C.c_size_t(pg.nbytes), C.byref(p)))
+        _lib.check(L.ocrs_device_upload(p, pg.ctypes.data_as(C.c_void_p), C.c_size_t(pg.nbytes)))
+        dptrs.append(p)
+    return dptrs
+
+
+def _check_page_against_golden(g, words, rects, loffs, lo, hi, chars, coffs):
+    assert np.array_equal(words, g["word_rects"])
+    gl = g["line_offsets"]
+    assert hi - lo == len(gl) - 1
+    base = int(loffs[lo])
+    assert np.array_equal(np.asarray(loffs[lo:hi + 1], np.int64) - base, gl)
+    assert np.array_equal(rects[base:int(loffs[hi])], g["line_rects"])
+    gc, gco = g["chars"], g["char_offsets"]
+    cbase = int(coffs[lo])
+    assert np.array_equal(np.asarray(coffs[lo:hi + 1], np.int64) - cbase, gco)
+    mine = chars[cbase:int(coffs[hi])]
+    got = np.stack([mine["ch"].astype(np.int64), mine["top"], mine["left"], mine["bottom"], mine["right"]], axis=1)
+    assert np.array_equal(got, gc.astype(np.int64))
+
+
+def test_full_pipeline_bench_sequence_16_pages_6_steps_in_flight(engine):
+    L = _lib.lib()
+    pages = [synth.synthetic_page(s, 1024, 1024, lines=80) for s in range(N_PAGES)]
+    dptrs = _upload(pages)
+
+    def step(_=None):
+        inputs = [engine.prepare_input_device(p.value, np.uint8, DimOrder.Hwc, 1024, 1024, 3) for p in dptrs]
+        words = engine.detect_words_batch(inputs)
+        rects, loffs, poffs = engine.find_text_lines_batch_raw(words)
+        chars, coffs = engine.recognize_text_batch_raw(inputs, rects, loffs, poffs)
+        return words, rects, loffs, poffs, chars, coffs
+
+    with ThreadPoolExecutor(max_workers=6) as ex:   # 6 whole steps in flight, as bench.py runs them
+        outs = list(ex.map(step, range(12)))
+    words, rects, loffs, poffs, chars, coffs = outs[0]
+    for o in outs[1:]:   # every in-flight step gives the same bits
+        assert all(np.array_equal(a, b) for a, b in zip(o[0], words))
+        assert np.array_equal(o[1], rects) and np.array_equal(o[2], loffs) and np.array_equal(o[3], poffs)
+        assert np.array_equal(o[4], chars) and np.array_equal(o[5], coffs)
+    assert len(loffs) - 1 > 70 * N_PAGES and len(chars) > 2500 * N_PAGES
+    checked = 0
+    for pi in range(N_PAGES):
+        g = _golden_page(pi, engine._digests)
+        if g is None:
+            continue
+        _check_page_against_golden(g, words[pi], rects, loffs, int(poffs[pi]), int(poffs[pi + 1]), chars, coffs)
+        checked += 1
+    assert checked >= 2
+    for p in dptrs:
+        _lib.check(L.ocrs_device_free(p))
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_ctc_steps_of_bench_pages_match_golden(engine, seed):
+    g = _golden_page(seed, engine._digests)
+    assert g is not None
+    px = synth.synthetic_page(seed, 1024, 1024, lines=80)
+    inp = engine.prepare_input(ImageSource.from_tensor(px, DimOrder.Hwc))
+    lo = g["line_offsets"]
+    lines = [g["line_rects"][lo[i]:lo[i + 1]] for i in range(len(lo) - 1)]
+    toks = engine.recognize_tokens(inp, lines)
+    to = g["token_offsets"]
+    assert len(toks) == len(to) - 1
+    for i, t in enumerate(toks):
+        assert np.array_equal(np.array(t, np.int32).reshape(-1, 2), g["tokens"][to[i]:to[i + 1]]), i
+
+
+def _crops_request(engine):
+    n = 2048
+    crops = synth.synthetic_line_crops(1000, n=n)
+    page = (crops.reshape(1, n * 64, 256) + 0.5).astype(np.float32)
+    inp = engine.prepare_input(ImageSource.from_tensor(page, DimOrder.Chw))
+    rects = np.zeros((n, 6), np.float32)
+    rects[:, 0] = 128.0
+    rects[:, 1] = np.arange(n) * 64.0 + 32.0
+    rects[:, 2], rects[:, 3] = 0.0, 1.0
+    rects[:, 4], rects[:, 5] = 256.0, 64.0
+    return inp, rects, n
+
+
+def test_recognition_only_2048_crops_match_golden(engine):
+    """configs[2], exactly as bench.py's recognition-only leg issues it (one request of 2048 lines)."""
+    g = np.load(os.path.join(GOLD, "bench_crops_2048.npz"))
+    assert tuple(g["model_digests"]) == engine._digests[1:]
+    inp, rects, n = _crops_request(engine)
+    loffs = np.arange(n + 1, dtype=np.uintp)
+    chars, coffs = engine.recognize_text_batch_raw([inp], rects, loffs, np.array([0, n], dtype=np.uintp))
+    assert np.array_equal(np.asarray(coffs, np.int64), g["char_offsets"])
+    got = np.stack([chars["ch"].astype(np.int64), chars["top"], chars["left"], chars["bottom"], chars["right"]], axis=1)
+    assert np.array_equal(got, g["chars"].astype(np.int64))
+    toks = engine.recognize_tokens(inp, [rects[i:i + 1] for i in range(n)])
+    to = g["token_offsets"]
+    flat = np.array([t for ts in toks for t in ts], np.int32).reshape(-1, 2)
+    assert np.array_equal(np.cumsum([0] + [len(t) for t in toks]), to)
+    assert np.array_equal(flat, g["tokens"])
+
+
+def test_gru_modes_give_identical_bits(engine):
+    """Persistent recurrence kernel (default) vs one launch per time step: same chars and boxes, on a request with
+    ragged lengths (one bench page: T from ~100 to 600) and on the 2048-line request (RT = 4 tiles per wave)."""
+    px = synth.synthetic_page(3, 1024, 1024, lines=80)
+    inp = engine.prepare_input(ImageSource.from_tensor(px, DimOrder.Hwc))
+    words = engine.detect_words(inp)
+    lines = engine.find_text_lines(inp, words)
+    rng = np.random.default_rng(0)
+    short = [l[: max(1, int(rng.integers(1, len(l) + 1)))] for l in lines[:40]]   # ragged: prefixes of lines
+    req = lines + short
+    cinp, crects, n = _crops_request(engine)
+    cl = np.arange(n + 1, dtype=np.uintp)
+    res = {}
+    try:
+        for mode in (0, 1):
+            _lib.set_option("gru_mode", mode)
+            a = engine.recognize_text(inp, req)
+            b = engine.recognize_text_batch_raw([cinp], crects, cl, np.array([0, n], dtype=np.uintp))
+            res[mode] = ([(str(t), [c.rect for c in t.chars()]) if t else None for t in a], b)
+    finally:
+        _lib.set_option("gru_mode", 0)
+    assert res[0][0] == res[1][0]
+    assert np.array_equal(res[0][1][0], res[1][1][0]) and np.array_equal(res[0][1][1], res[1][1][1])
+    assert sum(1 for t in res[0][0] if t) > 80
