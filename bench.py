@@ -7,10 +7,15 @@ on 1024x1024 pages + lines/sec recognition).
 One "step" = one pass of the full pipeline over one batch of synthetic pages
 that are already resident in HBM:  prepare_input -> detect_words (CNN @ 800x600,
 threshold, components -> rects) -> find_text_lines (host) -> recognize_text
-(line crops, CRNN, greedy CTC) -> TextLines on the host.  N>1: one process per
-GPU (torch.distributed / RCCL), pages sharded across ranks with no collective
-on the compute path (weak scaling: every rank owns `--pages` pages per step);
-the only exchange is the final result gather.
+(line crops, CRNN, greedy CTC) -> TextLines on the host.
+
+N > 1: one process per GPU.  Launched under `torch.distributed.run` the script is one rank; launched
+plainly as `python bench.py --gpus N` it re-executes itself under `torch.distributed.run` with N ranks on
+127.0.0.1.  Pages are sharded across ranks with no collective on the compute path (weak scaling: every rank
+owns `--pages` pages per step); the only exchange is the final result gather (RCCL all_gather).
+
+`--stream-pages P` is BASELINE.json configs[4]: P distinct pages (seeds 0..P-1), page i -> rank i mod N,
+processed in requests of `--pages` pages, every page resident in HBM before the timed region.
 
 Prints ONE JSON line (rank 0).  Real weights are not obtainable offline, so
 the models are the SURVEY.md §2.4 architectures with seeded synthetic weights.
@@ -19,26 +24,22 @@ import argparse
 import ctypes as C
 import json
 import os
+import socket
 import sys
 import time
-
-# cap host OpenMP pools before numpy/torch/oracle load (256-core GPU hosts)
-os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
-os.environ.setdefault("GOMP_SPINCOUNT", "0")
-_PHYS = max(1, (os.cpu_count() or 2) // 2)
-os.environ.setdefault("OMP_NUM_THREADS", str(min(_PHYS, 32)))
-os.environ.setdefault("MKL_NUM_THREADS", os.environ["OMP_NUM_THREADS"])
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md "HBM3E peak BW" (spec)
+# kernel classes of the detection CNN (HBM-bound: depthwise-separable U-Net)
+DETECTION_CLASSES = ("dwconv3x3", "gemm_pointwise_mfma", "gemm_convt_mfma", "pool", "padcat", "conv1x1_sigmoid",
+                     "conv_direct")
+MFMA_CLASSES = ("gemm_conv3x3_mfma", "gemm_gru_input_mfma", "gemm_gru_hidden_mfma", "gemm_linear_mfma")
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=36)
@@ -48,8 +49,11 @@ def parse():
                          "since warm-up began (0 = exactly W warm-up steps)")
     ap.add_argument("--pages", type=int, default=16, help="pages per step per GPU")
     ap.add_argument("--lines", type=int, default=80, help="text lines per synthetic page")
+    ap.add_argument("--stream-pages", type=int, default=0,
+                    help="configs[4]: this many DISTINCT pages (seeds 0..P-1) in total, page i -> rank i mod N, in requests "
+                         "of --pages pages; --steps is then derived (ceil(P / N / pages))")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-pages", type=int, default=3, help="pages in the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-pages", type=int, default=2, help="pages in the bounded CPU-baseline sample")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--inflight", type=int, default=6,
                     help="full steps kept in flight on separate host threads / HIP streams (default 6; 1 = the "
@@ -59,35 +63,132 @@ def parse():
                          "pipeline across steps: detect+layout of step i+1 overlap recognition of step i)")
     ap.add_argument("--profile-hint", action="store_true", help="print per-stage and per-kernel tables to stderr")
     ap.add_argument("--no-extras", action="store_true",
-                    help="skip the detection-only (configs[1]) and recognition-only (configs[2]) legs")
-    return ap.parse_args()
+                    help="skip the detection-only (configs[1]), recognition-only (configs[2]) and host-pixels legs")
+    ap.add_argument("--dist-selftest", action="store_true",
+                    help="exercise only the multi-rank plumbing (spawn, rendezvous, page sharding, result gather, "
+                         "reductions) with fake per-page results and no GPU: the CPU test of the N > 1 path")
+    return ap.parse_args(argv)
 
 
-def main():
-    args = parse()
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def maybe_spawn(args, argv):
+    """`python bench.py --gpus N` without a launcher: become N ranks (one per GPU) under torch.distributed.run."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
+
+
+def cap_host_threads(world_local):
+    """Host thread budget per rank: the box's cores are shared by the ranks of the node (8 ranks x (6 request threads
+    + layout pool + OpenMP pools) would otherwise oversubscribe it).  Must run before numpy/torch/oracle load."""
+    cores = os.cpu_count() or 2
+    phys = max(1, cores // 2)
+    per_rank = max(1, phys // max(1, world_local))
+    os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+    os.environ.setdefault("GOMP_SPINCOUNT", "0")
+    os.environ.setdefault("OMP_NUM_THREADS", str(min(per_rank, 32)))
+    os.environ.setdefault("MKL_NUM_THREADS", os.environ["OMP_NUM_THREADS"])
+    # find_text_lines_batch: one host thread per page of a request, at most this many per call
+    os.environ.setdefault("OCRS_LAYOUT_THREADS", str(max(2, min(16, per_rank // 2))))
+    return per_rank
+
+
+def dist_setup(args):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch.distributed as dist
+    # one rank per GPU; OCRS_DIST_BACKEND=gloo lets the multi-rank path be exercised on a box with fewer GPUs than
+    # ranks (ranks then share devices) and in the CPU self-test — the driver's runs use the default, nccl = RCCL
+    backend = os.environ.get("OCRS_DIST_BACKEND", "gloo" if args.dist_selftest else "nccl")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, local_rank, world, backend
+
+
+def reduce_over_ranks(elapsed, counts, world, red_dev):
+    """MAX of the elapsed time, SUM of the unit counts over ranks."""
+    if world == 1:
+        return elapsed, list(counts)
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    c = torch.tensor(list(counts), dtype=torch.int64, device=red_dev)
+    dist.all_reduce(c, op=dist.ReduceOp.SUM)
+    return float(t.item()), [int(v) for v in c.tolist()]
+
+
+def selftest_main(args):
+    """No GPU: the ranks shard `--stream-pages` (default 8 x N) fake pages, 'process' them, gather, reduce."""
+    cap_host_threads(int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))))
+    rank, _, world, backend = dist_setup(args)
+    import torch.distributed as dist
+    from ocrs_amd import dist as D
+    total = args.stream_pages or 8 * world
+    mine = D.shard_pages(total, rank, world)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    payload = {str(p): ["page %d line %d" % (p, i) for i in range(p % 3 + 1)] for p in mine}
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0 + 1e-3 * (rank + 1)   # MAX must pick the last rank's
+    gathered = D.gather_results(payload)
+    elapsed, (n_pages, n_lines) = reduce_over_ranks(elapsed, (len(mine), sum(len(v) for v in payload.values())), world, "cpu")
+    if rank == 0:
+        merged = {}
+        for g in gathered:
+            merged.update(g or {})
+        print(json.dumps({"metric": "dist-selftest", "n_gpus": world, "backend": backend, "pages": n_pages, "lines": n_lines,
+                          "gathered_pages": len(merged), "complete": sorted(int(k) for k in merged) == list(range(total)),
+                          "elapsed_is_max": elapsed >= 1e-3 * world, "omp_threads": os.environ["OMP_NUM_THREADS"],
+                          "layout_threads": os.environ["OCRS_LAYOUT_THREADS"]}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def make_pages(seeds, lines, synth):
+    """Synthetic pages for the given seeds; a process pool when there are many (35 ms of numpy per page)."""
+    seeds = list(seeds)
+    if len(seeds) <= 64:
+        return [synth.synthetic_page(s, 1024, 1024, lines=lines) for s in seeds]
+    import multiprocessing as mp
+    with mp.get_context("fork").Pool(min(32, max(1, (os.cpu_count() or 2) // 2))) as pool:
+        return pool.starmap(synth.synthetic_page, [(s, 1024, 1024, lines) for s in seeds], chunksize=8)
+
+
+def main():
+    argv = sys.argv[1:]
+    args = parse(argv)
+    maybe_spawn(args, argv)
+    if args.dist_selftest:
+        return selftest_main(args)
+    per_rank_cores = cap_host_threads(int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))))
+    import numpy as np
     import torch
     import torch.distributed as dist
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the ocrs_amd engine has no CPU fallback")
+    rank, local_rank, world, backend = dist_setup(args)
     if args.gpus != world and rank == 0:
-        print("bench.py: --gpus %d but WORLD_SIZE=%d: one process drives one GPU, launch N>1 with "
-              "`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`; measuring %d GPU(s)"
-              % (args.gpus, world, world), file=sys.stderr)
-    # one rank per GPU; OCRS_DIST_BACKEND=gloo lets the multi-rank path be exercised on a box with fewer GPUs than
-    # ranks (ranks then share devices) — the driver's runs use the default, nccl = RCCL
-    backend = os.environ.get("OCRS_DIST_BACKEND", "nccl")
+        print("bench.py: --gpus %d but WORLD_SIZE=%d; measuring %d GPU(s)" % (args.gpus, world, world), file=sys.stderr)
     dev_index = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend, rank=rank, world_size=world)
     red_dev = "cuda" if backend == "nccl" else "cpu"
 
-    import ocrs_amd
     from ocrs_amd import DimOrder, Model, OcrEngine, _lib, models, synth
     from ocrs_amd import dist as D
 
@@ -103,7 +204,12 @@ def main():
 
     # ---- synthetic pages, resident in HBM before the timed region
     B, H, W = args.pages, 1024, 1024
-    host_pages = [synth.synthetic_page(rank * B + i, H, W, lines=args.lines) for i in range(B)]
+    if args.stream_pages:
+        my_ids = D.shard_pages(args.stream_pages, rank, world)            # page i -> rank i mod N
+        args.steps = max(1, -(-max(len(D.shard_pages(args.stream_pages, r, world)) for r in range(world)) // B))
+    else:
+        my_ids = [rank * B + i for i in range(B)]
+    host_pages = make_pages(my_ids, args.lines, synth)
     dptrs = []
     for pg in host_pages:
         p = C.c_void_p()
@@ -111,8 +217,14 @@ def main():
         _lib.check(L.ocrs_device_upload(p, pg.ctypes.data_as(C.c_void_p), C.c_size_t(pg.nbytes)))
         dptrs.append(p)
 
-    def stage_a():  # prepare -> detect -> layout (GPU ~4 ms, then host)
-        inputs = [engine.prepare_input_device(p.value, np.uint8, DimOrder.Hwc, H, W, 3) for p in dptrs]
+    def request_pages(k):
+        """device pointers of step k's pages: the same B pages every step, or the k-th slice of the stream"""
+        if not args.stream_pages:
+            return dptrs
+        return dptrs[k * B:(k + 1) * B]
+
+    def stage_a(k=0):  # prepare -> detect -> layout (GPU ~4 ms, then host)
+        inputs = [engine.prepare_input_device(p.value, np.uint8, DimOrder.Hwc, H, W, 3) for p in request_pages(k)]
         words = engine.detect_words_batch(inputs)
         rects, loffs, poffs = engine.find_text_lines_batch_raw(words)
         return inputs, words, (rects, loffs, poffs)
@@ -122,31 +234,32 @@ def main():
         chars, coffs = engine.recognize_text_batch_raw(inputs, rects, loffs, poffs)
         return words, (rects, loffs, poffs), (chars, coffs)
 
-    def step():
-        return stage_b(stage_a())
+    def step(k=0):
+        if args.stream_pages and not request_pages(k):
+            return None
+        return stage_b(stage_a(k))
 
     from concurrent.futures import ThreadPoolExecutor
     pool = ThreadPoolExecutor(max_workers=1)
 
-    def run_steps(k):
+    def run_steps(k, collect=False):
         """k full steps.  Pipelined form: the library is thread-safe (one HIP stream per call), so
         stage A of step i+1 runs on a second host thread while this thread recognises step i."""
         if args.inflight > 1 and k >= 2:
             with ThreadPoolExecutor(max_workers=args.inflight) as ex:
-                return list(ex.map(lambda _: step(), range(k)))[-1]
+                outs = list(ex.map(step, range(k)))
+            return outs if collect else outs[-1]
         if args.no_pipeline or k < 2:
-            out = None
-            for _ in range(k):
-                out = step()
-            return out
-        fut = pool.submit(stage_a)
-        out = None
+            outs = [step(i) for i in range(k)]
+            return outs if collect else outs[-1]
+        fut = pool.submit(stage_a, 0)
+        outs = []
         for i in range(k):
             a = fut.result()
             if i + 1 < k:
-                fut = pool.submit(stage_a)
-            out = stage_b(a)
-        return out
+                fut = pool.submit(stage_a, i + 1)
+            outs.append(stage_b(a))
+        return outs if collect else outs[-1]
 
     def sync_all():
         torch.cuda.synchronize()
@@ -156,32 +269,32 @@ def main():
 
     t_warm = time.perf_counter()
     if args.warmup:
-        run_steps(args.warmup)
+        run_steps(min(args.warmup, args.steps) if args.stream_pages else args.warmup)
     # settle: the first seconds after start-up (allocator growth, clocks after another process used the GPU) run a few
     # per cent slower whatever W is; keep running untimed steps until 3 s have passed since warm-up began
     settle_steps = 0
     while args.settle_s > 0 and time.perf_counter() - t_warm < args.settle_s and settle_steps < 200:
-        run_steps(max(args.inflight, 1))
+        run_steps(min(max(args.inflight, 1), args.steps))
         settle_steps += max(args.inflight, 1)
-    # Calibration (untimed): one step with every kernel class timed picks the dominant class; during the
-    # timed region only that class carries per-launch HIP events (a handful of launches per step), so the
-    # live roofline figure does not slow the run down.  --profile-hint keeps all classes on.
-    dominant = None
+    # Per-launch HIP events (on the launching stream) in the timed region for the three MFMA classes only — the conv
+    # stack, the GRU input projections and the GRU recurrence: a dozen launches per step, so the live roofline figures
+    # do not slow the run.  One untimed calibration step times EVERY class (whole-pipeline FLOP count, shares).
+    # --profile-hint keeps all classes on.
+    cal = {}
+    timed_classes = ["gemm_conv3x3_mfma", "gemm_gru_input_mfma", "gemm_gru_hidden_mfma"]
     if not args.no_kernel_timing:
         engine.enable_timing(2)
         engine.set_kernel_timing_classes(None)
         engine.stage_times(reset=True)
-        step()
+        step(0)
         cal = {k: v for k, v in engine.kernel_stats(reset=True).items() if v["launches"] > 0}
-        if cal:
-            dominant = max(cal.items(), key=lambda kv: kv[1]["ms"])[0]
-        engine.set_kernel_timing_classes(None if args.profile_hint or dominant is None else [dominant])
+        engine.set_kernel_timing_classes(None if args.profile_hint else timed_classes)
     engine.enable_timing(0 if args.no_kernel_timing else 2)
     engine.stage_times(reset=True)
     sync_all()
     cpu0 = time.process_time()
     t0 = time.perf_counter()
-    out = run_steps(args.steps)
+    outs = run_steps(args.steps, collect=True)
     sync_all()
     elapsed = time.perf_counter() - t0
     host_cpu_s = time.process_time() - cpu0  # all host threads of this rank (layout analysis dominates)
@@ -189,38 +302,34 @@ def main():
     kstats = engine.kernel_stats(reset=True)
     engine.enable_timing(0)
 
-    words, (rects, loffs, poffs), (chars, coffs) = out
-    n_lines = len(loffs) - 1
-    n_words = sum(len(w) for w in words)
-    n_chars = len(chars)
-    # final result gather (the only inter-GPU exchange): decoded text of every page to rank 0
-    codes = chars["ch"]
+    outs = [o for o in outs if o is not None]
+    n_lines = sum(len(o[1][1]) - 1 for o in outs)
+    n_words = sum(sum(len(w) for w in o[0]) for o in outs)
+    n_chars = sum(len(o[2][0]) for o in outs)
+    n_pages = sum(len(o[0]) for o in outs)
+    # final result gather (the only inter-GPU exchange): decoded text of the LAST step's pages to rank 0
+    # (in stream mode: of every page)
     local_payload = {}
-    for i in range(B):
-        page_lines = []
-        for li in range(int(poffs[i]), int(poffs[i + 1])):
-            a, b = int(coffs[li]), int(coffs[li + 1])
-            page_lines.append("".join(map(chr, codes[a:b])) if b > a else None)
-        local_payload[str(rank * B + i)] = page_lines
+    for si, o in enumerate(outs if args.stream_pages else outs[-1:]):
+        words, (rects, loffs, poffs), (chars, coffs) = o
+        codes = chars["ch"]
+        for i in range(len(words)):
+            page_lines = []
+            for li in range(int(poffs[i]), int(poffs[i + 1])):
+                a, b = int(coffs[li]), int(coffs[li + 1])
+                page_lines.append("".join(map(chr, codes[a:b])) if b > a else None)
+            local_payload[str(my_ids[si * B + i] if args.stream_pages else my_ids[i])] = page_lines
     gathered = D.gather_results(local_payload)
-
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        cnt = torch.tensor([n_lines, n_words, n_chars], dtype=torch.int64, device=red_dev)
-        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
-        n_lines_all = int(cnt[0].item())
-    else:
-        n_lines_all = n_lines
+    elapsed, (n_pages_all, n_lines_all, n_words_all, n_chars_all) = reduce_over_ranks(
+        elapsed, (n_pages, n_lines, n_words, n_chars), world, red_dev)
 
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
         return
 
-    pages_total = world * B * args.steps
-    value = pages_total / elapsed
+    value = n_pages_all / elapsed
+    last = outs[-1]
     result = {
         "metric": "pages/sec end-to-end (1024x1024)",
         "value": round(value, 3),
@@ -231,59 +340,70 @@ def main():
         "extra_untimed_settle_steps": settle_steps,
         "ms_per_step": round(1000.0 * elapsed / args.steps, 3),
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if args.stream_pages else "weak",
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": "full pipeline (BASELINE.json configs[3]): %d synthetic 1024x1024 RGB u8 pages per step per GPU, "
-                        "~%d lines/page; prepare_input -> detect_words (U-Net @800x600 + threshold + components->rects) "
-                        "-> find_text_lines (host) -> recognize_text (crops, CRNN, greedy CTC)" % (B, args.lines),
+            "workload": ("page-sharded stream (BASELINE.json configs[4]): %d distinct synthetic 1024x1024 RGB u8 pages, page i -> "
+                         "rank i mod N, requests of %d pages" % (args.stream_pages, B)) if args.stream_pages else
+                        ("full pipeline (BASELINE.json configs[3]): %d synthetic 1024x1024 RGB u8 pages per step per GPU" % B) +
+                        ", ~%d lines/page; prepare_input -> detect_words (U-Net @800x600 + threshold + components->rects) "
+                        "-> find_text_lines (host) -> recognize_text (crops, CRNN, greedy CTC)" % args.lines,
             "pages_per_step_per_gpu": B,
-            "lines_per_page": round(n_lines / B, 1),
-            "words_per_page": round(n_words / B, 1),
+            "lines_per_page": round(n_lines / max(n_pages, 1), 1),
+            "words_per_page": round(n_words / max(n_pages, 1), 1),
             "weights": "seeded synthetic weights on the SURVEY.md §2.4 architectures (real ocrs weights unobtainable offline)",
-            "parallelism": "page-sharded, %d process(es) x 1 GPU, no data-path collective" % world,
+            "parallelism": "page-sharded, %d process(es) x 1 GPU, no data-path collective; result gather over %s" % (world, backend),
+            "gru": "persistent kernel per layer" if os.environ.get("OCRS_GRU_MODE", "0") == "0" else "one launch per time step",
             "step_overlap": ("%d whole steps in flight (one host thread + HIP stream each); the conv stacks of all "
-                             "requests run FIFO on one shared stream, the latency-bound GRU chains and the host layout "
-                             "overlap them; every step still does all of its work" % args.inflight) if args.inflight > 1 else
+                             "requests run FIFO on one shared stream, the GRU recurrences on another, the host layout "
+                             "overlaps both; every step still does all of its work" % args.inflight) if args.inflight > 1 else
                             ("none (stages strictly sequential)" if args.no_pipeline else
                              "2-stage software pipeline across steps: detect+layout of step i+1 (2nd host thread, own HIP "
                              "stream) overlap recognition of step i; every step still does all of its work"),
         },
-        "lines_per_s": round(n_lines_all * args.steps / elapsed, 1),
+        "lines_per_s": round(n_lines_all / elapsed, 1),
         "host_cpu_cores_busy_per_gpu": round(host_cpu_s / elapsed, 2),
-        "chars_last_step": n_chars,
+        "host_cores_budget_per_rank": per_rank_cores,
+        "chars_last_step": len(last[2][0]),
         "gathered_pages": sum(len(g) for g in gathered if g),
     }
 
-    # ---- stage table + roofline of the dominant kernel (HIP events, timed region)
+    # ---- stage table + rooflines (HIP events, timed region)
     result["stages_ms_per_step"] = {k: round(v[0] / args.steps, 4) for k, v in stages.items() if v[0] > 0}
     kt = {k: v for k, v in kstats.items() if v["launches"] > 0}
     if kt:
-        dom_name = dominant if dominant in kt else max(kt.items(), key=lambda kv: kv[1]["ms"])[0]
-        dom = kt[dom_name]
-        is_mfma = dom_name.startswith("gemm_") and dom_name not in ("gemm_pointwise_mfma", "gemm_convt_mfma")
-        avg_ms = dom["ms"] / dom["launches"]
-        if is_mfma:
-            achieved = dom["flops"] / dom["launches"] / (avg_ms * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4)}
-        else:
-            achieved = dom["bytes"] / dom["launches"] / (avg_ms * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": PEAK_HBM_GBS,
-                    "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBS, 4)}
-        roof["avg_launch_ms"] = round(avg_ms, 5)
-        roof["launches_per_step"] = round(dom["launches"] / args.steps, 2)
-        roof["share_of_gpu_kernel_time_in_calibration_step"] = round(
-            cal[dom_name]["ms"] / max(1e-9, sum(v["ms"] for v in cal.values())), 3) if dom_name in cal else None
-        tr = pmc_traffic(dom_name)  # L2-miss (HBM + Infinity Cache) bytes/launch from the rocprofv3 --pmc passes in profiles/
-        roof["traffic"] = tr["hbm_bytes_per_launch"] if tr else None
-        roof["traffic_unit"] = "bytes/launch"
-        roof["traffic_source"] = tr["source"] if tr else None
-        roof["algorithmic_bytes_per_launch"] = round(dom["bytes"] / max(dom["launches"], 1))
-        result["roofline"] = roof
-        if not args.no_kernel_timing and cal:
+        total_cal_ms = max(1e-9, sum(v["ms"] for v in cal.values()))
+
+        def roof_of(name):
+            dom = kt[name]
+            avg_ms = dom["ms"] / dom["launches"]
+            if name in MFMA_CLASSES:
+                achieved = dom["flops"] / dom["launches"] / (avg_ms * 1e-3) / 1e12
+                roof = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4)}
+            else:
+                achieved = dom["bytes"] / dom["launches"] / (avg_ms * 1e-3) / 1e9
+                roof = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": PEAK_HBM_GBS,
+                        "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBS, 4)}
+            roof["avg_launch_ms"] = round(avg_ms, 5)
+            roof["launches_per_step"] = round(dom["launches"] / args.steps, 2)
+            roof["share_of_gpu_kernel_time_in_calibration_step"] = round(cal[name]["ms"] / total_cal_ms, 3) if name in cal else None
+            tr = pmc_traffic(name)  # L2-miss (HBM + Infinity Cache) bytes/launch from the rocprofv3 --pmc passes in profiles/
+            roof["traffic"] = tr["hbm_bytes_per_launch"] if tr else None
+            roof["traffic_unit"] = "bytes/launch"
+            roof["traffic_source"] = tr["source"] if tr else None
+            roof["algorithmic_bytes_per_launch"] = round(dom["bytes"] / max(dom["launches"], 1))
+            return roof
+
+        # the dominant kernel = the class with the largest share of GPU kernel time in the calibration step
+        # among those timed live; every timed class is reported under "rooflines"
+        live = [k for k in kt if k in timed_classes or args.profile_hint]
+        dom_name = max(live or list(kt), key=lambda k: cal.get(k, kt[k])["ms"])
+        result["roofline"] = roof_of(dom_name)
+        result["rooflines"] = {k: roof_of(k) for k in kt if k in MFMA_CLASSES}
+        if cal:
             # whole-pipeline view: algorithmic FLOPs of ONE step (every kernel class, from the untimed calibration
             # step) over the measured step time — how much of the fp32 matrix peak the full job sustains
             tfl = sum(v["flops"] for v in cal.values()) / 1e12
@@ -298,42 +418,56 @@ def main():
             for k, v in sorted(kt.items(), key=lambda kv: -kv[1]["ms"]):
                 tf = v["flops"] / max(v["ms"], 1e-9) / 1e9
                 gb = v["bytes"] / max(v["ms"], 1e-9) / 1e6
-                print("%-24s %8.3f ms/step %6d launches/step %8.2f TFLOP/s %8.1f GB/s" % (
-                    k, v["ms"] / args.steps, v["launches"] // args.steps, tf, gb), file=sys.stderr)
+                print("%-24s %8.3f ms/step %8.1f launches/step %8.2f TFLOP/s %8.1f GB/s" % (
+                    k, v["ms"] / args.steps, v["launches"] / args.steps, tf, gb), file=sys.stderr)
             for k, v in stages.items():
                 print("stage %-18s %8.3f ms/step" % (k, v[0] / args.steps), file=sys.stderr)
 
     # ---- extra legs named by BASELINE.json (rank 0, N=1 only; not part of `value`)
     if world == 1 and not args.no_extras:
-        result["extras"] = extra_legs(engine, dptrs, H, W, synth, np, DimOrder, sync_all)
+        result["extras"] = extra_legs(engine, dptrs, host_pages, H, W, synth, np, DimOrder, sync_all, args)
+        if "roofline_detection" in result["extras"]:
+            result["roofline_detection"] = result["extras"].pop("roofline_detection")
+        if "value_incl_h2d" in result["extras"]:
+            result["value_incl_h2d"] = result["extras"]["value_incl_h2d"]
 
     # ---- CPU baseline: the oracle on the host cores, bounded sample (rank 0, N=1 only)
-    if world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(host_pages[: args.cpu_pages], engine)
+    if world == 1 and not args.no_cpu_baseline and not args.stream_pages:
+        words, (rects, loffs, poffs), (chars, coffs) = last
+        gpu_text = []
+        for i in range(min(args.cpu_pages, B)):
+            lines = []
+            for li in range(int(poffs[i]), int(poffs[i + 1])):
+                a, b = int(coffs[li]), int(coffs[li + 1])
+                if b > a:
+                    lines.append("".join(map(chr, chars["ch"][a:b])))
+            gpu_text.append(lines)
+        result["cpu_baseline"] = cpu_baseline(host_pages[: args.cpu_pages], engine, gpu_text, np)
     print(json.dumps(result), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
 
 def pmc_traffic(kernel_class):
-    """HBM bytes per launch of the dominant kernel class from the committed PMC summary
+    """HBM bytes per launch of a kernel class from the newest committed PMC summary that covers it
     (tools/profile.sh -> tools/pmc_summary.py -> profiles/*_pmc.json: separate FETCH_SIZE / WRITE_SIZE passes,
     FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  None if no summary covers the class."""
     import glob
-    match = {"gemm_conv3x3_mfma": "conv3x3_ragged_kernel", "gemm_gru_hidden_mfma": "gru_step_fused_kernel",
+    match = {"gemm_conv3x3_mfma": "conv3x3_ragged_kernel",
+             "gemm_gru_hidden_mfma": "gru_persistent_kernel" if os.environ.get("OCRS_GRU_MODE", "0") == "0" else "gru_step_fused_kernel",
              "gemm_gru_input_mfma": "gemm_tiled_kernelILi128ELb0", "dwconv3x3": "dwconv3x3_kernel"}.get(kernel_class)
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")))
-    if not match or not files:
+    if not match:
         return None
-    rows = [r for k, r in json.load(open(files[-1])).items() if match in k]
-    n = sum(r["launches"] for r in rows)
-    if not n:
-        return None
-    return {"hbm_bytes_per_launch": round(sum(r["hbm_bytes_per_launch"] * r["launches"] for r in rows) / n),
-            "source": os.path.relpath(files[-1], ROOT)}
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")), reverse=True):
+        rows = [r for k, r in json.load(open(f)).items() if match in k]
+        n = sum(r["launches"] for r in rows)
+        if n:
+            return {"hbm_bytes_per_launch": round(sum(r["hbm_bytes_per_launch"] * r["launches"] for r in rows) / n),
+                    "source": os.path.relpath(f, ROOT)}
+    return None
 
 
-def extra_legs(engine, dptrs, H, W, synth, np, DimOrder, sync_all):
+def extra_legs(engine, dptrs, host_pages, H, W, synth, np, DimOrder, sync_all, args):
     out = {}
     # configs[1]: detection only — 8 synthetic 1024x1024 pages, CNN forward + threshold + components -> rects
     inputs = [engine.prepare_input_device(p.value, np.uint8, DimOrder.Hwc, H, W, 3) for p in dptrs[:8]]
@@ -346,6 +480,28 @@ def extra_legs(engine, dptrs, H, W, synth, np, DimOrder, sync_all):
     sync_all()
     dt = time.perf_counter() - t0
     out["detection_only_pages_per_s"] = round(reps * len(inputs) / dt, 1)
+    # roofline of the detection CNN stack (the stack north_star names; depthwise-separable => HBM-bound):
+    # algorithmic bytes of its layers (from the loaded graph) over the summed duration of its kernels
+    if not args.no_kernel_timing:
+        engine.enable_timing(2)
+        engine.set_kernel_timing_classes(None)
+        engine.kernel_stats(reset=True)
+        for _ in range(3):
+            engine.detect_words_batch(inputs)
+        ks = {k: v for k, v in engine.kernel_stats(reset=True).items() if v["launches"] > 0 and k in DETECTION_CLASSES}
+        engine.enable_timing(0)
+        ms = sum(v["ms"] for v in ks.values())
+        by = sum(v["bytes"] for v in ks.values())
+        if ms > 0:
+            tr = [pmc_traffic(k) for k in ks]
+            out["roofline_detection"] = {
+                "bound": "hbm", "kernel": "detection CNN stack (%d launches per 8-page batch: %s)" % (
+                    sum(v["launches"] for v in ks.values()) // 3, ", ".join(sorted(ks))),
+                "achieved": round(by / ms / 1e6, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                "frac": round(by / ms / 1e6 / PEAK_HBM_GBS, 4),
+                "ms_per_8_pages": round(ms / 3, 4), "algorithmic_bytes_per_page": round(by / 3 / len(inputs)),
+                "traffic": None if not any(tr) else sum(t["hbm_bytes_per_launch"] for t in tr if t),
+                "per_class_ms_per_8_pages": {k: round(v["ms"] / 3, 4) for k, v in sorted(ks.items(), key=lambda kv: -kv[1]["ms"])}}
     # configs[2]: recognition only — 2048 line crops of 64x256 (padded to 300 by the engine exactly as
     # recognition.rs:437 does), CRNN forward + greedy CTC, batched.  The crops are stacked into one tall
     # grey page so that every line's crop+resize is the identity.
@@ -371,6 +527,29 @@ def extra_legs(engine, dptrs, H, W, synth, np, DimOrder, sync_all):
     dt = time.perf_counter() - t0
     out["recognition_only_lines_per_s"] = round(reps * n / dt, 1)
     out["recognition_only_config"] = "2048 crops 64x256 -> width group 300 (T=75), crop+CRNN+greedy CTC, %d chars decoded" % len(chars)
+    # host pixels -> HBM inside the timed region (ocrs-cli/src/main.rs:420-421 -> lib.rs:183-187): the same full
+    # pipeline, each step's pages handed over as HOST u8 buffers through ocrs_engine_prepare_input
+    from concurrent.futures import ThreadPoolExecutor
+    B = min(args.pages, len(host_pages))
+    srcs = [ImageSource.from_tensor(pg, DimOrder.Hwc) for pg in host_pages[:B]]
+
+    def host_step(_=None):
+        inputs = [engine.prepare_input(s) for s in srcs]
+        words = engine.detect_words_batch(inputs)
+        rects_, lo, po = engine.find_text_lines_batch_raw(words)
+        return engine.recognize_text_batch_raw(inputs, rects_, lo, po)
+
+    k = max(2 * args.inflight, 12)
+    with ThreadPoolExecutor(max_workers=max(1, args.inflight)) as ex:
+        list(ex.map(host_step, range(args.inflight)))
+        sync_all()
+        t0 = time.perf_counter()
+        list(ex.map(host_step, range(k)))
+        sync_all()
+        dt = time.perf_counter() - t0
+    out["value_incl_h2d"] = round(k * B / dt, 3)
+    out["value_incl_h2d_config"] = ("%d steps of %d pages, %d in flight, every page uploaded from pageable host memory "
+                                    "(3 MiB H2D per page) inside the timed region" % (k, B, args.inflight))
     # what this box sustains, next to the nominal peaks the roofline divides by
     from ocrs_amd._lib import measure_peaks
     tf, gbps = measure_peaks()
@@ -379,42 +558,56 @@ def extra_legs(engine, dptrs, H, W, synth, np, DimOrder, sync_all):
     return out
 
 
-def cpu_baseline(pages, engine):
-    """The CPU restatement (oracle/) timed on this box's host cores: C for image ops,
-    contours, crops and CTC; PyTorch-CPU fp32 for the two networks (what RTen's CPU path
-    does); layout analysis through the product's host C++ (it is host code in both
-    paths).  Reported next to the GPU number; it is not the target."""
+def cpu_baseline(pages, engine, gpu_text, np):
+    """The CPU restatement (oracle/) timed on this box's host cores, on a bounded sample of the same pages, with both
+    of its network back-ends: `exact` (the C fmaf-chain restatement, OpenMP) and `torch` (PyTorch-CPU fp32 — what
+    RTen's CPU path does); C for image ops, contours, crops and CTC in both; layout analysis through the product's
+    host C++ (it is host code in both paths).  `value` is the faster of the two.  Reported next to the GPU number;
+    it is not the target.  `text_match`: the text the GPU path decoded for these pages equals, line for line, what
+    the exact oracle decodes (the bit-exact parity proper is tests/test_gpu_bench_scale.py)."""
     import torch
     from oracle import pipeline as OP
     from oracle.nn import OracleGraph, OracleModel
+    from oracle.geometry import RotatedRect
     from ocrs_amd import models
 
     cores = int(os.environ["OMP_NUM_THREADS"])
     torch.set_num_threads(cores)
-    det = OracleModel(OracleGraph(models.synthetic_detection_bytes()), "torch")
-    rec = OracleModel(OracleGraph(models.synthetic_recognition_bytes()), "torch")
-    ora = OP.OcrEngine(detection_model=det, recognition_model=rec)
-    from oracle.geometry import RotatedRect
+    dg, rg = OracleGraph(models.synthetic_detection_bytes()), OracleGraph(models.synthetic_recognition_bytes())
 
-    def run(pg):
-        inp = ora.prepare_input(OP.ImageSource.from_tensor(pg, "hwc"))
-        words = ora.detect_words(inp)
-        arr = np.array([w.to_array() for w in words], np.float32).reshape(-1, 6)
-        lines = engine.find_text_lines(None, arr)  # host C++ (no GPU work)
-        olines = [[RotatedRect.from_array(r) for r in l] for l in lines]
-        return ora.recognize_text(inp, olines), len(olines)
+    def timed_run(backend):
+        ora = OP.OcrEngine(detection_model=OracleModel(dg, backend), recognition_model=OracleModel(rg, backend))
 
-    run(pages[0][:256, :256].copy())  # warm torch / oneDNN
-    t0 = time.perf_counter()
-    n_lines = 0
-    for pg in pages:
-        _, nl = run(pg)
-        n_lines += nl
-    dt = time.perf_counter() - t0
+        def run(pg):
+            inp = ora.prepare_input(OP.ImageSource.from_tensor(pg, "hwc"))
+            words = ora.detect_words(inp)
+            arr = np.array([w.to_array() for w in words], np.float32).reshape(-1, 6)
+            lines = engine.find_text_lines(None, arr)  # host C++ (no GPU work)
+            olines = [[RotatedRect.from_array(r) for r in l] for l in lines]
+            return [str(t) for t in ora.recognize_text(inp, olines) if t is not None], len(olines)
+
+        run(pages[0][:256, :256].copy())  # warm torch / oneDNN / OpenMP pools
+        t0 = time.perf_counter()
+        texts, n_lines = [], 0
+        for pg in pages:
+            t, nl = run(pg)
+            texts.append(t)
+            n_lines += nl
+        return time.perf_counter() - t0, texts, n_lines
+
+    dt_e, texts_e, n_lines = timed_run("exact")
+    dt_t, _, _ = timed_run("torch")
+    lines_total = sum(max(len(a), len(b)) for a, b in zip(texts_e, gpu_text))
+    lines_equal = sum(sum(1 for x, y in zip(a, b) if x == y) for a, b in zip(texts_e, gpu_text))
+    dt = min(dt_e, dt_t)
     return {"value": round(len(pages) / dt, 4), "unit": "pages/s", "cores": cores, "kind": "port",
             "lines_per_s": round(n_lines / dt, 2),
-            "sample": "%d of the same synthetic 1024x1024 pages, full pipeline, oracle (C image/contour/crop/CTC + "
-                      "torch-CPU fp32 networks, %d threads) in %.1f s" % (len(pages), cores, dt)}
+            "backend": "exact" if dt_e <= dt_t else "torch",
+            "pages_per_s_by_backend": {"exact": round(len(pages) / dt_e, 4), "torch": round(len(pages) / dt_t, 4)},
+            "text_match": lines_total > 0 and lines_equal == lines_total,
+            "text_lines_equal": "%d/%d" % (lines_equal, lines_total),
+            "sample": "%d of the same synthetic 1024x1024 pages, full pipeline, oracle (C image/contour/crop/CTC; networks: C "
+                      "fmaf-chain restatement %.1f s, torch-CPU fp32 %.1f s; %d threads)" % (len(pages), dt_e, dt_t, cores)}
 
 
 if __name__ == "__main__":

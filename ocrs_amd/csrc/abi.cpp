@@ -4,6 +4,7 @@
 #include <fstream>
 #include <thread>
 
+#include <atomic>
 #include "engine.hpp"
 #include "kernels.hpp"
 
@@ -400,8 +401,16 @@ ocrs_status ocrs_engine_find_text_lines_batch(const ocrs_engine* e, size_t n_pag
         if (n_pages <= 1) {
             for (size_t p = 0; p < n_pages; p++) work(p);
         } else {
+            // a bounded pool pulling pages from a shared counter: option "layout_threads" (0 = one thread per
+            // page up to the host's cores) keeps N ranks x in-flight requests from oversubscribing one host
+            const int opt = option(OPT_LAYOUT_THREADS);
+            const size_t hw = std::max(1u, std::thread::hardware_concurrency());
+            const size_t nth = std::min(n_pages, opt > 0 ? (size_t)opt : hw);
+            std::atomic<size_t> next{0};
+            auto loop = [&] { for (size_t p; (p = next.fetch_add(1)) < n_pages;) work(p); };
             std::vector<std::thread> th;
-            for (size_t p = 0; p < n_pages; p++) th.emplace_back(work, p);
+            for (size_t t = 1; t < nth; t++) th.emplace_back(loop);
+            loop();
             for (auto& t : th) t.join();
         }
         for (const std::string& er : errors)

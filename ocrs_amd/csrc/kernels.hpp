@@ -105,7 +105,10 @@ bool gru_step_fused(const float* gx, const float* wh, const float* bh, const flo
 // ---- kernels_gru.hip: all time steps of one bidirectional GRU layer in ONE persistent launch.
 // d_sync: gru_persistent_sync_words(M) words of scratch (zeroed by the call); its last word is non-zero
 // afterwards if a wait inside the kernel timed out.  Returns false if H is unsupported.
+// gru_persistent_prepare marks every word of y "unwritten" (the kernel's hand-off protocol reads y as its own
+// flag); call it on a stream ordered before gru_persistent.
 size_t gru_persistent_sync_words(int M);
+void gru_persistent_prepare(float* y, int64_t R, int H, hipStream_t s);
 bool gru_persistent(const float* gx, const float* wh, const float* bh, float* y, const int32_t* d_Tm, const int32_t* d_off,
                     int64_t R, int M, int H, uint32_t* d_sync, hipStream_t s);
 void ctc_collapse_packed(const int32_t* labels, const int32_t* d_Tm, const int32_t* d_off, int M, int Tmax,

@@ -12,15 +12,17 @@
 // (wave w: tiles base + w, base + 4 + w, ...).  The UB workgroups that own the slices of the same
 // rows form a "cluster"; the only data they exchange is the new hidden state of their rows.
 //
-// Exchange = the layer's own output.  y[row(t, m)][dir*H + unit] has to be written anyway; a wave
-// writes its 16 rows x 16 units with 16-byte WRITE-THROUGH stores, drains them (s_waitcnt vmcnt(0))
-// and bumps the arrival counter of (dir, tile).  The UB waves that need the tile's full state for the
-// next step poll that one counter (relaxed, agent scope), then read the y rows of the previous step
-// with cache-bypassing loads (MI355X_MICROARCH.md "inter-workgroup visibility", form R1: write-through
-// payload + drained flag on the producer, relaxed poll + bypassing loads on the consumer).  No grid
-// barrier: tiles never wait for each other, and nothing depends on workgroup placement or order
-// (blocks of a cluster are merely steered to one XCD for speed).  Every wait is bounded: on a
-// time-out the kernel raises the error word and returns, the host reports OCRS_ERR_DEVICE.
+// Exchange = the layer's own output, and the data is its own flag.  y[row(t, m)][dir*H + unit] has to be
+// written anyway; the host pre-fills y with the word 0xFFFFFFFF (a NaN no result can be: the epilogue maps that one
+// bit pattern to the canonical NaN).  A wave writes its 16 rows x 16 units with 16-byte WRITE-THROUGH stores and
+// moves on — no drain, no counter.  The UB waves that need the tile's full state for the next step read the y rows
+// of the previous step with cache-bypassing loads and look at every 32-bit word: any 0xFFFFFFFF left means "not yet
+// written", and the wave re-reads (MI355X_MICROARCH.md "inter-workgroup visibility", form R2 — the payload is the
+// flag — checked per 32-bit word, so no assumption about the atomicity of wider accesses is made).  The loads of
+// the next item are issued before the current item is computed whenever it belongs to another tile, so that by the
+// time they are checked the round trip is long over.  No grid barrier: tiles never wait for each other, and nothing
+// depends on workgroup placement or order (blocks of a cluster are merely steered to one XCD for speed).  Every
+// wait is bounded: on a time-out the kernel raises the error word and returns, the host reports OCRS_ERR_DEVICE.
 //
 // MFMA roles.  D = A.B with A = Wh^T (16 units x 4 k, from LDS) and B = h^T (4 k x 16 rows, from
 // registers), so a lane ends up with 4 CONSECUTIVE units of one row: the epilogue's gx reads and
@@ -45,7 +47,7 @@ struct GruParams {
     float* y;            // [R][2H]
     const int32_t* Tm;   // [M] sequence length of line m (descending)
     const int32_t* off;  // [Tmax + 1] first packed row of time t
-    uint32_t* sync;      // [2 * ntiles] arrival counters, then [1] error word; zeroed before the launch
+    uint32_t* sync;      // [1] error word; zeroed before the launch
     int64_t R;
     int M, ntiles, RT, ncl;
     uint32_t spin_limit;
@@ -74,58 +76,77 @@ __device__ __forceinline__ void transpose4(const f32x4& in, float* out) {
     out[3] = __uint_as_float(q13[1]);
 }
 
+constexpr unsigned kUnwritten = 0xFFFFFFFFu;  // what gru_persistent() fills y with
+
 template <int H>
 struct Loaded {             // everything one (tile, step) item reads from memory
     f32x4 h[H / 16];        // lane (row, kq): pieces q = 4j + kq of the row's previous state
     f32x4 hp;               // previous state of this lane's own 4 units
     f32x4 gr, gz, gn;       // gx of this lane's 4 units
     int64_t row;            // packed output row
+    const float* yp;        // the row's previous-step output (this direction's half); null: h = 0 (first step / idle lane)
     bool active;
 };
 
+// row bookkeeping + the gx operands of the epilogue (independent of the recurrence)
 template <int H>
-__device__ __forceinline__ bool issue_loads(const GruParams& p, int dir, int ub, int tile, int s, int i16, int kq,
-                                            Loaded<H>& L) {
+__device__ __forceinline__ void issue_meta(const GruParams& p, int dir, int ub, int tile, int s, int i16, int kq, Loaded<H>& L) {
     const int m = tile * 16 + i16;
     const int tm = m < p.M ? p.Tm[m] : 0;
     L.active = tm > s;
     const int t = dir ? tm - 1 - s : s;
     L.row = L.active ? (int64_t)p.off[t] + m : 0;
     const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
-    L.gr = L.gz = L.gn = zero;
+    L.gr = L.gz = L.gn = L.hp = zero;
+#pragma unroll
+    for (int j = 0; j < H / 16; j++) L.h[j] = zero;
+    L.yp = nullptr;
     if (L.active) {
         const float* g = p.gx + ((int64_t)dir * p.R + L.row) * 3 * H + ub * 16 + kq * 4;
         L.gr = *reinterpret_cast<const f32x4*>(g);
         L.gz = *reinterpret_cast<const f32x4*>(g + H);
         L.gn = *reinterpret_cast<const f32x4*>(g + 2 * H);
+        if (s > 0) L.yp = p.y + ((int64_t)p.off[dir ? tm - s : s - 1] + m) * 2 * H + dir * H;
     }
-    L.hp = zero;
+}
+
+// the previous state of the lane's row (no wait: the loads are checked by state_ready())
+template <int H>
+__device__ __forceinline__ void issue_state(int ub, int kq, Loaded<H>& L) {
+    if (L.yp) {
 #pragma unroll
-    for (int j = 0; j < H / 16; j++) L.h[j] = zero;
-    if (s == 0) return true;  // h(-1) = 0
-    // every slice of this tile's previous step must have landed: UB arrivals per step
-    gu32* ctr = (gu32*)(p.sync + (size_t)dir * p.ntiles + tile);
-    const uint32_t target = (uint32_t)(H / 16) * (uint32_t)s;
-    for (uint32_t spins = 0;; spins++) {
-        const uint32_t v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        if (v >= target) break;
-        __builtin_amdgcn_s_sleep(1);
-        if ((spins & 1023u) == 1023u) {
-            gu32* err = (gu32*)(p.sync + (size_t)2 * p.ntiles);
+        for (int j = 0; j < H / 16; j++) L.h[j] = load_bypass(L.yp + 16 * j + 4 * kq);
+        L.hp = load_bypass(L.yp + ub * 16 + kq * 4);
+    }
+}
+
+// true when no lane of the wave still sees an unwritten word
+template <int H>
+__device__ __forceinline__ bool state_ready(const Loaded<H>& L) {
+    unsigned mx = 0;
+#pragma unroll
+    for (int j = 0; j < H / 16; j++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) mx = max(mx, __float_as_uint(L.h[j][e]));
+#pragma unroll
+    for (int e = 0; e < 4; e++) mx = max(mx, __float_as_uint(L.hp[e]));
+    return !__any(mx == kUnwritten);
+}
+
+// wait until the previous state of every row of the tile is complete, re-reading as needed
+template <int H>
+__device__ __forceinline__ bool await_state(const GruParams& p, int ub, int kq, Loaded<H>& L) {
+    for (uint32_t spins = 0; !state_ready<H>(L); spins++) {
+        __builtin_amdgcn_s_sleep(2);
+        if ((spins & 255u) == 255u) {
+            gu32* err = (gu32*)p.sync;
             const uint32_t e = __builtin_amdgcn_readfirstlane(__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
             if (e != 0 || spins >= p.spin_limit) {
                 __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 return false;
             }
         }
-    }
-    asm volatile("" ::: "memory");
-    if (L.active) {
-        const int tp = dir ? tm - s : s - 1;
-        const float* yp = p.y + ((int64_t)p.off[tp] + m) * 2 * H + dir * H;
-#pragma unroll
-        for (int j = 0; j < H / 16; j++) L.h[j] = load_bypass(yp + 16 * j + 4 * kq);
-        L.hp = load_bypass(yp + ub * 16 + kq * 4);
+        issue_state<H>(ub, kq, L);
     }
     return true;
 }
@@ -165,14 +186,11 @@ __device__ __forceinline__ void compute_item(const GruParams& p, int dir, int ub
             const float rg = spec_sigmoidf(L.gr[r] + acc_r[r]);
             const float zg = spec_sigmoidf(L.gz[r] + acc_z[r]);
             const float ng = spec_tanhf(fmaf(rg, acc_n[r], L.gn[r]));
-            hn[r] = fmaf(zg, L.hp[r] - ng, ng);
+            const float hv = fmaf(zg, L.hp[r] - ng, ng);
+            hn[r] = __float_as_uint(hv) == kUnwritten ? __uint_as_float(0x7FC00000u) : hv;  // keep the flag word free
         }
-        store_through(p.y + L.row * 2 * H + dir * H + ub * 16 + kq * 4, hn);
+        store_through(p.y + L.row * 2 * H + dir * H + ub * 16 + kq * 4, hn);  // fire and forget: the data is the flag
     }
-    // publish: every byte this wave stored has left the CU before the counter moves
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane == 0)
-        __hip_atomic_fetch_add((gu32*)(p.sync + (size_t)dir * p.ntiles + tile), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 template <int H>
@@ -216,11 +234,11 @@ gru_persistent_kernel(GruParams p) {
         return (i < p.RT && tile < p.ntiles) ? p.Tm[tile * 16] : 0;
     };
     if (tile_T(0) <= 0) return;
-    // items in (step, tile) order; the loads of the NEXT item are issued before the current one is
+    // items in (step, tile) order; the state loads of the NEXT item are issued before the current one is
     // computed whenever it belongs to another tile (its inputs cannot depend on the current item)
     int s = 0, i = 0;
     Loaded<H> cur, nxt;
-    if (!issue_loads<H>(p, dir, ub, base, 0, i16, kq, cur)) return;
+    issue_meta<H>(p, dir, ub, base, 0, i16, kq, cur);
     for (;;) {
         int ns = s, ni = i + 1;
         if (tile_T(ni) <= s) { ns = s + 1; ni = 0; }
@@ -231,10 +249,12 @@ gru_persistent_kernel(GruParams p) {
         float w[H / 4];
 #pragma unroll
         for (int j = 0; j < H / 16; j++) transpose4(cur.h[j], &w[4 * j]);
-        if (early && !issue_loads<H>(p, dir, ub, base + 4 * ni, ns, i16, kq, nxt)) return;
+        if (have_next) issue_meta<H>(p, dir, ub, base + 4 * ni, ns, i16, kq, nxt);
+        if (early) issue_state<H>(ub, kq, nxt);
         compute_item<H>(p, dir, ub, base + 4 * i, i16, kq, lane, cur, w, lds_w, br, bz, bn);
         if (!have_next) break;
-        if (!early && !issue_loads<H>(p, dir, ub, base + 4 * ni, ns, i16, kq, nxt)) return;
+        if (!early) issue_state<H>(ub, kq, nxt);
+        if (!await_state<H>(p, ub, kq, nxt)) return;
         cur = nxt;
         s = ns;
         i = ni;
@@ -243,7 +263,12 @@ gru_persistent_kernel(GruParams p) {
 
 }  // namespace
 
-size_t gru_persistent_sync_words(int M) { return (size_t)2 * ((M + 15) / 16) + 1; }
+size_t gru_persistent_sync_words(int) { return 1; }
+
+// y -> all words "unwritten"; any stream that is ordered before the recurrence (it does not depend on gx)
+void gru_persistent_prepare(float* y, int64_t R, int H, hipStream_t s) {
+    if (R > 0) (void)hipMemsetAsync(y, 0xFF, (size_t)R * 2 * H * sizeof(float), s);
+}
 
 bool gru_persistent(const float* gx, const float* wh, const float* bh, float* y, const int32_t* d_Tm, const int32_t* d_off,
                     int64_t R, int M, int H, uint32_t* d_sync, hipStream_t s) {
@@ -259,11 +284,12 @@ bool gru_persistent(const float* gx, const float* wh, const float* bh, float* y,
     const int max_ncl = max_cids / 2;
     p.RT = (p.ntiles + 4 * max_ncl - 1) / (4 * max_ncl);
     p.ncl = (p.ntiles + 4 * p.RT - 1) / (4 * p.RT);
-    p.spin_limit = 4u << 20;  // polls of >= ~0.5 us each: seconds, far beyond any legitimate wait
+    p.spin_limit = 1u << 21;  // re-reads of >= ~1 us each: seconds, far beyond any legitimate wait
     const int groups = (2 * p.ncl + 7) / 8;
     const dim3 grid(8 * UB * groups);
     const size_t lds = (size_t)H * 48 * sizeof(float);
     (void)hipMemsetAsync(d_sync, 0, gru_persistent_sync_words(M) * sizeof(uint32_t), s);
+    // (y was filled with the "unwritten" word by gru_persistent_prepare)
     if (H == 256) hipLaunchKernelGGL((gru_persistent_kernel<256>), grid, dim3(256), lds, s, p);
     else if (H == 128) hipLaunchKernelGGL((gru_persistent_kernel<128>), grid, dim3(256), lds, s, p);
     else hipLaunchKernelGGL((gru_persistent_kernel<64>), grid, dim3(256), lds, s, p);

@@ -756,14 +756,16 @@ int HipModel::run_recognition_packed(Workspace& ws, const std::vector<PackedGrou
             int tok = timers ? timers->begin(ST_REC_GRU, st, 0) : -1;
             float* gx = ws.alloc_n<float>((size_t)2 * R * 3 * H);
             float* y = ws.alloc_n<float>((size_t)R * 2 * H);
+            const bool fused = (H == 256 || H == 128 || H == 64);
+            const bool persistent = fused && gru_mode() == GRU_PERSISTENT;
+            if (persistent) k::gru_persistent_prepare(y, R, H, st);  // "unwritten" marks; ahead of the input GEMM
             k::GemmDesc d{};
             d.A = cur; d.lda = I; d.B = op.aux0; d.ldb = 3 * H; d.bias = op.aux1; d.C = gx; d.ldc = 3 * H;
             d.M = (int)R; d.N = 3 * H; d.K = I; d.batch = 2;
             d.strideA = 0; d.strideB = (int64_t)I * 3 * H; d.strideBias = 3 * H; d.strideC = R * 3 * H;
             timed(KC_GEMM_GRU_INPUT, 2.0 * 2 * R * (double)d.N * d.K, 4.0 * ((double)R * I + 2.0 * R * d.N + 2.0 * d.K * d.N),
                   [&] { k::gemm(d, st); });
-            const bool fused = (H == 256 || H == 128 || H == 64);
-            if (fused && gru_mode() == GRU_PERSISTENT) {
+            if (persistent) {
                 // ONE launch for all Tmax steps of both directions (kernels_gru.hip).  Its workgroups wait on
                 // each other, so two such kernels must never be half-resident at the same time: every request's
                 // recurrences go through one process-wide stream (FIFO on the GPU, linked by events, no host wait).

@@ -1,0 +1,84 @@
+#!/bin/bash
+# One gpurun call = one session: tools/gpu_session.sh <tag> <section>...   (outputs under gpurun_out/<tag>/)
+# Sections: tests_new tests_all ab lat serial16 full multi stream prof pmc
+set -u
+export TMPDIR=/tmp
+TAG=$1; shift
+ROOT=$PWD
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+S=$OUT/summary.txt
+: > $S
+say() { echo "$@" | tee -a $S; }
+jsum() {  # file label
+python - "$1" "$2" <<'PY' | tee -a $S
+import json, sys
+f, label = sys.argv[1], sys.argv[2]
+try:
+    d = json.loads([l for l in open(f).read().splitlines() if l.startswith("{")][-1])
+    rl = d.get("rooflines", {})
+    print("%s: %.1f pages/s, %.2f ms/step, host cores %.2f | %s" % (label, d["value"], d["ms_per_step"], d.get("host_cpu_cores_busy_per_gpu", 0),
+          ", ".join("%s %.3f (%.2f ms x %.1f)" % (k.replace("gemm_", "").replace("_mfma", ""), v["frac"], v["avg_launch_ms"], v["launches_per_step"]) for k, v in rl.items())))
+    st = d.get("stages_ms_per_step")
+    if st: print("   stages:", {k: round(v, 2) for k, v in st.items()})
+    for k in ("roofline_detection", "value_incl_h2d", "cpu_baseline"):
+        if k in d: print("   %s: %s" % (k, json.dumps(d[k])[:400]))
+    if "extras" in d: print("   extras:", json.dumps({k: v for k, v in d["extras"].items() if "config" not in k})[:400])
+except Exception as e:
+    print(label, "parse failed:", e)
+PY
+}
+for sec in "$@"; do
+case $sec in
+tests_new)
+  say "== bench-scale tests"; timeout 900 python -m pytest tests/test_gpu_bench_scale.py -x -q > $OUT/test_bench_scale.log 2>&1; say "rc=$?"; tail -4 $OUT/test_bench_scale.log | tee -a $S;;
+tests_all)
+  say "== full GPU suite"; timeout 1500 python -m pytest tests -m gpu -x -q > $OUT/test_gpu_all.log 2>&1; say "rc=$?"; tail -4 $OUT/test_gpu_all.log | tee -a $S;;
+ab)
+  say "== default bench, GRU persistent (0) vs per-step (1)"
+  for mode in 0 1 0 1; do
+    OCRS_GRU_MODE=$mode timeout 300 python bench.py --no-cpu-baseline --no-extras > $OUT/bench_default_gru$mode.json 2> $OUT/bench_default_gru$mode.err; jsum $OUT/bench_default_gru$mode.json "gru_mode=$mode"
+  done;;
+lat)
+  say "== latency: 1 page per request, strictly serial stages"
+  for mode in 0 1; do
+    OCRS_GRU_MODE=$mode timeout 300 python bench.py --pages 1 --inflight 1 --no-pipeline --steps 20 --warmup 5 --settle-s 0 --no-cpu-baseline --no-extras > $OUT/bench_lat1_gru$mode.json 2> $OUT/bench_lat1_gru$mode.err; jsum $OUT/bench_lat1_gru$mode.json "1 page serial gru_mode=$mode"
+  done;;
+serial16)
+  say "== 16 pages per request, strictly serial (isolated kernel times)"
+  for mode in 0 1; do
+    OCRS_GRU_MODE=$mode timeout 300 python bench.py --pages 16 --inflight 1 --no-pipeline --steps 6 --warmup 2 --settle-s 0 --no-cpu-baseline --no-extras --profile-hint > $OUT/bench_serial16_gru$mode.json 2> $OUT/bench_serial16_gru$mode.err
+    jsum $OUT/bench_serial16_gru$mode.json "16 pages serial gru_mode=$mode"; grep -E "^gemm_|^dwconv|^conv|^pool|^other|^logsoft" $OUT/bench_serial16_gru$mode.err | tee -a $S
+  done;;
+full)
+  say "== default bench with every leg (extras, cpu baseline)"; timeout 900 python bench.py > $OUT/bench_full.json 2> $OUT/bench_full.err; say "rc=$?"; jsum $OUT/bench_full.json "default";;
+multi)
+  say "== 2 ranks on this one GPU (gloo, ranks share the device): exercises the self-spawn + gather path"
+  OCRS_DIST_BACKEND=gloo timeout 600 python bench.py --gpus 2 --steps 8 --warmup 4 --pages 8 --settle-s 0 --no-cpu-baseline --no-extras > $OUT/bench_2rank.json 2> $OUT/bench_2rank.err; say "rc=$?"; jsum $OUT/bench_2rank.json "2 ranks/1 GPU"; tail -3 $OUT/bench_2rank.err | cut -c1-300 | tee -a $S
+  say "== 2 ranks, RCCL backend on one GPU (may be refused by RCCL: informational)"
+  timeout 300 python bench.py --gpus 2 --steps 4 --warmup 2 --pages 8 --settle-s 0 --no-cpu-baseline --no-extras > $OUT/bench_2rank_rccl.json 2> $OUT/bench_2rank_rccl.err; say "rc=$?"; jsum $OUT/bench_2rank_rccl.json "2 ranks RCCL"; tail -2 $OUT/bench_2rank_rccl.err | cut -c1-300 | tee -a $S;;
+stream)
+  say "== configs[4] stream mode on 1 GPU: 512 distinct pages"; timeout 900 python bench.py --stream-pages 512 --warmup 4 --no-cpu-baseline --no-extras > $OUT/bench_stream512.json 2> $OUT/bench_stream512.err; say "rc=$?"; jsum $OUT/bench_stream512.json "stream 512";;
+prof)
+  say "== rocprofv3 kernel trace, default bench"
+  (cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats -d $ROOT/$OUT/prof -o default -- python $ROOT/bench.py --steps 18 --warmup 12 --no-cpu-baseline --no-extras > $ROOT/$OUT/prof_bench.json 2> $ROOT/$OUT/prof_bench.err); say "rc=$?"
+  db=$(find $OUT/prof -name "default*.db" | head -1)
+  [ -n "$db" ] && python tools/rocprof_summary.py "$db" $OUT/${TAG}_default_bench_kernel_stats.txt > /dev/null && head -16 $OUT/${TAG}_default_bench_kernel_stats.txt | cut -c1-200 | tee -a $S
+  jsum $OUT/prof_bench.json "under rocprof"
+  say "== rocprofv3 kernel trace, serial 16 pages (isolated kernels)"
+  (cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats -d $ROOT/$OUT/prof -o serial -- python $ROOT/bench.py --steps 3 --warmup 1 --settle-s 0 --inflight 1 --no-pipeline --no-cpu-baseline --no-extras --no-kernel-timing > /dev/null 2> $ROOT/$OUT/prof_serial.err); say "rc=$?"
+  db=$(find $OUT/prof -name "serial*.db" | head -1)
+  [ -n "$db" ] && python tools/rocprof_summary.py "$db" $OUT/${TAG}_serial_kernel_stats.txt > /dev/null && head -24 $OUT/${TAG}_serial_kernel_stats.txt | cut -c1-200 | tee -a $S
+  find $OUT/prof -size +30M -delete;;
+pmc)
+  say "== PMC passes (separate runs: FETCH_SIZE, WRITE_SIZE, MFMA busy), serial 16 pages"
+  BENCH="python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --no-kernel-timing --no-pipeline --inflight 1 --settle-s 0"
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $ROOT/$OUT/pmc -o fetch -- $BENCH > $ROOT/$OUT/pmc_fetch.log 2>&1); say "fetch rc=$?"
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $ROOT/$OUT/pmc -o write -- $BENCH > $ROOT/$OUT/pmc_write.log 2>&1); say "write rc=$?"
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE -d $ROOT/$OUT/pmc -o mfma -- $BENCH > $ROOT/$OUT/pmc_mfma.log 2>&1); say "mfma rc=$?"
+  python tools/pmc_summary.py $OUT/pmc $OUT/${TAG}_pmc_hbm.txt $OUT/${TAG}_pmc.json > /dev/null 2>$OUT/pmc_summary.err; head -40 $OUT/${TAG}_pmc_hbm.txt | cut -c1-220 | tee -a $S
+  find $OUT/pmc -size +30M -delete;;
+*) say "unknown section $sec";;
+esac
+done
+say done
