@@ -104,13 +104,15 @@ bool gru_step_fused(const float* gx, const float* wh, const float* bh, const flo
                     hipStream_t s);
 // ---- kernels_gru.hip: all time steps of one bidirectional GRU layer in ONE persistent launch.
 // d_sync: gru_persistent_sync_words(M) words of scratch (zeroed by the call); its last word is non-zero
-// afterwards if a wait inside the kernel timed out.  Returns false if H is unsupported.
+// afterwards if a wait inside the kernel timed out.  Returns false (nothing launched) if the shape is not
+// supported (H, more than 4096 lines, Tmax beyond the LDS table): the caller then runs gru_step_fused per step.
 // gru_persistent_prepare marks every word of y "unwritten" (the kernel's hand-off protocol reads y as its own
 // flag); call it on a stream ordered before gru_persistent.
 size_t gru_persistent_sync_words(int M);
+bool gru_persistent_supported(int M, int Tmax, int64_t R, int H);
 void gru_persistent_prepare(float* y, int64_t R, int H, hipStream_t s);
 bool gru_persistent(const float* gx, const float* wh, const float* bh, float* y, const int32_t* d_Tm, const int32_t* d_off,
-                    int64_t R, int M, int H, uint32_t* d_sync, hipStream_t s);
+                    int64_t R, int M, int Tmax, int H, uint32_t* d_sync, hipStream_t s);
 void ctc_collapse_packed(const int32_t* labels, const int32_t* d_Tm, const int32_t* d_off, int M, int Tmax,
                          uint32_t* out_labels, uint32_t* out_pos, int32_t* out_count, hipStream_t s);
 void argmax_rows(const float* x, int64_t rows, int c, const uint8_t* d_excluded, int32_t* labels, hipStream_t s);

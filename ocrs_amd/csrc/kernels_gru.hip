@@ -49,16 +49,24 @@ struct GruParams {
     const int32_t* off;  // [Tmax + 1] first packed row of time t
     uint32_t* sync;      // [1] error word; zeroed before the launch
     int64_t R;
-    int M, ntiles, RT, ncl;
+    int M, ntiles, RT, ncl, Tmax;
     uint32_t spin_limit;
 };
 
-// cache-bypassing 16-byte accesses (volatile => sc0 sc1 on gfx950: write-through store / L1-bypassing load)
-// Always GLOBAL (address_space(1)) instructions: a flat access would also tick lgkmcnt and take the slower path.
-typedef __attribute__((address_space(1))) f32x4 gf32x4;
+// Hand-off accesses to y: 16-byte raw-buffer loads/stores with the sc1 (agent-scope) cache bit — the store is
+// written through to memory, the load bypasses the CU's L1 (MI355X_MICROARCH.md: "`sc1` loads may replace the
+// acquire when the producer stored `sc1`").  Buffer intrinsics rather than `volatile` accesses: the compiler
+// follows a volatile access with s_waitcnt vmcnt(0), which would serialise the 17 loads of an item.  The buffer
+// resource spans y (< 4 GiB, checked by gru_plan); offsets are bytes.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+constexpr int kAuxSc1 = 16;
+__device__ __forceinline__ f32x4 load_bypass(__amdgpu_buffer_rsrc_t y, uint32_t byte_off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(y, (int)byte_off, 0, kAuxSc1));
+}
+__device__ __forceinline__ void store_through(__amdgpu_buffer_rsrc_t y, uint32_t byte_off, f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), y, (int)byte_off, 0, kAuxSc1);
+}
 typedef __attribute__((address_space(1))) uint32_t gu32;
-__device__ __forceinline__ f32x4 load_bypass(const float* p) { return *(const volatile gf32x4*)p; }
-__device__ __forceinline__ void store_through(float* p, f32x4 v) { *(volatile gf32x4*)p = v; }
 
 // 4x4 transpose between (register e, 16-lane group g):  out[a] in group g  =  in[g] of group a
 __device__ __forceinline__ void transpose4(const f32x4& in, float* out) {
@@ -83,40 +91,45 @@ struct Loaded {             // everything one (tile, step) item reads from memor
     f32x4 h[H / 16];        // lane (row, kq): pieces q = 4j + kq of the row's previous state
     f32x4 hp;               // previous state of this lane's own 4 units
     f32x4 gr, gz, gn;       // gx of this lane's 4 units
-    int64_t row;            // packed output row
-    const float* yp;        // the row's previous-step output (this direction's half); null: h = 0 (first step / idle lane)
+    uint32_t out_off;       // byte offset in y of this lane's 4 output units
+    uint32_t prev_off;      // byte offset in y of the row's previous-step output (this direction's half)
+    bool has_prev;          // false: h = 0 (first step / idle lane)
     bool active;
 };
 
-// row bookkeeping + the gx operands of the epilogue (independent of the recurrence)
+// row bookkeeping + the gx operands of the epilogue (independent of the recurrence).  tm = length of the lane's
+// row (0: no such row); off_l = the packed-row table off[] in LDS.  No global load here other than gx: a wait on
+// one would also wait for the write-through store of the previous item (vmcnt retires in order).
 template <int H>
-__device__ __forceinline__ void issue_meta(const GruParams& p, int dir, int ub, int tile, int s, int i16, int kq, Loaded<H>& L) {
+__device__ __forceinline__ void issue_meta(const GruParams& p, int dir, int ub, int tile, int tm, const int* off_l, int s,
+                                           int i16, int kq, Loaded<H>& L) {
     const int m = tile * 16 + i16;
-    const int tm = m < p.M ? p.Tm[m] : 0;
     L.active = tm > s;
     const int t = dir ? tm - 1 - s : s;
-    L.row = L.active ? (int64_t)p.off[t] + m : 0;
+    const int64_t row = L.active ? (int64_t)off_l[t] + m : 0;
+    L.out_off = (uint32_t)((row * 2 * H + dir * H + ub * 16 + kq * 4) * sizeof(float));
     const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
     L.gr = L.gz = L.gn = L.hp = zero;
 #pragma unroll
     for (int j = 0; j < H / 16; j++) L.h[j] = zero;
-    L.yp = nullptr;
+    L.has_prev = L.active && s > 0;
+    L.prev_off = 0;
     if (L.active) {
-        const float* g = p.gx + ((int64_t)dir * p.R + L.row) * 3 * H + ub * 16 + kq * 4;
+        const float* g = p.gx + ((int64_t)dir * p.R + row) * 3 * H + ub * 16 + kq * 4;
         L.gr = *reinterpret_cast<const f32x4*>(g);
         L.gz = *reinterpret_cast<const f32x4*>(g + H);
         L.gn = *reinterpret_cast<const f32x4*>(g + 2 * H);
-        if (s > 0) L.yp = p.y + ((int64_t)p.off[dir ? tm - s : s - 1] + m) * 2 * H + dir * H;
+        if (s > 0) L.prev_off = (uint32_t)((((int64_t)off_l[dir ? tm - s : s - 1] + m) * 2 * H + dir * H) * sizeof(float));
     }
 }
 
 // the previous state of the lane's row (no wait: the loads are checked by state_ready())
 template <int H>
-__device__ __forceinline__ void issue_state(int ub, int kq, Loaded<H>& L) {
-    if (L.yp) {
+__device__ __forceinline__ void issue_state(__amdgpu_buffer_rsrc_t y, int ub, int kq, Loaded<H>& L) {
+    if (L.has_prev) {
 #pragma unroll
-        for (int j = 0; j < H / 16; j++) L.h[j] = load_bypass(L.yp + 16 * j + 4 * kq);
-        L.hp = load_bypass(L.yp + ub * 16 + kq * 4);
+        for (int j = 0; j < H / 16; j++) L.h[j] = load_bypass(y, L.prev_off + (16 * j + 4 * kq) * 4);
+        L.hp = load_bypass(y, L.prev_off + (ub * 16 + kq * 4) * 4);
     }
 }
 
@@ -135,7 +148,7 @@ __device__ __forceinline__ bool state_ready(const Loaded<H>& L) {
 
 // wait until the previous state of every row of the tile is complete, re-reading as needed
 template <int H>
-__device__ __forceinline__ bool await_state(const GruParams& p, int ub, int kq, Loaded<H>& L) {
+__device__ __forceinline__ bool await_state(const GruParams& p, __amdgpu_buffer_rsrc_t y, int ub, int kq, Loaded<H>& L) {
     for (uint32_t spins = 0; !state_ready<H>(L); spins++) {
         __builtin_amdgcn_s_sleep(2);
         if ((spins & 255u) == 255u) {
@@ -146,14 +159,13 @@ __device__ __forceinline__ bool await_state(const GruParams& p, int ub, int kq, 
                 return false;
             }
         }
-        issue_state<H>(ub, kq, L);
+        issue_state<H>(y, ub, kq, L);
     }
     return true;
 }
 
 template <int H>
-__device__ __forceinline__ void compute_item(const GruParams& p, int dir, int ub, int tile, int i16, int kq, int lane,
-                                             const Loaded<H>& L, const float (&w)[H / 4], const float* lds_w,
+__device__ __forceinline__ void compute_item(__amdgpu_buffer_rsrc_t y, int lane, const Loaded<H>& L, const float (&w)[H / 4], const float* lds_w,
                                              const f32x4& br, const f32x4& bz, const f32x4& bn) {
     f32x4 acc_r = br, acc_z = bz, acc_n = bn;
     // A operand: lane (unit c = i16, kq) feeds Wh[4*s4 + kq][g*H + 16ub + c].  LDS holds, per (gate, block of 4
@@ -189,7 +201,7 @@ __device__ __forceinline__ void compute_item(const GruParams& p, int dir, int ub
             const float hv = fmaf(zg, L.hp[r] - ng, ng);
             hn[r] = __float_as_uint(hv) == kUnwritten ? __uint_as_float(0x7FC00000u) : hv;  // keep the flag word free
         }
-        store_through(p.y + L.row * 2 * H + dir * H + ub * 16 + kq * 4, hn);  // fire and forget: the data is the flag
+        store_through(y, L.out_off, hn);  // fire and forget: the data is the flag
     }
 }
 
@@ -222,42 +234,57 @@ gru_persistent_kernel(GruParams p) {
         float* dst = &lds_w[(((g * (H / 16) + blk) * 64) + kk * 16 + c4) * 4 + e];
         dst[0] = v.x; dst[4] = v.y; dst[8] = v.z; dst[12] = v.w;
     }
+    int* off_l = reinterpret_cast<int*>(lds_w + H * 48);  // off[0 .. Tmax]
+    for (int i = tid; i <= p.Tmax; i += 256) off_l[i] = p.off[i];
     const f32x4 br = *reinterpret_cast<const f32x4*>(bhd + j0 + kq * 4);
     const f32x4 bz = *reinterpret_cast<const f32x4*>(bhd + H + j0 + kq * 4);
     const f32x4 bn = *reinterpret_cast<const f32x4*>(bhd + 2 * H + j0 + kq * 4);
+    // this wave's tiles: base, base + 4, ... (RT <= 4 of them); per tile the length of the lane's row and of the
+    // tile's first (= longest) row, both kept in registers for the whole run
+    const int base = cl * 4 * p.RT + wave;
+    int tmr[4], tT[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int m = (base + 4 * i) * 16 + i16;
+        tmr[i] = (i < p.RT && m < p.M) ? p.Tm[m] : 0;
+        tT[i] = __builtin_amdgcn_readfirstlane(tmr[i]);
+    }
+    auto sel = [](const int (&a)[4], int i) { return i == 0 ? a[0] : i == 1 ? a[1] : i == 2 ? a[2] : i == 3 ? a[3] : 0; };
     __syncthreads();
     __builtin_amdgcn_s_setprio(3);  // a short dependent chain: outrank co-resident throughput kernels at issue
-
-    const int base = cl * 4 * p.RT + wave;  // this wave's tiles: base, base + 4, ...
-    auto tile_T = [&](int i) -> int {       // steps of the wave's i-th tile (its first row is its longest)
-        const int tile = base + 4 * i;
-        return (i < p.RT && tile < p.ntiles) ? p.Tm[tile * 16] : 0;
-    };
-    if (tile_T(0) <= 0) return;
+    if (tT[0] <= 0) return;
     // items in (step, tile) order; the state loads of the NEXT item are issued before the current one is
     // computed whenever it belongs to another tile (its inputs cannot depend on the current item)
+    // Two register sets used alternately (A holds the current item while B receives the next one's loads, then
+    // the roles swap): copying a set would make the wave wait for loads that are still in flight.
+    const __amdgpu_buffer_rsrc_t yb = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)(uint32_t)(p.R * 2 * H * sizeof(float)), 0x00020000);
     int s = 0, i = 0;
-    Loaded<H> cur, nxt;
-    issue_meta<H>(p, dir, ub, base, 0, i16, kq, cur);
-    for (;;) {
+    Loaded<H> bufA, bufB;
+    issue_meta<H>(p, dir, ub, base, tmr[0], off_l, 0, i16, kq, bufA);
+    // one item: returns 0 = done, 1 = go on, -1 = timed out
+    auto item = [&](Loaded<H>& cur, Loaded<H>& nxt) -> int {
         int ns = s, ni = i + 1;
-        if (tile_T(ni) <= s) { ns = s + 1; ni = 0; }
-        const bool have_next = tile_T(ni) > ns;
+        if (sel(tT, ni) <= s) { ns = s + 1; ni = 0; }
+        const bool have_next = sel(tT, ni) > ns;
         const bool early = have_next && ni != i;
         // B operand: lane (row, kq) feeds h[row][4*s4 + kq].  Turned BEFORE the next item's loads are issued so
         // that those can land in the registers the pieces leave behind.
         float w[H / 4];
 #pragma unroll
         for (int j = 0; j < H / 16; j++) transpose4(cur.h[j], &w[4 * j]);
-        if (have_next) issue_meta<H>(p, dir, ub, base + 4 * ni, ns, i16, kq, nxt);
-        if (early) issue_state<H>(ub, kq, nxt);
-        compute_item<H>(p, dir, ub, base + 4 * i, i16, kq, lane, cur, w, lds_w, br, bz, bn);
-        if (!have_next) break;
-        if (!early) issue_state<H>(ub, kq, nxt);
-        if (!await_state<H>(p, ub, kq, nxt)) return;
-        cur = nxt;
+        if (have_next) issue_meta<H>(p, dir, ub, base + 4 * ni, sel(tmr, ni), off_l, ns, i16, kq, nxt);
+        if (early) issue_state<H>(yb, ub, kq, nxt);
+        compute_item<H>(yb, lane, cur, w, lds_w, br, bz, bn);
+        if (!have_next) return 0;
+        if (!early) issue_state<H>(yb, ub, kq, nxt);
+        if (!await_state<H>(p, yb, ub, kq, nxt)) return -1;
         s = ns;
         i = ni;
+        return 1;
+    };
+    for (;;) {
+        if (item(bufA, bufB) <= 0) break;
+        if (item(bufB, bufA) <= 0) break;
     }
 }
 
@@ -270,26 +297,41 @@ void gru_persistent_prepare(float* y, int64_t R, int H, hipStream_t s) {
     if (R > 0) (void)hipMemsetAsync(y, 0xFF, (size_t)R * 2 * H * sizeof(float), s);
 }
 
-bool gru_persistent(const float* gx, const float* wh, const float* bh, float* y, const int32_t* d_Tm, const int32_t* d_off,
-                    int64_t R, int M, int H, uint32_t* d_sync, hipStream_t s) {
-    if (M <= 0) return true;
+// grid geometry; false if the shape is not supported
+static bool gru_plan(int M, int Tmax, int H, int* RT, int* ncl) {
     if (H != 256 && H != 128 && H != 64) return false;
+    const int ntiles = (M + 15) / 16;
+    const int UB = H / 16;
+    // Every workgroup of a cluster must be resident at once, so the grid stays at about one workgroup per CU
+    // (256), two per CU for requests of more than 2048 lines; a wave serves RT <= 4 row tiles.
+    int max_ncl = 256 / UB / 2 >= 1 ? 256 / UB / 2 : 1;
+    if ((ntiles + 4 * max_ncl - 1) / (4 * max_ncl) > 4) max_ncl *= 2;
+    *RT = (ntiles + 4 * max_ncl - 1) / (4 * max_ncl);
+    if (*RT > 4 || *RT < 1) return false;
+    *ncl = (ntiles + 4 * *RT - 1) / (4 * *RT);
+    return (size_t)H * 48 * sizeof(float) + ((size_t)Tmax + 1) * sizeof(int) <= 64 * 1024;
+}
+
+bool gru_persistent_supported(int M, int Tmax, int64_t R, int H) {
+    int RT, ncl;
+    // y is addressed through one buffer resource: < 4 GiB
+    return M > 0 && (uint64_t)R * 2 * H * sizeof(float) < (uint64_t(1) << 32) && gru_plan(M, Tmax, H, &RT, &ncl);
+}
+
+bool gru_persistent(const float* gx, const float* wh, const float* bh, float* y, const int32_t* d_Tm, const int32_t* d_off,
+                    int64_t R, int M, int Tmax, int H, uint32_t* d_sync, hipStream_t s) {
+    if (M <= 0) return true;
     GruParams p{};
     p.gx = gx; p.wh = wh; p.bh = bh; p.y = y; p.Tm = d_Tm; p.off = d_off; p.sync = d_sync;
-    p.R = R; p.M = M;
+    p.R = R; p.M = M; p.Tmax = Tmax;
     p.ntiles = (M + 15) / 16;
     const int UB = H / 16;
-    // at most ~256 workgroups (one per CU: every workgroup of a cluster must be resident at once)
-    const int max_cids = 256 / UB >= 2 ? 256 / UB : 2;          // clusters x directions
-    const int max_ncl = max_cids / 2;
-    p.RT = (p.ntiles + 4 * max_ncl - 1) / (4 * max_ncl);
-    p.ncl = (p.ntiles + 4 * p.RT - 1) / (4 * p.RT);
+    if (!gru_plan(M, Tmax, H, &p.RT, &p.ncl)) return false;
     p.spin_limit = 1u << 21;  // re-reads of >= ~1 us each: seconds, far beyond any legitimate wait
     const int groups = (2 * p.ncl + 7) / 8;
     const dim3 grid(8 * UB * groups);
-    const size_t lds = (size_t)H * 48 * sizeof(float);
-    (void)hipMemsetAsync(d_sync, 0, gru_persistent_sync_words(M) * sizeof(uint32_t), s);
-    // (y was filled with the "unwritten" word by gru_persistent_prepare)
+    const size_t lds = (size_t)H * 48 * sizeof(float) + ((size_t)Tmax + 1) * sizeof(int);
+    (void)hipMemsetAsync(d_sync, 0, gru_persistent_sync_words(M) * sizeof(uint32_t), s);  // (y: gru_persistent_prepare)
     if (H == 256) hipLaunchKernelGGL((gru_persistent_kernel<256>), grid, dim3(256), lds, s, p);
     else if (H == 128) hipLaunchKernelGGL((gru_persistent_kernel<128>), grid, dim3(256), lds, s, p);
     else hipLaunchKernelGGL((gru_persistent_kernel<64>), grid, dim3(256), lds, s, p);
