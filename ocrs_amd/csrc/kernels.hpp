@@ -75,6 +75,27 @@ void dwpw_fused(const float* x, int n, int h, int w, int cin, const float* wdw, 
 // depthwise 3x3 over concat([skip, centred-pad(up)]) without building the concatenation; false if unsupported
 bool dwconv3x3_cat(const float* skip, int n, int h, int w, int cs, const float* up, int uh, int uw, int cu, const float* wt,
                    const float* bias, int relu, float* y, hipStream_t s);
+// ---- kernels_det.hip: a whole DoubleConv block of the detection U-Net in one launch (LDS halo tiles):
+//   [cat(skip, pad(ConvT2x2/s2(x1)))] -> dw3x3 -> pw1x1 -> dw3x3 -> pw1x1 -> y  [-> maxpool 2x2 | -> conv1x1(->1) -> sigmoid]
+struct DoubleConvArgs {
+    const float* skip;            // [n,h,w,CS]; encoder: the block input
+    const float* x1;              // decoder: [n,h1,w1,CX] input of the ConvTranspose (else null)
+    const float *wt, *bt;         // ConvT [2][2][CX][CS], [CS]
+    const float *wd1, *bd1;       // dw1 [3][3][CIN], [CIN]   (CIN = CS, or 2*CS for a decoder block)
+    const float *wp1, *bp1;       // pw1 [CIN][CMID], [CMID]
+    const float *wd2, *bd2;       // dw2 [3][3][CMID], [CMID]
+    const float *wp2, *bp2;       // pw2 [CMID][COUT], [COUT]
+    const float *wf, *bf;         // final 1x1 conv [COUT], [1]
+    float* y;                     // [n,h,w,COUT], or [n,h,w,1] with the final conv
+    float* ypool;                 // [n,h/2,w/2,COUT] or null
+    int n, h, w, h1, w1;
+    int relu_d1, relu_p1, relu_d2, relu_p2, sigmoid;
+    int tiles_x, tiles_y;         // filled by the launcher
+};
+// true if a fused kernel exists for the shape (cs skip channels, cx ConvT input channels or 0, ...);
+// launches it when `launch` is set.
+bool double_conv_fused(const DoubleConvArgs& a, int cs, int cx, int cmid, int cout, bool pool, bool final_conv, bool launch,
+                       hipStream_t s);
 void maxpool(const float* x, int n, int h, int w, int c, int kh, int kw, float* y, hipStream_t s);
 void avgpool(const float* x, int n, int h, int w, int c, int kh, int kw, float* y, hipStream_t s);
 void padcat(const float* skip, int n, int sh, int sw, int cs, const float* x, int h, int w, int cx, float* y,

@@ -155,6 +155,56 @@ std::unique_ptr<HipModel> HipModel::load(const void* data, size_t len) {
             if (!other_use) { a.cat_into_next = true; b.reads_cat = true; }
         }
     }
+    // Whole DoubleConv blocks of the detection U-Net as one fused launch each (kernels_det.hip).
+    {
+        auto& ops = m->ops;
+        const int n = (int)ops.size();
+        auto uses = [&](int slot) {
+            int u = 0;
+            for (const GraphOp& o : ops) u += (o.in0 == slot) + (o.in1 == slot);
+            return u + ((uint32_t)slot == m->out_slot ? 1 : 0);
+        };
+        auto pw11 = [](const GraphOp& o) { return o.type == OP_CONV && o.kh == 1 && o.kw == 1; };
+        for (int i = 0; i + 3 < n; i++) {
+            DcBlock b;
+            int j = i;
+            if (ops[j].type == OP_CONVT2 && j + 1 < n && ops[j + 1].type == OP_PADCAT && ops[j + 1].in1 == ops[j].out &&
+                uses(ops[j].out) == 1 && uses(ops[j + 1].out) == 1) {
+                b.convt = j; b.cat = j + 1;
+                j += 2;
+            }
+            if (j + 3 >= n) continue;
+            const GraphOp &d1 = ops[j], &p1 = ops[j + 1], &d2 = ops[j + 2], &p2 = ops[j + 3];
+            if (d1.type != OP_DWCONV3 || !pw11(p1) || d2.type != OP_DWCONV3 || !pw11(p2)) continue;
+            if (b.cat >= 0 && d1.in0 != ops[b.cat].out) continue;
+            if (p1.in0 != d1.out || d2.in0 != p1.out || p2.in0 != d2.out) continue;
+            if (uses(d1.out) != 1 || uses(p1.out) != 1 || uses(d2.out) != 1) continue;
+            if (p1.cin != d1.cin || d2.cin != p1.cout || p2.cin != d2.cin) continue;
+            b.dw1 = j; b.pw1 = j + 1; b.dw2 = j + 2; b.pw2 = j + 3;
+            b.first = i; b.last = j + 3;
+            b.cmid = p1.cout; b.cout = p2.cout;
+            if (b.convt >= 0) {
+                b.cx = ops[b.convt].cin;
+                b.cs = d1.cin - ops[b.convt].cout;
+                if (b.cs != ops[b.convt].cout) continue;   // the kernels assume ConvT cout == skip channels
+            } else {
+                b.cs = d1.cin;
+            }
+            const int k = j + 4;
+            if (k < n && ops[k].type == OP_MAXPOOL && ops[k].kh == 2 && ops[k].kw == 2 && ops[k].in0 == p2.out && b.convt < 0) {
+                b.pool = k; b.last = k;
+            } else if (k < n && pw11(ops[k]) && ops[k].cout == 1 && ops[k].in0 == p2.out && uses(p2.out) == 1 && b.convt >= 0) {
+                b.fin = k; b.last = k;
+                if (k + 1 < n && ops[k + 1].type == OP_SIGMOID && ops[k + 1].fused_into_prev) { b.sig = k + 1; b.last = k + 1; }
+                else if (uses(ops[k].out) == 0) continue;
+            }
+            k::DoubleConvArgs none{};
+            if (!k::double_conv_fused(none, b.cs, b.cx, b.cmid, b.cout, b.pool >= 0, b.fin >= 0, false, nullptr)) continue;
+            ops[i].dc_block = (int)m->dc_blocks.size();
+            m->dc_blocks.push_back(b);
+            i = b.last;   // blocks do not overlap
+        }
+    }
     return m;
 }
 
@@ -271,11 +321,87 @@ float* HipModel::run_device(Workspace& ws, const float* d_in, int n, int h, int 
     };
     auto wbytes = [](const GraphOp& o, int j) { return (double)o.wcount[j] * 4.0; };
 
+    std::vector<char> covered(ops.size(), 0);   // ops already done by a fused DoubleConv launch
+    const bool det_fuse = option(OPT_DET_FUSE) != 0;
     for (size_t i = 0; i < n_run; i++) {
         const GraphOp& op = ops[i];
         const TensorShape a = shp[op.in0];
         const TensorShape o = shp[op.out];
         if (kind == 0) enter_stage(ST_DET_CNN);
+        if (covered[i]) {
+            for (int sl = 1; sl < (int)n_slots; sl++)   // any slot whose last reader this op was (incl. a skipped PADCAT's inputs)
+                if (last_use[sl] == (int)i && ptr[sl] && cap[sl]) {
+                    free_local.emplace(cap[sl], ptr[sl]);
+                    ptr[sl] = nullptr;
+                    cap[sl] = 0;
+                }
+            if (print_timing) OCRS_HIP(hipEventRecord(ev[i + 1], st));
+            continue;
+        }
+        if (det_fuse && op.dc_block >= 0) {
+            const DcBlock& b = dc_blocks[op.dc_block];
+            bool ok = (size_t)b.last < n_run;
+            for (int q = b.first; ok && q < b.last; q++)   // no intermediate may be what this run returns
+                if ((uint32_t)ops[q].out == ret_slot && q != b.pw2) ok = false;
+            if (ok && b.fin >= 0 && (uint32_t)ops[b.pw2].out == ret_slot) ok = false;
+            if (ok) {
+                const GraphOp &d1 = ops[b.dw1], &p1 = ops[b.pw1], &d2 = ops[b.dw2], &p2 = ops[b.pw2];
+                const int skip_slot = b.cat >= 0 ? ops[b.cat].in0 : d1.in0;
+                const TensorShape sk = shp[skip_slot];
+                k::DoubleConvArgs da{};
+                da.skip = ptr[skip_slot];
+                da.n = sk.n; da.h = sk.h; da.w = sk.w;
+                double px1 = 0;
+                if (b.convt >= 0) {
+                    const GraphOp& ct = ops[b.convt];
+                    const TensorShape x1 = shp[ct.in0];
+                    da.x1 = ptr[ct.in0]; da.h1 = x1.h; da.w1 = x1.w;
+                    da.wt = ct.w[0]; da.bt = ct.w[1];
+                    px1 = (double)x1.n * x1.h * x1.w;
+                    if (2 * x1.h > sk.h || 2 * x1.w > sk.w) ok = false;
+                }
+                da.wd1 = d1.w[0]; da.bd1 = d1.w[1]; da.wp1 = p1.w[0]; da.bp1 = p1.w[1];
+                da.wd2 = d2.w[0]; da.bd2 = d2.w[1]; da.wp2 = p2.w[0]; da.bp2 = p2.w[1];
+                da.relu_d1 = d1.relu; da.relu_p1 = p1.relu; da.relu_d2 = d2.relu; da.relu_p2 = p2.relu;
+                const double px = (double)sk.n * sk.h * sk.w;
+                double out_floats = 0;
+                if (ok) {
+                    if (b.fin >= 0) {
+                        const int fo = b.sig >= 0 ? ops[b.sig].out : ops[b.fin].out;
+                        auto r = get((size_t)shp[fo].count());
+                        ptr[fo] = r.first; cap[fo] = r.second;
+                        da.y = r.first; da.wf = ops[b.fin].w[0]; da.bf = ops[b.fin].w[1]; da.sigmoid = b.sig >= 0;
+                        out_floats = (double)shp[fo].count();
+                    } else {
+                        auto r = get((size_t)shp[p2.out].count());
+                        ptr[p2.out] = r.first; cap[p2.out] = r.second;
+                        da.y = r.first;
+                        out_floats = (double)shp[p2.out].count();
+                        if (b.pool >= 0) {
+                            auto rp = get((size_t)shp[ops[b.pool].out].count());
+                            ptr[ops[b.pool].out] = rp.first; cap[ops[b.pool].out] = rp.second;
+                            da.ypool = rp.first;
+                            out_floats += (double)shp[ops[b.pool].out].count();
+                        }
+                    }
+                    const int cin = d1.cin;
+                    const double fl = 2.0 * px * (9.0 * cin + (double)cin * b.cmid + 9.0 * b.cmid + (double)b.cmid * b.cout +
+                                                  (b.fin >= 0 ? b.cout : 0)) + 2.0 * px * (b.convt >= 0 ? (double)b.cx * b.cs : 0.0);
+                    timed(KC_DWCONV3X3, fl, 4.0 * (px * b.cs + px1 * b.cx + out_floats), [&] {
+                        k::double_conv_fused(da, b.cs, b.cx, b.cmid, b.cout, b.pool >= 0, b.fin >= 0, true, st);
+                    });
+                    for (int q = b.first + 1; q <= b.last; q++) covered[q] = 1;
+                    for (int sl = 1; sl < (int)n_slots; sl++)
+                        if (last_use[sl] == (int)i && ptr[sl] && cap[sl]) {
+                            free_local.emplace(cap[sl], ptr[sl]);
+                            ptr[sl] = nullptr;
+                            cap[sl] = 0;
+                        }
+                    if (print_timing) OCRS_HIP(hipEventRecord(ev[i + 1], st));
+                    continue;
+                }
+            }
+        }
         else if (op.type == OP_GRU) enter_stage(ST_REC_GRU);
         else if (op.type == OP_LINEAR || op.type == OP_LOGSOFTMAX) enter_stage(seen_seq ? ST_REC_HEAD : ST_REC_CONV);
         else enter_stage(seen_seq ? ST_REC_GRU : ST_REC_CONV);

@@ -31,6 +31,14 @@ struct GraphOp {
     bool done_by_prev = false;    // that 1x1 CONV
     bool cat_into_next = false;   // PADCAT whose only reader is the next op, a DWCONV3: the concatenation is never built
     bool reads_cat = false;       // that DWCONV3 (reads the two PADCAT inputs directly)
+    int dc_block = -1;            // index into HipModel::dc_blocks if a fused DoubleConv block starts at this op
+};
+
+// A DoubleConv block of the detection U-Net that one fused launch covers (kernels_det.hip); op indices, -1 = absent.
+struct DcBlock {
+    int first = -1, last = -1;
+    int convt = -1, cat = -1, dw1 = -1, pw1 = -1, dw2 = -1, pw2 = -1, pool = -1, fin = -1, sig = -1;
+    int cs = 0, cx = 0, cmid = 0, cout = 0;
 };
 
 struct TensorShape {  // NHWC activations, or [T,N,C] sequences (n=T, h=N, w=1, c=C)
@@ -58,6 +66,7 @@ struct CallbackModel : ModelBase {
 struct HipModel : ModelBase {
     uint32_t kind = 0;  // 0 detection, 1 recognition
     std::vector<GraphOp> ops;
+    std::vector<DcBlock> dc_blocks;
     uint32_t n_slots = 0, out_slot = 0;
     DevBuf weights;      // one slab: file blob + derived tensors
     bool is_callback() const override { return false; }

@@ -171,3 +171,29 @@ def test_gru_modes_give_identical_bits(engine):
     assert res[0][0] == res[1][0]
     assert np.array_equal(res[0][1][0], res[1][1][0]) and np.array_equal(res[0][1][1], res[1][1][1])
     assert sum(1 for t in res[0][0] if t) > 80
+
+
+@pytest.mark.parametrize("in_hw,depths", [((800, 600), (8, 16, 32, 32, 64, 128, 256)), ((160, 128), (8, 16, 32, 32)),
+                                           ((232, 184), (8, 16, 32, 32, 64))])
+def test_fused_double_conv_blocks_equal_unfused_and_oracle(in_hw, depths):
+    """Detection CNN: the fused LDS-tiled DoubleConv launches (option det_fuse = 1, default) against the unfused
+    kernels (det_fuse = 0), bit for bit, on 3 pages through the Model::run seam — tile edges that are not multiples of
+    the tile (600 = 18 x 32 + 24; 184 = 5 x 32 + 24), odd sizes under the pools (75 -> 37: the decoder pads `up`), and
+    the small model against the oracle's exact chain as well."""
+    from oracle.nn import OracleGraph
+    dbuf = M.detection_model_bytes(in_hw, depths)
+    model = Model.load_bytes(dbuf)
+    rng = np.random.default_rng(in_hw[0])
+    x = (rng.random((3, 1) + in_hw, dtype=np.float32) - np.float32(0.5))
+    x[:, :, 40:60, 30:90] = -0.5   # a dark blob, so that the hand-set "darkness" path fires
+    try:
+        _lib.set_option("det_fuse", 0)
+        ref = model.run(x)
+        _lib.set_option("det_fuse", 1)
+        got = model.run(x)
+    finally:
+        _lib.set_option("det_fuse", 1)
+    assert got.shape == ref.shape == (3, 1) + in_hw
+    assert np.array_equal(got, ref)
+    if in_hw[0] <= 256:
+        assert np.array_equal(got, OracleGraph(dbuf).run_exact(x))

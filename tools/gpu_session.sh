@@ -50,6 +50,11 @@ serial16)
     OCRS_GRU_MODE=$mode timeout 300 python bench.py --pages 16 --inflight 1 --no-pipeline --steps 6 --warmup 2 --settle-s 0 --no-cpu-baseline --no-extras --profile-hint > $OUT/bench_serial16_gru$mode.json 2> $OUT/bench_serial16_gru$mode.err
     jsum $OUT/bench_serial16_gru$mode.json "16 pages serial gru_mode=$mode"; grep -E "^gemm_|^dwconv|^conv|^pool|^other|^logsoft" $OUT/bench_serial16_gru$mode.err | tee -a $S
   done;;
+det)
+  say "== detection stack: fused LDS-tiled DoubleConv blocks (1) vs unfused kernels (0); extras legs only"
+  for f in 1 0; do
+    OCRS_DET_FUSE=$f timeout 400 python bench.py --steps 6 --warmup 3 --settle-s 0 --no-cpu-baseline > $OUT/bench_det$f.json 2> $OUT/bench_det$f.err; jsum $OUT/bench_det$f.json "det_fuse=$f"
+  done;;
 full)
   say "== default bench with every leg (extras, cpu baseline)"; timeout 900 python bench.py > $OUT/bench_full.json 2> $OUT/bench_full.err; say "rc=$?"; jsum $OUT/bench_full.json "default";;
 multi)
