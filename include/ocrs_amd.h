@@ -66,7 +66,8 @@ OCRS_API ocrs_status ocrs_set_device(int device);
 /* Process-wide integer tuning options (no reference counterpart: RTen's equivalents are compile-time).
  * Each also reads its initial value from the environment variable OCRS_<NAME IN CAPITALS>.
  *   "gru_mode"        0 = one persistent kernel per GRU layer (default), 1 = one launch per time step
- *   "det_fuse"        1 = fused / LDS-tiled detection kernels (default), 0 = the unfused ones
+ *   "det_fuse"        1 = fused LDS-tiled DoubleConv blocks of the detection U-Net where they win (default),
+ *                     2 = for every block shape that has a fused kernel, 0 = per-op kernels only
  *   "layout_threads"  host threads ocrs_engine_find_text_lines_batch may use (0 = automatic)
  * Results never depend on an option; OCRS_ERR_INVALID_ARGUMENT for an unknown name. */
 OCRS_API ocrs_status ocrs_set_option(const char* name, long value);

@@ -193,7 +193,7 @@ namespace {
 struct OptDef { const char* name; const char* env; long def; };
 const OptDef kOptDefs[OPT_COUNT] = {
     {"gru_mode", "OCRS_GRU_MODE", GRU_PERSISTENT},      // 0 persistent recurrence kernel, 1 one launch per time step
-    {"det_fuse", "OCRS_DET_FUSE", 1},                   // 1 fused/LDS-tiled detection kernels, 0 the unfused ones
+    {"det_fuse", "OCRS_DET_FUSE", 1},                   // fused DoubleConv blocks: 1 where they win, 2 every shape, 0 none
     {"layout_threads", "OCRS_LAYOUT_THREADS", 0},       // host threads of find_text_lines_batch (0 = automatic)
 };
 std::atomic<long> g_opts[OPT_COUNT];

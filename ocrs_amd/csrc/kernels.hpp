@@ -92,10 +92,11 @@ struct DoubleConvArgs {
     int relu_d1, relu_p1, relu_d2, relu_p2, sigmoid;
     int tiles_x, tiles_y;         // filled by the launcher
 };
-// true if a fused kernel exists for the shape (cs skip channels, cx ConvT input channels or 0, ...);
+// true if a fused kernel exists for the shape (cs skip channels, cx ConvT input channels or 0, ...) at this
+// fuse level (option "det_fuse": 1 = the shapes where fusion wins, 2 = every shape that has a kernel);
 // launches it when `launch` is set.
-bool double_conv_fused(const DoubleConvArgs& a, int cs, int cx, int cmid, int cout, bool pool, bool final_conv, bool launch,
-                       hipStream_t s);
+bool double_conv_fused(const DoubleConvArgs& a, int cs, int cx, int cmid, int cout, bool pool, bool final_conv, int fuse_level,
+                       bool launch, hipStream_t s);
 void maxpool(const float* x, int n, int h, int w, int c, int kh, int kw, float* y, hipStream_t s);
 void avgpool(const float* x, int n, int h, int w, int c, int kh, int kw, float* y, hipStream_t s);
 void padcat(const float* skip, int n, int sh, int sw, int cs, const float* x, int h, int w, int cx, float* y,

@@ -307,24 +307,30 @@ void launch_dc(const DoubleConvArgs& a0, hipStream_t s) {
 }  // namespace
 
 // Shapes with a fused kernel: (skip channels, ConvT input channels or 0, mid, out, pool, final).
-bool double_conv_fused(const DoubleConvArgs& a, int cs, int cx, int cmid, int cout, bool pool, bool final_conv, bool launch,
-                       hipStream_t s) {
+bool double_conv_fused(const DoubleConvArgs& a, int cs, int cx, int cmid, int cout, bool pool, bool final_conv, int fuse_level,
+                       bool launch, hipStream_t s) {
 #define OCRS_DC(CS, CX, CM, CO, TH, TW, P, F)                                                   \
     if (cs == CS && cx == CX && cmid == CM && cout == CO && pool == P && final_conv == F) {      \
         if (launch) launch_dc<DcCfg<CS, CX, CM, CO, TH, TW, P, F>>(a, s);                         \
         return true;                                                                             \
     }
+    // Shapes where one fused launch beats the per-op kernels (rocprofv3, 8 pages of 800x600, profiles/r2_det_*):
+    // encoder level 0 107 us vs 202, level 1 54 vs 93, level 2 46 vs 48; decoder level 0 268 vs 531, level 1 210 vs 208.
+    // Deeper levels (C >= 32 on <= 200x150 pixels) are thread-per-pixel VALU chains on few tiles and lose
+    // (decoder level 2: 322 us vs ~120, level 3: 200 vs ~90; encoder level 3: 40 vs 31), so they stay per-op.
     // encoder blocks (input -> skip [+ pooled])
     OCRS_DC(1, 0, 8, 8, 16, 32, true, false)
     OCRS_DC(8, 0, 16, 16, 8, 32, true, false)
     OCRS_DC(16, 0, 32, 32, 8, 16, true, false)
-    OCRS_DC(32, 0, 32, 32, 8, 16, true, false)
     // decoder blocks (skip + ConvT(x1) -> out [-> final conv + sigmoid])
     OCRS_DC(8, 16, 8, 8, 8, 32, false, true)
     OCRS_DC(8, 16, 8, 8, 8, 32, false, false)
     OCRS_DC(16, 32, 16, 16, 8, 16, false, false)
-    OCRS_DC(32, 32, 32, 32, 8, 16, false, false)
-    OCRS_DC(32, 64, 32, 32, 8, 16, false, false)
+    if (fuse_level >= 2) {   // every shape that has a kernel (tests / experiments)
+        OCRS_DC(32, 0, 32, 32, 8, 16, true, false)
+        OCRS_DC(32, 32, 32, 32, 8, 16, false, false)
+        OCRS_DC(32, 64, 32, 32, 8, 16, false, false)
+    }
 #undef OCRS_DC
     return false;
 }

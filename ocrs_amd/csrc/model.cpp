@@ -199,7 +199,7 @@ std::unique_ptr<HipModel> HipModel::load(const void* data, size_t len) {
                 else if (uses(ops[k].out) == 0) continue;
             }
             k::DoubleConvArgs none{};
-            if (!k::double_conv_fused(none, b.cs, b.cx, b.cmid, b.cout, b.pool >= 0, b.fin >= 0, false, nullptr)) continue;
+            if (!k::double_conv_fused(none, b.cs, b.cx, b.cmid, b.cout, b.pool >= 0, b.fin >= 0, 2, false, nullptr)) continue;
             ops[i].dc_block = (int)m->dc_blocks.size();
             m->dc_blocks.push_back(b);
             i = b.last;   // blocks do not overlap
@@ -322,7 +322,7 @@ float* HipModel::run_device(Workspace& ws, const float* d_in, int n, int h, int 
     auto wbytes = [](const GraphOp& o, int j) { return (double)o.wcount[j] * 4.0; };
 
     std::vector<char> covered(ops.size(), 0);   // ops already done by a fused DoubleConv launch
-    const bool det_fuse = option(OPT_DET_FUSE) != 0;
+    const int det_fuse = option(OPT_DET_FUSE);
     for (size_t i = 0; i < n_run; i++) {
         const GraphOp& op = ops[i];
         const TensorShape a = shp[op.in0];
@@ -340,7 +340,8 @@ float* HipModel::run_device(Workspace& ws, const float* d_in, int n, int h, int 
         }
         if (det_fuse && op.dc_block >= 0) {
             const DcBlock& b = dc_blocks[op.dc_block];
-            bool ok = (size_t)b.last < n_run;
+            bool ok = (size_t)b.last < n_run &&
+                      k::double_conv_fused(k::DoubleConvArgs{}, b.cs, b.cx, b.cmid, b.cout, b.pool >= 0, b.fin >= 0, det_fuse, false, nullptr);
             for (int q = b.first; ok && q < b.last; q++)   // no intermediate may be what this run returns
                 if ((uint32_t)ops[q].out == ret_slot && q != b.pw2) ok = false;
             if (ok && b.fin >= 0 && (uint32_t)ops[b.pw2].out == ret_slot) ok = false;
@@ -388,7 +389,7 @@ float* HipModel::run_device(Workspace& ws, const float* d_in, int n, int h, int 
                     const double fl = 2.0 * px * (9.0 * cin + (double)cin * b.cmid + 9.0 * b.cmid + (double)b.cmid * b.cout +
                                                   (b.fin >= 0 ? b.cout : 0)) + 2.0 * px * (b.convt >= 0 ? (double)b.cx * b.cs : 0.0);
                     timed(KC_DWCONV3X3, fl, 4.0 * (px * b.cs + px1 * b.cx + out_floats), [&] {
-                        k::double_conv_fused(da, b.cs, b.cx, b.cmid, b.cout, b.pool >= 0, b.fin >= 0, true, st);
+                        k::double_conv_fused(da, b.cs, b.cx, b.cmid, b.cout, b.pool >= 0, b.fin >= 0, det_fuse, true, st);
                     });
                     for (int q = b.first + 1; q <= b.last; q++) covered[q] = 1;
                     for (int sl = 1; sl < (int)n_slots; sl++)

@@ -189,11 +189,13 @@ def test_fused_double_conv_blocks_equal_unfused_and_oracle(in_hw, depths):
     try:
         _lib.set_option("det_fuse", 0)
         ref = model.run(x)
-        _lib.set_option("det_fuse", 1)
+        _lib.set_option("det_fuse", 2)   # every block shape that has a fused kernel
+        got2 = model.run(x)
+        _lib.set_option("det_fuse", 1)   # the default: only the shapes where fusion wins
         got = model.run(x)
     finally:
         _lib.set_option("det_fuse", 1)
     assert got.shape == ref.shape == (3, 1) + in_hw
-    assert np.array_equal(got, ref)
+    assert np.array_equal(got, ref) and np.array_equal(got2, ref)
     if in_hw[0] <= 256:
         assert np.array_equal(got, OracleGraph(dbuf).run_exact(x))

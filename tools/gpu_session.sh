@@ -55,6 +55,14 @@ det)
   for f in 1 0; do
     OCRS_DET_FUSE=$f timeout 400 python bench.py --steps 6 --warmup 3 --settle-s 0 --no-cpu-baseline > $OUT/bench_det$f.json 2> $OUT/bench_det$f.err; jsum $OUT/bench_det$f.json "det_fuse=$f"
   done;;
+detprof)
+  say "== rocprofv3 kernel trace of the detection-only loop (tools/det_bench.py), fused vs unfused"
+  for f in 1 0; do
+    (cd /tmp && OCRS_DET_FUSE=$f timeout 300 rocprofv3 --kernel-trace --stats -d $ROOT/$OUT/detprof -o det$f -- python $ROOT/tools/det_bench.py 20 > $ROOT/$OUT/detprof$f.log 2>&1); tail -1 $OUT/detprof$f.log | tee -a $S
+    db=$(find $OUT/detprof -name "det${f}*.db" | head -1)
+    [ -n "$db" ] && python tools/rocprof_summary.py "$db" $OUT/${TAG}_det_fuse${f}_kernel_stats.txt > /dev/null && head -34 $OUT/${TAG}_det_fuse${f}_kernel_stats.txt | cut -c1-200 | tee -a $S
+  done
+  find $OUT/detprof -size +30M -delete;;
 full)
   say "== default bench with every leg (extras, cpu baseline)"; timeout 900 python bench.py > $OUT/bench_full.json 2> $OUT/bench_full.err; say "rc=$?"; jsum $OUT/bench_full.json "default";;
 multi)
