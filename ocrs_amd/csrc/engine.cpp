@@ -122,26 +122,38 @@ void ocrs_engine::detect(const ocrs_page* const* pages, size_t n, std::vector<st
         StageScope sc(T, ST_CONTOUR_RECTS, st, 3);
         k::contour_rects(d_mask, N, h, w, b, max_comp, arena, /*expand*/ 3.0f, min_area, /*eps*/ 2.0f, st);
     }
+    // One round trip in the common case: the counts travel together with the first kSpec candidate rects of every
+    // page (a page of text has a few hundred to ~1 500 components); only a page with more needs a second one.
+    constexpr int kSpec = 2048;
+    const int spec = std::min(max_comp, kSpec);
     std::vector<int32_t> counts(N), ovf(N);
+    std::vector<std::vector<float>> hr(N);
+    std::vector<std::vector<uint8_t>> hv(N);
     ws.download(counts.data(), b.n_roots, N * sizeof(int32_t));
     ws.download(ovf.data(), b.overflow, N * sizeof(int32_t));
+    for (int i = 0; i < N; i++) {
+        hr[i].resize((size_t)spec * 6);
+        hv[i].resize(spec);
+        ws.download(hr[i].data(), b.rects + (size_t)i * max_comp * 6, hr[i].size() * sizeof(float));
+        ws.download(hv[i].data(), b.valid + (size_t)i * max_comp, spec);
+    }
     ws.sync();
     for (int i = 0; i < N; i++)
         if (ovf[i] || counts[i] > max_comp)
             fail(OCRS_ERR_CAPACITY, "text mask of page %d has too many components or border pixels (%d components)", i,
                  counts[i]);
     rects_out->assign(n, {});
-    std::vector<std::vector<float>> hr(N);
-    std::vector<std::vector<uint8_t>> hv(N);
-    for (int i = 0; i < N; i++) {  // all pages' results in one round trip
+    bool more = false;
+    for (int i = 0; i < N; i++) {
         const int cnt = counts[i];
-        if (cnt == 0) continue;
+        if (cnt <= spec) continue;
+        more = true;
         hr[i].resize((size_t)cnt * 6);
         hv[i].resize(cnt);
         ws.download(hr[i].data(), b.rects + (size_t)i * max_comp * 6, hr[i].size() * sizeof(float));
         ws.download(hv[i].data(), b.valid + (size_t)i * max_comp, cnt);
     }
-    ws.sync();
+    if (more) ws.sync();
     for (int i = 0; i < N; i++) {
         auto& out = (*rects_out)[i];
         for (int c = 0; c < counts[i]; c++)
