@@ -67,7 +67,8 @@ void* DevicePool::alloc(size_t bytes) {
     {
         // smallest cached block that fits, if it wastes at most a quarter of the request
         std::lock_guard<std::mutex> g(mu_);
-        auto it = free_.lower_bound(sz);
+        static const bool exact = getenv("OCRS_POOL_EXACT") != nullptr;
+        auto it = exact ? free_.find(sz) : free_.lower_bound(sz);
         if (it != free_.end() && it->first <= sz + sz / 4) {
             void* p = it->second;
             const size_t got = it->first;

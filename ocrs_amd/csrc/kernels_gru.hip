@@ -29,6 +29,8 @@
 // the y store are one 16-byte access per gate / per lane in the natural layouts.  The B operand
 // wants lane (row, kq) to hold h[row][4*s + kq]; rows are fetched as 16-byte pieces and turned by a
 // 4x4 transpose across the four 16-lane groups (v_permlane16_swap / v_permlane32_swap).
+#include <cstdlib>
+
 #include "kernels.hpp"
 #include "spec_math.hpp"
 
@@ -50,6 +52,7 @@ struct GruParams {
     uint32_t* sync;      // [1] error word; zeroed before the launch
     int64_t R;
     int M, ntiles, RT, ncl, Tmax;
+    int prio;            // s_setprio level of the waves (0..3)
     uint32_t spin_limit;
 };
 
@@ -251,7 +254,9 @@ gru_persistent_kernel(GruParams p) {
     }
     auto sel = [](const int (&a)[4], int i) { return i == 0 ? a[0] : i == 1 ? a[1] : i == 2 ? a[2] : i == 3 ? a[3] : 0; };
     __syncthreads();
-    __builtin_amdgcn_s_setprio(3);  // a short dependent chain: outrank co-resident throughput kernels at issue
+    if (p.prio >= 3) __builtin_amdgcn_s_setprio(3);  // a short dependent chain: outrank co-resident throughput kernels at issue
+    else if (p.prio == 2) __builtin_amdgcn_s_setprio(2);
+    else if (p.prio == 1) __builtin_amdgcn_s_setprio(1);
     if (tT[0] <= 0) return;
     // items in (step, tile) order; the state loads of the NEXT item are issued before the current one is
     // computed whenever it belongs to another tile (its inputs cannot depend on the current item)
@@ -298,13 +303,13 @@ void gru_persistent_prepare(float* y, int64_t R, int H, hipStream_t s) {
 }
 
 // grid geometry; false if the shape is not supported
-static bool gru_plan(int M, int Tmax, int H, int* RT, int* ncl) {
+static bool gru_plan(int M, int Tmax, int H, int* RT, int* ncl, int max_blocks = 256) {
     if (H != 256 && H != 128 && H != 64) return false;
     const int ntiles = (M + 15) / 16;
     const int UB = H / 16;
     // Every workgroup of a cluster must be resident at once, so the grid stays at about one workgroup per CU
     // (256), two per CU for requests of more than 2048 lines; a wave serves RT <= 4 row tiles.
-    int max_ncl = 256 / UB / 2 >= 1 ? 256 / UB / 2 : 1;
+    int max_ncl = max_blocks / UB / 2 >= 1 ? max_blocks / UB / 2 : 1;
     if ((ntiles + 4 * max_ncl - 1) / (4 * max_ncl) > 4) max_ncl *= 2;
     *RT = (ntiles + 4 * max_ncl - 1) / (4 * max_ncl);
     if (*RT > 4 || *RT < 1) return false;
@@ -326,7 +331,11 @@ bool gru_persistent(const float* gx, const float* wh, const float* bh, float* y,
     p.R = R; p.M = M; p.Tmax = Tmax;
     p.ntiles = (M + 15) / 16;
     const int UB = H / 16;
-    if (!gru_plan(M, Tmax, H, &p.RT, &p.ncl)) return false;
+    int max_blocks = 256;
+    if (const char* e = getenv("OCRS_GRU_BLOCKS")) max_blocks = atoi(e) > 0 ? atoi(e) : 256;
+    if (!gru_plan(M, Tmax, H, &p.RT, &p.ncl, max_blocks) && !gru_plan(M, Tmax, H, &p.RT, &p.ncl)) return false;
+    p.prio = 3;
+    if (const char* e = getenv("OCRS_GRU_PRIO")) p.prio = atoi(e);
     p.spin_limit = 1u << 21;  // re-reads of >= ~1 us each: seconds, far beyond any legitimate wait
     const int groups = (2 * p.ncl + 7) / 8;
     const dim3 grid(8 * UB * groups);
