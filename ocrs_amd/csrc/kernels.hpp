@@ -111,8 +111,9 @@ void to_seq(const float* x, int n, int w, int c, float* y, hipStream_t s);
 // gx: [2][T*N][3H] (dir-major), gh: [2][N][3H], h: [2][N][H], y: [T][N][2H].
 void gru_gates(const float* gx, const float* gh, float* h, float* y, int T, int N, int H, int step, hipStream_t s);
 // log_softmax over C (+ optional -inf masking of excluded labels) + argmax.
-// logits/logp: [rows][C]; labels: [rows] (first max).  logp may be null.
-void log_softmax_argmax(const float* logits, int64_t rows, int c, const uint8_t* d_excluded /*[C] or null*/,
+// logits/logp: [rows][C]; labels: [rows] (first max).  logp may be null.  Returns false (nothing launched)
+// if C is too large for the kernel's LDS staging (more than ~630 classes).
+bool log_softmax_argmax(const float* logits, int64_t rows, int c, const uint8_t* d_excluded /*[C] or null*/,
                         float* logp, int32_t* labels, hipStream_t s);
 // Ragged sequence batch (lines sorted by length, rows off[t] + m); see kernels_nn.hip.
 void to_seq_packed(const float* x, int n, int T, int c, const int32_t* d_pos, const int32_t* d_off, float* y,

@@ -902,14 +902,27 @@ log_softmax_argmax_kernel(const float* __restrict__ logits, int64_t rows, int c,
         }
 }
 
-void log_softmax_argmax(const float* logits, int64_t rows, int c, const uint8_t* d_excluded, float* logp,
+bool log_softmax_argmax(const float* logits, int64_t rows, int c, const uint8_t* d_excluded, float* logp,
                         int32_t* labels, hipStream_t s) {
-    if (rows <= 0) return;
+    if (rows <= 0) return true;
     int cp = (c & 1) ? c : c + 1;
     size_t lds = (size_t)LSM_ROWS * cp * sizeof(float);
+    // 64 rows x C floats are staged in LDS: beyond 64 KB the launch needs the opt-in, beyond the CU's 160 KB
+    // (an alphabet of more than ~630 classes) this kernel cannot run — the caller reports it as a capacity error
+    // instead of a generic launch failure
+    if (lds > 160 * 1024) return false;
+    if (lds > 64 * 1024) {
+        static size_t raised = 0;
+        if (lds > raised) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&log_softmax_argmax_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            raised = 160 * 1024;
+        }
+    }
     int grid = (int)((rows + LSM_ROWS - 1) / LSM_ROWS);
     hipLaunchKernelGGL(log_softmax_argmax_kernel, dim3(grid), dim3(LSM_ROWS), lds, s, logits, rows, c, d_excluded, logp,
                        labels);
+    return true;
 }
 
 // ---------------------------------------------------------------------------

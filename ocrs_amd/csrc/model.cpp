@@ -54,8 +54,10 @@ std::unique_ptr<HipModel> HipModel::load(const void* data, size_t len) {
     FileHeader hd;
     memcpy(&hd, data, sizeof hd);
     if (memcmp(hd.magic, "OCRSMDL1", 8) != 0 || hd.version != 1) fail(OCRS_ERR_IO, "not an OCRSMDL1 model file");
+    if (hd.n_ops > (1u << 20) || hd.n_slots == 0 || hd.n_slots > (1u << 20) || hd.out_slot >= hd.n_slots)
+        fail(OCRS_ERR_IO, "model file header out of range (%u ops, %u slots, output slot %u)", hd.n_ops, hd.n_slots, hd.out_slot);
     const size_t table = sizeof(FileHeader) + (size_t)hd.n_ops * sizeof(FileOp);
-    if (len < table + hd.blob_floats * sizeof(float)) fail(OCRS_ERR_IO, "model file truncated");
+    if (len < table || hd.blob_floats > (len - table) / sizeof(float)) fail(OCRS_ERR_IO, "model file truncated");
     const float* blob = reinterpret_cast<const float*>(static_cast<const char*>(data) + table);
 
     auto m = std::make_unique<HipModel>();
@@ -76,7 +78,41 @@ std::unique_ptr<HipModel> HipModel::load(const void* data, size_t len) {
         const FileOp& f = fops[i];
         if (f.type >= OP_COUNT || f.n_w > 8) fail(OCRS_ERR_IO, "bad op record %u", i);
         for (uint32_t j = 0; j < f.n_w; j++)
-            if (f.w[j].off + f.w[j].cnt > hd.blob_floats) fail(OCRS_ERR_IO, "weight reference out of range in op %u", i);
+            if (f.w[j].off > hd.blob_floats || f.w[j].cnt > hd.blob_floats - f.w[j].off)
+                fail(OCRS_ERR_IO, "weight reference out of range in op %u", i);
+        // A malformed or stale file must fail here, not index out of bounds in infer()/run_device() or on the device:
+        // slot numbers within the table, weight tensors of exactly the sizes the op's shape implies.
+        {
+            const int64_t ns = hd.n_slots;
+            const bool two_in = f.type == OP_PADCAT;
+            if (f.in0 < 0 || f.in0 >= ns || f.out <= 0 || f.out >= ns || (two_in ? (f.in1 < 0 || f.in1 >= ns) : false) ||
+                (!two_in && f.in1 >= ns))
+                fail(OCRS_ERR_IO, "slot index out of range in op %u", i);
+            auto want = [&](uint32_t j, int64_t cnt) {
+                if (j >= f.n_w || cnt < 0 || (int64_t)f.w[j].cnt != cnt)
+                    fail(OCRS_ERR_IO, "op %u (%s): weight tensor %u has %llu floats, the op's shape needs %lld", i,
+                         kOpNames[f.type], j, j < f.n_w ? (unsigned long long)f.w[j].cnt : 0ull, (long long)cnt);
+            };
+            auto pos = [&](int64_t v, const char* what) {
+                if (v <= 0 || v > (1 << 20)) fail(OCRS_ERR_IO, "op %u (%s): bad %s %lld", i, kOpNames[f.type], what, (long long)v);
+            };
+            switch (f.type) {
+                case OP_CONV: pos(f.kh, "kh"); pos(f.kw, "kw"); pos(f.cin, "cin"); pos(f.cout, "cout");
+                    want(0, (int64_t)f.kh * f.kw * f.cin * f.cout); want(1, f.cout); break;
+                case OP_DWCONV3: pos(f.cin, "channels"); want(0, 9LL * f.cin); want(1, f.cin); break;
+                case OP_MAXPOOL: case OP_AVGPOOL: pos(f.kh, "kh"); pos(f.kw, "kw"); break;
+                case OP_CONVT2: pos(f.cin, "cin"); pos(f.cout, "cout"); want(0, 4LL * f.cin * f.cout); want(1, f.cout); break;
+                case OP_GRU: pos(f.cin, "input size"); pos(f.hidden, "hidden size");
+                    if (f.n_w != 8) fail(OCRS_ERR_IO, "GRU op %u needs 8 weight tensors", i);
+                    for (uint32_t d = 0; d < 2; d++) {
+                        want(4 * d + 0, 3LL * f.cin * f.hidden); want(4 * d + 1, 3LL * f.hidden);
+                        want(4 * d + 2, 3LL * f.hidden * f.hidden); want(4 * d + 3, 3LL * f.hidden);
+                    }
+                    break;
+                case OP_LINEAR: pos(f.cin, "cin"); pos(f.cout, "cout"); want(0, (int64_t)f.cin * f.cout); want(1, f.cout); break;
+                default: break;
+            }
+        }
         GraphOp op{};
         op.type = f.type; op.in0 = f.in0; op.in1 = f.in1; op.out = f.out;
         op.relu = f.relu; op.kh = f.kh; op.kw = f.kw; op.cin = f.cin; op.cout = f.cout; op.hidden = f.hidden;
@@ -560,8 +596,9 @@ float* HipModel::run_device(Workspace& ws, const float* d_in, int n, int h, int 
             }
             case OP_LOGSOFTMAX:
                 timed(KC_LOGSOFTMAX_ARGMAX, 0, 4.0 * a.count() * (y ? 2.0 : 1.0), [&] {
-                    k::log_softmax_argmax(x, (int64_t)a.n * a.h * a.w, a.c, is_final_logsoftmax ? d_excluded : nullptr, y,
-                                          is_final_logsoftmax ? d_labels : nullptr, st);
+                    if (!k::log_softmax_argmax(x, (int64_t)a.n * a.h * a.w, a.c, is_final_logsoftmax ? d_excluded : nullptr, y,
+                                               is_final_logsoftmax ? d_labels : nullptr, st))
+                        fail(OCRS_ERR_CAPACITY, "LogSoftmax over %d classes exceeds the kernel's LDS staging (max ~630)", a.c);
                 });
                 break;
             default: fail(OCRS_ERR_RUN_FAILED, "model run failed: bad op");
@@ -957,7 +994,10 @@ int HipModel::run_recognition_packed(Workspace& ws, const std::vector<PackedGrou
                 *d_logp = lp;
             }
             timed(KC_LOGSOFTMAX_ARGMAX, 0, 4.0 * R * curC * (lp ? 2.0 : 1.0),
-                  [&] { k::log_softmax_argmax(cur, R, curC, d_excluded, lp, d_labels, st); });
+                  [&] {
+                      if (!k::log_softmax_argmax(cur, R, curC, d_excluded, lp, d_labels, st))
+                          fail(OCRS_ERR_CAPACITY, "LogSoftmax over %d classes exceeds the kernel's LDS staging (max ~630)", curC);
+                  });
             if (tok >= 0) timers->end(tok, st);
             classes = curC;
         }

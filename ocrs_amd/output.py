@@ -28,8 +28,10 @@ def ocr_json(input_path, input_hw, text_lines):
 
 
 def format_json_output(input_path, input_hw, text_lines):
-    """output.rs:98-101 (serde_json::to_string_pretty)."""
-    return json.dumps(ocr_json(input_path, input_hw, text_lines), indent=2, ensure_ascii=False)
+    """output.rs:98-101 (serde_json::to_string_pretty).  serde_json without `preserve_order` keeps `json!` maps in a
+    BTreeMap, so the reference emits every object's keys in alphabetical order (ocrs-cli/test-data/
+    format-json-expected.json: image_height, image_width, paragraphs, url / text, vertices, words): sort_keys."""
+    return json.dumps(ocr_json(input_path, input_hw, text_lines), indent=2, ensure_ascii=False, sort_keys=True)
 
 
 def format_text_output(text_lines):

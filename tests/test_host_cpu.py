@@ -152,6 +152,10 @@ def test_format_json_output_matches_reference_golden(lib):
     got = json.loads(output.format_json_output("image.jpeg", (256, 256), lines))
     exp = json.load(open(os.path.join(ROOT, "tests", "golden", "reference", "format-json-expected.json")))["expected"]
     assert got == exp
+    # textual: serde_json (no `preserve_order`) writes every object's keys alphabetically, as the golden file has them
+    text = output.format_json_output("image.jpeg", (256, 256), lines)
+    assert text == json.dumps(exp, indent=2, ensure_ascii=False, sort_keys=True)
+    assert text.index('"image_height"') < text.index('"image_width"') < text.index('"paragraphs"') < text.index('"url"')
     assert output.format_text_output(lines).split("\n") == ["line one", "line two"]
 
 
@@ -196,3 +200,31 @@ def test_no_gpu_means_a_loud_error_not_a_cpu_fallback(lib):
         ocrs_amd.Model.load_bytes(buf)
     with pytest.raises(ocrs_amd.OcrsError):
         _lib.require_gpu()
+
+
+def test_malformed_model_files_are_rejected_at_load(lib):
+    """A stale or corrupted .ocrsm must fail with OCRS_ERR_IO at load (before any device work), not index out of
+    bounds later: slot numbers, weight-tensor sizes and blob ranges are validated (model.cpp HipModel::load)."""
+    import struct
+    import models_util as M
+    from ocrs_amd import Model
+    from ocrs_amd._lib import OcrsError
+    good = bytearray(M.detection_model_bytes((160, 128), (8, 16, 32, 32)))
+    hdr, opsz = struct.calcsize("<8sII4qIIIIQ"), struct.calcsize("<I9iII16Q")
+
+    def expect_io(buf):
+        with pytest.raises(OcrsError) as e:
+            Model.load_bytes(bytes(buf))
+        assert e.value.status_name == "IO", e.value
+
+    bad = bytearray(good); struct.pack_into("<i", bad, hdr + 4, 1 << 20)          # op 0: in0 far outside the slot table
+    expect_io(bad)
+    bad = bytearray(good); struct.pack_into("<i", bad, hdr + 3 * opsz + 12, -5)   # op 3: negative output slot
+    expect_io(bad)
+    bad = bytearray(good); struct.pack_into("<i", bad, hdr + opsz + 7 * 4, 999)   # op 1 (1x1 conv): cin no longer matches its weights
+    expect_io(bad)
+    bad = bytearray(good); struct.pack_into("<Q", bad, hdr + 48 + 8, 2 ** 62)     # op 0: weight count overflows the blob
+    expect_io(bad)
+    expect_io(good[: len(good) // 2])                                               # truncated blob
+    bad = bytearray(good); struct.pack_into("<I", bad, 8 + 4 + 4 + 32 + 8, 10 ** 6)  # header: output slot outside the table
+    expect_io(bad)

@@ -206,3 +206,19 @@ def test_importer_refuses_what_the_executor_cannot_run():
         next(n for n in m.nodes if n.op == "GRU").attrs["direction"] = "forward"
     with pytest.raises(OnnxImportError, match="GRU node .*bidirectional"):
         import_onnx(_mutate(rec, forward_only))
+
+
+def test_export_for_reference_tool_runs_end_to_end(tmp_path):
+    """tools/export_for_reference.py: the artefacts a machine WITH the Rust toolchain needs to
+    run the reference on the same synthetic models — det/rec as .onnx (round trip byte-identical to the .ocrsm) and
+    the bench's page 0 as PNG — are produced here."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("export_for_reference", os.path.join(root, "tools", "export_for_reference.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.main(str(tmp_path))
+    names = sorted(p.name for p in tmp_path.iterdir())
+    assert names == ["det.ocrsm", "det.onnx", "page.png", "rec.ocrsm", "rec.onnx"]
+    assert (tmp_path / "rec.onnx").stat().st_size > 9_000_000 and (tmp_path / "page.png").stat().st_size > 100_000
