@@ -555,6 +555,30 @@ def extra_legs(engine, dptrs, host_pages, H, W, synth, np, DimOrder, sync_all, a
     out["value_incl_h2d"] = round(k * B / dt, 3)
     out["value_incl_h2d_config"] = ("%d steps of %d pages, %d in flight, every page uploaded from pageable host memory "
                                     "(3 MiB H2D per page) inside the timed region" % (k, B, args.inflight))
+    # image decode stays on the host, as in the reference (ocrs-cli/src/main.rs:312-333 decodes with the `image` crate
+    # before OcrEngine::prepare_input): what it costs per page on one host core, and how many cores a GPU running at
+    # `value` pages/s would keep busy decoding
+    try:
+        import io
+        from PIL import Image
+        img = Image.fromarray(host_pages[0], "RGB")
+        enc = {}
+        for fmt, kw in (("PNG", {}), ("JPEG", {"quality": 90})):
+            buf = io.BytesIO()
+            img.save(buf, fmt, **kw)
+            enc[fmt] = buf.getvalue()
+        dec = {}
+        for fmt, data in enc.items():
+            np.asarray(Image.open(io.BytesIO(data)).convert("RGB"))
+            t0 = time.perf_counter()
+            for _ in range(6):
+                np.asarray(Image.open(io.BytesIO(data)).convert("RGB"))
+            dec[fmt] = (time.perf_counter() - t0) / 6
+        out["host_decode"] = {"png_ms_per_page": round(1e3 * dec["PNG"], 2), "jpeg_ms_per_page": round(1e3 * dec["JPEG"], 2),
+                              "png_bytes": len(enc["PNG"]), "jpeg_bytes": len(enc["JPEG"]),
+                              "how": "PIL decode of one synthetic 1024x1024 RGB page to a u8 HWC array, one host core"}
+    except Exception as e:  # PIL missing: the leg is informational
+        out["host_decode"] = {"error": str(e)}
     # what this box sustains, next to the nominal peaks the roofline divides by
     from ocrs_amd._lib import measure_peaks
     tf, gbps = measure_peaks()

@@ -167,12 +167,16 @@ __device__ __forceinline__ bool await_state(const GruParams& p, __amdgpu_buffer_
     return true;
 }
 
+// The three gate accumulators of one item (D layout 16x16: lane holds D[i = 4*kq + r][j = i16] = unit 16ub + 4kq + r
+// of row i16).
+struct GateAcc { f32x4 r, z, n; };
+
 template <int H>
-__device__ __forceinline__ void compute_item(__amdgpu_buffer_rsrc_t y, int lane, const Loaded<H>& L, const float (&w)[H / 4], const float* lds_w,
-                                             const f32x4& br, const f32x4& bz, const f32x4& bn) {
+__device__ __forceinline__ GateAcc mfma_chain(int lane, const float (&w)[H / 4], const float* lds_w, const f32x4& br,
+                                              const f32x4& bz, const f32x4& bn) {
     f32x4 acc_r = br, acc_z = bz, acc_n = bn;
     // A operand: lane (unit c = i16, kq) feeds Wh[4*s4 + kq][g*H + 16ub + c].  LDS holds, per (gate, block of 4
-    // steps), one 16-byte piece per lane (lds_slot()): a conflict-free ds_read_b128 fetches 4 steps of one gate.
+    // steps), one 16-byte piece per lane: a conflict-free ds_read_b128 fetches 4 steps of one gate.
     // Reads run one block ahead of the MFMAs that consume them.
     const f32x4* ap = reinterpret_cast<const f32x4*>(lds_w) + lane;
     f32x4 ar = ap[0], az = ap[(H / 16) * 64], an = ap[2 * (H / 16) * 64];
@@ -193,19 +197,51 @@ __device__ __forceinline__ void compute_item(__amdgpu_buffer_rsrc_t y, int lane,
         }
         ar = nr; az = nz; an = nn;
     }
-    // D layout 16x16: lane holds D[i = 4*kq + r][j = i16] = unit 16ub + 4kq + r of row i16
-    if (L.active) {
-        f32x4 hn;
+    return GateAcc{acc_r, acc_z, acc_n};
+}
+
+// spec_expf / spec_sigmoidf / spec_tanhf (spec_math.hpp) without the early return for NaN — the same value through
+// a final select — so that the gate arithmetic is straight-line code the scheduler can interleave with MFMAs.
+__device__ __forceinline__ float expf_sl(float x0) {
+    float x = x0 > 88.0f ? 88.0f : x0;
+    x = x < -87.0f ? -87.0f : x;
+    const float kf = rintf(x * 1.44269504088896341f);
+    float r = fmaf(kf, -0.693145751953125f, x);
+    r = fmaf(kf, -1.42860682030941723212e-6f, r);
+    float q = 1.98412698412698413e-4f;
+    q = fmaf(q, r, 1.38888888888888894e-3f);
+    q = fmaf(q, r, 8.33333333333333322e-3f);
+    q = fmaf(q, r, 4.16666666666666644e-2f);
+    q = fmaf(q, r, 1.66666666666666657e-1f);
+    q = fmaf(q, r, 0.5f);
+    q = fmaf(q, r, 1.0f);
+    q = fmaf(q, r, 1.0f);
+    const float v = __int_as_float(__float_as_int(q) + (((int)kf) << 23));
+    return x0 != x0 ? x0 : v;
+}
+__device__ __forceinline__ float sigmoidf_sl(float x) { return 1.0f / (1.0f + expf_sl(-x)); }
+__device__ __forceinline__ float tanhf_sl(float x) {
+    const float t = expf_sl(2.0f * x);
+    return (t - 1.0f) / (t + 1.0f);
+}
+
+// gates + new state of the lane's 4 units; `store` = this lane's row is live at this step
+template <int H>
+__device__ __forceinline__ void epilogue_store(__amdgpu_buffer_rsrc_t y, const GateAcc& a, const f32x4& gr, const f32x4& gz,
+                                               const f32x4& gn, const f32x4& hp, uint32_t out_off, bool store) {
+    f32x4 hn;
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const float rg = spec_sigmoidf(L.gr[r] + acc_r[r]);
-            const float zg = spec_sigmoidf(L.gz[r] + acc_z[r]);
-            const float ng = spec_tanhf(fmaf(rg, acc_n[r], L.gn[r]));
-            const float hv = fmaf(zg, L.hp[r] - ng, ng);
-            hn[r] = __float_as_uint(hv) == kUnwritten ? __uint_as_float(0x7FC00000u) : hv;  // keep the flag word free
-        }
-        store_through(y, L.out_off, hn);  // fire and forget: the data is the flag
+    for (int r = 0; r < 4; r++) {
+        const float rg = sigmoidf_sl(gr[r] + a.r[r]);
+        const float zg = sigmoidf_sl(gz[r] + a.z[r]);
+        const float ng = tanhf_sl(fmaf(rg, a.n[r], gn[r]));
+        const float hv = fmaf(zg, hp[r] - ng, ng);
+        hn[r] = __float_as_uint(hv) == kUnwritten ? __uint_as_float(0x7FC00000u) : hv;  // keep the flag word free
     }
+    // fire and forget (the data is the flag).  Unconditional instruction: a lane with nothing to store aims past
+    // the buffer and the hardware range check drops it — a branch here would let the compiler sink the whole gate
+    // arithmetic under it, out of the MFMA shadow.
+    store_through(y, store ? out_off : 0xFFFFFFF0u, hn);
 }
 
 template <int H>
@@ -260,9 +296,9 @@ gru_persistent_kernel(GruParams p) {
     if (tT[0] <= 0) return;
     // items in (step, tile) order; the state loads of the NEXT item are issued before the current one is
     // computed whenever it belongs to another tile (its inputs cannot depend on the current item)
+    const __amdgpu_buffer_rsrc_t yb = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)(uint32_t)(p.R * 2 * H * sizeof(float)), 0x00020000);
     // Two register sets used alternately (A holds the current item while B receives the next one's loads, then
     // the roles swap): copying a set would make the wave wait for loads that are still in flight.
-    const __amdgpu_buffer_rsrc_t yb = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)(uint32_t)(p.R * 2 * H * sizeof(float)), 0x00020000);
     int s = 0, i = 0;
     Loaded<H> bufA, bufB;
     issue_meta<H>(p, dir, ub, base, tmr[0], off_l, 0, i16, kq, bufA);
@@ -279,7 +315,8 @@ gru_persistent_kernel(GruParams p) {
         for (int j = 0; j < H / 16; j++) transpose4(cur.h[j], &w[4 * j]);
         if (have_next) issue_meta<H>(p, dir, ub, base + 4 * ni, sel(tmr, ni), off_l, ns, i16, kq, nxt);
         if (early) issue_state<H>(yb, ub, kq, nxt);
-        compute_item<H>(yb, lane, cur, w, lds_w, br, bz, bn);
+        const GateAcc acc = mfma_chain<H>(lane, w, lds_w, br, bz, bn);
+        epilogue_store<H>(yb, acc, cur.gr, cur.gz, cur.gn, cur.hp, cur.out_off, cur.active);
         if (!have_next) return 0;
         if (!early) issue_state<H>(yb, ub, kq, nxt);
         if (!await_state<H>(p, yb, ub, kq, nxt)) return -1;
