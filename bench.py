@@ -118,7 +118,13 @@ def dist_setup(args):
     backend = os.environ.get("OCRS_DIST_BACKEND", "gloo" if args.dist_selftest else "nccl")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend, rank=rank, world_size=world)
+        if backend == "nccl":   # RCCL: bind the communicator to this rank's GPU explicitly
+            import torch
+            dev = torch.device("cuda", local_rank % torch.cuda.device_count())
+            torch.cuda.set_device(dev)
+            dist.init_process_group(backend, rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, local_rank, world, backend
 
 
@@ -395,6 +401,12 @@ def main():
             roof["avg_launch_ms"] = round(avg_ms, 5)
             roof["launches_per_step"] = round(dom["launches"] / args.steps, 2)
             roof["share_of_gpu_kernel_time_in_calibration_step"] = round(cal[name]["ms"] / total_cal_ms, 3) if name in cal else None
+            # the same kernels with the GPU to themselves (the untimed calibration step runs one request alone):
+            # `frac` above is measured LIVE, i.e. while the other in-flight requests' kernels share the CUs
+            if name in cal and cal[name]["ms"] > 0:
+                iso = ((cal[name]["flops"] / 1e12) if name in MFMA_CLASSES else (cal[name]["bytes"] / 1e9)) / (cal[name]["ms"] * 1e-3)
+                roof["frac_alone"] = round(iso / (PEAK_FP32_MFMA_TFLOPS if name in MFMA_CLASSES else PEAK_HBM_GBS), 4)
+                roof["avg_launch_ms_alone"] = round(cal[name]["ms"] / cal[name]["launches"], 5)
             tr = pmc_traffic(name)  # L2-miss (HBM + Infinity Cache) bytes/launch from the rocprofv3 --pmc passes in profiles/
             roof["traffic"] = tr["hbm_bytes_per_launch"] if tr else None
             roof["traffic_unit"] = "bytes/launch"

@@ -397,8 +397,118 @@ static void launch_gemm(const GemmDesc& d, hipStream_t s) {
         hipLaunchKernelGGL((gemm_mfma_kernel<NT, false, false>), grid, dim3(256), lds, s, d);
 }
 
+// ---------------------------------------------------------------------------
+// Small-M variant (the pointwise convs and ConvTransposes of the deep U-Net levels: 864 .. 15 000 rows,
+// K = 64 .. 512, N up to 512).  The two kernels above walk K in chunks with a barrier and a fresh
+// round of A loads per chunk; with a handful of workgroups that chain of latencies IS the run time
+// (30-85 us for 0.05-0.4 GFLOP).  Here a wave owns one 32 x 32 output tile: the whole B panel
+// [K][32] is staged in LDS once, the wave's A fragment is fetched 128 k at a time, one chunk
+// ahead of the MFMAs that consume it, and the grid is (M/128) x (N/32) workgroups.
+// Same chain as everywhere: acc = bias; k ascending (v_mfma_f32_32x32x2_f32).
+// ---------------------------------------------------------------------------
+constexpr int GS_KC = 128;  // A chunk (k values) held in registers: GS_KC / 2 per lane
+
+template <bool CONVT>
+__global__ void __launch_bounds__(256) gemm_small_kernel(GemmDesc d) {
+    extern __shared__ __attribute__((aligned(16))) float lds_b[];  // [K][32]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const float* __restrict__ A = d.A;
+    const float* __restrict__ B = d.B;
+    float* __restrict__ C = d.C;
+    const int n0 = blockIdx.y * 32;
+    const int64_t row_base = ((int64_t)blockIdx.x * 4 + wave) * 32;
+    const int64_t rowc = row_base + l31 < d.M ? row_base + l31 : (int64_t)d.M - 1;
+    const float* __restrict__ arow = A + rowc * d.lda;
+    // ---- B panel -> LDS (zero beyond N)
+    for (int i = tid; i < d.K * 8; i += 256) {
+        const int kk = i >> 3, c4 = (i & 7) * 4;
+        const float* src = B + (int64_t)kk * d.ldb + n0 + c4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n0 + c4 + 3 < d.N && (d.ldb & 3) == 0 && (((uintptr_t)B) & 15) == 0) {
+            v = *reinterpret_cast<const float4*>(src);
+        } else {
+            if (n0 + c4 + 0 < d.N) v.x = src[0];
+            if (n0 + c4 + 1 < d.N) v.y = src[1];
+            if (n0 + c4 + 2 < d.N) v.z = src[2];
+            if (n0 + c4 + 3 < d.N) v.w = src[3];
+        }
+        *reinterpret_cast<float4*>(&lds_b[kk * 32 + c4]) = v;
+    }
+    // ---- A fragment of the first chunk: lane (row l31, half) feeds A[row][2*kk + half]
+    float a_cur[GS_KC / 2], a_nxt[GS_KC / 2];
+    auto load_a = [&](int k0, float (&a)[GS_KC / 2]) {
+#pragma unroll
+        for (int j = 0; j < GS_KC / 4; j++) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k0 + 4 * j < d.K) v = *reinterpret_cast<const float4*>(arow + k0 + 4 * j);
+            a[2 * j] = half ? v.y : v.x;
+            a[2 * j + 1] = half ? v.w : v.z;
+        }
+    };
+    load_a(0, a_cur);
+    f32x16 acc;
+    {
+        const int col = n0 + l31;
+        const float bv = (d.bias && col < d.N) ? d.bias[col] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[r] = bv;
+    }
+    __syncthreads();
+    for (int k0 = 0; k0 < d.K; k0 += GS_KC) {
+        const bool more = k0 + GS_KC < d.K;
+        if (more) load_a(k0 + GS_KC, a_nxt);
+        const float* bp = &lds_b[(k0 + half) * 32 + l31];
+        if (k0 + GS_KC <= d.K) {
+#pragma unroll
+            for (int kk = 0; kk < GS_KC / 2; kk++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[kk], bp[kk * 64], acc, 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < GS_KC / 2; kk++)
+                if (k0 + 2 * kk < d.K) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[kk], bp[kk * 64], acc, 0, 0, 0);
+        }
+        if (more) {
+#pragma unroll
+            for (int kk = 0; kk < GS_KC / 2; kk++) a_cur[kk] = a_nxt[kk];
+        }
+    }
+    // ---- epilogue.  C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const int col = n0 + l31;
+    if (col >= d.N) return;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int64_t rr = row_base + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (rr >= d.M) continue;
+        float v = acc[r];
+        if (d.relu) v = v > 0.0f ? v : 0.0f;
+        if (CONVT) {
+            const int64_t hw = (int64_t)d.H * d.W;
+            const int64_t img = rr / hw;
+            const int rem = (int)(rr - img * hw);
+            const int y = rem / d.W, x = rem - y * d.W;
+            const int q = col / d.Cout, co = col - q * d.Cout;
+            const int dy = q >> 1, dx = q & 1;
+            C[((img * 2 * d.H + 2 * y + dy) * (2 * (int64_t)d.W) + 2 * x + dx) * d.Cout + co] = v;
+        } else {
+            C[rr * d.ldc + col] = v;
+        }
+    }
+}
+
+static bool gemm_small_ok(const GemmDesc& d) {
+    return !d.im2col && d.batch <= 1 && d.M <= 16384 && d.K >= 16 && d.K <= 512 && (d.K & 3) == 0 && (d.lda & 3) == 0 &&
+           (((uintptr_t)d.A) & 15) == 0;
+}
+
 void gemm(const GemmDesc& d, hipStream_t s) {
     if (d.M <= 0 || d.N <= 0) return;
+    if (gemm_small_ok(d)) {
+        const dim3 grid((unsigned)((d.M + 127) / 128), (unsigned)((d.N + 31) / 32));
+        const size_t lds = (size_t)d.K * 32 * sizeof(float);
+        if (d.convt) hipLaunchKernelGGL((gemm_small_kernel<true>), grid, dim3(256), lds, s, d);
+        else hipLaunchKernelGGL((gemm_small_kernel<false>), grid, dim3(256), lds, s, d);
+        return;
+    }
     const bool tiled_ok = !d.convt && d.N >= 64 && (d.K % TG_BK) == 0 && d.M >= 256 &&
                           (d.im2col ? (d.Cin % TG_BK) == 0 : ((d.lda & 3) == 0 && ((uintptr_t)d.A & 15) == 0));
     if (tiled_ok) {
