@@ -63,12 +63,21 @@ OCRS_API void ocrs_buffer_free(void* p);
 OCRS_API ocrs_status ocrs_device_count(int* n);
 OCRS_API ocrs_status ocrs_set_device(int device);
 
+/* rten::ctc::CtcDecoder::decode_beam (as called at ocrs/src/recognition.rs:512-514) on a host matrix of
+ * log-probabilities [T][C] (blank = class 0): the steps (label, position) of the best prefix.  `impl`: 0 = the
+ * host implementation the engine uses, 1 = the same function written as the algorithm is usually stated (slow;
+ * the test oracle of 0), 2 = the HIP kernel the engine uses for DecodeMethod::BeamSearch (uploads the matrix).
+ * Outputs are malloc'ed (ocrs_buffer_free). */
+OCRS_API ocrs_status ocrs_ctc_beam_search(const float* logp, int t, int c, uint32_t width, int impl, uint32_t** labels,
+                                          uint32_t** positions, size_t* n);
+
 /* Process-wide integer tuning options (no reference counterpart: RTen's equivalents are compile-time).
  * Each also reads its initial value from the environment variable OCRS_<NAME IN CAPITALS>.
  *   "gru_mode"        0 = one persistent kernel per GRU layer (default), 1 = one launch per time step
  *   "det_fuse"        1 = fused LDS-tiled DoubleConv blocks of the detection U-Net where they win (default),
  *                     2 = for every block shape that has a fused kernel, 0 = per-op kernels only
  *   "layout_threads"  host threads ocrs_engine_find_text_lines_batch may use (0 = automatic)
+ *   "beam_gpu"        1 = DecodeMethod::BeamSearch runs on the GPU (default), 0 = on the host (threaded over lines)
  * Results never depend on an option; OCRS_ERR_INVALID_ARGUMENT for an unknown name. */
 OCRS_API ocrs_status ocrs_set_option(const char* name, long value);
 

@@ -43,7 +43,7 @@ class OcrsError(RuntimeError):
 
 # Every symbol include/ocrs_amd.h declares (tests check they are all exported).
 DECLARED_SYMBOLS = [
-    "ocrs_last_error", "ocrs_buffer_free", "ocrs_device_count", "ocrs_set_device", "ocrs_set_option", "ocrs_model_load_file",
+    "ocrs_last_error", "ocrs_buffer_free", "ocrs_device_count", "ocrs_set_device", "ocrs_set_option", "ocrs_ctc_beam_search", "ocrs_model_load_file",
     "ocrs_model_load_bytes", "ocrs_model_from_callback", "ocrs_model_input_shape", "ocrs_model_run",
     "ocrs_model_flops", "ocrs_model_free", "ocrs_engine_new", "ocrs_engine_free", "ocrs_image_source_check_bytes",
     "ocrs_engine_prepare_input", "ocrs_engine_prepare_input_device", "ocrs_page_free", "ocrs_page_dims",
@@ -103,6 +103,20 @@ def measure_peaks():
 def set_option(name, value):
     """ocrs_set_option: process-wide tuning knob (results never depend on it)."""
     check(lib().ocrs_set_option(name.encode(), C.c_long(int(value))))
+
+
+def ctc_beam_search(logp, width, impl=0):
+    """ocrs_ctc_beam_search on a [T, C] float32 matrix -> [(label, pos)]."""
+    import numpy as np
+    a = np.ascontiguousarray(logp, np.float32)
+    t, c = a.shape
+    lab, pos, n = C.POINTER(C.c_uint32)(), C.POINTER(C.c_uint32)(), C.c_size_t(0)
+    check(lib().ocrs_ctc_beam_search(a.ctypes.data_as(C.POINTER(C.c_float)), t, c, C.c_uint32(width), int(impl),
+                                     C.byref(lab), C.byref(pos), C.byref(n)))
+    out = [(int(lab[i]), int(pos[i])) for i in range(n.value)]
+    lib().ocrs_buffer_free(lab)
+    lib().ocrs_buffer_free(pos)
+    return out
 
 
 def require_gpu():

@@ -123,6 +123,50 @@ ocrs_status ocrs_set_device(int device) {
     return guarded([&] { select_device(device); });
 }
 
+ocrs_status ocrs_ctc_beam_search(const float* logp, int t, int c, uint32_t width, int impl, uint32_t** labels,
+                                 uint32_t** positions, size_t* n) {
+    return guarded([&] {
+        if (!logp || !labels || !positions || !n || t < 0 || c < 1) fail(OCRS_ERR_INVALID_ARGUMENT, "bad argument");
+        std::vector<uint32_t> l, p;
+        if (impl == 2 && t > 0) {   // the HIP kernel, on this matrix as a one-line packed batch
+            bind_thread_to_device();
+            if (!k::ctc_beam_supported(c, (int)width)) fail(OCRS_ERR_CAPACITY, "beam search on the GPU supports up to 128 classes and width 128");
+            Workspace ws;
+            std::vector<int32_t> meta(1 + t + 1);
+            meta[0] = t;
+            for (int i = 0; i <= t; i++) meta[1 + i] = i;   // off[t] = t: one line, row t = time t
+            int32_t* d_meta = ws.alloc_n<int32_t>(meta.size());
+            float* d_logp = ws.alloc_n<float>((size_t)t * c);
+            ws.upload(d_meta, meta.data(), meta.size() * sizeof(int32_t));
+            ws.upload(d_logp, logp, (size_t)t * c * sizeof(float));
+            const size_t arena = k::ctc_beam_arena_entries(t, (int)width);
+            int2* d_nodes = ws.alloc_n<int2>(arena);
+            int2* d_posn = ws.alloc_n<int2>(arena);
+            uint32_t* d_ol = ws.alloc_n<uint32_t>(t);
+            uint32_t* d_op = ws.alloc_n<uint32_t>(t);
+            int32_t* d_cnt = ws.alloc_n<int32_t>(1);
+            k::ctc_beam_packed(d_logp, d_meta, d_meta + 1, 1, t, c, (int)width, nullptr, d_nodes, d_posn, d_ol, d_op, d_cnt, ws.s());
+            std::vector<uint32_t> hl(t), hp(t);
+            int32_t cnt = 0;
+            ws.download(hl.data(), d_ol, (size_t)t * 4);
+            ws.download(hp.data(), d_op, (size_t)t * 4);
+            ws.download(&cnt, d_cnt, 4);
+            ws.sync();
+            OCRS_HIP(hipGetLastError());
+            l.assign(hl.begin(), hl.begin() + cnt);
+            p.assign(hp.begin(), hp.begin() + cnt);
+        } else {
+            const std::vector<CtcStep> st = t == 0 ? std::vector<CtcStep>()
+                                                  : (impl == 1 ? ctc_beam_search_reference(logp, t, c, c, width) : ctc_beam_search(logp, t, c, c, width));
+            l.resize(st.size()); p.resize(st.size());
+            for (size_t i = 0; i < st.size(); i++) { l[i] = st[i].label; p[i] = st[i].pos; }
+        }
+        *labels = dup_buffer(l);
+        *positions = dup_buffer(p);
+        *n = st.size();
+    });
+}
+
 ocrs_status ocrs_set_option(const char* name, long value) {
     return guarded([&] {
         if (!set_option(name, value)) fail(OCRS_ERR_INVALID_ARGUMENT, "unknown option '%s'", name ? name : "(null)");

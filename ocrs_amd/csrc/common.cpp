@@ -196,6 +196,7 @@ const OptDef kOptDefs[OPT_COUNT] = {
     {"gru_mode", "OCRS_GRU_MODE", GRU_PERSISTENT},      // 0 persistent recurrence kernel, 1 one launch per time step
     {"det_fuse", "OCRS_DET_FUSE", 1},                   // fused DoubleConv blocks: 1 where they win, 2 every shape, 0 none
     {"layout_threads", "OCRS_LAYOUT_THREADS", 0},       // host threads of find_text_lines_batch (0 = automatic)
+    {"beam_gpu", "OCRS_BEAM_GPU", 1},                   // 1 CTC beam search on the GPU, 0 on the host
 };
 std::atomic<long> g_opts[OPT_COUNT];
 std::once_flag g_opts_once;

@@ -447,6 +447,7 @@ void ocrs_engine::recognize(const ocrs_page* const* pages, size_t n_pages,
             std::vector<int32_t> hc;
             int Tmax = 0;
             uint32_t gru_status[8] = {0};  // time-out words of the persistent GRU kernels (0 = fine)
+            bool gpu_beam = false;         // beam search already done on the GPU: hl/hp/hc hold its steps
             std::vector<float> logp;      // beam search only: packed [R][C]
             std::vector<int32_t> off;     // beam search only
         };
@@ -502,6 +503,30 @@ void ocrs_engine::recognize(const ocrs_page* const* pages, size_t n_pages,
             int32_t* d_labels = w.alloc_n<int32_t>((size_t)plan.R);
             float* d_logp = nullptr;
             hm->run_recognition_packed(w, pg, plan, (int)rec_h, T, d_excl, d_labels, beam ? &d_logp : nullptr);
+            if (beam && option(OPT_BEAM_GPU) && k::ctc_beam_supported(C, (int)beam_width)) {
+                // rten decode_beam (recognition.rs:512-514) on the GPU, one workgroup per line (kernels_beam.hip)
+                const int Tmax = plan.Tmax;
+                sub.Tmax = Tmax;
+                sub.gpu_beam = true;
+                const size_t arena = k::ctc_beam_arena_entries(Tmax, (int)beam_width);
+                int2* d_nodes = w.alloc_n<int2>((size_t)M * arena);
+                int2* d_posn = w.alloc_n<int2>((size_t)M * arena);
+                uint32_t* d_ol = w.alloc_n<uint32_t>((size_t)M * Tmax);
+                uint32_t* d_op = w.alloc_n<uint32_t>((size_t)M * Tmax);
+                int32_t* d_cnt = w.alloc_n<int32_t>(M);
+                {
+                    StageScope sc(T, ST_CTC, sst);
+                    k::ctc_beam_packed(d_logp, plan.d_Tm, plan.d_off, M, Tmax, C, (int)beam_width, d_excl, d_nodes, d_posn, d_ol,
+                                       d_op, d_cnt, sst);
+                }
+                sub.hl.resize((size_t)M * Tmax);
+                sub.hp.resize((size_t)M * Tmax);
+                sub.hc.resize(M);
+                w.download(sub.hl.data(), d_ol, sub.hl.size() * 4, sst);
+                w.download(sub.hp.data(), d_op, sub.hp.size() * 4, sst);
+                w.download(sub.hc.data(), d_cnt, (size_t)M * 4, sst);
+                return;
+            }
             if (beam) {
                 sub.logp.resize((size_t)plan.R * C);
                 sub.off = hoff;
@@ -529,7 +554,7 @@ void ocrs_engine::recognize(const ocrs_page* const* pages, size_t n_pages,
         auto unpack = [&](const Sub& sub) {
             for (uint32_t st8 : sub.gru_status)
                 if (st8) fail(OCRS_ERR_DEVICE, "GRU recurrence kernel timed out waiting for a peer workgroup");
-            if (beam) {  // rten decode_beam (recognition.rs:512-514), host side, one thread per slice of lines
+            if (beam && !sub.gpu_beam) {  // rten decode_beam (recognition.rs:512-514), host side, one thread per slice of lines
                 const size_t M = sub.slots.size();
                 const unsigned nth = (unsigned)std::max<size_t>(1, std::min<size_t>({(size_t)std::thread::hardware_concurrency(), (size_t)32, M}));
                 std::vector<std::thread> th;

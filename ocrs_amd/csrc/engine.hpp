@@ -19,6 +19,8 @@ struct CtcStep { uint32_t label, pos; };
 
 // ctc_beam.cpp — rten decode_beam (recognition.rs:512-514)
 std::vector<CtcStep> ctc_beam_search(const float* logp, int T, int C, int row_stride, uint32_t width);
+// the same function written as the algorithm is usually stated (trie + candidate map); tests compare the two
+std::vector<CtcStep> ctc_beam_search_reference(const float* logp, int T, int C, int row_stride, uint32_t width);
 
 struct TextChar {  // text_items.rs:48-54
     uint32_t ch;

@@ -139,6 +139,14 @@ bool gru_persistent(const float* gx, const float* wh, const float* bh, float* y,
 void ctc_collapse_packed(const int32_t* labels, const int32_t* d_Tm, const int32_t* d_off, int M, int Tmax,
                          uint32_t* out_labels, uint32_t* out_pos, int32_t* out_count, hipStream_t s);
 void argmax_rows(const float* x, int64_t rows, int c, const uint8_t* d_excluded, int32_t* labels, hipStream_t s);
+// ---- kernels_beam.hip: CTC prefix beam search (rten decode_beam) on the packed log-probabilities, one workgroup
+// per line; same results as the host's ctc_beam_search.  d_nodes / d_posn: M * ctc_beam_arena_entries(Tmax, width)
+// int2 each (scratch).  Outputs in the layout of ctc_collapse_packed.  false if (C, width) is not supported.
+bool ctc_beam_supported(int C, int width);
+size_t ctc_beam_arena_entries(int Tmax, int width);
+bool ctc_beam_packed(const float* logp, const int32_t* d_Tm, const int32_t* d_off, int M, int Tmax, int C, int width,
+                     const uint8_t* d_excluded, int2* d_nodes, int2* d_posn, uint32_t* out_labels, uint32_t* out_pos,
+                     int32_t* out_count, hipStream_t s);
 // Greedy CTC collapse (rten decode_greedy): labels [T][N] -> per line (label,pos) lists.
 void ctc_collapse(const int32_t* labels, int T, int N, uint32_t* out_labels, uint32_t* out_pos, int32_t* out_count,
                   hipStream_t s);

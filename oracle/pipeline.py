@@ -185,6 +185,40 @@ class TextLine:
         return out
 
 
+def _beam_exp_nonpos(d):
+    """exp(d), d <= 0 (ocrs_amd/csrc/beam_math.hpp exp_nonpos): plain IEEE double mul/add, Horner, 2^k by ldexp."""
+    if not (d > -700.0):
+        return 0.0
+    kf = float(round(d * 1.4426950408889634))   # round-half-even, as rint
+    r = d - kf * 0.6931471803691238
+    r = r - kf * 1.9082149292705877e-10
+    p = 1.6059043836821613e-10
+    for c in (2.08767569878681e-09, 2.505210838544172e-08, 2.755731922398589e-07, 2.7557319223985893e-06,
+              2.48015873015873e-05, 0.0001984126984126984, 0.001388888888888889, 0.008333333333333333,
+              0.041666666666666664, 0.16666666666666666, 0.5, 1.0, 1.0):
+        p = p * r + c
+    return p * math.ldexp(1.0, int(kf))
+
+
+def _beam_log1p_unit(x):
+    """log(1 + x), 0 <= x <= 1 (beam_math.hpp log1p_unit): 2 atanh(x / (2 + x)), odd series to z^33."""
+    z = x / (2.0 + x)
+    z2 = z * z
+    p = 1.0 / 33.0
+    for n in range(31, 0, -2):
+        p = p * z2 + 1.0 / float(n)
+    return 2.0 * (z * p)
+
+
+def beam_lse(a, b):
+    if a == -math.inf:
+        return b
+    if b == -math.inf:
+        return a
+    m, lo = (a, b) if a > b else (b, a)
+    return m + _beam_log1p_unit(_beam_exp_nonpos(lo - m))
+
+
 def ctc_beam_search(seq_tc, width):
     """rten::ctc::CtcDecoder::decode_beam (recognition.rs:512-514): CTC prefix beam
     search over log-probabilities [T, C] (blank = 0).  Returns [(label, pos)] of the
@@ -195,7 +229,9 @@ def ctc_beam_search(seq_tc, width):
     Bi-Directional Recurrent DNNs", Alg. 1) with every choice spelled out so that the
     HIP engine's host implementation can match it exactly — parity with rten itself
     is UNPINNED:
-      * scores are float64 log-probabilities, log-sum-exp via m + log(exp(a-m)+exp(b-m));
+      * scores are float64 log-probabilities; log-sum-exp is the FIXED polynomial form of beam_lse below (the
+        product's beam_math.hpp restated operation for operation: libm, ocml and CPython round exp/log differently
+        in the last place, a fixed sequence of IEEE multiplies / adds / one divide does not);
       * candidates of a step are kept in first-insertion order, keyed by label sequence;
         the positions of a prefix are those of its first insertion;
       * beams are expanded in their current order, blank first, then labels 1..C-1
@@ -206,13 +242,7 @@ def ctc_beam_search(seq_tc, width):
     T, C = seq_tc.shape
     NEG = -math.inf
 
-    def lse(a, b):
-        if a == NEG:
-            return b
-        if b == NEG:
-            return a
-        m = a if a > b else b
-        return m + math.log(math.exp(a - m) + math.exp(b - m))
+    lse = beam_lse
 
     beams = [((), (), 0.0, NEG)]  # (labels, positions, p_blank, p_nonblank)
     for t in range(T):

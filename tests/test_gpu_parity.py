@@ -619,3 +619,52 @@ def test_bench_call_sequence_batch_apis_match_single_page_path_and_oracle():
     assert Model.load_bytes(rbuf).flops(1, 64, 300) > 1e8
     for p in dptrs:
         _lib.check(L.ocrs_device_free(p))
+
+
+def test_gpu_beam_search_equals_host_on_random_matrices():
+    """kernels_beam.hip (radix-select prefix beam search, one workgroup per line) against the host implementation
+    (itself checked against the textbook formulation and the oracle in tests/test_host_cpu.py): identical steps
+    (label, position) for widths 1..128, sharp / flat distributions, excluded labels, T up to 600."""
+    from ocrs_amd import _lib
+    rng = np.random.default_rng(11)
+
+    def logp(T, C, peak):
+        z = rng.normal(0, 3, (T, C))
+        for t in range(T):
+            z[t, (t // 3) % C] += peak
+        return (z - np.log(np.exp(z).sum(1, keepdims=True))).astype(np.float32)
+
+    cases = [(40, 12, 1), (40, 12, 3), (60, 20, 10), (80, 97, 25), (50, 97, 100), (30, 5, 100), (120, 97, 7), (1, 97, 100),
+             (600, 97, 100), (200, 97, 128), (75, 128, 64)]
+    for T, C, w in cases:
+        lp = logp(T, C, float(rng.choice([0.3, 3.0, 8.0])))
+        if C > 6:
+            lp[:, 5] = -np.inf
+            lp[T // 2, 1:] = -np.inf
+        assert _lib.ctc_beam_search(lp, w, 2) == _lib.ctc_beam_search(lp, w, 0), (T, C, w)
+    # quantised scores: many exact ties at the pruning threshold (slot order must decide)
+    lp = np.round(logp(60, 97, 0.3) * 2) / 2
+    assert _lib.ctc_beam_search(lp.astype(np.float32), 50, 2) == _lib.ctc_beam_search(lp.astype(np.float32), 50, 0)
+
+
+def test_beam_search_gpu_and_host_paths_of_the_engine_agree():
+    """DecodeMethod::BeamSearch(100) through the engine: GPU kernel (option beam_gpu = 1, default) vs host threads
+    (0) on the lines of a page — same text, same char boxes."""
+    from ocrs_amd import DecodeMethod, _lib
+    rbuf = M.recognition_model_bytes()
+    px = synth.synthetic_page(6, 300, 640, lines=10, columns=1)
+    eng = OcrEngine(detection_model=Model.load_bytes(M.detection_model_bytes()), recognition_model=Model.load_bytes(rbuf),
+                    decode_method=DecodeMethod.BeamSearch(100))
+    inp = eng.prepare_input(ImageSource.from_tensor(px, DimOrder.Hwc))
+    lines = eng.find_text_lines(inp, eng.detect_words(inp))
+    assert len(lines) >= 5
+    res = {}
+    try:
+        for mode in (1, 0):
+            _lib.set_option("beam_gpu", mode)
+            got = eng.recognize_text(inp, lines)
+            res[mode] = [(str(t), [c.rect for c in t.chars()]) if t else None for t in got]
+    finally:
+        _lib.set_option("beam_gpu", 1)
+    assert res[1] == res[0]
+    assert sum(1 for t in res[1] if t) >= 5

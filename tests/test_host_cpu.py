@@ -228,3 +228,45 @@ def test_malformed_model_files_are_rejected_at_load(lib):
     expect_io(good[: len(good) // 2])                                               # truncated blob
     bad = bytearray(good); struct.pack_into("<I", bad, 8 + 4 + 4 + 32 + 8, 10 ** 6)  # header: output slot outside the table
     expect_io(bad)
+
+
+# ---------------------------------------------------------------- recognition.rs:512-514 (decode_beam)
+def _random_logp(rng, T, C, peak):
+    z = rng.normal(0, 3, (T, C))
+    for t in range(T):
+        z[t, (t // 3) % C] += peak
+    return (z - np.log(np.exp(z).sum(1, keepdims=True))).astype(np.float32)
+
+
+def test_fast_beam_search_equals_the_textbook_formulation(lib):
+    """The engine's prefix beam search (closed-form insertion keys, nth_element) against the same function written as
+    the algorithm is usually stated (label trie + per-step candidate map + stable sort), through the C ABI:
+    identical steps (label, position) for widths 1..100, with excluded (-inf) labels, sharp and flat distributions."""
+    from ocrs_amd import _lib
+    rng = np.random.default_rng(7)
+    cases = [(40, 12, 1), (40, 12, 3), (60, 20, 10), (80, 97, 25), (50, 97, 100), (30, 5, 100), (120, 97, 7), (1, 97, 100)]
+    for T, C, w in cases:
+        lp = _random_logp(rng, T, C, float(rng.choice([0.3, 3.0, 8.0])))
+        if C > 6:
+            lp[:, 5] = -np.inf
+            lp[T // 2, 1:] = -np.inf     # a step where only the blank is allowed
+        fast, ref = _lib.ctc_beam_search(lp, w, 0), _lib.ctc_beam_search(lp, w, 1)
+        assert fast == ref, (T, C, w)
+    assert _lib.ctc_beam_search(np.zeros((0, 97), np.float32), 10, 0) == []
+
+
+def test_beam_search_host_equals_oracle(lib):
+    """... and against the oracle's Python restatement (oracle/pipeline.py::ctc_beam_search), which evaluates the
+    same fixed float64 log-sum-exp (beam_math.hpp) operation for operation."""
+    from ocrs_amd import _lib
+    from oracle import pipeline as OP
+    rng = np.random.default_rng(8)
+    for T, C, w in [(30, 8, 1), (30, 8, 4), (40, 20, 7), (25, 97, 30), (20, 97, 100)]:
+        lp = _random_logp(rng, T, C, float(rng.choice([0.3, 2.0, 8.0])))
+        got = _lib.ctc_beam_search(lp, w, 0)
+        assert got == [(int(a), int(b)) for a, b in OP.ctc_beam_search(lp, w)], (T, C, w)
+    # the fixed log-sum-exp stays within a few ulp of libm's
+    import math
+    for _ in range(2000):
+        a, b = float(rng.uniform(-60, 0)), float(rng.uniform(-60, 0))
+        assert abs(OP.beam_lse(a, b) - (max(a, b) + math.log1p(math.exp(-abs(a - b))))) < 1e-14
