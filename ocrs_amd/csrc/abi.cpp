@@ -163,7 +163,7 @@ ocrs_status ocrs_ctc_beam_search(const float* logp, int t, int c, uint32_t width
         }
         *labels = dup_buffer(l);
         *positions = dup_buffer(p);
-        *n = st.size();
+        *n = l.size();
     });
 }
 

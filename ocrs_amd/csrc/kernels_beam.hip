@@ -26,6 +26,7 @@ using beam::kNegInf;
 using beam::lse;
 
 constexpr int BEAM_MAX_W = 128, BEAM_LIST = 1024;
+constexpr int BEAM_NT = 1024;   // threads per line: the per-step loops are chains of LDS latencies, 16 waves hide them
 
 struct BeamArgs {
     const float* logp;        // packed [R][C]
@@ -46,19 +47,36 @@ __device__ __forceinline__ uint64_t sortable(double x) {   // order-preserving m
     return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
 }
 
-// add `n = 1` to hist[digit] for every active lane, one LDS atomic per distinct digit of the wave
+// hist[digit] += 1 for every active lane.  High bytes of the keys are concentrated on a few values (the scores
+// share their exponent), low bytes are spread: two rounds of "leader adds the population count of its digit"
+// take care of the former without contention, plain atomics of the latter without a 64-round loop.
 __device__ __forceinline__ void hist_add(uint32_t* hist, unsigned digit, bool active) {
     uint64_t todo = __ballot(active);
-    while (todo) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        if (!todo) break;
         const int leader = __ffsll((long long)todo) - 1;
         const unsigned d = __shfl(digit, leader);
         const uint64_t same = __ballot(active && digit == d) & todo;
-        if ((threadIdx.x & 63) == leader) atomicAdd(&hist[d], (uint32_t)__popcll(same));
+        if (lane == leader) atomicAdd(&hist[d], (uint32_t)__popcll(same));
         todo &= ~same;
     }
+    if ((todo >> lane) & 1) atomicAdd(&hist[digit], 1u);
 }
 
-__global__ void __launch_bounds__(256)
+// append `value` to list[] for every lane with `take`, one atomic on the counter per wave
+__device__ __forceinline__ void list_append(uint16_t* list, int* counter, bool take, uint16_t value) {
+    const uint64_t mask = __ballot(take);
+    if (!mask) return;
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    if (lane == __ffsll((long long)mask) - 1) base = atomicAdd(counter, (int)__popcll(mask));
+    base = __shfl(base, __ffsll((long long)mask) - 1);
+    if (take) list[base + __popcll(mask & ((1ull << lane) - 1))] = value;
+}
+
+__global__ void __launch_bounds__(BEAM_NT)
 ctc_beam_kernel(BeamArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int C = a.C, W = a.W, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -87,8 +105,8 @@ ctc_beam_kernel(BeamArgs a) {
     int* sel_idx = nlab + W;
     int* sorted = sel_idx + W;
     uint32_t* hist = reinterpret_cast<uint32_t*>(sorted + W);          // [256]
-    uint32_t* cnt256 = hist + 256;                                     // [256] per-thread counts for the ordered gather
-    int* ctl = reinterpret_cast<int*>(cnt256 + 256);                   // [16] control words
+    uint32_t* cnt256 = hist + 256;                                     // [BEAM_NT] slot (w*64 + 63): ties in wave w (ordered gather)
+    int* ctl = reinterpret_cast<int*>(cnt256 + BEAM_NT);                 // [16] control words
     uint16_t* list = reinterpret_cast<uint16_t*>(ctl + 16);            // [BEAM_LIST] compacted slots
     uint8_t* child = reinterpret_cast<uint8_t*>(list + BEAM_LIST);     // [W*C] which beam IS this extension (255 none)
     enum { NB = 0, NODE_CNT, POS_CNT, N_PRESENT, DIGIT, KLEFT, BUCKET, N_LIST, N_SEL, N_GT_TOTAL };
@@ -121,7 +139,7 @@ ctc_beam_kernel(BeamArgs a) {
                     if (node[j] == pr) { p = j; break; }
             pidx[tid] = p;
         }
-        for (int i = tid; i < N; i += 256) { key[i] = 0; child[i] = 255; }
+        for (int i = tid; i < N; i += BEAM_NT) { key[i] = 0; child[i] = 255; }
         if (tid == 0) ctl[N_PRESENT] = 0;
         __syncthreads();
         if (tid < nb && pidx[tid] >= 0) child[pidx[tid] * C + lab[tid]] = (uint8_t)tid;
@@ -145,7 +163,7 @@ ctc_beam_kernel(BeamArgs a) {
             key[slot] = sortable(lse(b, nbv));
             present++;
         }
-        for (int idx = tid; idx < N; idx += 256) {
+        for (int idx = tid; idx < N; idx += BEAM_NT) {
             const int i = idx / C, c = idx - i * C;
             if (c == 0) continue;
             const double lp = row[c];
@@ -153,7 +171,9 @@ ctc_beam_kernel(BeamArgs a) {
             key[idx] = sortable((c == lab[i] ? pb[i] : tot[i]) + lp);
             present++;
         }
-        atomicAdd(&ctl[N_PRESENT], present);
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) present += __shfl_down(present, d);
+        if (lane == 0) atomicAdd(&ctl[N_PRESENT], present);
         __syncthreads();
         const int keep = min(W, ctl[N_PRESENT]);
         // ---- 3. radix select: thr = the keep-th largest key
@@ -162,10 +182,10 @@ ctc_beam_kernel(BeamArgs a) {
         bool use_list = false;
         for (int pass = 0; pass < 8; pass++) {
             const int shift = 56 - 8 * pass;
-            hist[tid] = 0;
+            if (tid < 256) hist[tid] = 0;
             __syncthreads();
             const int n_it = use_list ? ctl[N_LIST] : N;
-            for (int base = 0; base < n_it; base += 256) {
+            for (int base = 0; base < n_it; base += BEAM_NT) {
                 const int q = base + tid;
                 bool act = q < n_it;
                 unsigned digit = 0;
@@ -206,8 +226,10 @@ ctc_beam_kernel(BeamArgs a) {
             if (!use_list && pass < 7 && bucket <= BEAM_LIST) {   // the undecided bucket is small: compact it
                 if (tid == 0) ctl[N_LIST] = 0;
                 __syncthreads();
-                for (int q = tid; q < N; q += 256)
-                    if ((key[q] >> shift) == (prefix >> shift)) list[atomicAdd(&ctl[N_LIST], 1)] = (uint16_t)q;
+                for (int base = 0; base < N; base += BEAM_NT) {
+                    const int q = base + tid;
+                    list_append(list, &ctl[N_LIST], q < N && (key[q] >> shift) == (prefix >> shift), (uint16_t)q);
+                }
                 use_list = true;
             }
             __syncthreads();
@@ -215,15 +237,31 @@ ctc_beam_kernel(BeamArgs a) {
         const uint64_t thr = prefix;   // kleft of the keys equal to thr survive, lowest slots first
         // ---- 4. gather the survivors: key > thr, and the first kleft (in slot order) of key == thr
         {
-            const int chunk = (N + 255) / 256;
+            const int chunk = (N + BEAM_NT - 1) / BEAM_NT;
             const int lo = tid * chunk, hi = min(N, lo + chunk);
             int eq = 0;
             for (int q = lo; q < hi; q++) eq += key[q] == thr;
-            cnt256[tid] = (uint32_t)eq;
+            {   // cnt256[w*64 + 63] = number of ties in wave w
+                int tot_w = eq;
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) tot_w += __shfl_down(tot_w, d);
+                tot_w = __shfl(tot_w, 0);
+                if (lane == 63) cnt256[tid] = (uint32_t)tot_w;
+            }
             if (tid == 0) ctl[N_SEL] = 0;
             __syncthreads();
+            // exclusive prefix of the per-thread tie counts (threads own consecutive slot ranges)
             int before = 0;
-            for (int j = 0; j < tid; j++) before += (int)cnt256[j];
+            {
+                int incl = eq;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const int o = __shfl_up(incl, d);
+                    if (lane >= d) incl += o;
+                }
+                before = incl - eq;
+                for (int wv = 0; wv < wave; wv++) before += (int)cnt256[wv * 64 + 63];   // totals of the lower waves
+            }
             for (int q = lo; q < hi; q++) {
                 const uint64_t kv = key[q];
                 bool take = kv > thr;
@@ -308,7 +346,7 @@ size_t beam_lds_bytes(int W, int C) {
     b += (size_t)W * 8 * 7;                // pb pnb tot spb spnb npb npnb
     b += (size_t)W * 8;                    // sel_key
     b += (size_t)W * 4 * 11;               // node par pos lab pidx nnode npar npos nlab sel_idx sorted
-    b += 256 * 4 * 2 + 16 * 4;             // hist cnt256 ctl
+    b += 256 * 4 + BEAM_NT * 4 + 16 * 4;   // hist cnt256 ctl
     b += BEAM_LIST * 2;                    // list
     b += (size_t)W * C;                    // child
     return (b + 15) & ~size_t(15);
@@ -339,7 +377,7 @@ bool ctc_beam_packed(const float* logp, const int32_t* d_Tm, const int32_t* d_of
                                   160 * 1024);
         raised = 160 * 1024;
     }
-    hipLaunchKernelGGL(ctc_beam_kernel, dim3(M), dim3(256), lds, s, a);
+    hipLaunchKernelGGL(ctc_beam_kernel, dim3(M), dim3(BEAM_NT), lds, s, a);
     return true;
 }
 
