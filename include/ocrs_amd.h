@@ -78,6 +78,9 @@ OCRS_API ocrs_status ocrs_ctc_beam_search(const float* logp, int t, int c, uint3
  *                     2 = for every block shape that has a fused kernel, 0 = per-op kernels only
  *   "layout_threads"  host threads ocrs_engine_find_text_lines_batch may use (0 = automatic)
  *   "beam_gpu"        1 = DecodeMethod::BeamSearch runs on the GPU (default), 0 = on the host (threaded over lines)
+ *   "gru_local"       persistent GRU kernel: 1 = a cluster of workgroups that finds itself on one XCD hands its state
+ *                     over through that XCD's L2 (default), 0 = always through write-through stores
+ *   "gru_scatter"     test knob: 1 = spread every cluster over all XCDs (exercises the write-through path), default 0
  * Results never depend on an option; OCRS_ERR_INVALID_ARGUMENT for an unknown name. */
 OCRS_API ocrs_status ocrs_set_option(const char* name, long value);
 

@@ -197,6 +197,8 @@ const OptDef kOptDefs[OPT_COUNT] = {
     {"det_fuse", "OCRS_DET_FUSE", 1},                   // fused DoubleConv blocks: 1 where they win, 2 every shape, 0 none
     {"layout_threads", "OCRS_LAYOUT_THREADS", 0},       // host threads of find_text_lines_batch (0 = automatic)
     {"beam_gpu", "OCRS_BEAM_GPU", 1},                   // 1 CTC beam search on the GPU, 0 on the host
+    {"gru_local", "OCRS_GRU_LOCAL", 1},                 // persistent GRU: 1 same-XCD clusters hand off through L2, 0 always write-through
+    {"gru_scatter", "OCRS_GRU_SCATTER", 0},             // persistent GRU test knob: 1 spreads every cluster over the XCDs
 };
 std::atomic<long> g_opts[OPT_COUNT];
 std::once_flag g_opts_once;

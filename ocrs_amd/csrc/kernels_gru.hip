@@ -9,7 +9,7 @@
 // Decomposition.  Rows (text lines, sorted by sequence length descending) are cut into 16-row
 // tiles; the H hidden units into UB = H/16 slices.  A workgroup = 4 waves that share ONE 16-unit
 // slice of Wh (H x 48 floats, staged into LDS once for all T steps) and serve 4*RT row tiles
-// (wave w: tiles base + w, base + 4 + w, ...).  The UB workgroups that own the slices of the same
+// (dealt in snake order over the waves of a direction, so that every wave gets long and short tiles).  The UB workgroups that own the slices of the same
 // rows form a "cluster"; the only data they exchange is the new hidden state of their rows.
 //
 // Exchange = the layer's own output, and the data is its own flag.  y[row(t, m)][dir*H + unit] has to be
@@ -31,6 +31,7 @@
 // 4x4 transpose across the four 16-lane groups (v_permlane16_swap / v_permlane32_swap).
 #include <cstdlib>
 
+#include "common.hpp"
 #include "kernels.hpp"
 #include "spec_math.hpp"
 
@@ -50,9 +51,12 @@ struct GruParams {
     const int32_t* Tm;   // [M] sequence length of line m (descending)
     const int32_t* off;  // [Tmax + 1] first packed row of time t
     uint32_t* sync;      // [1] error word; zeroed before the launch
+    uint32_t* place;     // [grid] XCD id + 1 of every workgroup, written by the kernel; zeroed before the launch
     int64_t R;
     int M, ntiles, RT, ncl, Tmax;
     int prio;            // s_setprio level of the waves (0..3)
+    int allow_local;     // 0: write-through hand-offs whatever the placement (OCRS_GRU_LOCAL=0)
+    int scatter;         // 1: clusters deliberately spread over the XCDs (OCRS_GRU_SCATTER=1; tests the census)
     uint32_t spin_limit;
 };
 
@@ -68,6 +72,12 @@ __device__ __forceinline__ f32x4 load_bypass(__amdgpu_buffer_rsrc_t y, uint32_t 
 }
 __device__ __forceinline__ void store_through(__amdgpu_buffer_rsrc_t y, uint32_t byte_off, f32x4 v) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), y, (int)byte_off, 0, kAuxSc1);
+}
+// Plain store: the line stays in the XCD's L2, where the bypassing loads of the SAME XCD find it (an L2 hit instead
+// of a trip over the fabric: 1.0-1.2 us less per step).  Invisible to other XCDs until the kernel ends, so only a
+// cluster whose workgroups have all found themselves on one XCD uses it (cluster_is_local below).
+__device__ __forceinline__ void store_local(__amdgpu_buffer_rsrc_t y, uint32_t byte_off, f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), y, (int)byte_off, 0, 0);
 }
 typedef __attribute__((address_space(1))) uint32_t gu32;
 
@@ -228,7 +238,7 @@ __device__ __forceinline__ float tanhf_sl(float x) {
 // gates + new state of the lane's 4 units; `store` = this lane's row is live at this step
 template <int H>
 __device__ __forceinline__ void epilogue_store(__amdgpu_buffer_rsrc_t y, const GateAcc& a, const f32x4& gr, const f32x4& gz,
-                                               const f32x4& gn, const f32x4& hp, uint32_t out_off, bool store) {
+                                               const f32x4& gn, const f32x4& hp, uint32_t out_off, bool store, bool local) {
     f32x4 hn;
 #pragma unroll
     for (int r = 0; r < 4; r++) {
@@ -241,7 +251,9 @@ __device__ __forceinline__ void epilogue_store(__amdgpu_buffer_rsrc_t y, const G
     // fire and forget (the data is the flag).  Unconditional instruction: a lane with nothing to store aims past
     // the buffer and the hardware range check drops it — a branch here would let the compiler sink the whole gate
     // arithmetic under it, out of the MFMA shadow.
-    store_through(y, store ? out_off : 0xFFFFFFF0u, hn);
+    const uint32_t o = store ? out_off : 0xFFFFFFF0u;
+    if (local) store_local(y, o, hn);  // wave-uniform
+    else store_through(y, o, hn);
 }
 
 template <int H>
@@ -252,14 +264,19 @@ gru_persistent_kernel(GruParams p) {
     // blocks of one cluster share blockIdx % 8 (observed: block b runs on XCD b % 8 — speed only)
     const int b = blockIdx.x;
     const int q = b >> 3;
-    const int ub = q % UB;
-    const int cid = (q / UB) * 8 + (b & 7);
+    // (p.scatter, a test knob, deals consecutive blocks to a cluster instead: every cluster then spans all XCDs)
+    const int ub = p.scatter ? b % UB : q % UB;
+    const int cid = p.scatter ? b / UB : (q / UB) * 8 + (b & 7);
     if (cid >= 2 * p.ncl) return;
     const int dir = cid & 1, cl = cid >> 1;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i16 = lane & 15, kq = lane >> 4;
+    // Placement census, part 1: publish which XCD this workgroup runs on (+1: the host zeroed the table).
+    uint32_t xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
+    if (tid == 0) __hip_atomic_store((gu32*)p.place + cid * UB + ub, xcc + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const float* __restrict__ whd = p.wh + (int64_t)dir * H * 3 * H;
     const float* __restrict__ bhd = p.bh + (int64_t)dir * 3 * H;
     const int j0 = ub * 16;
@@ -278,13 +295,19 @@ gru_persistent_kernel(GruParams p) {
     const f32x4 br = *reinterpret_cast<const f32x4*>(bhd + j0 + kq * 4);
     const f32x4 bz = *reinterpret_cast<const f32x4*>(bhd + H + j0 + kq * 4);
     const f32x4 bn = *reinterpret_cast<const f32x4*>(bhd + 2 * H + j0 + kq * 4);
-    // this wave's tiles: base, base + 4, ... (RT <= 4 of them); per tile the length of the lane's row and of the
+    // this wave's tiles: tile_of(0), tile_of(1), ... (RT <= 4 of them); per tile the length of the lane's row and of the
     // tile's first (= longest) row, both kept in registers for the whole run
-    const int base = cl * 4 * p.RT + wave;
+    // Lines are sorted by length, so tile k is at least as long as tile k + 1, and a wave is busy for the SUM of its
+    // tiles' lengths: tiles are dealt to the 4*ncl waves of a direction in snake order (pass 0 ascending, pass 1
+    // descending, ...), which gives every wave a long, a short and a middling tile.  (Dealing consecutive tiles to
+    // one cluster left the cluster of the 12 longest tiles running twice as long as the average: 8.4 -> 4.x ms per
+    // layer at 1 232 lines of 100..600 steps.)
+    const int nslots = 4 * p.ncl, slot = cl * 4 + wave;
+    auto tile_of = [&](int i) { return i * nslots + ((i & 1) ? nslots - 1 - slot : slot); };
     int tmr[4], tT[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        const int m = (base + 4 * i) * 16 + i16;
+        const int m = tile_of(i) * 16 + i16;
         tmr[i] = (i < p.RT && m < p.M) ? p.Tm[m] : 0;
         tT[i] = __builtin_amdgcn_readfirstlane(tmr[i]);
     }
@@ -294,6 +317,25 @@ gru_persistent_kernel(GruParams p) {
     else if (p.prio == 2) __builtin_amdgcn_s_setprio(2);
     else if (p.prio == 1) __builtin_amdgcn_s_setprio(1);
     if (tT[0] <= 0) return;
+    // Placement census, part 2: the UB workgroups of the cluster read each other's entries; all of them see the same
+    // UB values, so all of them take the same decision.  One XCD for the whole cluster (what the grid layout aims
+    // for and the dispatcher has always delivered) -> hand-offs through that XCD's L2; anything else -> write-through
+    // stores.  Placement therefore changes speed only.
+    bool local;
+    {
+        const gu32* pl = (const gu32*)p.place + cid * UB;
+        uint32_t v = xcc + 1u;
+        for (uint32_t spins = 0;; spins++) {
+            if (lane < UB) v = __hip_atomic_load(pl + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!__any(v == 0u)) break;
+            __builtin_amdgcn_s_sleep(8);
+            if (spins >= p.spin_limit) {
+                __hip_atomic_store((gu32*)p.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return;
+            }
+        }
+        local = !__any(v != xcc + 1u) && p.allow_local;
+    }
     // items in (step, tile) order; the state loads of the NEXT item are issued before the current one is
     // computed whenever it belongs to another tile (its inputs cannot depend on the current item)
     const __amdgpu_buffer_rsrc_t yb = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)(uint32_t)(p.R * 2 * H * sizeof(float)), 0x00020000);
@@ -301,7 +343,7 @@ gru_persistent_kernel(GruParams p) {
     // the roles swap): copying a set would make the wave wait for loads that are still in flight.
     int s = 0, i = 0;
     Loaded<H> bufA, bufB;
-    issue_meta<H>(p, dir, ub, base, tmr[0], off_l, 0, i16, kq, bufA);
+    issue_meta<H>(p, dir, ub, tile_of(0), tmr[0], off_l, 0, i16, kq, bufA);
     // one item: returns 0 = done, 1 = go on, -1 = timed out
     auto item = [&](Loaded<H>& cur, Loaded<H>& nxt) -> int {
         int ns = s, ni = i + 1;
@@ -313,10 +355,10 @@ gru_persistent_kernel(GruParams p) {
         float w[H / 4];
 #pragma unroll
         for (int j = 0; j < H / 16; j++) transpose4(cur.h[j], &w[4 * j]);
-        if (have_next) issue_meta<H>(p, dir, ub, base + 4 * ni, sel(tmr, ni), off_l, ns, i16, kq, nxt);
+        if (have_next) issue_meta<H>(p, dir, ub, tile_of(ni), sel(tmr, ni), off_l, ns, i16, kq, nxt);
         if (early) issue_state<H>(yb, ub, kq, nxt);
         const GateAcc acc = mfma_chain<H>(lane, w, lds_w, br, bz, bn);
-        epilogue_store<H>(yb, acc, cur.gr, cur.gz, cur.gn, cur.hp, cur.out_off, cur.active);
+        epilogue_store<H>(yb, acc, cur.gr, cur.gz, cur.gn, cur.hp, cur.out_off, cur.active, local);
         if (!have_next) return 0;
         if (!early) issue_state<H>(yb, ub, kq, nxt);
         if (!await_state<H>(p, yb, ub, kq, nxt)) return -1;
@@ -332,7 +374,8 @@ gru_persistent_kernel(GruParams p) {
 
 }  // namespace
 
-size_t gru_persistent_sync_words(int) { return 1; }
+constexpr int kMaxGrid = 4096;
+size_t gru_persistent_sync_words(int) { return kMaxGrid + 1; }  // placement table + error word (last)
 
 // y -> all words "unwritten"; any stream that is ordered before the recurrence (it does not depend on gx)
 void gru_persistent_prepare(float* y, int64_t R, int H, hipStream_t s) {
@@ -364,7 +407,9 @@ bool gru_persistent(const float* gx, const float* wh, const float* bh, float* y,
                     int64_t R, int M, int Tmax, int H, uint32_t* d_sync, hipStream_t s) {
     if (M <= 0) return true;
     GruParams p{};
-    p.gx = gx; p.wh = wh; p.bh = bh; p.y = y; p.Tm = d_Tm; p.off = d_off; p.sync = d_sync;
+    p.gx = gx; p.wh = wh; p.bh = bh; p.y = y; p.Tm = d_Tm; p.off = d_off;
+    p.place = d_sync;
+    p.sync = d_sync + kMaxGrid;
     p.R = R; p.M = M; p.Tmax = Tmax;
     p.ntiles = (M + 15) / 16;
     const int UB = H / 16;
@@ -376,6 +421,9 @@ bool gru_persistent(const float* gx, const float* wh, const float* bh, float* y,
     p.spin_limit = 1u << 21;  // re-reads of >= ~1 us each: seconds, far beyond any legitimate wait
     const int groups = (2 * p.ncl + 7) / 8;
     const dim3 grid(8 * UB * groups);
+    if (grid.x > (unsigned)kMaxGrid) return false;
+    p.allow_local = option(OPT_GRU_LOCAL) != 0;
+    p.scatter = option(OPT_GRU_SCATTER) != 0;
     const size_t lds = (size_t)H * 48 * sizeof(float) + ((size_t)Tmax + 1) * sizeof(int);
     (void)hipMemsetAsync(d_sync, 0, gru_persistent_sync_words(M) * sizeof(uint32_t), s);  // (y: gru_persistent_prepare)
     if (H == 256) hipLaunchKernelGGL((gru_persistent_kernel<256>), grid, dim3(256), lds, s, p);

@@ -161,15 +161,23 @@ def test_gru_modes_give_identical_bits(engine):
     cl = np.arange(n + 1, dtype=np.uintp)
     res = {}
     try:
-        for mode in (0, 1):
-            _lib.set_option("gru_mode", mode)
+        # mode 0 = persistent kernel, 1 = per-step launches; 2, 3 = persistent with the hand-off forced to
+        # write-through stores (gru_local 0) and with clusters spread over all XCDs (gru_scatter 1: the in-kernel
+        # placement census must then choose write-through by itself)
+        for mode in (0, 1, 2, 3):
+            _lib.set_option("gru_mode", 1 if mode == 1 else 0)
+            _lib.set_option("gru_local", 0 if mode == 2 else 1)
+            _lib.set_option("gru_scatter", 1 if mode == 3 else 0)
             a = engine.recognize_text(inp, req)
             b = engine.recognize_text_batch_raw([cinp], crects, cl, np.array([0, n], dtype=np.uintp))
             res[mode] = ([(str(t), [c.rect for c in t.chars()]) if t else None for t in a], b)
     finally:
         _lib.set_option("gru_mode", 0)
-    assert res[0][0] == res[1][0]
-    assert np.array_equal(res[0][1][0], res[1][1][0]) and np.array_equal(res[0][1][1], res[1][1][1])
+        _lib.set_option("gru_local", 1)
+        _lib.set_option("gru_scatter", 0)
+    for mode in (1, 2, 3):
+        assert res[0][0] == res[mode][0], mode
+        assert np.array_equal(res[0][1][0], res[mode][1][0]) and np.array_equal(res[0][1][1], res[mode][1][1]), mode
     assert sum(1 for t in res[0][0] if t) > 80
 
 
