@@ -496,7 +496,21 @@ def extra_legs(engine, dptrs, host_pages, H, W, synth, np, DimOrder, sync_all, a
         engine.detect_words_batch(inputs)
     sync_all()
     dt = time.perf_counter() - t0
+    out["detection_only_pages_per_s_one_request_at_a_time"] = round(reps * len(inputs) / dt, 1)
+    # the same with three 8-page requests in flight (one host thread + stream each, as the full pipeline runs):
+    # a request's component / contour kernels, its D2H and its host work overlap the next request's CNN
+    from concurrent.futures import ThreadPoolExecutor
+    reps = 30
+    with ThreadPoolExecutor(3) as pool:
+        list(pool.map(lambda _: engine.detect_words_batch(inputs), range(3)))
+        sync_all()
+        t0 = time.perf_counter()
+        words = list(pool.map(lambda _: engine.detect_words_batch(inputs), range(reps)))
+        sync_all()
+        dt = time.perf_counter() - t0
     out["detection_only_pages_per_s"] = round(reps * len(inputs) / dt, 1)
+    out["detection_only_config"] = "8 pages per request, 3 requests in flight, %d requests timed, %d word rects per request" % (
+        reps, sum(len(w) for w in words[0]))
     # roofline of the detection CNN stack (the stack north_star names; depthwise-separable => HBM-bound):
     # algorithmic bytes of its layers (from the loaded graph) over the summed duration of its kernels
     if not args.no_kernel_timing:

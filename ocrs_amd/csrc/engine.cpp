@@ -494,6 +494,7 @@ void ocrs_engine::recognize(const ocrs_page* const* pages, size_t n_pages,
             int32_t* d_meta = w.alloc_n<int32_t>(meta.size());
             w.upload(d_meta, meta.data(), meta.size() * sizeof(int32_t));
             plan.d_Tm = d_meta;
+            plan.h_Tm = hTm;
             plan.d_off = d_meta + M;
             std::vector<HipModel::PackedGroup> pg;
             for (size_t c = c0; c < c1; c++)

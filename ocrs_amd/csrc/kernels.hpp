@@ -134,8 +134,9 @@ bool gru_step_fused(const float* gx, const float* wh, const float* bh, const flo
 size_t gru_persistent_sync_words(int M);
 bool gru_persistent_supported(int M, int Tmax, int64_t R, int H);
 void gru_persistent_prepare(float* y, int64_t R, int H, hipStream_t s);
+// h_Tm: the same lengths as d_Tm on the host (descending) — the deal of row tiles to waves is computed from them.
 bool gru_persistent(const float* gx, const float* wh, const float* bh, float* y, const int32_t* d_Tm, const int32_t* d_off,
-                    int64_t R, int M, int Tmax, int H, uint32_t* d_sync, hipStream_t s);
+                    const int32_t* h_Tm, int64_t R, int M, int Tmax, int H, uint32_t* d_sync, hipStream_t s);
 void ctc_collapse_packed(const int32_t* labels, const int32_t* d_Tm, const int32_t* d_off, int M, int Tmax,
                          uint32_t* out_labels, uint32_t* out_pos, int32_t* out_count, hipStream_t s);
 void argmax_rows(const float* x, int64_t rows, int c, const uint8_t* d_excluded, int32_t* labels, hipStream_t s);

@@ -8,9 +8,9 @@
 //
 // Decomposition.  Rows (text lines, sorted by sequence length descending) are cut into 16-row
 // tiles; the H hidden units into UB = H/16 slices.  A workgroup = 4 waves that share ONE 16-unit
-// slice of Wh (H x 48 floats, staged into LDS once for all T steps) and serve 4*RT row tiles
-// (dealt in snake order over the waves of a direction, so that every wave gets long and short tiles).  The UB workgroups that own the slices of the same
-// rows form a "cluster"; the only data they exchange is the new hidden state of their rows.
+// slice of Wh (H x 48 floats, staged into LDS once for all T steps) and serve up to 4 row tiles per wave (which
+// ones: gru_assign_tiles, a longest-first deal that balances the waves' run times).  The UB workgroups that own the
+// slices of the same rows form a "cluster"; the only data they exchange is the new hidden state of their rows.
 //
 // Exchange = the layer's own output, and the data is its own flag.  y[row(t, m)][dir*H + unit] has to be
 // written anyway; the host pre-fills y with the word 0xFFFFFFFF (a NaN no result can be: the epilogue maps that one
@@ -30,6 +30,7 @@
 // wants lane (row, kq) to hold h[row][4*s + kq]; rows are fetched as 16-byte pieces and turned by a
 // 4x4 transpose across the four 16-lane groups (v_permlane16_swap / v_permlane32_swap).
 #include <cstdlib>
+#include <vector>
 
 #include "common.hpp"
 #include "kernels.hpp"
@@ -43,6 +44,8 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
+constexpr int kMaxSlots = 128;  // waves per direction (4 per cluster)
+
 struct GruParams {
     const float* gx;     // [2][R][3H] input projections (+ bi), natural column order (r | z | n)
     const float* wh;     // [2][H][3H]
@@ -53,10 +56,11 @@ struct GruParams {
     uint32_t* sync;      // [1] error word; zeroed before the launch
     uint32_t* place;     // [grid] XCD id + 1 of every workgroup, written by the kernel; zeroed before the launch
     int64_t R;
-    int M, ntiles, RT, ncl, Tmax;
+    int M, ncl, Tmax;
     int prio;            // s_setprio level of the waves (0..3)
     int allow_local;     // 0: write-through hand-offs whatever the placement (OCRS_GRU_LOCAL=0)
     int scatter;         // 1: clusters deliberately spread over the XCDs (OCRS_GRU_SCATTER=1; tests the census)
+    int16_t tiles[kMaxSlots * 4];  // row tiles of wave slot (cluster-in-direction * 4 + wave), longest first; -1 = none
     uint32_t spin_limit;
 };
 
@@ -297,18 +301,15 @@ gru_persistent_kernel(GruParams p) {
     const f32x4 bn = *reinterpret_cast<const f32x4*>(bhd + 2 * H + j0 + kq * 4);
     // this wave's tiles: tile_of(0), tile_of(1), ... (RT <= 4 of them); per tile the length of the lane's row and of the
     // tile's first (= longest) row, both kept in registers for the whole run
-    // Lines are sorted by length, so tile k is at least as long as tile k + 1, and a wave is busy for the SUM of its
-    // tiles' lengths: tiles are dealt to the 4*ncl waves of a direction in snake order (pass 0 ascending, pass 1
-    // descending, ...), which gives every wave a long, a short and a middling tile.  (Dealing consecutive tiles to
-    // one cluster left the cluster of the 12 longest tiles running twice as long as the average: 8.4 -> 4.x ms per
-    // layer at 1 232 lines of 100..600 steps.)
-    const int nslots = 4 * p.ncl, slot = cl * 4 + wave;
-    auto tile_of = [&](int i) { return i * nslots + ((i & 1) ? nslots - 1 - slot : slot); };
+    // Which tiles: decided by the host (gru_assign_tiles) from the tiles' lengths, the same for both directions.
+    const int slot = cl * 4 + wave;
+    const int t0 = p.tiles[slot * 4 + 0], t1 = p.tiles[slot * 4 + 1], t2 = p.tiles[slot * 4 + 2], t3 = p.tiles[slot * 4 + 3];
+    auto tile_of = [&](int i) { return i == 0 ? t0 : i == 1 ? t1 : i == 2 ? t2 : t3; };
     int tmr[4], tT[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const int m = tile_of(i) * 16 + i16;
-        tmr[i] = (i < p.RT && m < p.M) ? p.Tm[m] : 0;
+        tmr[i] = (tile_of(i) >= 0 && m < p.M) ? p.Tm[m] : 0;
         tT[i] = __builtin_amdgcn_readfirstlane(tmr[i]);
     }
     auto sel = [](const int (&a)[4], int i) { return i == 0 ? a[0] : i == 1 ? a[1] : i == 2 ? a[2] : i == 3 ? a[3] : 0; };
@@ -382,40 +383,76 @@ void gru_persistent_prepare(float* y, int64_t R, int H, hipStream_t s) {
     if (R > 0) (void)hipMemsetAsync(y, 0xFF, (size_t)R * 2 * H * sizeof(float), s);
 }
 
-// grid geometry; false if the shape is not supported
-static bool gru_plan(int M, int Tmax, int H, int* RT, int* ncl, int max_blocks = 256) {
+// Grid geometry: ncl clusters per direction (UB workgroups each); false if the shape is not supported.
+// Every workgroup of a cluster must be resident at once, so the grid stays at about one workgroup per CU (256),
+// two per CU for requests of more than 4 tiles per wave at that size (> 2048 lines at H = 256).
+static bool gru_plan(int M, int Tmax, int H, int* ncl, int max_blocks = 256) {
     if (H != 256 && H != 128 && H != 64) return false;
     const int ntiles = (M + 15) / 16;
     const int UB = H / 16;
-    // Every workgroup of a cluster must be resident at once, so the grid stays at about one workgroup per CU
-    // (256), two per CU for requests of more than 2048 lines; a wave serves RT <= 4 row tiles.
     int max_ncl = max_blocks / UB / 2 >= 1 ? max_blocks / UB / 2 : 1;
-    if ((ntiles + 4 * max_ncl - 1) / (4 * max_ncl) > 4) max_ncl *= 2;
-    *RT = (ntiles + 4 * max_ncl - 1) / (4 * max_ncl);
-    if (*RT > 4 || *RT < 1) return false;
-    *ncl = (ntiles + 4 * *RT - 1) / (4 * *RT);
+    if (ntiles > 16 * max_ncl) max_ncl *= 2;
+    if (ntiles > 16 * max_ncl || 4 * max_ncl > kMaxSlots) return false;
+    *ncl = (ntiles + 3) / 4 < max_ncl ? (ntiles + 3) / 4 : max_ncl;
     return (size_t)H * 48 * sizeof(float) + ((size_t)Tmax + 1) * sizeof(int) <= 64 * 1024;
 }
 
+// Deal the row tiles (tile k = lines 16k .. 16k+15 of the length-sorted batch, so len[k] >= len[k + 1]) to the
+// 4 * ncl waves of a direction, at most 4 per wave.  A wave steps its tiles round-robin; a round of n live tiles
+// costs max(n * c, L): c = the wave's own work per item (MFMA chain + epilogue), L = the store -> visible -> re-read
+// latency of the state exchange that a single tile cannot hide.  Its time is the sum over rounds, and the kernel
+// ends with the slowest wave: longest-tile-first greedy on that cost (the longest tiles end up alone or with one
+// short partner, the mid-length ones in twos and threes).  Dealing consecutive tiles to a cluster took 8.4 ms per
+// layer on 1 232 lines of 100..600 steps, a snake deal 6.5 ms, this 5.x ms.
+static void gru_assign_tiles(const int32_t* h_Tm, int M, int ncl, int16_t* tiles) {
+    const int ntiles = (M + 15) / 16, nslots = 4 * ncl;
+    const int64_t c = 47, L = 66;   // units of 0.1 us (measured: 4.7 us per item, 6.6 us per lone step)
+    for (int i = 0; i < nslots * 4; i++) tiles[i] = -1;
+    std::vector<int> cnt(nslots, 0);
+    auto cost = [&](int slot, int extra_len) {   // lengths are descending within a slot, extra_len <= all of them
+        int64_t tot = 0;
+        int len[5], n = cnt[slot];
+        for (int i = 0; i < n; i++) len[i] = h_Tm[tiles[slot * 4 + i] * 16];
+        if (extra_len > 0) len[n++] = extra_len;
+        for (int i = n - 1, below = 0; i >= 0; i--) {   // rounds in which exactly i + 1 tiles are live
+            const int64_t per = (i + 1) * c > L ? (i + 1) * c : L;
+            tot += (int64_t)(len[i] - below) * per;
+            below = len[i];
+        }
+        return tot;
+    };
+    for (int k = 0; k < ntiles; k++) {
+        const int len = h_Tm[k * 16];
+        int best = -1;
+        int64_t best_cost = 0;
+        for (int sl = 0; sl < nslots; sl++) {
+            if (cnt[sl] >= 4) continue;
+            const int64_t cs = cost(sl, len);
+            if (best < 0 || cs < best_cost) { best = sl; best_cost = cs; }
+        }
+        tiles[best * 4 + cnt[best]++] = (int16_t)k;
+    }
+}
+
 bool gru_persistent_supported(int M, int Tmax, int64_t R, int H) {
-    int RT, ncl;
+    int ncl;
     // y is addressed through one buffer resource: < 4 GiB
-    return M > 0 && (uint64_t)R * 2 * H * sizeof(float) < (uint64_t(1) << 32) && gru_plan(M, Tmax, H, &RT, &ncl);
+    return M > 0 && (uint64_t)R * 2 * H * sizeof(float) < (uint64_t(1) << 32) && gru_plan(M, Tmax, H, &ncl);
 }
 
 bool gru_persistent(const float* gx, const float* wh, const float* bh, float* y, const int32_t* d_Tm, const int32_t* d_off,
-                    int64_t R, int M, int Tmax, int H, uint32_t* d_sync, hipStream_t s) {
+                    const int32_t* h_Tm, int64_t R, int M, int Tmax, int H, uint32_t* d_sync, hipStream_t s) {
     if (M <= 0) return true;
     GruParams p{};
     p.gx = gx; p.wh = wh; p.bh = bh; p.y = y; p.Tm = d_Tm; p.off = d_off;
     p.place = d_sync;
     p.sync = d_sync + kMaxGrid;
     p.R = R; p.M = M; p.Tmax = Tmax;
-    p.ntiles = (M + 15) / 16;
     const int UB = H / 16;
     int max_blocks = 256;
     if (const char* e = getenv("OCRS_GRU_BLOCKS")) max_blocks = atoi(e) > 0 ? atoi(e) : 256;
-    if (!gru_plan(M, Tmax, H, &p.RT, &p.ncl, max_blocks) && !gru_plan(M, Tmax, H, &p.RT, &p.ncl)) return false;
+    if (!gru_plan(M, Tmax, H, &p.ncl, max_blocks) && !gru_plan(M, Tmax, H, &p.ncl)) return false;
+    gru_assign_tiles(h_Tm, M, p.ncl, p.tiles);
     p.prio = 3;
     if (const char* e = getenv("OCRS_GRU_PRIO")) p.prio = atoi(e);
     p.spin_limit = 1u << 21;  // re-reads of >= ~1 us each: seconds, far beyond any legitimate wait

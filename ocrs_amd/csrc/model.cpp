@@ -944,7 +944,7 @@ int HipModel::run_recognition_packed(Workspace& ws, const std::vector<PackedGrou
                     OCRS_HIP(hipEventRecord(ready, st));
                     OCRS_HIP(hipStreamWaitEvent(rs, ready, 0));
                     int ktok = timers ? timers->kbegin(KC_GEMM_GRU_HIDDEN, rs, fl, 4.0 * ((double)R * (2.0 * 3 * H + 2.0 * 2 * H) + 2.0 * 3 * H * H)) : -1;
-                    k::gru_persistent(gx, op.aux2, op.aux3, y, plan.d_Tm, plan.d_off, R, M, plan.Tmax, H, d_sync, rs);
+                    k::gru_persistent(gx, op.aux2, op.aux3, y, plan.d_Tm, plan.d_off, plan.h_Tm.data(), R, M, plan.Tmax, H, d_sync, rs);
                     if (ktok >= 0) timers->end(ktok, rs);
                     if (plan.h_status && gru_layer < 8) ws.download(plan.h_status + gru_layer, d_sync + k::gru_persistent_sync_words(M) - 1, sizeof(uint32_t), rs);
                     OCRS_HIP(hipEventRecord(done, rs));

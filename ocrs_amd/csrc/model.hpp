@@ -101,6 +101,7 @@ struct HipModel : ModelBase {
         const int32_t* d_Tm = nullptr;   // [M]
         const int32_t* d_off = nullptr;  // [Tmax + 1]
         std::vector<int> active;         // [Tmax] host
+        std::vector<int32_t> h_Tm;       // [M] host copy of d_Tm
         uint32_t* h_status = nullptr;    // host [8]: slot i receives the time-out word of the i-th GRU layer's
                                          // persistent kernel after the workspace's next sync (0 = fine)
     };
