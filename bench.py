@@ -42,7 +42,7 @@ MFMA_CLASSES = ("gemm_conv3x3_mfma", "gemm_gru_input_mfma", "gemm_gru_hidden_mfm
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=36)
+    ap.add_argument("--steps", type=int, default=72)
     ap.add_argument("--warmup", type=int, default=36)
     ap.add_argument("--settle-s", type=float, default=3.0,
                     help="keep running untimed steps after the W warm-up steps until this many seconds have passed "

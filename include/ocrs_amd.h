@@ -80,6 +80,8 @@ OCRS_API ocrs_status ocrs_ctc_beam_search(const float* logp, int t, int c, uint3
  *   "beam_gpu"        1 = DecodeMethod::BeamSearch runs on the GPU (default), 0 = on the host (threaded over lines)
  *   "gru_local"       persistent GRU kernel: 1 = a cluster of workgroups that finds itself on one XCD hands its state
  *                     over through that XCD's L2 (default), 0 = always through write-through stores
+ *   "rec_max_pixels"  input pixels (padded line batch) one recognition sub-request may hold; larger requests are run
+ *                     as consecutive sub-requests (default 0 = 2e9, sized for the activation memory of one GPU)
  *   "gru_scatter"     test knob: 1 = spread every cluster over all XCDs (exercises the write-through path), default 0
  * Results never depend on an option; OCRS_ERR_INVALID_ARGUMENT for an unknown name. */
 OCRS_API ocrs_status ocrs_set_option(const char* name, long value);

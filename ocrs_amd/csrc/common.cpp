@@ -199,6 +199,7 @@ const OptDef kOptDefs[OPT_COUNT] = {
     {"beam_gpu", "OCRS_BEAM_GPU", 1},                   // 1 CTC beam search on the GPU, 0 on the host
     {"gru_local", "OCRS_GRU_LOCAL", 1},                 // persistent GRU: 1 same-XCD clusters hand off through L2, 0 always write-through
     {"gru_scatter", "OCRS_GRU_SCATTER", 0},             // persistent GRU test knob: 1 spreads every cluster over the XCDs
+    {"rec_max_pixels", "OCRS_REC_MAX_PIXELS", 0},       // input pixels per recognition sub-request (0 = 2e9, the memory budget)
 };
 std::atomic<long> g_opts[OPT_COUNT];
 std::once_flag g_opts_once;
@@ -213,6 +214,11 @@ void init_options() {
 int option(Option o) {
     std::call_once(g_opts_once, init_options);
     return (int)g_opts[o].load(std::memory_order_relaxed);
+}
+
+long option_long(Option o) {
+    std::call_once(g_opts_once, init_options);
+    return g_opts[o].load(std::memory_order_relaxed);
 }
 
 bool set_option(const char* name, long value) {

@@ -243,25 +243,62 @@ RecLine ocrs_engine::make_rec_line(const std::vector<RotatedRect>& words, size_t
     return l;
 }
 
+// Activations of the recognition conv stack scale with the input (~100 B per input pixel of the padded line
+// batch).  A request beyond the budget is run as consecutive sub-requests over contiguous runs of its lines
+// (lines are independent: recognition.rs:448-503 itself works in chunks of 20), so the caller never has to
+// know the limit.  Option "rec_max_pixels" overrides the budget (tests).
+static double rec_pixel_budget() {
+    const long v = option_long(OPT_REC_MAX_PIXELS);
+    return v > 0 ? (double)v : 2.0e9;
+}
+
 void ocrs_engine::recognize(const ocrs_page* const* pages, size_t n_pages,
                             const std::vector<std::vector<std::vector<RotatedRect>>>& lines_per_page,
                             std::vector<std::vector<CtcStep>>* steps_out, std::vector<RecLine>* rec_lines_out,
                             std::vector<uint32_t>* ctc_len_out) const {
     if (!recognition) fail(OCRS_ERR_MODEL_NOT_LOADED, "Recognition model not loaded");
-    const bool beam = decode_method == OCRS_DECODE_BEAM_SEARCH;
     const uint32_t rec_h = rec_input_height();
-    const size_t alphabet_len = alphabet.size();
-
     std::vector<RecLine> lines;
     for (size_t p = 0; p < n_pages; p++)
         for (const auto& words : lines_per_page[p]) lines.push_back(make_rec_line(words, p, lines.size()));
     const size_t L = lines.size();
-    steps_out->assign(L, {});
-    ctc_len_out->assign(L, 0);
-    if (L == 0) {
+    const double budget = rec_pixel_budget();
+    double total = 0.0;
+    for (const RecLine& l : lines) total += (double)rec_h * l.group_width;
+    if (total <= budget) {
+        recognize_lines(pages, n_pages, lines, steps_out, ctc_len_out);
         *rec_lines_out = std::move(lines);
         return;
     }
+    steps_out->assign(L, {});
+    ctc_len_out->assign(L, 0);
+    for (size_t b = 0; b < L;) {
+        size_t e = b;
+        double px = 0.0;
+        while (e < L && (e == b || px + (double)rec_h * lines[e].group_width <= budget)) px += (double)rec_h * lines[e++].group_width;
+        std::vector<RecLine> part(lines.begin() + b, lines.begin() + e);
+        std::vector<std::vector<CtcStep>> st;
+        std::vector<uint32_t> cl;
+        recognize_lines(pages, n_pages, part, &st, &cl);
+        for (size_t i = b; i < e; i++) {
+            (*steps_out)[i] = std::move(st[i - b]);
+            (*ctc_len_out)[i] = cl[i - b];
+        }
+        b = e;
+    }
+    *rec_lines_out = std::move(lines);
+}
+
+void ocrs_engine::recognize_lines(const ocrs_page* const* pages, size_t n_pages, const std::vector<RecLine>& lines,
+                                  std::vector<std::vector<CtcStep>>* steps_out, std::vector<uint32_t>* ctc_len_out) const {
+    const bool beam = decode_method == OCRS_DECODE_BEAM_SEARCH;
+    const uint32_t rec_h = rec_input_height();
+    const size_t alphabet_len = alphabet.size();
+
+    const size_t L = lines.size();
+    steps_out->assign(L, {});
+    ctc_len_out->assign(L, 0);
+    if (L == 0) return;
 
     // group by padded width (recognition.rs:430-446); std::map gives a deterministic order
     std::map<uint32_t, std::vector<size_t>> groups;
@@ -310,11 +347,9 @@ void ocrs_engine::recognize(const ocrs_page* const* pages, size_t n_pages,
                 chunks.push_back(std::move(ch));
             }
         }
-        // activations of the conv stack scale with the input (~100 B per input pixel): refuse requests
-        // that cannot fit one device instead of failing inside an allocation
-        if ((double)off * 100.0 > 200e9)
-            fail(OCRS_ERR_CAPACITY, "recognition request too large (%lld input pixels): split the lines over several calls",
-                 (long long)off);
+        // (ocrs_engine::recognize keeps a request within the activation budget; a single line beyond it is refused)
+        if ((double)off > std::max(rec_pixel_budget(), 2.0e9))
+            fail(OCRS_ERR_CAPACITY, "text line too large for the recognition model (%lld input pixels)", (long long)off);
         std::vector<k::LineDesc> descs;
         std::vector<int32_t> poly;
         for (const Chunk& ch : chunks)
@@ -332,10 +367,7 @@ void ocrs_engine::recognize(const ocrs_page* const* pages, size_t n_pages,
                 descs.push_back(d);
                 for (const PointI& p : ln.polygon) { poly.push_back(p.y); poly.push_back(p.x); }
             }
-        if (descs.empty()) {
-            *rec_lines_out = std::move(lines);
-            return;
-        }
+        if (descs.empty()) return;
         k::LineDesc* d_descs = ws.alloc_n<k::LineDesc>(descs.size());
         int32_t* d_poly = ws.alloc_n<int32_t>(poly.size());
         OCRS_HIP(hipMemcpyAsync(d_descs, descs.data(), descs.size() * sizeof(k::LineDesc), hipMemcpyHostToDevice, st));
@@ -602,7 +634,6 @@ void ocrs_engine::recognize(const ocrs_page* const* pages, size_t n_pages,
         }
     }
     if (T) T->collect();
-    *rec_lines_out = std::move(lines);
 }
 
 // recognition.rs:241-311 for one line

@@ -64,6 +64,9 @@ struct ocrs_engine {
                    const std::vector<std::vector<std::vector<ocrs::geom::RotatedRect>>>& lines_per_page,
                    std::vector<std::vector<ocrs::CtcStep>>* steps, std::vector<ocrs::RecLine>* rec_lines,
                    std::vector<uint32_t>* ctc_input_len) const;
+    // one sub-request of `recognize` (within the activation budget); outputs indexed like `lines`
+    void recognize_lines(const ocrs_page* const* pages, size_t n_pages, const std::vector<ocrs::RecLine>& lines,
+                         std::vector<std::vector<ocrs::CtcStep>>* steps, std::vector<uint32_t>* ctc_input_len) const;
 
     std::vector<ocrs::TextChar> text_line_from_result(const ocrs::RecLine& line, uint32_t ctc_input_len,
                                                       const std::vector<ocrs::CtcStep>& steps) const;

@@ -147,6 +147,26 @@ def test_recognition_only_2048_crops_match_golden(engine):
     assert np.array_equal(flat, g["tokens"])
 
 
+def test_oversized_recognition_request_is_split_into_sub_requests(engine):
+    """A request whose padded line batch exceeds the activation budget ("rec_max_pixels", 2e9 by default) is run as
+    consecutive sub-requests; with the budget forced down to ~1/7 of one bench page's lines, and to one line, the
+    chars and boxes must be exactly those of the unsplit call."""
+    px = synth.synthetic_page(5, 1024, 1024, lines=80)
+    inp = engine.prepare_input(ImageSource.from_tensor(px, DimOrder.Hwc))
+    lines = engine.find_text_lines(inp, engine.detect_words(inp))
+    ref = [(str(t), [c.rect for c in t.chars()]) if t else None for t in engine.recognize_text(inp, lines)]
+    res = {}
+    try:
+        for budget in (64 * 1200 * 12, 64 * 50):   # ~12 lines per sub-request; one line per sub-request
+            _lib.set_option("rec_max_pixels", budget)
+            res[budget] = [(str(t), [c.rect for c in t.chars()]) if t else None for t in engine.recognize_text(inp, lines)]
+    finally:
+        _lib.set_option("rec_max_pixels", 0)
+    assert sum(1 for t in ref if t) > 60
+    for budget, got in res.items():
+        assert got == ref, budget
+
+
 def test_gru_modes_give_identical_bits(engine):
     """Persistent recurrence kernel (default) vs one launch per time step: same chars and boxes, on a request with
     ragged lengths (one bench page: T from ~100 to 600) and on the 2048-line request (RT = 4 tiles per wave)."""
