@@ -167,6 +167,35 @@ def test_oversized_recognition_request_is_split_into_sub_requests(engine):
         assert got == ref, budget
 
 
+def test_more_than_2048_lines_second_wave_of_gru_clusters(engine):
+    """2 560 lines = 160 row tiles: more than the 32 wave slots x 4 tiles of a 256-workgroup grid, so the persistent
+    GRU kernel is launched with 512 workgroups — the second half becomes resident as workgroups of the first exit
+    (clusters never depend on each other).  Chars and boxes must equal the per-step kernel's, and the first 2 048
+    lines (same crops, lines are independent) the golden request's."""
+    g = np.load(os.path.join(GOLD, "bench_crops_2048.npz"))
+    inp, rects, n = _crops_request(engine)
+    extra = 512
+    idx = np.concatenate([np.arange(n), np.arange(extra)])          # the first 512 crops again, as lines 2048..2559
+    rects2 = rects[idx]
+    m = n + extra
+    loffs = np.arange(m + 1, dtype=np.uintp)
+    res = {}
+    try:
+        for mode in (0, 1):
+            _lib.set_option("gru_mode", mode)
+            res[mode] = engine.recognize_text_batch_raw([inp], rects2, loffs, np.array([0, m], dtype=np.uintp))
+    finally:
+        _lib.set_option("gru_mode", 0)
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    chars, coffs = res[0]
+    coffs = np.asarray(coffs, np.int64)
+    assert np.array_equal(coffs[: n + 1], g["char_offsets"])
+    k = int(coffs[n])
+    got = np.stack([chars["ch"].astype(np.int64), chars["top"], chars["left"], chars["bottom"], chars["right"]], axis=1)
+    assert np.array_equal(got[:k], g["chars"].astype(np.int64))
+    assert np.array_equal(got[k:], got[: int(coffs[extra])])   # the repeated crops decode to the same text and boxes
+
+
 def test_gru_modes_give_identical_bits(engine):
     """Persistent recurrence kernel (default) vs one launch per time step: same chars and boxes, on a request with
     ragged lengths (one bench page: T from ~100 to 600) and on the 2048-line request (RT = 4 tiles per wave)."""
