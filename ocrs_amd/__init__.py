@@ -405,7 +405,21 @@ class OcrEngine:
 
     # ---- lib.rs:237-256
     def recognize_text(self, inp, lines):
-        return self.recognize_text_batch([inp], [lines])[0]
+        """OcrEngine::recognize_text (lib.rs:237-256) through the single-page entry point a Rust binding uses."""
+        rects, offs = _pack_lines(lines)
+        chars = C.POINTER(_lib.TextCharC)()
+        coffs = C.POINTER(C.c_size_t)()
+        check(lib().ocrs_engine_recognize_text(
+            self._h, inp._h, rects.ctypes.data_as(C.POINTER(C.c_float)), offs.ctypes.data_as(C.POINTER(C.c_size_t)),
+            C.c_size_t(len(lines)), C.byref(chars), C.byref(coffs)))
+        out = []
+        for li in range(len(lines)):
+            a, b = coffs[li], coffs[li + 1]
+            out.append(TextLine([TextChar(chr(chars[k].ch), (chars[k].top, chars[k].left, chars[k].bottom, chars[k].right))
+                                 for k in range(a, b)]) if b > a else None)
+        lib().ocrs_buffer_free(chars)
+        lib().ocrs_buffer_free(coffs)
+        return out
 
     def recognize_text_batch(self, inputs, lines_per_page):
         n = len(inputs)

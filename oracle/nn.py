@@ -154,26 +154,18 @@ class OracleGraph:
                 elif t == OP_TOSEQ:
                     y = a[:, :, 0, :].permute(2, 0, 1).contiguous()  # [N,C,1,W] -> [T,N,C]
                 elif t == OP_GRU:
+                    # ATen's native bidirectional GRU (same gate order r|z|n and the same candidate formula
+                    # n = tanh(gx_n + r * (h Wh_n + bh_n)) as the graph's GRU): the time loop runs in C++, which is
+                    # what a native runtime such as rten does — a Python loop of 600 small matmuls per chunk would
+                    # make this baseline an order of magnitude slower than the reference's CPU path.
                     hd = op["hidden"]
-                    outs = []
+                    flat = []
                     for d in range(2):
                         wi, bi, wh, bh = cw[4 * d:4 * d + 4]
-                        wi = wi.reshape(op["cin"], 3 * hd)
-                        wh = wh.reshape(hd, 3 * hd)
-                        gx = a @ wi + bi
-                        T = a.shape[0]
-                        hcur = torch.zeros(a.shape[1], hd)
-                        ys = [None] * T
-                        for s in range(T):
-                            tt = T - 1 - s if d == 1 else s
-                            gh = hcur @ wh + bh
-                            r = torch.sigmoid(gx[tt, :, :hd] + gh[:, :hd])
-                            z = torch.sigmoid(gx[tt, :, hd:2 * hd] + gh[:, hd:2 * hd])
-                            nn_ = torch.tanh(gx[tt, :, 2 * hd:] + r * gh[:, 2 * hd:])
-                            hcur = (1 - z) * nn_ + z * hcur
-                            ys[tt] = hcur
-                        outs.append(torch.stack(ys))
-                    y = torch.cat(outs, dim=2)
+                        flat += [wi.reshape(op["cin"], 3 * hd).t().contiguous(), wh.reshape(hd, 3 * hd).t().contiguous(),
+                                 bi.reshape(-1).contiguous(), bh.reshape(-1).contiguous()]
+                    h0 = torch.zeros(2, a.shape[1], hd)
+                    y, _ = torch._VF.gru(a, h0, flat, True, 1, 0.0, False, True, False)
                 elif t == OP_LINEAR:
                     y = a @ cw[0].reshape(op["cin"], op["cout"]) + cw[1]
                 elif t == OP_LOGSOFTMAX:
