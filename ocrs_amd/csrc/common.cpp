@@ -165,14 +165,16 @@ HostPool& host_pool() {
 
 hipStream_t heavy_stream() {
     static hipStream_t s = [] {
-        // Lowest queue priority: the conv stacks are long throughput-bound grids whose blocks live ~200 us;
-        // the latency-bound kernels of the request streams (1 200 dependent GRU steps per request) must get
-        // the slots those blocks free first.  Measured on the default bench: 182/176 -> 188/185 pages/s, and
-        // with the request streams at the highest priority and 6 steps in flight 199/207.
+        // Highest queue priority.  The conv stacks are the critical resource of the pipeline: their stream never runs
+        // dry in steady state and a step takes as long as its conv stack does.  (Round 1 ran this stream at the LOWEST
+        // priority so that the 1 200 dependent GRU step launches of a request would get freed CU slots first; with
+        // the recurrence in one persistent launch per layer that reason is gone.  The GPU is work-conserving — every
+        // combination of stream priorities measured the same 256-259 pages/s — but here the dominant kernels are
+        // stretched least by what runs beside them: 9.9-10.4 ms per launch against 11.2-11.4.)
         hipStream_t h;
         int least = 0, greatest = 0;
         OCRS_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        OCRS_HIP(hipStreamCreateWithPriority(&h, hipStreamNonBlocking, least));
+        OCRS_HIP(hipStreamCreateWithPriority(&h, hipStreamNonBlocking, greatest));
         return h;
     }();
     return s;
