@@ -299,7 +299,7 @@ gru_persistent_kernel(GruParams p) {
     const f32x4 br = *reinterpret_cast<const f32x4*>(bhd + j0 + kq * 4);
     const f32x4 bz = *reinterpret_cast<const f32x4*>(bhd + H + j0 + kq * 4);
     const f32x4 bn = *reinterpret_cast<const f32x4*>(bhd + 2 * H + j0 + kq * 4);
-    // this wave's tiles: tile_of(0), tile_of(1), ... (RT <= 4 of them); per tile the length of the lane's row and of the
+    // this wave's tiles: tile_of(0), tile_of(1), ... (at most 4 of them); per tile the length of the lane's row and of the
     // tile's first (= longest) row, both kept in registers for the whole run
     // Which tiles: decided by the host (gru_assign_tiles) from the tiles' lengths, the same for both directions.
     const int slot = cl * 4 + wave;
@@ -403,7 +403,7 @@ static bool gru_plan(int M, int Tmax, int H, int* ncl, int max_blocks = 256) {
 // latency of the state exchange that a single tile cannot hide.  Its time is the sum over rounds, and the kernel
 // ends with the slowest wave: longest-tile-first greedy on that cost (the longest tiles end up alone or with one
 // short partner, the mid-length ones in twos and threes).  Dealing consecutive tiles to a cluster took 8.4 ms per
-// layer on 1 232 lines of 100..600 steps, a snake deal 6.5 ms, this 5.x ms.
+// layer on 1 232 lines of 100..600 steps, a snake deal 6.5 ms, this 4.7 ms.
 static void gru_assign_tiles(const int32_t* h_Tm, int M, int ncl, int16_t* tiles) {
     const int ntiles = (M + 15) / 16, nslots = 4 * ncl;
     const int64_t c = 47, L = 66;   // units of 0.1 us (measured: 4.7 us per item, 6.6 us per lone step)
