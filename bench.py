@@ -613,56 +613,111 @@ def extra_legs(engine, dptrs, host_pages, H, W, synth, np, DimOrder, sync_all, a
     return out
 
 
-def cpu_baseline(pages, engine, gpu_text, np):
-    """The CPU restatement (oracle/) timed on this box's host cores, on a bounded sample of the same pages, with both
-    of its network back-ends: `exact` (the C fmaf-chain restatement, OpenMP) and `torch` (PyTorch-CPU fp32 — what
-    RTen's CPU path does); C for image ops, contours, crops and CTC in both; layout analysis through the product's
-    host C++ (it is host code in both paths).  `value` is the faster of the two.  Reported next to the GPU number;
-    it is not the target.  `text_match`: the text the GPU path decoded for these pages equals, line for line, what
-    the exact oracle decodes (the bit-exact parity proper is tests/test_gpu_bench_scale.py)."""
+def _cpu_worker_init(threads):
+    os.environ["OMP_NUM_THREADS"] = str(threads)
+    os.environ["MKL_NUM_THREADS"] = str(threads)
+    os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+
+
+_CPU_W = {}
+
+
+def _cpu_worker_run(task):
+    """One page through the oracle in a worker process (CPU only; layout through the product's host C++, which is host
+    code in both paths).  task = (backend, page or None for the warm-up, threads)."""
+    backend, page, threads = task
+    import ctypes as C
+    import numpy as np
     import torch
+    sys.path.insert(0, ROOT)
     from oracle import pipeline as OP
     from oracle.nn import OracleGraph, OracleModel
     from oracle.geometry import RotatedRect
-    from ocrs_amd import models
+    from ocrs_amd import _lib, models
+    torch.set_num_threads(threads)
+    if backend not in _CPU_W:
+        dg, rg = OracleGraph(models.synthetic_detection_bytes()), OracleGraph(models.synthetic_recognition_bytes())
+        _CPU_W[backend] = OP.OcrEngine(detection_model=OracleModel(dg, backend), recognition_model=OracleModel(rg, backend))
+    ora = _CPU_W[backend]
+    if page is None:
+        from ocrs_amd import synth
+        page = synth.synthetic_page(0, 1024, 1024, lines=80)[:256, :256].copy()
+    L = _lib.lib()
+    t0 = time.perf_counter()
+    inp = ora.prepare_input(OP.ImageSource.from_tensor(page, "hwc"))
+    words = ora.detect_words(inp)
+    a = np.ascontiguousarray(np.array([w.to_array() for w in words], np.float32).reshape(-1, 6))
+    lr, lo, nl = C.POINTER(C.c_float)(), C.POINTER(C.c_size_t)(), C.c_size_t(0)
+    _lib.check(L.ocrs_engine_find_text_lines(None, None, a.ctypes.data_as(C.POINTER(C.c_float)), C.c_size_t(len(a)),
+                                             C.byref(lr), C.byref(lo), C.byref(nl)))
+    offs = [lo[i] for i in range(nl.value + 1)]
+    flat = np.ctypeslib.as_array(lr, shape=(max(len(a), 1) * 6,))[: len(a) * 6].reshape(-1, 6).copy()
+    L.ocrs_buffer_free(lr)
+    L.ocrs_buffer_free(lo)
+    olines = [[RotatedRect.from_array(r) for r in flat[offs[i]:offs[i + 1]]] for i in range(nl.value)]
+    text = [str(t) for t in ora.recognize_text(inp, olines) if t is not None]
+    return time.perf_counter() - t0, text, len(olines)
 
+
+def cpu_baseline(pages, engine, gpu_text, np):
+    """The CPU restatement (oracle/) timed on this box's host cores on a bounded sample of the same pages.
+      * `exact` back-end (the C fmaf-chain restatement of the networks, OpenMP over all budgeted threads), the sampled
+        pages one after the other: this is the checker — `text_match` says that the text the GPU path decoded for these
+        pages equals, line for line, what it decodes (the bit-exact parity proper is tests/test_gpu_bench_scale.py);
+      * `torch` back-end (PyTorch-CPU fp32 convolutions / ATen GRU — what a native CPU runtime such as RTen does),
+        run the way a CPU deployment would use the box: W worker processes x T threads covering the same cores, one
+        page per worker at a time (a single page cannot keep 32+ threads busy: the reference's recognition works in
+        chunks of <= 20 lines).  `value` is the best of the legs.
+    C for image ops, contours, crops and CTC in all legs; layout analysis through the product's host C++ (it is host
+    code in both paths).  Reported next to the GPU number; it is not the target."""
+    import multiprocessing as mp
     cores = int(os.environ["OMP_NUM_THREADS"])
-    torch.set_num_threads(cores)
-    dg, rg = OracleGraph(models.synthetic_detection_bytes()), OracleGraph(models.synthetic_recognition_bytes())
-
-    def timed_run(backend):
-        ora = OP.OcrEngine(detection_model=OracleModel(dg, backend), recognition_model=OracleModel(rg, backend))
-
-        def run(pg):
-            inp = ora.prepare_input(OP.ImageSource.from_tensor(pg, "hwc"))
-            words = ora.detect_words(inp)
-            arr = np.array([w.to_array() for w in words], np.float32).reshape(-1, 6)
-            lines = engine.find_text_lines(None, arr)  # host C++ (no GPU work)
-            olines = [[RotatedRect.from_array(r) for r in l] for l in lines]
-            return [str(t) for t in ora.recognize_text(inp, olines) if t is not None], len(olines)
-
-        run(pages[0][:256, :256].copy())  # warm torch / oneDNN / OpenMP pools
-        t0 = time.perf_counter()
-        texts, n_lines = [], 0
-        for pg in pages:
-            t, nl = run(pg)
-            texts.append(t)
-            n_lines += nl
-        return time.perf_counter() - t0, texts, n_lines
-
-    dt_e, texts_e, n_lines = timed_run("exact")
-    dt_t, _, _ = timed_run("torch")
+    # leg 1: exact, sequential, all threads (in this process)
+    t0 = time.perf_counter()
+    _cpu_worker_run(("exact", None, cores))
+    texts_e, n_lines = [], 0
+    t0 = time.perf_counter()
+    for pg in pages:
+        _, t, nl = _cpu_worker_run(("exact", pg, cores))
+        texts_e.append(t)
+        n_lines += nl
+    dt_e = time.perf_counter() - t0
+    # leg 2: torch, W workers x T threads
+    T = 4 if cores >= 8 else max(1, cores // 2)
+    W = max(1, cores // T)
+    rate_t, n_pages_t, dt_t = 0.0, 0, 0.0
+    lines_t = 0
+    try:
+        from concurrent.futures import ProcessPoolExecutor
+        # (an executor rather than mp.Pool: a worker that dies while starting breaks the pool loudly instead of being
+        # respawned for ever; every wait below is bounded)
+        with ProcessPoolExecutor(W, mp_context=mp.get_context("spawn"), initializer=_cpu_worker_init, initargs=(T,)) as pool:
+            for f in [pool.submit(_cpu_worker_run, ("torch", None, T)) for _ in range(W)]:   # import + warm-up everywhere
+                f.result(timeout=300)
+            t0 = time.perf_counter()
+            futs = [pool.submit(_cpu_worker_run, ("torch", pages[i % len(pages)], T)) for i in range(W)]
+            outs = [f.result(timeout=300) for f in futs]
+            dt_t = time.perf_counter() - t0
+        n_pages_t = len(outs)
+        rate_t = n_pages_t / dt_t
+        lines_t = sum(o[2] for o in outs)
+    except Exception as e:  # a box that cannot spawn workers still reports the sequential leg
+        print("cpu_baseline: parallel leg failed: %r" % (e,), file=sys.stderr)
+        rate_t, n_pages_t, dt_t = 0.0, 0, 0.0
     lines_total = sum(max(len(a), len(b)) for a, b in zip(texts_e, gpu_text))
     lines_equal = sum(sum(1 for x, y in zip(a, b) if x == y) for a, b in zip(texts_e, gpu_text))
-    dt = min(dt_e, dt_t)
-    return {"value": round(len(pages) / dt, 4), "unit": "pages/s", "cores": cores, "kind": "port",
-            "lines_per_s": round(n_lines / dt, 2),
-            "backend": "exact" if dt_e <= dt_t else "torch",
-            "pages_per_s_by_backend": {"exact": round(len(pages) / dt_e, 4), "torch": round(len(pages) / dt_t, 4)},
+    rate_e = len(pages) / dt_e
+    best_t = rate_t >= rate_e
+    return {"value": round(max(rate_e, rate_t), 4), "unit": "pages/s", "cores": cores, "kind": "port",
+            "lines_per_s": round((lines_t / dt_t) if best_t and dt_t > 0 else n_lines / dt_e, 2),
+            "backend": "torch" if best_t else "exact",
+            "pages_per_s_by_backend": {"exact": round(rate_e, 4), "torch": round(rate_t, 4)},
             "text_match": lines_total > 0 and lines_equal == lines_total,
             "text_lines_equal": "%d/%d" % (lines_equal, lines_total),
-            "sample": "%d of the same synthetic 1024x1024 pages, full pipeline, oracle (C image/contour/crop/CTC; networks: C "
-                      "fmaf-chain restatement %.1f s, torch-CPU fp32 %.1f s; %d threads)" % (len(pages), dt_e, dt_t, cores)}
+            "sample": "full pipeline on the oracle (C image/contour/crop/CTC, host C++ layout). exact: %d of the same synthetic "
+                      "1024x1024 pages one after the other, networks = C fmaf-chain restatement, %d threads, %.1f s.  torch: "
+                      "%d pages (the same ones, repeated) on %d worker processes x %d threads, networks = PyTorch-CPU fp32, "
+                      "%.1f s" % (len(pages), cores, dt_e, n_pages_t, W, T, dt_t)}
 
 
 if __name__ == "__main__":
