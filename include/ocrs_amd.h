@@ -71,6 +71,13 @@ OCRS_API ocrs_status ocrs_set_device(int device);
 OCRS_API ocrs_status ocrs_ctc_beam_search(const float* logp, int t, int c, uint32_t width, int impl, uint32_t** labels,
                                           uint32_t** positions, size_t* n);
 
+/* Test hook (host only, no GPU work): how the persistent GRU kernel would deal the 16-line row tiles of a request
+ * to its waves.  lengths_desc = sequence lengths of the lines, descending (tile k = lines 16k .. 16k+15).
+ * *n_clusters = clusters per direction; tiles[512]: for wave slot s = cluster * 4 + wave, tiles[4s .. 4s+3] are the
+ * tile indices it serves (longest first), -1 = none.  OCRS_ERR_CAPACITY if the shape has no persistent plan. */
+OCRS_API ocrs_status ocrs_gru_tile_plan(const int32_t* lengths_desc, size_t n_lines, int hidden, int32_t* n_clusters,
+                                        int16_t* tiles);
+
 /* Process-wide integer tuning options (no reference counterpart: RTen's equivalents are compile-time).
  * Each also reads its initial value from the environment variable OCRS_<NAME IN CAPITALS>.
  *   "gru_mode"        0 = one persistent kernel per GRU layer (default), 1 = one launch per time step

@@ -434,6 +434,14 @@ static void gru_assign_tiles(const int32_t* h_Tm, int M, int ncl, int16_t* tiles
     }
 }
 
+// The deal gru_persistent would use for these (descending) line lengths: clusters per direction and, per wave slot
+// (cluster * 4 + wave), up to 4 row-tile indices, -1 = none.  Host only (tests).
+bool gru_tile_plan(const int32_t* h_Tm, int M, int H, int* ncl, int16_t* tiles /* [kMaxSlots * 4] */) {
+    if (M <= 0 || !gru_plan(M, h_Tm[0], H, ncl)) return false;
+    gru_assign_tiles(h_Tm, M, *ncl, tiles);
+    return true;
+}
+
 bool gru_persistent_supported(int M, int Tmax, int64_t R, int H) {
     int ncl;
     // y is addressed through one buffer resource: < 4 GiB
