@@ -3,6 +3,7 @@
 
     python tests/golden/make_golden_bench.py pages [seed ...]   # default seeds 0 1
     python tests/golden/make_golden_bench.py crops
+    python tests/golden/make_golden_bench.py odd_large | odd_small   # pages of other sizes (ODD_PAGES below)
 
 `pages`: BASELINE.json configs[3] — the bench's own 1024x1024 synthetic pages (ocrs_amd.synth.synthetic_page(seed,
 1024, 1024, lines=80)) through the whole oracle pipeline with the bench's two models: word rects, line grouping,
@@ -83,18 +84,28 @@ def engine():
     return ora, np.array([M.digest(dbuf), M.digest(rbuf)])
 
 
-def pages(seeds):
+ODD_PAGES = {   # name -> (seed, height, width, lines, columns): sizes the bench does not use
+    "odd_large": (101, 2200, 3000, 60, 2),    # larger than the detection input (800x600) in both dimensions, landscape
+    "odd_small": (102, 97, 211, 3, 1),        # smaller than the detection input, odd dimensions
+}
+
+
+def pages(seeds, odd=None):
     ora, digests = engine()
     for seed in seeds:
         t0 = time.time()
-        px = synth.synthetic_page(seed, 1024, 1024, lines=80)
+        if odd:
+            seed, hh, ww, nl, ncol = ODD_PAGES[odd]
+            px = synth.synthetic_page(seed, hh, ww, lines=nl, columns=ncol)
+        else:
+            px = synth.synthetic_page(seed, 1024, 1024, lines=80)
         inp = ora.prepare_input(OP.ImageSource.from_tensor(px, "hwc"))
         words = ora.detect_words(inp)
         lines = ora.find_text_lines(inp, words)
         results = recognize_with_steps(ora, inp, lines)
         toks, toff, chars, coff = pack(results)
         np.savez_compressed(
-            os.path.join(HERE, "bench_page_seed%d.npz" % seed), model_digests=digests,
+            os.path.join(HERE, ("page_%s.npz" % odd) if odd else ("bench_page_seed%d.npz" % seed)), model_digests=digests,
             word_rects=np.array([w.to_array() for w in words], np.float32).reshape(-1, 6),
             line_rects=np.array([w.to_array() for l in lines for w in l], np.float32).reshape(-1, 6),
             line_offsets=np.cumsum([0] + [len(l) for l in lines]).astype(np.int64),
@@ -126,5 +137,7 @@ if __name__ == "__main__":
         pages([int(s) for s in sys.argv[2:]] or [0, 1])
     elif what == "crops":
         crops()
+    elif what in ODD_PAGES:
+        pages([0], odd=what)
     else:
         raise SystemExit(__doc__)

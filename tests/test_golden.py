@@ -128,3 +128,30 @@ def test_oracle_reproduces_bench_crops_golden_sample():
         for i in range(20):
             steps = np.array(clib.ctc_greedy(out[i]), np.int32).reshape(-1, 2)
             assert np.array_equal(steps, g["tokens"][to[c0 + i]:to[c0 + i + 1]])
+
+
+def test_oracle_reproduces_small_odd_page_golden_end_to_end():
+    """page_odd_small.npz (97x211 page, make_golden_bench.py odd_small): the whole oracle pipeline again — word rects,
+    lines (oracle layout AND the product's host layout), text — so that a drift of the oracle or of the synthetic
+    models/pages shows up on the CPU, not only as a GPU-test failure."""
+    from ocrs_amd import OcrEngine, synth
+    g = np.load(os.path.join(G, "page_odd_small.npz"))
+    dbuf, rbuf = M.detection_model_bytes(), M.recognition_model_bytes()
+    assert [M.digest(dbuf), M.digest(rbuf)] == list(g["model_digests"]), "synthetic model files changed: regenerate goldens"
+    ora = OP.OcrEngine(detection_model=OracleModel(OracleGraph(dbuf), "exact"),
+                       recognition_model=OracleModel(OracleGraph(rbuf), "exact"))
+    px = synth.synthetic_page(102, 97, 211, lines=3, columns=1)
+    inp = ora.prepare_input(OP.ImageSource.from_tensor(px, "hwc"))
+    words = ora.detect_words(inp)
+    assert np.array_equal(np.array([w.to_array() for w in words], np.float32).reshape(-1, 6), g["word_rects"])
+    lines = ora.find_text_lines(inp, words)
+    flat = np.array([w.to_array() for l in lines for w in l], np.float32).reshape(-1, 6)
+    assert np.array_equal(flat, g["line_rects"])
+    assert np.array_equal(np.cumsum([0] + [len(l) for l in lines]), g["line_offsets"])
+    host_lines = OcrEngine().find_text_lines(None, g["word_rects"])
+    assert np.array_equal(np.concatenate(host_lines), g["line_rects"])
+    text = ora.recognize_text(inp, lines)
+    co = g["char_offsets"]
+    for i, t in enumerate(text):
+        exp = "".join(chr(c) for c in g["chars"][co[i]:co[i + 1], 0])
+        assert (str(t) if t is not None else "") == exp

@@ -117,6 +117,36 @@ def test_ctc_steps_of_bench_pages_match_golden(engine, seed):
         assert np.array_equal(np.array(t, np.int32).reshape(-1, 2), g["tokens"][to[i]:to[i + 1]]), i
 
 
+@pytest.mark.parametrize("name,seed,hh,ww,nl,ncol", [("odd_large", 101, 2200, 3000, 60, 2), ("odd_small", 102, 97, 211, 3, 1)])
+def test_pages_of_other_sizes_match_golden(engine, name, seed, hh, ww, nl, ncol):
+    """Pages that are not the bench's 1024x1024: a 2200x3000 landscape page (larger than the 800x600 detection input
+    in both dimensions: down-scaling, word rects scaled back, long lines) and a 97x211 one (padded up, odd sizes) —
+    word rects, line grouping, CTC steps, char boxes against oracle goldens (make_golden_bench.py odd_large/odd_small),
+    through the single-page entry points and through the batch ones with both pages of a kind in one request."""
+    g = np.load(os.path.join(GOLD, "page_%s.npz" % name))
+    assert tuple(g["model_digests"]) == engine._digests
+    px = synth.synthetic_page(seed, hh, ww, lines=nl, columns=ncol)
+    inp = engine.prepare_input(ImageSource.from_tensor(px, DimOrder.Hwc))
+    words = engine.detect_words(inp)
+    assert np.array_equal(np.array(words, np.float32).reshape(-1, 6), g["word_rects"])
+    lines = engine.find_text_lines(inp, words)
+    lo = g["line_offsets"]
+    assert len(lines) == len(lo) - 1
+    for i, l in enumerate(lines):
+        assert np.array_equal(np.array(l, np.float32).reshape(-1, 6), g["line_rects"][lo[i]:lo[i + 1]])
+    toks = engine.recognize_tokens(inp, lines)
+    to = g["token_offsets"]
+    for i, t in enumerate(toks):
+        assert np.array_equal(np.array(t, np.int32).reshape(-1, 2), g["tokens"][to[i]:to[i + 1]]), i
+    # batch entry points, two copies of the page in one request
+    inputs = [inp, engine.prepare_input(ImageSource.from_tensor(px, DimOrder.Hwc))]
+    bw = engine.detect_words_batch(inputs)
+    rects, loffs, poffs = engine.find_text_lines_batch_raw(bw)
+    chars, coffs = engine.recognize_text_batch_raw(inputs, rects, loffs, poffs)
+    for pi in range(2):
+        _check_page_against_golden(g, bw[pi], rects, loffs, int(poffs[pi]), int(poffs[pi + 1]), chars, coffs)
+
+
 def _crops_request(engine):
     n = 2048
     crops = synth.synthetic_line_crops(1000, n=n)
