@@ -175,6 +175,11 @@ OCRS_API ocrs_status ocrs_image_source_check_bytes(size_t len, uint32_t width, u
 OCRS_API ocrs_status ocrs_engine_prepare_input(const ocrs_engine* e, const void* pixels, ocrs_pixel_type type,
                                       ocrs_dim_order order, int height, int width, int channels,
                                       ocrs_page** out);
+/* Several equally sized host images in one call: all uploads and conversions are queued on one stream and waited
+ * for once (OcrEngine::prepare_input, lib.rs:183-187, per image).  out[n] receives the pages. */
+OCRS_API ocrs_status ocrs_engine_prepare_input_batch(const ocrs_engine* e, const void* const* pixels, size_t n,
+                                                     ocrs_pixel_type type, ocrs_dim_order order, int height, int width,
+                                                     int channels, ocrs_page** out);
 /* Same, with `pixels` already resident in HBM (device pointer): the form
  * bench.py times, and the one a GPU image decoder would hand over. */
 OCRS_API ocrs_status ocrs_engine_prepare_input_device(const ocrs_engine* e, const void* d_pixels, ocrs_pixel_type type,
@@ -267,6 +272,11 @@ OCRS_API ocrs_status ocrs_device_malloc(size_t bytes, void** d_ptr);
 OCRS_API ocrs_status ocrs_device_free(void* d_ptr);
 OCRS_API ocrs_status ocrs_device_upload(void* d_dst, const void* h_src, size_t bytes);
 OCRS_API ocrs_status ocrs_device_synchronize(void);
+/* Page-locked host memory: ocrs_engine_prepare_input{,_batch} from such a buffer is a DMA transfer that overlaps
+ * GPU work (from ordinary memory the runtime stages every copy through a bounce buffer).  An image decoder that
+ * writes its output here hands pages over at PCIe speed. */
+OCRS_API ocrs_status ocrs_host_malloc(size_t bytes, void** h_ptr);
+OCRS_API ocrs_status ocrs_host_free(void* h_ptr);
 /* Rates this device sustains: register-only fp32 MFMA loop (TFLOP/s) and a large float4 copy
  * (GB/s, read + write).  Reported by bench.py beside the nominal peaks the roofline uses. */
 OCRS_API ocrs_status ocrs_device_measure_peaks(double* mfma_f32_tflops, double* hbm_copy_gbps);

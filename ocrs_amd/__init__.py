@@ -306,6 +306,16 @@ class OcrEngine:
                                               image.order, h, w, c, C.byref(h_out)))
         return OcrInput(h_out)
 
+    def prepare_input_batch_raw(self, host_ptrs, dtype, order, h, w, c):
+        """n equally sized host images given as raw pointers (e.g. pinned buffers from ocrs_host_malloc): one call,
+        one wait."""
+        n = len(host_ptrs)
+        arr = (C.c_void_p * n)(*host_ptrs)
+        out = (C.c_void_p * n)()
+        check(lib().ocrs_engine_prepare_input_batch(self._h, arr, C.c_size_t(n), 0 if dtype == np.uint8 else 1, order,
+                                                    h, w, c, out))
+        return [OcrInput(C.c_void_p(out[i])) for i in range(n)]
+
     def prepare_input_device(self, d_ptr, dtype, order, h, w, c):
         """Pixels already in HBM (a raw device pointer), e.g. from bench.py."""
         h_out = C.c_void_p()

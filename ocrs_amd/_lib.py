@@ -54,7 +54,7 @@ DECLARED_SYMBOLS = [
     "ocrs_engine_prepare_recognition_input", "ocrs_text_item_rotated_rect", "ocrs_rotated_rect_corners", "ocrs_engine_get_text", "ocrs_device_malloc", "ocrs_device_free",
     "ocrs_device_upload", "ocrs_device_synchronize", "ocrs_device_measure_peaks", "ocrs_engine_enable_timing", "ocrs_stage_count",
     "ocrs_stage_name", "ocrs_engine_stage_times", "ocrs_kernel_class_count", "ocrs_kernel_class_name",
-    "ocrs_engine_kernel_stats", "ocrs_engine_set_kernel_timing_mask", "ocrs_gru_tile_plan",
+    "ocrs_engine_kernel_stats", "ocrs_engine_set_kernel_timing_mask", "ocrs_gru_tile_plan", "ocrs_host_malloc", "ocrs_host_free", "ocrs_engine_prepare_input_batch",
 ]
 
 _lib = None

@@ -345,6 +345,27 @@ ocrs_status ocrs_engine_prepare_input(const ocrs_engine* e, const void* pixels, 
     });
 }
 
+ocrs_status ocrs_engine_prepare_input_batch(const ocrs_engine* e, const void* const* pixels, size_t n, ocrs_pixel_type type,
+                                            ocrs_dim_order order, int height, int width, int channels, ocrs_page** out) {
+    return guarded([&] {
+        if (!e || !out || (n > 0 && !pixels)) fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
+        for (size_t i = 0; i < n; i++) check_image_args(pixels[i], height, width, channels);
+        Workspace ws;
+        const size_t bytes = (size_t)height * width * channels * (type == OCRS_U8 ? 1 : 4);
+        std::vector<std::unique_ptr<ocrs_page>> made;   // freed if a later page fails
+        for (size_t i = 0; i < n; i++) {
+            // every copy and conversion is queued before the one wait below: from pinned memory (ocrs_host_malloc)
+            // the copies are DMA transfers that overlap the conversion kernels of the pages before them
+            void* d_px = ws.alloc(bytes);
+            OCRS_HIP(hipMemcpyAsync(d_px, pixels[i], bytes, hipMemcpyHostToDevice, ws.s()));
+            made.emplace_back(make_page(d_px, type, order, height, width, channels, ws.s(), e->tm()));
+        }
+        ws.sync();
+        if (e->tm()) e->tm()->collect();
+        for (size_t i = 0; i < n; i++) out[i] = made[i].release();
+    });
+}
+
 ocrs_status ocrs_engine_prepare_input_device(const ocrs_engine* e, const void* d_pixels, ocrs_pixel_type type,
                                              ocrs_dim_order order, int height, int width, int channels,
                                              ocrs_page** out) {
@@ -644,6 +665,16 @@ ocrs_status ocrs_device_free(void* d_ptr) {
 }
 ocrs_status ocrs_device_upload(void* d_dst, const void* h_src, size_t bytes) {
     return guarded([&] { OCRS_HIP(hipMemcpy(d_dst, h_src, bytes, hipMemcpyHostToDevice)); });
+}
+ocrs_status ocrs_host_malloc(size_t bytes, void** h_ptr) {
+    return guarded([&] {
+        if (!h_ptr) fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
+        bind_thread_to_device();
+        OCRS_HIP(hipHostMalloc(h_ptr, bytes ? bytes : 1, hipHostMallocDefault));
+    });
+}
+ocrs_status ocrs_host_free(void* h_ptr) {
+    return guarded([&] { OCRS_HIP(hipHostFree(h_ptr)); });
 }
 ocrs_status ocrs_device_synchronize(void) {
     return guarded([&] { OCRS_HIP(hipDeviceSynchronize()); });

@@ -6,13 +6,15 @@ canonical fmaf-chain order of DESIGN.md §4) and additionally stay within 1e-4
 
 Run with:  python -m pytest tests -m gpu
 """
+import ctypes as C
+
 import numpy as np
 import pytest
 
 import kat_util as K
 import models_util as M
 import ocrs_amd
-from ocrs_amd import DimOrder, ImageSource, Model, OcrEngine, synth
+from ocrs_amd import DimOrder, ImageSource, Model, OcrEngine, _lib, synth
 from oracle import clib
 from oracle import pipeline as OP
 from oracle.geometry import Rect, RotatedRect
@@ -53,6 +55,34 @@ def test_prepare_input_rgb8_fast_path_full_page():
 
 
 # ------------------------------------------------------------------ reference KATs through the engine
+def test_prepare_input_batch_from_pinned_host_memory_equals_single_calls():
+    """ocrs_engine_prepare_input_batch (several host images, one wait) from page-locked buffers (ocrs_host_malloc) and
+    from ordinary arrays gives the same grey pages as ocrs_engine_prepare_input image by image (= the oracle's, tested
+    above), for u8 HWC and f32 CHW."""
+    L = _lib.lib()
+    eng = OcrEngine()
+    rng = np.random.default_rng(11)
+    for dtype, order, shape in ((np.uint8, DimOrder.Hwc, (37, 53, 3)), (np.float32, DimOrder.Chw, (3, 37, 53))):
+        imgs = [(rng.integers(0, 256, shape).astype(np.uint8) if dtype == np.uint8 else rng.random(shape, np.float32))
+                for _ in range(5)]
+        ref = [eng.prepare_input(ImageSource.from_tensor(im, order)).image() for im in imgs]
+        pinned = []
+        for im in imgs:
+            hp = C.c_void_p()
+            _lib.check(L.ocrs_host_malloc(C.c_size_t(im.nbytes), C.byref(hp)))
+            C.memmove(hp, im.ctypes.data_as(C.c_void_p), im.nbytes)
+            pinned.append(hp)
+        h, w = (shape[0], shape[1]) if order == DimOrder.Hwc else (shape[1], shape[2])
+        for ptrs in ([p.value for p in pinned], [im.ctypes.data for im in imgs]):
+            got = eng.prepare_input_batch_raw(ptrs, dtype, order, h, w, 3)
+            assert len(got) == 5
+            for g, r in zip(got, ref):
+                assert np.array_equal(g.image(), r)
+        for hp in pinned:
+            _lib.check(L.ocrs_host_free(hp))
+    assert eng.prepare_input_batch_raw([], np.uint8, DimOrder.Hwc, 4, 4, 3) == []
+
+
 def test_kat_detect_words_fake_model():  # lib.rs:466-488
     det = Model.from_callable(K.FAKE_DETECTION_SHAPE, K.fake_detection_run)
     eng = OcrEngine(detection_model=det)
