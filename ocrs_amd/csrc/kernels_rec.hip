@@ -56,23 +56,50 @@ conv1_relu_pool_ragged_kernel(const float* __restrict__ x, RaggedView in, const 
     const float* __restrict__ xg = x + in.poff[g];
     float* __restrict__ yg = y + out.poff[g] * cout;
     const int cq = cout >> 2;
-    for (int i = threadIdx.x; i < 256 * cq; i += 256) {
-        const int64_t r = (int64_t)tile * 256 + i / cq;
+    // (pixel, channel quad) of this thread's first item; the next item is 256 / cq pixels further on.  One 64-bit
+    // division per thread up front, then the coordinates are stepped with carries (32-bit): the per-item 64-bit
+    // div / mod chain cost more than the 144 FMAs of the item.
+    const int step_px = 256 / cq;                       // cq divides 256 (cout = 16, 32 or 64)
+    const int q = threadIdx.x % cq;
+    int64_t r = (int64_t)tile * 256 + threadIdx.x / cq;
+    int ox = (int)(r % ow);
+    int64_t t0 = r / ow;
+    int oy = (int)(t0 % oh);
+    int64_t img = t0 / oh;
+    // the thread's channel quad never changes: its 9 x 4 weights and 4 biases live in registers
+    float wq[9][4], bq[4];
+#pragma unroll
+    for (int t = 0; t < 9; t++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) wq[t][c] = sw[t * cout + 4 * q + c];
+#pragma unroll
+    for (int c = 0; c < 4; c++) bq[c] = sw[9 * 64 + 4 * q + c];
+    for (int it = 0; it < cq; it++, r += step_px) {
         if (r >= rows) break;
-        const int q = i % cq;
-        const int ox = (int)(r % ow);
-        const int oy = (int)((r / ow) % oh);
-        const int64_t img = r / ((int64_t)ow * oh);
+        if (it > 0) {
+            ox += step_px;
+            while (ox >= ow) { ox -= ow; if (++oy == oh) { oy = 0; img++; } }
+        }
         const float* xi = xg + img * ih * iw;
         // 4x4 input patch around the 2x2 conv outputs
         float p[4][4];
+        const int iy0 = 2 * oy - 1, ix0 = 2 * ox - 1;
+        if (iy0 >= 0 && iy0 + 3 < ih && ix0 >= 0 && ix0 + 3 < iw) {
+            // the whole patch is inside the image (all but the border pixels): one base pointer, constant offsets
+            const float* pp = xi + (int64_t)iy0 * iw + ix0;
 #pragma unroll
-        for (int a = 0; a < 4; a++)
+            for (int a = 0; a < 4; a++)
 #pragma unroll
-            for (int b = 0; b < 4; b++) {
-                const int iy = 2 * oy - 1 + a, ix = 2 * ox - 1 + b;
-                p[a][b] = ((unsigned)iy < (unsigned)ih && (unsigned)ix < (unsigned)iw) ? xi[(int64_t)iy * iw + ix] : 0.0f;
-            }
+                for (int b = 0; b < 4; b++) p[a][b] = pp[a * iw + b];
+        } else {
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    const int iy = iy0 + a, ix = ix0 + b;
+                    p[a][b] = ((unsigned)iy < (unsigned)ih && (unsigned)ix < (unsigned)iw) ? xi[(int64_t)iy * iw + ix] : 0.0f;
+                }
+        }
         float m[4];
 #pragma unroll
         for (int py = 0; py < 2; py++)
@@ -80,15 +107,14 @@ conv1_relu_pool_ragged_kernel(const float* __restrict__ x, RaggedView in, const 
             for (int px = 0; px < 2; px++) {
                 float acc[4];
 #pragma unroll
-                for (int c = 0; c < 4; c++) acc[c] = sw[9 * 64 + 4 * q + c];
+                for (int c = 0; c < 4; c++) acc[c] = bq[c];
 #pragma unroll
                 for (int ky = 0; ky < 3; ky++)
 #pragma unroll
                     for (int kx = 0; kx < 3; kx++) {
                         const float xv = p[py + ky][px + kx];
-                        const float* w = &sw[(ky * 3 + kx) * cout + 4 * q];
 #pragma unroll
-                        for (int c = 0; c < 4; c++) acc[c] = fmaf(xv, w[c], acc[c]);
+                        for (int c = 0; c < 4; c++) acc[c] = fmaf(xv, wq[ky * 3 + kx][c], acc[c]);
                     }
 #pragma unroll
                 for (int c = 0; c < 4; c++) {

@@ -649,7 +649,7 @@ float* HipModel::run_prefix_ragged(Workspace& ws, hipStream_t exec, const std::v
             if (op.kh != 3 || op.kw != 3 || !op.relu) return nullptr;
             if (op.cin == 1) {
                 if (i + 1 >= ts || ops[i + 1].type != OP_MAXPOOL || ops[i + 1].kh != 2 || ops[i + 1].kw != 2) return nullptr;
-                if (op.cout > 64 || (op.cout % 4) != 0) return nullptr;
+                if (op.cout > 64 || op.cout < 4 || (op.cout & (op.cout - 1)) != 0) return nullptr;  // 4, 8, 16, 32, 64
             } else if ((op.cin % 32) != 0 || op.cout < 64 || (op.cout % 4) != 0) {
                 return nullptr;
             }
