@@ -202,6 +202,7 @@ const OptDef kOptDefs[OPT_COUNT] = {
     {"gru_local", "OCRS_GRU_LOCAL", 1},                 // persistent GRU: 1 same-XCD clusters hand off through L2, 0 always write-through
     {"gru_scatter", "OCRS_GRU_SCATTER", 0},             // persistent GRU test knob: 1 spreads every cluster over the XCDs
     {"rec_max_pixels", "OCRS_REC_MAX_PIXELS", 0},       // input pixels per recognition sub-request (0 = 2e9, the memory budget)
+    {"gemm_nfast", "OCRS_GEMM_NFAST", 1},               // dense GEMMs: column tiles of a row tile side by side on one XCD
 };
 std::atomic<long> g_opts[OPT_COUNT];
 std::once_flag g_opts_once;

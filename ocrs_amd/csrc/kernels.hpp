@@ -61,6 +61,8 @@ struct GemmDesc {
     int convt; int Cout;
     // batched (blockIdx.z) strides, elements
     int batch; int64_t strideA, strideB, strideBias, strideC;
+    // set by the launcher (gemm_tiled, dense A): 1-D grid, the column tiles of a row tile run side by side on one XCD
+    int nfast = 0, nx = 0, ny = 0;
 };
 void gemm(const GemmDesc& d, hipStream_t s);
 // Direct conv (k x k, same padding, Cout % 4 == 0) for tiny contractions / odd shapes.

@@ -11,6 +11,7 @@
 //   * exp / log / sigmoid / tanh are the fixed polynomials below (only fmaf,
 //     rint, IEEE divide and exponent-field arithmetic), never libm/ocml.
 // Built with -ffp-contract=off: an fma happens only where fmaf() is written.
+#include "common.hpp"
 #include "kernels.hpp"
 #include "spec_math.hpp"
 
@@ -191,10 +192,22 @@ __global__ void __launch_bounds__(256, 4) gemm_tiled_kernel(GemmDesc d) {
     const float* __restrict__ bias = d.bias ? d.bias + (int64_t)z * d.strideBias : nullptr;
     float* __restrict__ C = d.C + (int64_t)z * d.strideC;
     // XCD-aware row-block order (see kernels_rec.hip): consecutive row blocks share im2col rows / A panels
-    const int nwg = gridDim.x, xcd = blockIdx.x & 7, xq = nwg >> 3, xr = nwg & 7;
-    const int mblk = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (blockIdx.x >> 3);
+    int mblk, nblk;
+    if (d.nfast) {
+        // dense A with several column tiles: the ny column tiles of a row tile are consecutive blocks of ONE XCD
+        // (block b runs on XCD b % 8), so the A tile is fetched from HBM once and served ny - 1 times by that L2
+        // (with the column tile on blockIdx.y every row tile was re-read from memory once per column tile).
+        const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+        nblk = q % d.ny;
+        mblk = (q / d.ny) * 8 + xcd;
+        if (mblk >= d.nx) return;
+    } else {
+        const int nwg = gridDim.x, xcd = blockIdx.x & 7, xq = nwg >> 3, xr = nwg & 7;
+        mblk = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (blockIdx.x >> 3);
+        nblk = blockIdx.y;
+    }
     const int64_t m0 = (int64_t)mblk * TG_BM;
-    const int n0 = blockIdx.y * BN;
+    const int n0 = nblk * BN;
 
     // ---- per-thread load assignments
     // A: 128 rows x TG_BK/4 float4 per chunk; thread handles rows ar + AROWS*j, float4 column akq
@@ -381,7 +394,12 @@ static void launch_gemm_tiled(const GemmDesc& d, hipStream_t s) {
     const bool pair = !d.im2col && (d.K % (2 * TG_BK)) == 0 && (d.ldb & 3) == 0 && (((uintptr_t)d.B) & 15) == 0 &&
                       (d.strideB & 3) == 0 && (d.N & 3) == 0 && d.N >= 4;
     if (d.im2col) hipLaunchKernelGGL((gemm_tiled_kernel<BN, true, false>), grid, dim3(256), lds, s, d);
-    else if (pair) hipLaunchKernelGGL((gemm_tiled_kernel<BN, false, true>), grid, dim3(256), lds, s, d);
+    else if (pair && grid.y > 1 && option(OPT_GEMM_NFAST)) {
+        GemmDesc e = d;
+        e.nfast = 1; e.nx = (int)grid.x; e.ny = (int)grid.y;
+        const dim3 g1((unsigned)((grid.x + 7) / 8 * 8 * grid.y), 1, grid.z);
+        hipLaunchKernelGGL((gemm_tiled_kernel<BN, false, true>), g1, dim3(256), lds, s, e);
+    } else if (pair) hipLaunchKernelGGL((gemm_tiled_kernel<BN, false, true>), grid, dim3(256), lds, s, d);
     else hipLaunchKernelGGL((gemm_tiled_kernel<BN, false, false>), grid, dim3(256), lds, s, d);
 }
 
