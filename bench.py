@@ -587,7 +587,7 @@ def extra_legs(engine, dptrs, host_pages, H, W, synth, np, DimOrder, sync_all, a
     def pageable_step(_=None):
         return rest([engine.prepare_input(s) for s in srcs])
 
-    k = max(2 * args.inflight, 12)
+    k = max(6 * args.inflight, 36)
     rates = {}
     for name, fn in (("pinned", pinned_step), ("pageable", pageable_step)):
         with ThreadPoolExecutor(max_workers=max(1, args.inflight)) as ex:
