@@ -223,30 +223,85 @@ __device__ __forceinline__ int dir_dx(int d) { return (int)((0x1A90u >> (2 * d))
 
 template <bool WRITE>
 __device__ int trace_border(const uint8_t* __restrict__ m, int h, int w, int sy, int sx, uint32_t* out) {
-    auto at = [&](int y, int x) -> bool {
-        return (unsigned)y < (unsigned)h && (unsigned)x < (unsigned)w && m[y * w + x] != 0;
+    // the 8 neighbours of (y, x) as a bit mask (bit d = direction d is foreground), fetched with 8 INDEPENDENT byte
+    // loads: a step of the walk costs one memory latency instead of one per neighbour examined
+    auto neighbours = [&](int y, int x) -> unsigned {
+        unsigned mk = 0;
+#pragma unroll
+        for (int d = 0; d < 8; d++) {
+            const int yy = y + dir_dy(d), xx = x + dir_dx(d);
+            const bool in = (unsigned)yy < (unsigned)h && (unsigned)xx < (unsigned)w;
+            const uint8_t v = m[in ? yy * w + xx : 0];
+            mk |= (in && v != 0) ? (1u << d) : 0u;
+        }
+        return mk;
     };
-    int first = -1;
-    for (int d = 0; d < 8; d++)  // 3.1: clockwise from W
-        if (at(sy + dir_dy(d), sx + dir_dx(d))) { first = d; break; }
-    if (first < 0) {
+    const unsigned nb0 = neighbours(sy, sx);
+    if (nb0 == 0) {
         if (WRITE) out[0] = ((uint32_t)sy << 16) | (uint32_t)sx;
         return 1;
     }
+    const int first = __ffs((int)nb0) - 1;  // 3.1: clockwise from W = lowest set direction
     const int i1 = sy + dir_dy(first), j1 = sx + dir_dx(first);
     int i3 = sy, j3 = sx, d0 = first, n = 0;
+    unsigned nb = nb0;
     for (;;) {
         int i4 = i3, j4 = j3, dn = d0;
+#pragma unroll
         for (int s = 1; s <= 8; s++) {  // 3.3: counter-clockwise from the element after (i2,j2)
-            int d = (d0 - s) & 7;
-            int yy = i3 + dir_dy(d), xx = j3 + dir_dx(d);
-            if (at(yy, xx)) { i4 = yy; j4 = xx; dn = d; break; }
+            const int d = (d0 - s) & 7;
+            if ((nb >> d) & 1u) { i4 = i3 + dir_dy(d); j4 = j3 + dir_dx(d); dn = d; break; }
         }
         if (WRITE) out[n] = ((uint32_t)i3 << 16) | (uint32_t)j3;
         n++;
         if (i4 == sy && j4 == sx && i3 == i1 && j3 == j1) break;  // 3.5
         i3 = i4; j3 = j4;
         d0 = (dn + 4) & 7;  // the pixel we came from, seen from the new current pixel
+        nb = neighbours(i3, j3);
+    }
+    return n;
+}
+
+// The same walk by a whole wavefront: lane d < 8 fetches neighbour d, a ballot gives the mask, the walk state is
+// wave-uniform (scalar registers).  One memory latency and a handful of scalar instructions per border pixel —
+// a single lane running trace_border pays the issue latency of every instruction of the step.
+__device__ int trace_border_wave(const uint8_t* __restrict__ m, int h, int w, int sy, int sx, uint32_t* out, int lane) {
+    const int ldy = dir_dy(lane & 7), ldx = dir_dx(lane & 7);
+    auto neighbours = [&](int y, int x) -> unsigned {
+        const int yy = y + ldy, xx = x + ldx;
+        const bool in = lane < 8 && (unsigned)yy < (unsigned)h && (unsigned)xx < (unsigned)w;
+        const uint8_t v = m[in ? yy * w + xx : 0];
+        return (unsigned)(__ballot(in && v != 0) & 0xffull);
+    };
+    const unsigned nb0 = neighbours(sy, sx);
+    if (nb0 == 0) {
+        if (lane == 0) out[0] = ((uint32_t)sy << 16) | (uint32_t)sx;
+        return 1;
+    }
+    const int first = __ffs((int)nb0) - 1;
+    const int i1 = sy + dir_dy(first), j1 = sx + dir_dx(first);
+    int i3 = sy, j3 = sx, d0 = first, n = 0;
+    unsigned nb = nb0;
+    for (;;) {
+        // 3.3: the first set direction counter-clockwise from d0 - 1: rotate the mask so that direction d0 - 1 is bit 7,
+        // d0 - 2 bit 6, ...; the highest set bit is the answer
+        const unsigned rot = ((nb | (nb << 8)) >> (d0 & 7)) & 0xffu;      // bit k = direction (d0 + k) & 7; k = 0 is d0 itself
+        // search order s = 1..8 -> directions d0-1, ..., d0-8 (= d0): bits 7, 6, ..., 1, then 0
+        int dn = d0, i4 = i3, j4 = j3;
+        const unsigned hi = rot & 0xfeu;
+        if (hi) {
+            const int k = 31 - __clz((int)hi);
+            dn = (d0 + k) & 7;
+        } else if (rot & 1u) {
+            dn = d0;
+        }
+        if (rot) { i4 = i3 + dir_dy(dn); j4 = j3 + dir_dx(dn); }
+        if (lane == 0) out[n] = ((uint32_t)i3 << 16) | (uint32_t)j3;
+        n++;
+        if (i4 == sy && j4 == sx && i3 == i1 && j3 == j1) break;
+        i3 = i4; j3 = j4;
+        d0 = (dn + 4) & 7;
+        nb = neighbours(i3, j3);
     }
     return n;
 }
@@ -317,7 +372,7 @@ contour_rect_kernel(const uint8_t* __restrict__ mask, int h, int w, const int32_
         const int root = roots[slot];
 
         // ---- 1. border following (serial by nature): lane 0 writes the points
-        if (lane == 0) trace_border<true>(m, h, w, root / w, root % w, pts);
+        trace_border_wave(m, h, w, root / w, root % w, pts, lane);
         for (int k = lane; k < n; k += 64) keep[k] = 0;
         WAVE_SYNC();
 
