@@ -89,6 +89,8 @@ OCRS_API ocrs_status ocrs_gru_tile_plan(const int32_t* lengths_desc, size_t n_li
  *                     over through that XCD's L2 (default), 0 = always through write-through stores
  *   "rec_max_pixels"  input pixels (padded line batch) one recognition sub-request may hold; larger requests are run
  *                     as consecutive sub-requests (default 0 = 2e9, sized for the activation memory of one GPU)
+ *   "gru_gates"       1 = requests small enough that every 16-line row tile gets its own cluster of workgroups run the
+ *                     gate-per-wave recurrence kernel (default), 0 = always the general persistent kernel
  *   "gemm_nfast"      1 = dense GEMMs run the column tiles of a row tile side by side on one XCD (default), 0 = column
  *                     tile on the grid's y axis
  *   "gru_scatter"     test knob: 1 = spread every cluster over all XCDs (exercises the write-through path), default 0

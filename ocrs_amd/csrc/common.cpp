@@ -203,6 +203,7 @@ const OptDef kOptDefs[OPT_COUNT] = {
     {"gru_scatter", "OCRS_GRU_SCATTER", 0},             // persistent GRU test knob: 1 spreads every cluster over the XCDs
     {"rec_max_pixels", "OCRS_REC_MAX_PIXELS", 0},       // input pixels per recognition sub-request (0 = 2e9, the memory budget)
     {"gemm_nfast", "OCRS_GEMM_NFAST", 1},               // dense GEMMs: column tiles of a row tile side by side on one XCD
+    {"gru_gates", "OCRS_GRU_GATES", 1},                 // persistent GRU: gate-per-wave kernel when every row tile gets its own cluster
 };
 std::atomic<long> g_opts[OPT_COUNT];
 std::once_flag g_opts_once;

@@ -373,9 +373,168 @@ gru_persistent_kernel(GruParams p) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Gate-per-wave variant for requests with so few row tiles that every tile gets a cluster of its own (<= 8 tiles per
+// direction at H = 256: a single page).  There the recurrence is a pure latency chain — T dependent steps, nothing to
+// interleave — and the longest link of a step is the wave's 192 MFMAs.  Here the three gates of a step run on three
+// waves (three SIMDs) at once, 64 MFMAs each, and the fourth wave does the gate arithmetic and the store:
+//   waves 0..2 (gate r, z, n):  previous state of the tile (polled as above) -> 4x4 transposes -> 64-MFMA chain of
+//                               their gate -> accumulators to LDS -> workgroup barrier
+//   wave 3:                     gx of the step (prefetched one step ahead) and the previous state of its own 4 units
+//                               (kept in registers: it wrote them) -> barrier -> gates from LDS -> sigma / tanh -> store
+// Same arithmetic per output (each gate's chain is the k-ascending fmaf chain), so the bits equal the other paths'.
+// The exchange buffer needs no second barrier: a gate wave can only write step s + 1's accumulators after it has seen
+// the tile's state of step s, which includes what this workgroup's wave 3 stored after reading step s's accumulators.
+// ---------------------------------------------------------------------------------------------------------------
+template <int H>
+__device__ __forceinline__ f32x4 gate_chain(int lane, const float (&w)[H / 4], const float* lds_w, int g, const f32x4& bias) {
+    f32x4 acc = bias;
+    const f32x4* ap = reinterpret_cast<const f32x4*>(lds_w) + g * (H / 16) * 64 + lane;
+    f32x4 a = ap[0];
+#pragma unroll
+    for (int blk = 0; blk < H / 16; blk++) {
+        f32x4 na = a;
+        if (blk + 1 < H / 16) na = ap[(blk + 1) * 64];
+#pragma unroll
+        for (int e = 0; e < 4; e++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], w[4 * blk + e], acc, 0, 0, 0);
+        a = na;
+    }
+    return acc;
+}
+
+template <int H>
+__global__ void __launch_bounds__(256)
+gru_gates_kernel(GruParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds_w[];  // H*48 floats | off[Tmax+1] | exchange | abort
+    constexpr int UB = H / 16;
+    const int b = blockIdx.x;
+    const int q = b >> 3;
+    const int ub = p.scatter ? b % UB : q % UB;
+    const int cid = p.scatter ? b / UB : (q / UB) * 8 + (b & 7);
+    if (cid >= 2 * p.ncl) return;
+    const int dir = cid & 1, tile = cid >> 1;    // one tile per cluster
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i16 = lane & 15, kq = lane >> 4;
+    uint32_t xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
+    if (tid == 0) __hip_atomic_store((gu32*)p.place + cid * UB + ub, xcc + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const float* __restrict__ whd = p.wh + (int64_t)dir * H * 3 * H;
+    const float* __restrict__ bhd = p.bh + (int64_t)dir * 3 * H;
+    const int j0 = ub * 16;
+    for (int i = tid; i < H * 12; i += 256) {   // Wh slice -> LDS, layout as in gru_persistent_kernel
+        const int k = i / 12, qq = i - k * 12;
+        const int g = qq >> 2, c4 = (qq & 3) * 4;
+        const float4 v = *reinterpret_cast<const float4*>(whd + (int64_t)k * 3 * H + g * H + j0 + c4);
+        const int blk = k >> 4, e = (k >> 2) & 3, kk = k & 3;
+        float* dst = &lds_w[(((g * (H / 16) + blk) * 64) + kk * 16 + c4) * 4 + e];
+        dst[0] = v.x; dst[4] = v.y; dst[8] = v.z; dst[12] = v.w;
+    }
+    int* off_l = reinterpret_cast<int*>(lds_w + H * 48);
+    for (int i = tid; i <= p.Tmax; i += 256) off_l[i] = p.off[i];
+    // exchange area behind the off table, 16-byte aligned: 3 gates x 64 lanes x 16 bytes, then the abort word
+    f32x4* xch = reinterpret_cast<f32x4*>(lds_w + H * 48 + (((p.Tmax + 1) + 3) & ~3));
+    int* abort_w = reinterpret_cast<int*>(xch + 3 * 64);
+    if (tid == 0) *abort_w = 0;
+    const int m = tile * 16 + i16;
+    const int tm = m < p.M ? p.Tm[m] : 0;
+    const int T = __builtin_amdgcn_readfirstlane(tm);   // lane 0 = the tile's first = longest row
+    __syncthreads();
+    if (p.prio >= 3) __builtin_amdgcn_s_setprio(3);
+    else if (p.prio == 2) __builtin_amdgcn_s_setprio(2);
+    else if (p.prio == 1) __builtin_amdgcn_s_setprio(1);
+    if (T <= 0) return;
+    bool local;
+    {   // placement census, part 2 (see gru_persistent_kernel)
+        const gu32* pl = (const gu32*)p.place + cid * UB;
+        uint32_t v = xcc + 1u;
+        for (uint32_t spins = 0;; spins++) {
+            if (lane < UB) v = __hip_atomic_load(pl + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!__any(v == 0u)) break;
+            __builtin_amdgcn_s_sleep(8);
+            if (spins >= p.spin_limit) {
+                __hip_atomic_store((gu32*)p.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *abort_w = 1;   // the other waves leave at their next barrier
+                break;
+            }
+        }
+        local = !__any(v != xcc + 1u) && p.allow_local;
+    }
+    const __amdgpu_buffer_rsrc_t yb = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)(uint32_t)(p.R * 2 * H * sizeof(float)), 0x00020000);
+    if (wave < 3) {
+        const f32x4 bias = *reinterpret_cast<const f32x4*>(bhd + wave * H + j0 + kq * 4);
+        Loaded<H> L;
+        const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+        L.gr = L.gz = L.gn = zero;
+        L.out_off = 0;
+        for (int s = 0; s < T; s++) {
+            L.active = tm > s;
+            L.has_prev = L.active && s > 0;
+            L.hp = zero;
+#pragma unroll
+            for (int j = 0; j < H / 16; j++) L.h[j] = zero;
+            L.prev_off = L.has_prev ? (uint32_t)((((int64_t)off_l[dir ? tm - s : s - 1] + m) * 2 * H + dir * H) * sizeof(float)) : 0u;
+            issue_state<H>(yb, ub, kq, L);
+            if (!await_state<H>(p, yb, ub, kq, L)) *abort_w = 1;
+            float w[H / 4];
+#pragma unroll
+            for (int j = 0; j < H / 16; j++) transpose4(L.h[j], &w[4 * j]);
+            xch[wave * 64 + lane] = gate_chain<H>(lane, w, lds_w, wave, bias);
+            __syncthreads();
+            if (*abort_w) return;
+        }
+    } else {
+        f32x4 hp = {0.0f, 0.0f, 0.0f, 0.0f};
+        f32x4 gr, gz, gn, ngr, ngz, ngn;
+        uint32_t out_off, nout_off;
+        bool active, nactive;
+        auto fetch = [&](int s, f32x4& r_, f32x4& z_, f32x4& n_, uint32_t& o_, bool& a_) {
+            a_ = tm > s;
+            const int t = dir ? tm - 1 - s : s;
+            const int64_t row = a_ ? (int64_t)off_l[t] + m : 0;
+            o_ = (uint32_t)((row * 2 * H + dir * H + ub * 16 + kq * 4) * sizeof(float));
+            const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+            r_ = z_ = n_ = zero;
+            if (a_) {
+                const float* g = p.gx + ((int64_t)dir * p.R + row) * 3 * H + ub * 16 + kq * 4;
+                r_ = *reinterpret_cast<const f32x4*>(g);
+                z_ = *reinterpret_cast<const f32x4*>(g + H);
+                n_ = *reinterpret_cast<const f32x4*>(g + 2 * H);
+            }
+        };
+        fetch(0, gr, gz, gn, out_off, active);
+        for (int s = 0; s < T; s++) {
+            if (s + 1 < T) fetch(s + 1, ngr, ngz, ngn, nout_off, nactive);
+            __syncthreads();
+            if (*abort_w) return;
+            GateAcc a;
+            a.r = xch[lane]; a.z = xch[64 + lane]; a.n = xch[128 + lane];
+            f32x4 hn;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const float rg = sigmoidf_sl(gr[r] + a.r[r]);
+                const float zg = sigmoidf_sl(gz[r] + a.z[r]);
+                const float ng = tanhf_sl(fmaf(rg, a.n[r], gn[r]));
+                const float hv = fmaf(zg, hp[r] - ng, ng);
+                hn[r] = __float_as_uint(hv) == kUnwritten ? __uint_as_float(0x7FC00000u) : hv;
+            }
+            const uint32_t o = active ? out_off : 0xFFFFFFF0u;
+            if (local) store_local(yb, o, hn);
+            else store_through(yb, o, hn);
+            if (active) hp = hn;    // what the next step would read back as this row's previous state
+            gr = ngr; gz = ngz; gn = ngn; out_off = nout_off; active = nactive;
+        }
+    }
+}
+
 }  // namespace
 
 constexpr int kMaxGrid = 4096;
+static size_t gru_gates_lds_bytes(int H, int Tmax) {   // Wh slice | off table (padded to 16 bytes) | 3 x 64 x 16 B | abort word
+    return (size_t)H * 48 * sizeof(float) + (size_t)(((Tmax + 1) + 3) & ~3) * sizeof(int) + 3 * 64 * 16 + 16;
+}
 size_t gru_persistent_sync_words(int) { return kMaxGrid + 1; }  // placement table + error word (last)
 
 // y -> all words "unwritten"; any stream that is ordered before the recurrence (it does not depend on gx)
@@ -448,9 +607,40 @@ bool gru_persistent_supported(int M, int Tmax, int64_t R, int H) {
     return M > 0 && (uint64_t)R * 2 * H * sizeof(float) < (uint64_t(1) << 32) && gru_plan(M, Tmax, H, &ncl);
 }
 
+// gate-per-wave kernel: every tile has a cluster of its own
+static bool gru_gates_plan(int M, int Tmax, int H, int* ncl) {
+    if (H != 256 && H != 128 && H != 64) return false;
+    const int ntiles = (M + 15) / 16, UB = H / 16;
+    const int max_ncl = 256 / UB / 2 >= 1 ? 256 / UB / 2 : 1;
+    if (ntiles > max_ncl) return false;
+    *ncl = ntiles;
+    return gru_gates_lds_bytes(H, Tmax) <= 64 * 1024;
+}
+
 bool gru_persistent(const float* gx, const float* wh, const float* bh, float* y, const int32_t* d_Tm, const int32_t* d_off,
                     const int32_t* h_Tm, int64_t R, int M, int Tmax, int H, uint32_t* d_sync, hipStream_t s) {
     if (M <= 0) return true;
+    if (option(OPT_GRU_GATES)) {
+        GruParams g{};
+        if (gru_gates_plan(M, Tmax, H, &g.ncl)) {
+            g.gx = gx; g.wh = wh; g.bh = bh; g.y = y; g.Tm = d_Tm; g.off = d_off;
+            g.place = d_sync;
+            g.sync = d_sync + kMaxGrid;
+            g.R = R; g.M = M; g.Tmax = Tmax;
+            g.prio = 3;
+            g.spin_limit = 1u << 21;
+            g.allow_local = option(OPT_GRU_LOCAL) != 0;
+            g.scatter = option(OPT_GRU_SCATTER) != 0;
+            const int UBg = H / 16;
+            const dim3 grid(8 * UBg * ((2 * g.ncl + 7) / 8));
+            const size_t lds = gru_gates_lds_bytes(H, Tmax);
+            (void)hipMemsetAsync(d_sync, 0, gru_persistent_sync_words(M) * sizeof(uint32_t), s);
+            if (H == 256) hipLaunchKernelGGL((gru_gates_kernel<256>), grid, dim3(256), lds, s, g);
+            else if (H == 128) hipLaunchKernelGGL((gru_gates_kernel<128>), grid, dim3(256), lds, s, g);
+            else hipLaunchKernelGGL((gru_gates_kernel<64>), grid, dim3(256), lds, s, g);
+            return true;
+        }
+    }
     GruParams p{};
     p.gx = gx; p.wh = wh; p.bh = bh; p.y = y; p.Tm = d_Tm; p.off = d_off;
     p.place = d_sync;

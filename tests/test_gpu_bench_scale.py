@@ -243,10 +243,13 @@ def test_gru_modes_give_identical_bits(engine):
         # mode 0 = persistent kernel, 1 = per-step launches; 2, 3 = persistent with the hand-off forced to
         # write-through stores (gru_local 0) and with clusters spread over all XCDs (gru_scatter 1: the in-kernel
         # placement census must then choose write-through by itself)
-        for mode in (0, 1, 2, 3):
+        # 4 = without the gate-per-wave kernel (gru_gates 0): the one-page request then runs on the general kernel;
+        # 5, 6 = the gate-per-wave kernel with forced write-through / scattered clusters
+        for mode in (0, 1, 2, 3, 4, 5, 6):
             _lib.set_option("gru_mode", 1 if mode == 1 else 0)
-            _lib.set_option("gru_local", 0 if mode == 2 else 1)
-            _lib.set_option("gru_scatter", 1 if mode == 3 else 0)
+            _lib.set_option("gru_local", 0 if mode in (2, 5) else 1)
+            _lib.set_option("gru_scatter", 1 if mode in (3, 6) else 0)
+            _lib.set_option("gru_gates", 0 if mode in (2, 3, 4) else 1)
             a = engine.recognize_text(inp, req)
             b = engine.recognize_text_batch_raw([cinp], crects, cl, np.array([0, n], dtype=np.uintp))
             res[mode] = ([(str(t), [c.rect for c in t.chars()]) if t else None for t in a], b)
@@ -254,7 +257,8 @@ def test_gru_modes_give_identical_bits(engine):
         _lib.set_option("gru_mode", 0)
         _lib.set_option("gru_local", 1)
         _lib.set_option("gru_scatter", 0)
-    for mode in (1, 2, 3):
+        _lib.set_option("gru_gates", 1)
+    for mode in (1, 2, 3, 4, 5, 6):
         assert res[0][0] == res[mode][0], mode
         assert np.array_equal(res[0][1][0], res[mode][1][0]) and np.array_equal(res[0][1][1], res[mode][1][1]), mode
     assert sum(1 for t in res[0][0] if t) > 80
