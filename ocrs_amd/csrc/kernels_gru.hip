@@ -375,8 +375,8 @@ gru_persistent_kernel(GruParams p) {
 
 
 // ---------------------------------------------------------------------------------------------------------------
-// Gate-per-wave variant for requests with so few row tiles that every tile gets a cluster of its own (<= 8 tiles per
-// direction at H = 256: a single page).  There the recurrence is a pure latency chain — T dependent steps, nothing to
+// Gate-per-wave variant for requests with so few row tiles that every tile gets a cluster of its own (<= 16 tiles per
+// direction at H = 256: up to three pages).  There the recurrence is a pure latency chain — T dependent steps, nothing to
 // interleave — and the longest link of a step is the wave's 192 MFMAs.  Here the three gates of a step run on three
 // waves (three SIMDs) at once, 64 MFMAs each, and the fourth wave does the gate arithmetic and the store:
 //   waves 0..2 (gate r, z, n):  previous state of the tile (polled as above) -> 4x4 transposes -> 64-MFMA chain of
@@ -611,7 +611,10 @@ bool gru_persistent_supported(int M, int Tmax, int64_t R, int H) {
 static bool gru_gates_plan(int M, int Tmax, int H, int* ncl) {
     if (H != 256 && H != 128 && H != 64) return false;
     const int ntiles = (M + 15) / 16, UB = H / 16;
-    const int max_ncl = 256 / UB / 2 >= 1 ? 256 / UB / 2 : 1;
+    // one workgroup per CU holds 256 / UB / 2 clusters per direction; at 117 VGPRs and 55 KB of LDS two workgroups
+    // share a CU, so twice as many tiles can have a cluster of their own, all resident at once (beyond that the
+    // clusters would run in two rounds, which only pays if the later tiles are short)
+    const int max_ncl = (256 / UB / 2 >= 1 ? 256 / UB / 2 : 1) * 2;
     if (ntiles > max_ncl) return false;
     *ncl = ntiles;
     return gru_gates_lds_bytes(H, Tmax) <= 64 * 1024;
