@@ -174,7 +174,7 @@ hipStream_t heavy_stream() {
         hipStream_t h;
         int least = 0, greatest = 0;
         OCRS_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        OCRS_HIP(hipStreamCreateWithPriority(&h, hipStreamNonBlocking, greatest));
+        OCRS_HIP(hipStreamCreateWithPriority(&h, hipStreamNonBlocking, getenv("OCRS_HEAVY_LOW") ? least : greatest));
         return h;
     }();
     return s;

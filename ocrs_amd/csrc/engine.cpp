@@ -586,7 +586,7 @@ void ocrs_engine::recognize_lines(const ocrs_page* const* pages, size_t n_pages,
         };
         auto unpack = [&](const Sub& sub) {
             for (uint32_t st8 : sub.gru_status)
-                if (st8) fail(OCRS_ERR_DEVICE, "GRU recurrence kernel timed out waiting for a peer workgroup");
+                if (st8) fail(OCRS_ERR_DEVICE, "GRU recurrence kernel timed out waiting for a peer workgroup (status 0x%x)", st8);
             if (beam && !sub.gpu_beam) {  // rten decode_beam (recognition.rs:512-514), host side, one thread per slice of lines
                 const size_t M = sub.slots.size();
                 const unsigned nth = (unsigned)std::max<size_t>(1, std::min<size_t>({(size_t)std::thread::hardware_concurrency(), (size_t)32, M}));

@@ -375,8 +375,8 @@ gru_persistent_kernel(GruParams p) {
 
 
 // ---------------------------------------------------------------------------------------------------------------
-// Gate-per-wave variant for requests with so few row tiles that every tile gets a cluster of its own (<= 16 tiles per
-// direction at H = 256: up to three pages).  There the recurrence is a pure latency chain — T dependent steps, nothing to
+// Gate-per-wave variant for requests with so few row tiles that every tile gets a cluster of its own (<= 8 tiles per
+// direction at H = 256: a single page).  There the recurrence is a pure latency chain — T dependent steps, nothing to
 // interleave — and the longest link of a step is the wave's 192 MFMAs.  Here the three gates of a step run on three
 // waves (three SIMDs) at once, 64 MFMAs each, and the fourth wave does the gate arithmetic and the store:
 //   waves 0..2 (gate r, z, n):  previous state of the tile (polled as above) -> 4x4 transposes -> 64-MFMA chain of
@@ -407,6 +407,12 @@ template <int H>
 __global__ void __launch_bounds__(256)
 gru_gates_kernel(GruParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds_w[];  // H*48 floats | off[Tmax+1] | exchange | abort
+    // ONE workgroup of this kernel per CU, enforced through the register file: the clobber makes the allocation
+    // exceed 256 registers per lane, i.e. one wave per SIMD.  At its natural 117 registers two workgroups can share a
+    // CU, and in that placement (seen as soon as another request's kernels occupy part of the chip) waits for a peer
+    // workgroup's state timed out — every run with 2+ requests in flight, none with this line, none for the general
+    // kernel, whose 299 registers impose the same placement.  Cause not established; kept out by construction.
+    asm volatile("v_accvgpr_write_b32 a200, 0" ::: "a200");
     constexpr int UB = H / 16;
     const int b = blockIdx.x;
     const int q = b >> 3;
@@ -455,7 +461,7 @@ gru_gates_kernel(GruParams p) {
             if (!__any(v == 0u)) break;
             __builtin_amdgcn_s_sleep(8);
             if (spins >= p.spin_limit) {
-                __hip_atomic_store((gu32*)p.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store((gu32*)p.sync, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 *abort_w = 1;   // the other waves leave at their next barrier
                 break;
             }
@@ -611,10 +617,12 @@ bool gru_persistent_supported(int M, int Tmax, int64_t R, int H) {
 static bool gru_gates_plan(int M, int Tmax, int H, int* ncl) {
     if (H != 256 && H != 128 && H != 64) return false;
     const int ntiles = (M + 15) / 16, UB = H / 16;
-    // one workgroup per CU holds 256 / UB / 2 clusters per direction; at 117 VGPRs and 55 KB of LDS two workgroups
-    // share a CU, so twice as many tiles can have a cluster of their own, all resident at once (beyond that the
-    // clusters would run in two rounds, which only pays if the later tiles are short)
-    const int max_ncl = (256 / UB / 2 >= 1 ? 256 / UB / 2 : 1) * 2;
+    // One workgroup per CU, as for the general kernel: 256 / UB / 2 clusters per direction.  (Two workgroups per CU
+    // ran 2-3 page requests 15-20 % faster when alone, but see the note on placement in gru_gates_kernel: requests
+    // timed out as soon as several were in flight.  A multi-tile variant of this kernel for the 16-page request
+    // was also built: 7.2 vs 4.6 ms per layer, the general kernel's three interleaved chains per wave use the
+    // matrix cores better.)
+    const int max_ncl = 256 / UB / 2 >= 1 ? 256 / UB / 2 : 1;
     if (ntiles > max_ncl) return false;
     *ncl = ntiles;
     return gru_gates_lds_bytes(H, Tmax) <= 64 * 1024;

@@ -147,6 +147,33 @@ def test_pages_of_other_sizes_match_golden(engine, name, seed, hh, ww, nl, ncol)
         _check_page_against_golden(g, bw[pi], rects, loffs, int(poffs[pi]), int(poffs[pi + 1]), chars, coffs)
 
 
+def test_single_page_requests_in_flight_concurrently(engine):
+    """One-page requests (the gate-per-wave GRU kernel's case) from 6 host threads at once, 8 rounds each: every
+    result equals the sequential one.  (With several requests in flight the kernels of the others occupy part of the
+    chip while a persistent recurrence kernel runs; a placement of that kernel that only appears then once made
+    waits for peer workgroups time out — kernels_gru.hip, gru_gates_kernel.)"""
+    pages = [synth.synthetic_page(s, 1024, 1024, lines=80) for s in (0, 1, 2)]
+
+    def run(pi):
+        inp = engine.prepare_input(ImageSource.from_tensor(pages[pi], DimOrder.Hwc))
+        words = engine.detect_words(inp)
+        lines = engine.find_text_lines(inp, words)
+        return [(str(t), [c.rect for c in t.chars()]) if t else None for t in engine.recognize_text(inp, lines)]
+
+    ref = [run(pi) for pi in range(3)]
+    assert all(sum(1 for t in r if t) > 60 for r in ref)
+    with ThreadPoolExecutor(max_workers=6) as ex:
+        outs = list(ex.map(lambda k: (k % 3, run(k % 3)), range(48)))
+    for pi, got in outs:
+        assert got == ref[pi]
+    # page 0 is also pinned by its golden fixture (chars of every line)
+    g = _golden_page(0, engine._digests)
+    co = g["char_offsets"]
+    for i, t in enumerate(ref[0]):
+        exp = "".join(chr(c) for c in g["chars"][co[i]:co[i + 1], 0])
+        assert (t[0] if t else "") == exp
+
+
 def _crops_request(engine):
     n = 2048
     crops = synth.synthetic_line_crops(1000, n=n)
