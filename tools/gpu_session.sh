@@ -1,6 +1,6 @@
 #!/bin/bash
 # One gpurun call = one session: tools/gpu_session.sh <tag> <section>...   (outputs under gpurun_out/<tag>/)
-# Sections: tests_new tests_all ab lat serial16 full multi stream prof pmc
+# Sections: tests_new tests_all ab lat serial16 det detprof full multi stream conc prof pmc
 set -u
 export TMPDIR=/tmp
 TAG=$1; shift
@@ -91,6 +91,12 @@ pmc)
   (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE -d $ROOT/$OUT/pmc -o mfma -- $BENCH > $ROOT/$OUT/pmc_mfma.log 2>&1); say "mfma rc=$?"
   python tools/pmc_summary.py $OUT/pmc $OUT/${TAG}_pmc_hbm.txt $OUT/${TAG}_pmc.json > /dev/null 2>$OUT/pmc_summary.err; head -40 $OUT/${TAG}_pmc_hbm.txt | cut -c1-220 | tee -a $S
   find $OUT/pmc -size +30M -delete;;
+conc)
+  say "== small requests in flight: 1 and 2 pages per request, 6 and 12 in flight (gate-per-wave GRU kernel under concurrency)"
+  for a in "--pages 1 --inflight 6" "--pages 1 --inflight 12" "--pages 2 --inflight 6"; do
+    timeout 300 python bench.py $a --steps 120 --warmup 20 --settle-s 1 --no-cpu-baseline --no-extras > $OUT/bench_conc.json 2> $OUT/bench_conc.err; rc=$?
+    say "$a rc=$rc"; jsum $OUT/bench_conc.json "$a"; [ $rc -ne 0 ] && tail -2 $OUT/bench_conc.err | cut -c1-300 | tee -a $S
+  done;;
 *) say "unknown section $sec";;
 esac
 done
