@@ -168,6 +168,14 @@ template <int H>
 __device__ __forceinline__ bool await_state(const GruParams& p, __amdgpu_buffer_rsrc_t y, int ub, int kq, Loaded<H>& L) {
     for (uint32_t spins = 0; !state_ready<H>(L); spins++) {
         __builtin_amdgcn_s_sleep(2);
+        // Back off when the wait is a long one (a peer workgroup not resident yet, or held up): a re-read costs 17
+        // line fetches per lane group, and a CU whose pollers re-issue them back to back can keep its own memory
+        // pipeline so full that the store everybody is waiting for does not get through (seen with two workgroups
+        // of gru_gates_kernel on one CU: six pollers, waits of seconds).  The first re-reads stay immediate.
+        if (spins >= 4u) {
+            const uint32_t n = spins < 36u ? (spins >> 2) : 9u;   // 1 .. 9 x 1024 clocks
+            for (uint32_t z = 0; z < n; z++) __builtin_amdgcn_s_sleep(16);
+        }
         if ((spins & 255u) == 255u) {
             gu32* err = (gu32*)p.sync;
             const uint32_t e = __builtin_amdgcn_readfirstlane(__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
@@ -407,12 +415,18 @@ template <int H>
 __global__ void __launch_bounds__(256)
 gru_gates_kernel(GruParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds_w[];  // H*48 floats | off[Tmax+1] | exchange | abort
+    // ONE workgroup of this kernel per CU, through the register file: the clobber pushes the allocation past 256
+    // registers per lane, i.e. one wave per SIMD.  At its natural 117 registers the hardware puts two workgroups on a
+    // CU as soon as other requests' kernels occupy part of the chip; their six polling waves then kept that CU's
+    // memory pipeline so full that the awaited stores did not get through (waits of seconds, every run with 2+
+    // requests in flight, before await_state backed off).  With the back-off the shared placement works as well, but
+    // one workgroup per CU — what the general kernel's 299 registers impose anyway — is 5 % faster under load.
+    asm volatile("v_accvgpr_write_b32 a200, 0" ::: "a200");
     // ONE workgroup of this kernel per CU, enforced through the register file: the clobber makes the allocation
     // exceed 256 registers per lane, i.e. one wave per SIMD.  At its natural 117 registers two workgroups can share a
     // CU, and in that placement (seen as soon as another request's kernels occupy part of the chip) waits for a peer
     // workgroup's state timed out — every run with 2+ requests in flight, none with this line, none for the general
     // kernel, whose 299 registers impose the same placement.  Cause not established; kept out by construction.
-    asm volatile("v_accvgpr_write_b32 a200, 0" ::: "a200");
     constexpr int UB = H / 16;
     const int b = blockIdx.x;
     const int q = b >> 3;
