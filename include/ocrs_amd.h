@@ -56,12 +56,17 @@ OCRS_API const char* ocrs_last_error(void);
 /* Release any buffer handed out through a `T**` out-parameter. */
 OCRS_API void ocrs_buffer_free(void* p);
 
-/* Number of HIP devices visible; ocrs_set_device selects the device for the WHOLE PROCESS (every
- * thread that enters the library is bound to it; stream and memory pools are per process).  The
- * deployment model is one process per GPU: call it once, with LOCAL_RANK, before
- * creating any handle.  Default: device 0. */
+/* Devices.  Every handle (model, engine, page) belongs to ONE HIP device, and every entry point binds the calling
+ * host thread to its handle's device for the duration of the call: one process may hold engines on several GPUs
+ * (and use them from any thread), or one process per GPU may each use its own.  The reference engine is immutable
+ * `&self` (ocrs/src/lib.rs:183-256), which is what makes both shapes natural.
+ *   ocrs_device_count  HIP devices visible
+ *   ocrs_set_device    the DEFAULT device: where handles created without an explicit device live (the
+ *                      one-process-per-GPU deployment calls it once, with LOCAL_RANK; initially 0)
+ *   ocrs_get_device    the current default */
 OCRS_API ocrs_status ocrs_device_count(int* n);
 OCRS_API ocrs_status ocrs_set_device(int device);
+OCRS_API ocrs_status ocrs_get_device(int* device);
 
 /* rten::ctc::CtcDecoder::decode_beam (as called at ocrs/src/recognition.rs:512-514) on a host matrix of
  * log-probabilities [T][C] (blank = class 0): the steps (label, position) of the best prefix.  `impl`: 0 = the
@@ -94,6 +99,12 @@ OCRS_API ocrs_status ocrs_gru_tile_plan(const int32_t* lengths_desc, size_t n_li
  *   "gemm_nfast"      1 = dense GEMMs run the column tiles of a row tile side by side on one XCD (default), 0 = column
  *                     tile on the grid's y axis
  *   "gru_scatter"     test knob: 1 = spread every cluster over all XCDs (exercises the write-through path), default 0
+ *   "coalesce"        the reference API is one page per call with concurrency from host threads (ocrs-cli/src/main.rs:420-446,
+ *                     recognition.rs:465-485); small detect / recognize requests that wait at the same time are merged into one
+ *                     ragged request per stage (lines are independent: nobody's bits change).  Value = merged batches in flight
+ *                     per engine and stage (default 2), 0 = every call runs on its own
+ *   "coalesce_pages"  pages per merged batch (default 16); requests of half that size or more are never merged
+ *   "coalesce_window_us"  while other batches are in flight, how long the next one lets its queue fill (default 300)
  * Results never depend on an option; OCRS_ERR_INVALID_ARGUMENT for an unknown name. */
 OCRS_API ocrs_status ocrs_set_option(const char* name, long value);
 
@@ -108,6 +119,12 @@ typedef struct ocrs_model ocrs_model;
  * fixed-graph file and uploads the weights to HBM. */
 OCRS_API ocrs_status ocrs_model_load_file(const char* path, ocrs_model** out);
 OCRS_API ocrs_status ocrs_model_load_bytes(const void* data, size_t len, ocrs_model** out);
+/* The same with the weights on an explicit device (device < 0: the default device).  The file is validated on the
+ * host first; a malformed file fails with OCRS_ERR_IO before any device is touched. */
+OCRS_API ocrs_status ocrs_model_load_file_on_device(const char* path, int device, ocrs_model** out);
+OCRS_API ocrs_status ocrs_model_load_bytes_on_device(const void* data, size_t len, int device, ocrs_model** out);
+/* Device that holds the model's weights (-1 for a callback model). */
+OCRS_API ocrs_status ocrs_model_device(const ocrs_model* m, int* device);
 
 /* A model implemented by the caller — the counterpart of implementing
  * `trait Model` in Rust (the reference's tests inject FakeDetectionModel /
@@ -163,9 +180,12 @@ typedef struct ocrs_engine_params {
     const char* allowed_chars; /* UTF-8 */
 } ocrs_engine_params;
 
-/* OcrEngine::new (lib.rs:132-180). */
+/* OcrEngine::new (lib.rs:132-180).  The engine lives on its models' device (both models must be on the same one;
+ * an engine with callback models only lives on the default device); pages it prepares live there too, and a page
+ * can only be given to an engine of its own device (OCRS_ERR_INVALID_ARGUMENT otherwise). */
 OCRS_API ocrs_status ocrs_engine_new(const ocrs_engine_params* params, ocrs_engine** out);
 OCRS_API void ocrs_engine_free(ocrs_engine* e);
+OCRS_API ocrs_status ocrs_engine_device(const ocrs_engine* e, int* device);
 
 typedef enum ocrs_dim_order { OCRS_HWC = 0, OCRS_CHW = 1 } ocrs_dim_order; /* DimOrder, preprocess.rs:50-57 */
 typedef enum ocrs_pixel_type { OCRS_U8 = 0, OCRS_F32 = 1 } ocrs_pixel_type; /* ImagePixels, preprocess.rs:9-14 */
@@ -268,11 +288,79 @@ OCRS_API ocrs_status ocrs_engine_prepare_recognition_input(const ocrs_engine* e,
 OCRS_API ocrs_status ocrs_engine_get_text(const ocrs_engine* e, const ocrs_page* page, char** text);
 
 /* ------------------------------------------------------------------------
+ * Several GPUs in one process: an engine group.  One engine (and one replica of the weights) per member device;
+ * page i of a call is dealt to member i mod G, every member runs its share on its own host
+ * thread and streams, results come back in page order.  Pages are independent (OcrEngine is immutable `&self`,
+ * ocrs/src/lib.rs:183-256), so there is no collective on the compute path; the only exchange is the gather of the
+ * packed results, by one of two transports that deliver the same bytes:
+ *   OCRS_GATHER_HOST  every member hands its results over through its own pinned staging / PCIe link
+ *   OCRS_GATHER_RCCL  the packed results ({rect f32 x 6} per word, {char, box} per character) are all-gathered
+ *                     device to device over xGMI (ncclCommInitAll communicator, one grouped ncclAllGather) and read
+ *                     back from the root member
+ *   OCRS_GATHER_AUTO  RCCL when the group has more than one member and all devices are distinct, else host.
+ * RCCL does not accept the same device twice in one communicator: such a group (useful on a one-GPU box) always uses
+ * the host transport; ocrs_group_last_gather reports what a call used and why.
+ * ---------------------------------------------------------------------- */
+typedef struct ocrs_engine_group ocrs_engine_group;
+typedef enum ocrs_gather_mode { OCRS_GATHER_AUTO = 0, OCRS_GATHER_HOST = 1, OCRS_GATHER_RCCL = 2 } ocrs_gather_mode;
+
+typedef struct ocrs_group_params { /* OcrEngineParams (lib.rs:38-71) + the member devices */
+    const void* detection_model;   /* `.ocrsm` image (as for ocrs_model_load_bytes) or NULL */
+    size_t detection_model_len;
+    const void* recognition_model;
+    size_t recognition_model_len;
+    const int* devices;            /* member m runs on devices[m] */
+    size_t n_devices;
+    int debug;
+    ocrs_decode_method decode_method;
+    uint32_t beam_width;
+    const char* alphabet;
+    const char* allowed_chars;
+    ocrs_gather_mode gather;
+} ocrs_group_params;
+
+OCRS_API ocrs_status ocrs_engine_group_new(const ocrs_group_params* params, ocrs_engine_group** out);
+OCRS_API void ocrs_engine_group_free(ocrs_engine_group* g);
+OCRS_API ocrs_status ocrs_engine_group_size(const ocrs_engine_group* g, size_t* n_members);
+/* Member i's engine (borrowed; usable with every ocrs_engine_* call) and device. */
+OCRS_API ocrs_status ocrs_engine_group_member(const ocrs_engine_group* g, size_t i, const ocrs_engine** engine, int* device);
+/* The dealing rule on its own (host only): member_of_page[i] = i mod n_members; pages_per_member may be NULL. */
+OCRS_API ocrs_status ocrs_group_deal(size_t n_pages, size_t n_members, size_t* member_of_page, size_t* pages_per_member);
+
+/* OcrEngine::prepare_input (lib.rs:183-187) for n equally sized host images: image i is uploaded to and converted on
+ * member i mod G.  out[n] receives the pages (each lives on its member's device). */
+OCRS_API ocrs_status ocrs_group_prepare_input_batch(const ocrs_engine_group* g, const void* const* pixels, size_t n,
+                                                    ocrs_pixel_type type, ocrs_dim_order order, int height, int width,
+                                                    int channels, ocrs_page** out);
+/* The same with image i already resident on member i mod G's device (ocrs_device_malloc_on). */
+OCRS_API ocrs_status ocrs_group_prepare_input_device_batch(const ocrs_engine_group* g, const void* const* d_pixels, size_t n,
+                                                           ocrs_pixel_type type, ocrs_dim_order order, int height, int width,
+                                                           int channels, ocrs_page** out);
+/* OcrEngine::detect_words (lib.rs:193-199) over pages dealt as above (page i must live on member i mod G's device);
+ * output as ocrs_engine_detect_words_batch. */
+OCRS_API ocrs_status ocrs_group_detect_words_batch(ocrs_engine_group* g, const ocrs_page* const* pages, size_t n_pages,
+                                                   float** rects, size_t* offsets);
+/* OcrEngine::recognize_text (lib.rs:237-256); arguments and output as ocrs_engine_recognize_text_batch.
+ * (find_text_lines is host work: ocrs_engine_find_text_lines_batch serves a group as it is.) */
+OCRS_API ocrs_status ocrs_group_recognize_text_batch(ocrs_engine_group* g, const ocrs_page* const* pages, size_t n_pages,
+                                                     const size_t* page_line_offsets, const float* line_rects,
+                                                     const size_t* line_offsets, size_t n_lines, ocrs_text_char** chars,
+                                                     size_t** char_offsets);
+/* The gather on its own: payloads[m] / bytes[m] = member m's packed bytes (host memory); *out receives their
+ * concatenation in member order through the group's transport, offsets[G + 1] the boundaries. */
+OCRS_API ocrs_status ocrs_group_gather(ocrs_engine_group* g, const void* const* payloads, const size_t* bytes, void** out,
+                                       size_t* offsets);
+/* Transport of the group's most recent gather: 1 host, 2 RCCL (0: none yet), the payload bytes it moved, and — when the
+ * group resolved to the host transport — why (static string, "" otherwise).  Any argument may be NULL. */
+OCRS_API ocrs_status ocrs_group_last_gather(const ocrs_engine_group* g, int* transport, size_t* bytes, const char** why_host);
+
+/* ------------------------------------------------------------------------
  * Measurement hooks (bench.py; not part of the reference surface).
  * ---------------------------------------------------------------------- */
 /* Device memory helpers so that bench inputs can be made HBM-resident without
- * torch in the loop. */
-OCRS_API ocrs_status ocrs_device_malloc(size_t bytes, void** d_ptr);
+ * torch in the loop.  free / upload take pointers of any device. */
+OCRS_API ocrs_status ocrs_device_malloc(size_t bytes, void** d_ptr);                 /* on the default device */
+OCRS_API ocrs_status ocrs_device_malloc_on(int device, size_t bytes, void** d_ptr);
 OCRS_API ocrs_status ocrs_device_free(void* d_ptr);
 OCRS_API ocrs_status ocrs_device_upload(void* d_dst, const void* h_src, size_t bytes);
 OCRS_API ocrs_status ocrs_device_synchronize(void);

@@ -55,6 +55,10 @@ DECLARED_SYMBOLS = [
     "ocrs_device_upload", "ocrs_device_synchronize", "ocrs_device_measure_peaks", "ocrs_engine_enable_timing", "ocrs_stage_count",
     "ocrs_stage_name", "ocrs_engine_stage_times", "ocrs_kernel_class_count", "ocrs_kernel_class_name",
     "ocrs_engine_kernel_stats", "ocrs_engine_set_kernel_timing_mask", "ocrs_gru_tile_plan", "ocrs_host_malloc", "ocrs_host_free", "ocrs_engine_prepare_input_batch",
+    "ocrs_get_device", "ocrs_model_load_file_on_device", "ocrs_model_load_bytes_on_device", "ocrs_model_device", "ocrs_engine_device",
+    "ocrs_engine_group_new", "ocrs_engine_group_free", "ocrs_engine_group_size", "ocrs_engine_group_member", "ocrs_group_deal",
+    "ocrs_group_prepare_input_batch", "ocrs_group_prepare_input_device_batch", "ocrs_group_detect_words_batch",
+    "ocrs_group_recognize_text_batch", "ocrs_group_gather", "ocrs_group_last_gather", "ocrs_device_malloc_on",
 ]
 
 _lib = None

@@ -5,104 +5,14 @@
 #include <thread>
 
 #include <atomic>
+#include "abi_util.hpp"
 #include "engine.hpp"
 #include "kernels.hpp"
 
 using namespace ocrs;
 using namespace ocrs::geom;
 
-namespace {
-
-template <class F>
-ocrs_status guarded(F&& f) {
-    try {
-        bind_thread_to_device();
-        f();
-        set_last_error("");
-        return OCRS_OK;
-    } catch (const Error& e) {
-        set_last_error(e.what());
-        return e.status;
-    } catch (const std::bad_alloc&) {
-        set_last_error("out of host memory");
-        return OCRS_ERR_DEVICE;
-    } catch (const std::exception& e) {
-        set_last_error(e.what());
-        return OCRS_ERR_RUN_FAILED;
-    }
-}
-
-template <class T>
-T* dup_buffer(const std::vector<T>& v) {
-    T* p = static_cast<T*>(malloc(std::max<size_t>(v.size(), 1) * sizeof(T)));
-    if (!p) throw std::bad_alloc();
-    if (!v.empty()) memcpy(p, v.data(), v.size() * sizeof(T));
-    return p;
-}
-
-std::u32string decode_utf8(const char* s) {
-    std::u32string out;
-    const unsigned char* p = reinterpret_cast<const unsigned char*>(s);
-    while (*p) {
-        uint32_t c = *p++;
-        int extra = c >= 0xF0 ? 3 : c >= 0xE0 ? 2 : c >= 0xC0 ? 1 : 0;
-        if (extra) c &= (0x3F >> extra);
-        while (extra-- > 0 && *p) c = (c << 6) | (*p++ & 0x3F);
-        out.push_back((char32_t)c);
-    }
-    return out;
-}
-
-void append_utf8(std::string& s, uint32_t c) {
-    if (c < 0x80) s.push_back((char)c);
-    else if (c < 0x800) { s.push_back((char)(0xC0 | (c >> 6))); s.push_back((char)(0x80 | (c & 0x3F))); }
-    else if (c < 0x10000) {
-        s.push_back((char)(0xE0 | (c >> 12))); s.push_back((char)(0x80 | ((c >> 6) & 0x3F)));
-        s.push_back((char)(0x80 | (c & 0x3F)));
-    } else {
-        s.push_back((char)(0xF0 | (c >> 18))); s.push_back((char)(0x80 | ((c >> 12) & 0x3F)));
-        s.push_back((char)(0x80 | ((c >> 6) & 0x3F))); s.push_back((char)(0x80 | (c & 0x3F)));
-    }
-}
-
-// lib.rs:34 with the EUR sign restored (lib.rs:33)
-const char kDefaultAlphabet[] =
-    " 0123456789!\"#$%&'()*+,-./:;<=>?@[\\]^_`{|}~\xE2\x82\xAC"
-    "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz";
-
-std::vector<std::vector<RotatedRect>> unpack_lines(const float* rects, const size_t* offsets, size_t first,
-                                                   size_t last) {
-    std::vector<std::vector<RotatedRect>> lines;
-    for (size_t i = first; i < last; i++) {
-        std::vector<RotatedRect> words;
-        for (size_t k = offsets[i]; k < offsets[i + 1]; k++) words.push_back(RotatedRect::from_array(rects + 6 * k));
-        lines.push_back(std::move(words));
-    }
-    return lines;
-}
-
-ocrs_page* make_page(const void* d_pixels, ocrs_pixel_type type, ocrs_dim_order order, int height, int width,
-                     int channels, hipStream_t st, StageTimers* T) {
-    auto page = std::make_unique<ocrs_page>();
-    page->h = height;
-    page->w = width;
-    page->grey = DevBuf((size_t)height * width * sizeof(float));
-    {
-        StageScope sc(T, ST_PREPARE, st);
-        k::prepare_image(d_pixels, type == OCRS_U8, order == OCRS_HWC, height, width, channels, page->grey.as<float>(), st);
-    }
-    OCRS_HIP(hipGetLastError());
-    return page.release();
-}
-
-void check_image_args(const void* pixels, int height, int width, int channels) {
-    if (!pixels) fail(OCRS_ERR_INVALID_ARGUMENT, "pixels is null");
-    // ImageSource::from_tensor (preprocess.rs:116-122)
-    if (!(channels == 1 || channels == 3 || channels == 4)) fail(OCRS_ERR_IMAGE_SOURCE, "channel count is not 1, 3 or 4");
-    if (height <= 0 || width <= 0) fail(OCRS_ERR_INVALID_ARGUMENT, "image has no pixels");
-}
-
-}  // namespace
+using namespace ocrs::abi;
 
 extern "C" {
 
@@ -123,6 +33,13 @@ ocrs_status ocrs_set_device(int device) {
     return guarded([&] { select_device(device); });
 }
 
+ocrs_status ocrs_get_device(int* device) {
+    return guarded([&] {
+        if (!device) fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
+        *device = default_device();
+    });
+}
+
 ocrs_status ocrs_gru_tile_plan(const int32_t* lengths_desc, size_t n_lines, int hidden, int32_t* n_clusters, int16_t* tiles) {
     return guarded([&] {
         if (!lengths_desc || !n_clusters || !tiles || n_lines == 0 || n_lines > (size_t)1 << 20)
@@ -132,7 +49,7 @@ ocrs_status ocrs_gru_tile_plan(const int32_t* lengths_desc, size_t n_lines, int 
                 fail(OCRS_ERR_INVALID_ARGUMENT, "lengths must be positive and descending");
         int ncl = 0;
         if (!k::gru_tile_plan(lengths_desc, (int)n_lines, hidden, &ncl, tiles))
-            fail(OCRS_ERR_CAPACITY, "no persistent-kernel plan for this shape (the engine then runs one launch per time step)");
+            fail(OCRS_ERR_CAPACITY, "no persistent-kernel plan for this shape (the engine then runs the recurrence as one fused launch per time step)");
         *n_clusters = ncl;
     });
 }
@@ -143,7 +60,7 @@ ocrs_status ocrs_ctc_beam_search(const float* logp, int t, int c, uint32_t width
         if (!logp || !labels || !positions || !n || t < 0 || c < 1) fail(OCRS_ERR_INVALID_ARGUMENT, "bad argument");
         std::vector<uint32_t> l, p;
         if (impl == 2 && t > 0) {   // the HIP kernel, on this matrix as a one-line packed batch
-            bind_thread_to_device();
+            DeviceScope bind(-1);
             if (!k::ctc_beam_supported(c, (int)width)) fail(OCRS_ERR_CAPACITY, "beam search on the GPU supports up to 128 classes and width 128");
             Workspace ws;
             std::vector<int32_t> meta(1 + t + 1);
@@ -188,24 +105,37 @@ ocrs_status ocrs_set_option(const char* name, long value) {
 }
 
 // ------------------------------------------------------------------ models
-ocrs_status ocrs_model_load_bytes(const void* data, size_t len, ocrs_model** out) {
+ocrs_status ocrs_model_load_bytes_on_device(const void* data, size_t len, int device, ocrs_model** out) {
     return guarded([&] {
         if (!data || !out) fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
         auto m = std::make_unique<ocrs_model>();
-        m->impl = HipModel::load(data, len);
+        m->impl = HipModel::load(data, len, device);   // validates first, binds to the device for the upload only
         *out = m.release();
     });
 }
 
-ocrs_status ocrs_model_load_file(const char* path, ocrs_model** out) {
+ocrs_status ocrs_model_load_bytes(const void* data, size_t len, ocrs_model** out) {
+    return ocrs_model_load_bytes_on_device(data, len, -1, out);
+}
+
+ocrs_status ocrs_model_load_file_on_device(const char* path, int device, ocrs_model** out) {
     return guarded([&] {
         if (!path || !out) fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
         std::ifstream f(path, std::ios::binary);
         if (!f) fail(OCRS_ERR_IO, "cannot open model file %s", path);
         std::vector<char> buf((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
         auto m = std::make_unique<ocrs_model>();
-        m->impl = HipModel::load(buf.data(), buf.size());
+        m->impl = HipModel::load(buf.data(), buf.size(), device);
         *out = m.release();
+    });
+}
+
+ocrs_status ocrs_model_load_file(const char* path, ocrs_model** out) { return ocrs_model_load_file_on_device(path, -1, out); }
+
+ocrs_status ocrs_model_device(const ocrs_model* m, int* device) {
+    return guarded([&] {
+        if (!m || !device) fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
+        *device = m->impl->device;
     });
 }
 
@@ -247,6 +177,7 @@ ocrs_status ocrs_model_run(const ocrs_model* m, const float* input, const int64_
             return;
         }
         const auto* hm = static_cast<const HipModel*>(m->impl.get());
+        DeviceScope bind(hm->device);
         if (c != 1) fail(OCRS_ERR_RUN_FAILED, "model run failed: expected 1 input channel, got %lld", (long long)c);
         for (int i = 2; i < 4; i++)
             if (hm->input_shape[i] >= 0 && hm->input_shape[i] != in_shape[i])
@@ -296,23 +227,14 @@ void ocrs_model_free(ocrs_model* m) { delete m; }
 ocrs_status ocrs_engine_new(const ocrs_engine_params* params, ocrs_engine** out) {
     return guarded([&] {
         if (!params || !out) fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
-        auto e = std::make_unique<ocrs_engine>();
-        e->detection = params->detection_model ? params->detection_model->impl.get() : nullptr;
-        e->recognition = params->recognition_model ? params->recognition_model->impl.get() : nullptr;
-        e->debug = params->debug != 0;
-        e->decode_method = params->decode_method;
-        e->beam_width = params->beam_width ? params->beam_width : 100;
-        e->alphabet = decode_utf8(params->alphabet ? params->alphabet : kDefaultAlphabet);
-        if (params->allowed_chars) {  // lib.rs:153-170
-            const std::u32string allowed = decode_utf8(params->allowed_chars);
-            e->excluded.assign(e->alphabet.size() + 1, 0);
-            for (size_t i = 0; i < e->alphabet.size(); i++)
-                if (allowed.find(e->alphabet[i]) == std::u32string::npos) e->excluded[i + 1] = 1;
-            e->has_excluded = true;
-            e->d_excluded = DevBuf(e->excluded.size());
-            OCRS_HIP(hipMemcpy(e->d_excluded.p, e->excluded.data(), e->excluded.size(), hipMemcpyHostToDevice));
-        }
-        *out = e.release();
+        *out = make_engine(*params).release();
+    });
+}
+
+ocrs_status ocrs_engine_device(const ocrs_engine* e, int* device) {
+    return guarded([&] {
+        if (!e || !device) fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
+        *device = e->device;
     });
 }
 
@@ -331,7 +253,7 @@ ocrs_status ocrs_image_source_check_bytes(size_t len, uint32_t width, uint32_t h
 
 ocrs_status ocrs_engine_prepare_input(const ocrs_engine* e, const void* pixels, ocrs_pixel_type type,
                                       ocrs_dim_order order, int height, int width, int channels, ocrs_page** out) {
-    return guarded([&] {
+    return guarded_on(e ? e->device : -1, [&] {
         if (!e || !out) fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
         check_image_args(pixels, height, width, channels);
         Workspace ws;
@@ -347,7 +269,7 @@ ocrs_status ocrs_engine_prepare_input(const ocrs_engine* e, const void* pixels, 
 
 ocrs_status ocrs_engine_prepare_input_batch(const ocrs_engine* e, const void* const* pixels, size_t n, ocrs_pixel_type type,
                                             ocrs_dim_order order, int height, int width, int channels, ocrs_page** out) {
-    return guarded([&] {
+    return guarded_on(e ? e->device : -1, [&] {
         if (!e || !out || (n > 0 && !pixels)) fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
         for (size_t i = 0; i < n; i++) check_image_args(pixels[i], height, width, channels);
         Workspace ws;
@@ -369,7 +291,7 @@ ocrs_status ocrs_engine_prepare_input_batch(const ocrs_engine* e, const void* co
 ocrs_status ocrs_engine_prepare_input_device(const ocrs_engine* e, const void* d_pixels, ocrs_pixel_type type,
                                              ocrs_dim_order order, int height, int width, int channels,
                                              ocrs_page** out) {
-    return guarded([&] {
+    return guarded_on(e ? e->device : -1, [&] {
         if (!e || !out) fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
         check_image_args(d_pixels, height, width, channels);
         Workspace ws;
@@ -391,7 +313,7 @@ ocrs_status ocrs_page_dims(const ocrs_page* p, int* height, int* width) {
 }
 
 ocrs_status ocrs_page_image(const ocrs_page* p, float* out_hw) {
-    return guarded([&] {
+    return guarded_on(p ? p->device() : -1, [&] {
         if (!p || !out_hw) fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
         OCRS_HIP(hipMemcpy(out_hw, p->grey.p, (size_t)p->h * p->w * sizeof(float), hipMemcpyDeviceToHost));
     });
@@ -399,8 +321,9 @@ ocrs_status ocrs_page_image(const ocrs_page* p, float* out_hw) {
 
 ocrs_status ocrs_engine_detect_words_batch(const ocrs_engine* e, const ocrs_page* const* pages, size_t n_pages,
                                            float** rects, size_t* offsets) {
-    return guarded([&] {
+    return guarded_on(e ? e->device : -1, [&] {
         if (!e || !pages || !rects || !offsets) fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
+        check_pages_on(e, pages, n_pages);
         std::vector<std::vector<RotatedRect>> rr;
         e->detect(pages, n_pages, &rr, nullptr);
         std::vector<float> flat;
@@ -425,8 +348,9 @@ ocrs_status ocrs_engine_detect_words(const ocrs_engine* e, const ocrs_page* page
 }
 
 ocrs_status ocrs_engine_detect_text_pixels(const ocrs_engine* e, const ocrs_page* page, float* out_hw) {
-    return guarded([&] {
+    return guarded_on(e ? e->device : -1, [&] {
         if (!e || !page || !out_hw) fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
+        check_pages_on(e, &page, 1);
         e->detect(&page, 1, nullptr, out_hw);
     });
 }
@@ -517,9 +441,10 @@ ocrs_status ocrs_engine_recognize_text_batch(const ocrs_engine* e, const ocrs_pa
                                              const size_t* page_line_offsets, const float* line_rects,
                                              const size_t* line_offsets, size_t n_lines, ocrs_text_char** chars,
                                              size_t** char_offsets) {
-    return guarded([&] {
+    return guarded_on(e ? e->device : -1, [&] {
         if (!e || !pages || !page_line_offsets || !line_offsets || !chars || !char_offsets)
             fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
+        check_pages_on(e, pages, n_pages);
         if (page_line_offsets[n_pages] != n_lines) fail(OCRS_ERR_INVALID_ARGUMENT, "page_line_offsets do not cover n_lines");
         std::vector<std::vector<std::vector<RotatedRect>>> lpp(n_pages);
         for (size_t p = 0; p < n_pages; p++)
@@ -550,9 +475,10 @@ ocrs_status ocrs_engine_recognize_text(const ocrs_engine* e, const ocrs_page* pa
 ocrs_status ocrs_engine_recognize_tokens(const ocrs_engine* e, const ocrs_page* page, const float* line_rects,
                                          const size_t* line_offsets, size_t n_lines, uint32_t** labels,
                                          uint32_t** positions, size_t** token_offsets) {
-    return guarded([&] {
+    return guarded_on(e ? e->device : -1, [&] {
         if (!e || !page || !line_offsets || !labels || !positions || !token_offsets)
             fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
+        check_pages_on(e, &page, 1);
         std::vector<std::vector<std::vector<RotatedRect>>> lpp(1);
         lpp[0] = unpack_lines(line_rects, line_offsets, 0, n_lines);
         std::vector<std::vector<CtcStep>> steps;
@@ -590,15 +516,15 @@ ocrs_status ocrs_rotated_rect_corners(const float rect6[6], float out8[8]) {
 
 ocrs_status ocrs_engine_prepare_recognition_input(const ocrs_engine* e, const ocrs_page* page, const float* line,
                                                   size_t n_words, float** out, int* height, int* width) {
-    return guarded([&] {
+    return guarded_on(e ? e->device : -1, [&] {
         if (!e || !page || !line || !out || !height || !width) fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
+        check_pages_on(e, &page, 1);
         if (!e->recognition) fail(OCRS_ERR_MODEL_NOT_LOADED, "Recognition model not loaded");
         std::vector<RotatedRect> words(n_words);
         for (size_t i = 0; i < n_words; i++) words[i] = RotatedRect::from_array(line + 6 * i);
         RecLine ln = e->make_rec_line(words, 0, 0);
         const int rec_h = (int)e->rec_input_height();
         const int rw = (int)ln.resized_width;
-        if (ln.polygon.size() > 512) fail(OCRS_ERR_CAPACITY, "text line has more than 128 words");
         Workspace ws;
         k::LineDesc d{};
         d.page = 0; d.poly_off = 0; d.poly_n = (int32_t)ln.polygon.size();
@@ -630,8 +556,9 @@ ocrs_status ocrs_engine_prepare_recognition_input(const ocrs_engine* e, const oc
 }
 
 ocrs_status ocrs_engine_get_text(const ocrs_engine* e, const ocrs_page* page, char** text) {
-    return guarded([&] {  // lib.rs:290-300
+    return guarded_on(e ? e->device : -1, [&] {  // lib.rs:290-300
         if (!e || !page || !text) fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
+        check_pages_on(e, &page, 1);
         std::vector<std::vector<RotatedRect>> rr;
         e->detect(&page, 1, &rr, nullptr);
         std::vector<std::vector<std::vector<RotatedRect>>> lpp(1);
@@ -658,44 +585,46 @@ ocrs_status ocrs_engine_get_text(const ocrs_engine* e, const ocrs_page* page, ch
 
 // ------------------------------------------------------------------ measurement hooks
 ocrs_status ocrs_device_malloc(size_t bytes, void** d_ptr) {
-    return guarded([&] { OCRS_HIP(hipMalloc(d_ptr, bytes)); });
+    return guarded_on(-1, [&] { OCRS_HIP(hipMalloc(d_ptr, bytes)); });
+}
+ocrs_status ocrs_device_malloc_on(int device, size_t bytes, void** d_ptr) {
+    return guarded_on(device, [&] { OCRS_HIP(hipMalloc(d_ptr, bytes)); });
 }
 ocrs_status ocrs_device_free(void* d_ptr) {
-    return guarded([&] { OCRS_HIP(hipFree(d_ptr)); });
+    return guarded_on(-1, [&] { OCRS_HIP(hipFree(d_ptr)); });
 }
 ocrs_status ocrs_device_upload(void* d_dst, const void* h_src, size_t bytes) {
-    return guarded([&] { OCRS_HIP(hipMemcpy(d_dst, h_src, bytes, hipMemcpyHostToDevice)); });
+    return guarded_on(-1, [&] { OCRS_HIP(hipMemcpy(d_dst, h_src, bytes, hipMemcpyHostToDevice)); });
 }
 ocrs_status ocrs_host_malloc(size_t bytes, void** h_ptr) {
-    return guarded([&] {
+    return guarded_on(-1, [&] {
         if (!h_ptr) fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
-        bind_thread_to_device();
-        OCRS_HIP(hipHostMalloc(h_ptr, bytes ? bytes : 1, hipHostMallocDefault));
+        OCRS_HIP(hipHostMalloc(h_ptr, bytes ? bytes : 1, hipHostMallocPortable));   // usable with every device of a group
     });
 }
 ocrs_status ocrs_host_free(void* h_ptr) {
-    return guarded([&] { OCRS_HIP(hipHostFree(h_ptr)); });
+    return guarded_on(-1, [&] { OCRS_HIP(hipHostFree(h_ptr)); });
 }
 ocrs_status ocrs_device_synchronize(void) {
-    return guarded([&] { OCRS_HIP(hipDeviceSynchronize()); });
+    return guarded_on(-1, [&] { OCRS_HIP(hipDeviceSynchronize()); });
 }
 
 ocrs_status ocrs_device_measure_peaks(double* mfma_f32_tflops, double* hbm_copy_gbps) {
-    return guarded([&] {
+    return guarded_on(-1, [&] {
         if (!mfma_f32_tflops || !hbm_copy_gbps) fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
         k::measure_peaks(mfma_f32_tflops, hbm_copy_gbps);
     });
 }
 
 ocrs_status ocrs_engine_enable_timing(ocrs_engine* e, int enable) {
-    return guarded([&] {
+    return guarded_on(e ? e->device : -1, [&] {
         if (!e) fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
         e->timers.enabled = enable != 0;
         e->timers.kernels_enabled = enable >= 2;
     });
 }
 ocrs_status ocrs_engine_set_kernel_timing_mask(ocrs_engine* e, uint32_t mask) {
-    return guarded([&] {
+    return guarded_on(e ? e->device : -1, [&] {
         if (!e) fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
         e->timers.kernel_mask = mask;
     });
@@ -704,7 +633,7 @@ int ocrs_kernel_class_count(void) { return KC_COUNT; }
 const char* ocrs_kernel_class_name(int cls) { return cls >= 0 && cls < KC_COUNT ? kKernelClassNames[cls] : ""; }
 ocrs_status ocrs_engine_kernel_stats(ocrs_engine* e, double* ms, uint64_t* launches, double* flops, double* bytes,
                                      int reset) {
-    return guarded([&] {
+    return guarded_on(e ? e->device : -1, [&] {
         if (!e) fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
         e->timers.collect();
         for (int i = 0; i < KC_COUNT; i++) {
@@ -719,7 +648,7 @@ ocrs_status ocrs_engine_kernel_stats(ocrs_engine* e, double* ms, uint64_t* launc
 int ocrs_stage_count(void) { return ST_COUNT; }
 const char* ocrs_stage_name(int stage) { return stage >= 0 && stage < ST_COUNT ? kStageNames[stage] : ""; }
 ocrs_status ocrs_engine_stage_times(ocrs_engine* e, double* ms, uint64_t* launches, int reset) {
-    return guarded([&] {
+    return guarded_on(e ? e->device : -1, [&] {
         if (!e) fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
         e->timers.collect();
         for (int i = 0; i < ST_COUNT; i++) {

@@ -14,22 +14,51 @@ void set_last_error(const std::string& msg) { g_last_error = msg; }
 const std::string& last_error() { return g_last_error; }
 
 namespace {
-std::atomic<int> g_device{-1};
-thread_local int t_bound_device = -1;
+std::atomic<int> g_default_device{0};
+thread_local DeviceContext* t_ctx = nullptr;   // set by DeviceScope
+constexpr int kMaxDevices = 64;
+std::mutex g_ctx_mu;
+std::atomic<DeviceContext*> g_ctx[kMaxDevices];
 }  // namespace
 
-void select_device(int device) {
-    OCRS_HIP(hipSetDevice(device));
-    g_device.store(device);
-    t_bound_device = device;
+DeviceContext& device_context(int device) {
+    if (device < 0 || device >= kMaxDevices) fail(OCRS_ERR_INVALID_ARGUMENT, "device index %d out of range", device);
+    DeviceContext* c = g_ctx[device].load(std::memory_order_acquire);
+    if (c) return *c;
+    std::lock_guard<std::mutex> g(g_ctx_mu);
+    c = g_ctx[device].load(std::memory_order_relaxed);
+    if (!c) {
+        c = new DeviceContext(device);   // lives for the process (HIP may be gone by the time statics are destroyed)
+        g_ctx[device].store(c, std::memory_order_release);
+    }
+    return *c;
 }
 
-void bind_thread_to_device() {
-    const int d = g_device.load();
-    if (d >= 0 && t_bound_device != d) {
-        OCRS_HIP(hipSetDevice(d));
-        t_bound_device = d;
-    }
+int default_device() { return g_default_device.load(); }
+
+void select_device(int device) {
+    int n = 0;
+    OCRS_HIP(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) fail(OCRS_ERR_INVALID_ARGUMENT, "device %d does not exist (%d visible)", device, n);
+    OCRS_HIP(hipSetDevice(device));
+    g_default_device.store(device);
+}
+
+DeviceContext& ctx() {
+    if (t_ctx) return *t_ctx;
+    return device_context(default_device());
+}
+
+DeviceScope::DeviceScope(int device) : prev_(t_ctx) {
+    DeviceContext& c = device_context(device < 0 ? default_device() : device);
+    // always: other code on this thread (torch, the caller) may have switched the thread's device between our calls
+    OCRS_HIP(hipSetDevice(c.device));
+    t_ctx = &c;
+}
+
+DeviceScope::~DeviceScope() {
+    t_ctx = prev_;
+    if (prev_) (void)hipSetDevice(prev_->device);
 }
 
 const char* const kStageNames[ST_COUNT] = {
@@ -64,6 +93,7 @@ static size_t pool_cap_bytes() {
 
 void* DevicePool::alloc(size_t bytes) {
     size_t sz = round_size(bytes);
+    if (ctx().device != device_) fail(OCRS_ERR_DEVICE, "internal: allocation from device %d's pool on a thread bound to device %d", device_, ctx().device);
     {
         // smallest cached block that fits, if it wastes at most a quarter of the request
         std::lock_guard<std::mutex> g(mu_);
@@ -124,11 +154,6 @@ DevicePool::~DevicePool() {
     // Process teardown: the HIP runtime may already be gone; leak on purpose.
 }
 
-DevicePool& pool() {
-    static DevicePool* p = new DevicePool();
-    return *p;
-}
-
 // ---------------------------------------------------------------- HostPool
 void* HostPool::alloc(size_t bytes) {
     const size_t sz = round_size(bytes);
@@ -143,7 +168,7 @@ void* HostPool::alloc(size_t bytes) {
         }
     }
     void* p = nullptr;
-    OCRS_HIP(hipHostMalloc(&p, sz, hipHostMallocDefault));
+    OCRS_HIP(hipHostMalloc(&p, sz, hipHostMallocPortable));
     std::lock_guard<std::mutex> g(mu_);
     live_[p] = sz;
     return p;
@@ -158,37 +183,42 @@ void HostPool::release(void* p) {
     live_.erase(it);
 }
 
-HostPool& host_pool() {
-    static HostPool* p = new HostPool();
-    return *p;
-}
-
-hipStream_t heavy_stream() {
-    static hipStream_t s = [] {
+hipStream_t DeviceContext::heavy_stream() {
+    std::lock_guard<std::mutex> g(lazy_mu_);
+    if (!heavy_) {
         // Highest queue priority.  The conv stacks are the critical resource of the pipeline: their stream never runs
         // dry in steady state and a step takes as long as its conv stack does.  (Round 1 ran this stream at the LOWEST
         // priority so that the 1 200 dependent GRU step launches of a request would get freed CU slots first; with
         // the recurrence in one persistent launch per layer that reason is gone.  The GPU is work-conserving — every
         // combination of stream priorities measured the same 256-259 pages/s — but here the dominant kernels are
         // stretched least by what runs beside them: 9.9-10.4 ms per launch against 11.2-11.4.)
-        hipStream_t h;
+        DeviceScope bind(device);
         int least = 0, greatest = 0;
         OCRS_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        OCRS_HIP(hipStreamCreateWithPriority(&h, hipStreamNonBlocking, getenv("OCRS_HEAVY_LOW") ? least : greatest));
-        return h;
-    }();
-    return s;
+        OCRS_HIP(hipStreamCreateWithPriority(&heavy_, hipStreamNonBlocking, getenv("OCRS_HEAVY_LOW") ? least : greatest));
+    }
+    return heavy_;
 }
 
-hipStream_t recurrent_stream() {
-    static hipStream_t s = [] {
-        hipStream_t h;
+hipStream_t DeviceContext::recurrent_stream() {
+    std::lock_guard<std::mutex> g(lazy_mu_);
+    if (!recurrent_) {
+        DeviceScope bind(device);
         int least = 0, greatest = 0;
         OCRS_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        OCRS_HIP(hipStreamCreateWithPriority(&h, hipStreamNonBlocking, greatest));
-        return h;
-    }();
-    return s;
+        OCRS_HIP(hipStreamCreateWithPriority(&recurrent_, hipStreamNonBlocking, greatest));
+    }
+    return recurrent_;
+}
+
+int DeviceContext::cu_count() {
+    std::lock_guard<std::mutex> g(lazy_mu_);
+    if (!cus_) {
+        hipDeviceProp_t prop;
+        OCRS_HIP(hipGetDeviceProperties(&prop, device));
+        cus_ = prop.multiProcessorCount;
+    }
+    return cus_;
 }
 
 // ---------------------------------------------------------------- options
@@ -204,6 +234,9 @@ const OptDef kOptDefs[OPT_COUNT] = {
     {"rec_max_pixels", "OCRS_REC_MAX_PIXELS", 0},       // input pixels per recognition sub-request (0 = 2e9, the memory budget)
     {"gemm_nfast", "OCRS_GEMM_NFAST", 1},               // dense GEMMs: column tiles of a row tile side by side on one XCD
     {"gru_gates", "OCRS_GRU_GATES", 1},                 // persistent GRU: gate-per-wave kernel when every row tile gets its own cluster
+    {"coalesce", "OCRS_COALESCE", 2},                   // merged batches of small requests in flight per engine and stage (0 = no merging)
+    {"coalesce_pages", "OCRS_COALESCE_PAGES", 16},      // pages per merged batch; requests of half that size or more run on their own
+    {"coalesce_window_us", "OCRS_COALESCE_WINDOW_US", 300},  // how long a would-be leader lets the queue fill while other batches run
 };
 std::atomic<long> g_opts[OPT_COUNT];
 std::once_flag g_opts_once;
@@ -236,16 +269,11 @@ bool set_option(const char* name, long value) {
 }
 
 // ---------------------------------------------------------------- streams
-namespace {
-std::mutex g_stream_mu;
-std::vector<std::pair<hipStream_t, hipEvent_t>> g_streams[2];  // [0] default priority, [1] highest priority
-}  // namespace
-
-StreamLease::StreamLease(bool high_priority) : high_(high_priority) {
-    high_ = true;  // every request stream outranks the shared conv-stack stream (see heavy_stream())
+StreamLease::StreamLease(bool high_priority) : ctx_(&ctx()), high_(high_priority) {
+    high_ = true;  // every request stream outranks nothing and is outranked by nothing: all at the highest priority (see heavy_stream())
     {
-        std::lock_guard<std::mutex> g(g_stream_mu);
-        auto& v = g_streams[high_ ? 1 : 0];
+        std::lock_guard<std::mutex> g(ctx_->stream_mu);
+        auto& v = ctx_->streams;
         if (!v.empty()) {
             s_ = v.back().first;
             done_ = v.back().second;
@@ -253,19 +281,15 @@ StreamLease::StreamLease(bool high_priority) : high_(high_priority) {
             return;
         }
     }
-    if (high_) {
-        int least = 0, greatest = 0;
-        OCRS_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        OCRS_HIP(hipStreamCreateWithPriority(&s_, hipStreamNonBlocking, greatest));
-    } else {
-        OCRS_HIP(hipStreamCreateWithFlags(&s_, hipStreamNonBlocking));
-    }
+    int least = 0, greatest = 0;
+    OCRS_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    OCRS_HIP(hipStreamCreateWithPriority(&s_, hipStreamNonBlocking, greatest));
     OCRS_HIP(hipEventCreateWithFlags(&done_, hipEventBlockingSync | hipEventDisableTiming));
 }
 
 StreamLease::~StreamLease() {
-    std::lock_guard<std::mutex> g(g_stream_mu);
-    g_streams[high_ ? 1 : 0].emplace_back(s_, done_);
+    std::lock_guard<std::mutex> g(ctx_->stream_mu);
+    ctx_->streams.emplace_back(s_, done_);
 }
 
 // ---------------------------------------------------------------- timers
@@ -274,8 +298,9 @@ std::vector<StageTimers::Pending>& StageTimers::pending() {
     return p;
 }
 std::vector<hipEvent_t>& StageTimers::free_events() {
-    static thread_local std::vector<hipEvent_t> f;
-    return f;
+    // events belong to the device they were created on: one free list per (host thread, device)
+    static thread_local std::map<int, std::vector<hipEvent_t>> f;
+    return f[ctx().device];
 }
 
 hipEvent_t StageTimers::get_event() {

@@ -45,28 +45,33 @@ struct Error : std::runtime_error {
 
 void set_last_error(const std::string& msg);
 
-// The device chosen with ocrs_set_device() is process-wide (one process per GPU); HIP's current
-// device is per host thread, so every API entry binds the calling thread to it.
-void select_device(int device);
-void bind_thread_to_device();
+// ---------------------------------------------------------------------------------------------------------
+// Devices.  Every handle (model, engine, page, engine group member) belongs to ONE HIP device; every API entry
+// binds the calling host thread to its handle's device for the duration of the call (DeviceScope) — HIP's current
+// device is per host thread.  One process can therefore drive several GPUs (ocrs_engine_group_*), or one GPU per
+// process (ocrs_set_device = the default device of handles created without an explicit one).
+// Everything that used to be a process singleton — the caching allocators, the stream pool, the shared conv-stack
+// and recurrence streams with the mutexes that order submissions to them — lives in the device's DeviceContext.
+// ---------------------------------------------------------------------------------------------------------
 
 // Size-bucketed caching allocator: hipMalloc is far too slow to sit on the
 // per-page path, and stages need scratch whose size depends on the page.
 class DevicePool {
   public:
+    explicit DevicePool(int device) : device_(device) {}
     ~DevicePool();
-    void* alloc(size_t bytes);
-    void release(void* p);
+    void* alloc(size_t bytes);     // the calling thread must be bound to this pool's device
+    void release(void* p);         // any thread
     void trim();
+    int device() const { return device_; }
 
   private:
+    const int device_;
     std::mutex mu_;
     std::multimap<size_t, void*> free_;
     std::map<void*, size_t> live_;
     size_t cached_ = 0;  // bytes in free_
 };
-
-DevicePool& pool();
 
 // Pinned host staging (hipHostMalloc), cached by size.  Device-to-host results go through it: a
 // hipMemcpyAsync into PAGEABLE memory does not return until the stream has reached and finished the
@@ -82,38 +87,84 @@ class HostPool {
     std::multimap<size_t, void*> free_;
     std::map<void*, size_t> live_;
 };
-HostPool& host_pool();
 
-// One process-wide stream for the throughput-bound conv stacks of all in-flight requests (model.cpp).
-hipStream_t heavy_stream();
-// One process-wide stream for the persistent GRU recurrences (kernels_gru.hip): their workgroups wait on each
-// other, so they are serialised on the device; highest queue priority.
-hipStream_t recurrent_stream();
+struct DeviceContext {
+    const int device;
+    DevicePool pool;
+    HostPool host_pool;
+    // One stream per device for the throughput-bound conv stacks of all in-flight requests (model.cpp), and one
+    // for the persistent GRU recurrences (kernels_gru.hip): their workgroups wait on each other, so they are
+    // serialised on the device; both at the highest queue priority.  The *_phase mutexes keep "record event, make
+    // the shared stream wait, launch, record, make the request stream wait" atomic per request.
+    std::mutex heavy_phase, rec_phase;
+    hipStream_t heavy_stream();
+    hipStream_t recurrent_stream();
+    int cu_count();
+    // recycled per-call streams (StreamLease)
+    std::mutex stream_mu;
+    std::vector<std::pair<hipStream_t, hipEvent_t>> streams;
+
+    explicit DeviceContext(int d) : device(d), pool(d) {}
+
+  private:
+    std::mutex lazy_mu_;
+    hipStream_t heavy_ = nullptr, recurrent_ = nullptr;
+    int cus_ = 0;
+};
+
+// Registry (contexts are created on first use and live for the process).
+DeviceContext& device_context(int device);
+// Default device of the process: ocrs_set_device(), initially 0.
+int default_device();
+void select_device(int device);
+// The context the calling thread is bound to (the default device's if no DeviceScope is active).
+DeviceContext& ctx();
+
+// Binds the calling thread to `device` (< 0: the default device) for the lifetime of the object; nests.
+class DeviceScope {
+  public:
+    explicit DeviceScope(int device);
+    ~DeviceScope();
+    DeviceScope(const DeviceScope&) = delete;
+    DeviceScope& operator=(const DeviceScope&) = delete;
+
+  private:
+    DeviceContext* prev_;
+};
+
+inline DevicePool& pool() { return ctx().pool; }
+inline HostPool& host_pool() { return ctx().host_pool; }
+inline hipStream_t heavy_stream() { return ctx().heavy_stream(); }
+inline hipStream_t recurrent_stream() { return ctx().recurrent_stream(); }
 
 // Process-wide tuning options (ocrs_set_option; initial value from the environment variable OCRS_<NAME>).
 // Integer-valued, looked up by name; unknown names are rejected by the ABI.
-enum Option { OPT_GRU_MODE = 0, OPT_DET_FUSE, OPT_LAYOUT_THREADS, OPT_BEAM_GPU, OPT_GRU_LOCAL, OPT_GRU_SCATTER, OPT_REC_MAX_PIXELS, OPT_GEMM_NFAST, OPT_GRU_GATES, OPT_COUNT };
+enum Option { OPT_GRU_MODE = 0, OPT_DET_FUSE, OPT_LAYOUT_THREADS, OPT_BEAM_GPU, OPT_GRU_LOCAL, OPT_GRU_SCATTER, OPT_REC_MAX_PIXELS, OPT_GEMM_NFAST, OPT_GRU_GATES,
+              OPT_COALESCE, OPT_COALESCE_PAGES, OPT_COALESCE_WINDOW_US, OPT_COUNT };
 enum { GRU_PERSISTENT = 0, GRU_STEP = 1 };
 int option(Option o);
 long option_long(Option o);
 bool set_option(const char* name, long value);  // false: unknown name
 inline int gru_mode() { return option(OPT_GRU_MODE); }
 
-// RAII device buffer from the pool.
+// RAII device buffer from the pool of the device the allocating thread is bound to; remembers its pool, so it may
+// be released from any thread (e.g. ocrs_page_free on a thread bound to another device).
 struct DevBuf {
     void* p = nullptr;
     size_t bytes = 0;
+    DevicePool* owner = nullptr;
     DevBuf() = default;
-    explicit DevBuf(size_t n) : p(n ? pool().alloc(n) : nullptr), bytes(n) {}
+    explicit DevBuf(size_t n) : bytes(n), owner(n ? &pool() : nullptr) { p = n ? owner->alloc(n) : nullptr; }
     DevBuf(const DevBuf&) = delete;
     DevBuf& operator=(const DevBuf&) = delete;
-    DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr; o.bytes = 0; }
+    DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes), owner(o.owner) { o.p = nullptr; o.bytes = 0; o.owner = nullptr; }
     DevBuf& operator=(DevBuf&& o) noexcept {
-        if (this != &o) { reset(); p = o.p; bytes = o.bytes; o.p = nullptr; o.bytes = 0; }
+        if (this != &o) { reset(); p = o.p; bytes = o.bytes; owner = o.owner; o.p = nullptr; o.bytes = 0; o.owner = nullptr; }
         return *this;
     }
     ~DevBuf() { reset(); }
-    void reset() { if (p) pool().release(p); p = nullptr; bytes = 0; }
+    void reset() { if (p && owner) owner->release(p); p = nullptr; bytes = 0; owner = nullptr; }
+    int device() const { return owner ? owner->device() : -1; }
     template <class T> T* as() const { return static_cast<T*>(p); }
 };
 
@@ -122,7 +173,7 @@ struct PinnedBuf {
     void* p = nullptr;
     size_t bytes = 0;
     PinnedBuf() = default;
-    explicit PinnedBuf(size_t n) : bytes(n) { if (n) OCRS_HIP(hipHostMalloc(&p, n, hipHostMallocDefault)); }
+    explicit PinnedBuf(size_t n) : bytes(n) { if (n) OCRS_HIP(hipHostMalloc(&p, n, hipHostMallocPortable)); }
     PinnedBuf(const PinnedBuf&) = delete;
     PinnedBuf& operator=(const PinnedBuf&) = delete;
     ~PinnedBuf() { if (p) (void)hipHostFree(p); }
@@ -155,6 +206,7 @@ class StreamLease {
     hipError_t sync_noexcept() const noexcept { return wait_done(); }
 
   private:
+    DeviceContext* ctx_;   // the pool the stream goes back to
     hipStream_t s_;
     hipEvent_t done_;
     bool high_;
@@ -225,6 +277,7 @@ struct StageScope {
 // the pool, so no other call can be handed memory that is still in flight.
 struct Workspace {
     StreamLease stream;
+    HostPool& hpool = host_pool();             // of the device this call is bound to (fixed at construction)
     std::vector<DevBuf> bufs;
     std::vector<hipEvent_t> events;            // cross-stream dependencies created by this call
     hipEvent_t make_event() {
@@ -240,7 +293,7 @@ struct Workspace {
     std::vector<void*> upload_staging;
     void upload(void* d_dst, const void* h_src, size_t bytes) {
         if (!bytes) return;
-        void* pin = host_pool().alloc(bytes);
+        void* pin = hpool.alloc(bytes);
         memcpy(pin, h_src, bytes);
         upload_staging.push_back(pin);
         OCRS_HIP(hipMemcpyAsync(d_dst, pin, bytes, hipMemcpyHostToDevice, stream.get()));
@@ -251,7 +304,7 @@ struct Workspace {
     std::vector<Download> downloads;
     void download(void* h_dst, const void* d_src, size_t bytes, hipStream_t st = nullptr) {
         if (!bytes) return;
-        void* pin = host_pool().alloc(bytes);
+        void* pin = hpool.alloc(bytes);
         downloads.push_back(Download{pin, h_dst, bytes});
         OCRS_HIP(hipMemcpyAsync(pin, d_src, bytes, hipMemcpyDeviceToHost, st ? st : stream.get()));
     }
@@ -261,10 +314,10 @@ struct Workspace {
     void finish_downloads(bool copy) {  // call only after the stream has drained
         for (const Download& d : downloads) {
             if (copy) memcpy(d.dst, d.pinned, d.bytes);
-            host_pool().release(d.pinned);
+            hpool.release(d.pinned);
         }
         downloads.clear();
-        for (void* p : upload_staging) host_pool().release(p);
+        for (void* p : upload_staging) hpool.release(p);
         upload_staging.clear();
     }
     void sync() {

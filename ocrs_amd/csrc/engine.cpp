@@ -13,8 +13,8 @@ using namespace ocrs::geom;
 // ===========================================================================
 // Detection — detection.rs:104-200
 // ===========================================================================
-void ocrs_engine::detect(const ocrs_page* const* pages, size_t n, std::vector<std::vector<RotatedRect>>* rects_out,
-                         float* host_map) const {
+void ocrs_engine::detect_now(const ocrs_page* const* pages, size_t n, std::vector<std::vector<RotatedRect>>* rects_out,
+                             float* host_map) const {
     if (!detection) fail(OCRS_ERR_MODEL_NOT_LOADED, "Detection model not loaded");
     if (n == 0) {
         if (rects_out) rects_out->clear();
@@ -97,31 +97,41 @@ void ocrs_engine::detect(const ocrs_page* const* pages, size_t n, std::vector<st
 
     // connected components -> rects (detection.rs:41-62)
     const int64_t px = (int64_t)h * w;
+    // Scratch is sized for pages of text: up to 65 536 components and 2 border points per pixel.  The reference
+    // takes ANY mask (detection.rs:41-62), so a page that does not fit (salt noise, dense halftone) gets its
+    // component stage re-run on its own with buffers for the worst case — below.
     const int max_comp = (int)std::min<int64_t>(65536, px / 2 + 16);
     const int64_t arena = 2 * px + 64;
-    k::CclBuffers b{};
-    b.labels = ws.alloc_n<int32_t>((size_t)N * px);
-    b.row_counts = ws.alloc_n<int32_t>((size_t)N * h);
-    b.row_offsets = ws.alloc_n<int32_t>((size_t)N * h);
-    b.n_roots = ws.alloc_n<int32_t>(N);
-    b.roots = ws.alloc_n<int32_t>((size_t)N * max_comp);
-    b.lengths = ws.alloc_n<int32_t>((size_t)N * max_comp);
-    b.offsets = ws.alloc_n<int32_t>((size_t)N * max_comp);
-    b.overflow = ws.alloc_n<int32_t>(N);
-    b.pts = ws.alloc_n<uint32_t>((size_t)N * arena);
-    b.tmp = ws.alloc_n<uint32_t>((size_t)N * arena * 4);
-    b.keep = ws.alloc_n<uint8_t>((size_t)N * arena);
-    b.rects = ws.alloc_n<float>((size_t)N * max_comp * 6);
-    b.valid = ws.alloc_n<uint8_t>((size_t)N * max_comp);
-    OCRS_HIP(hipMemsetAsync(b.overflow, 0, N * sizeof(int32_t), st));
-    {
-        StageScope sc(T, ST_CCL, st, 6);
-        k::ccl_label(d_mask, N, h, w, b, max_comp, st);
-    }
-    {
-        StageScope sc(T, ST_CONTOUR_RECTS, st, 3);
-        k::contour_rects(d_mask, N, h, w, b, max_comp, arena, /*expand*/ 3.0f, min_area, /*eps*/ 2.0f, st);
-    }
+    auto alloc_ccl = [&](int np, int mc, int64_t ar) {
+        k::CclBuffers b{};
+        b.labels = ws.alloc_n<int32_t>((size_t)np * px);
+        b.row_counts = ws.alloc_n<int32_t>((size_t)np * h);
+        b.row_offsets = ws.alloc_n<int32_t>((size_t)np * h);
+        b.n_roots = ws.alloc_n<int32_t>(np);
+        b.roots = ws.alloc_n<int32_t>((size_t)np * mc);
+        b.lengths = ws.alloc_n<int32_t>((size_t)np * mc);
+        b.offsets = ws.alloc_n<int32_t>((size_t)np * mc);
+        b.overflow = ws.alloc_n<int32_t>(np);
+        b.pts = ws.alloc_n<uint32_t>((size_t)np * ar);
+        b.tmp = ws.alloc_n<uint32_t>((size_t)np * ar * 4);
+        b.keep = ws.alloc_n<uint8_t>((size_t)np * ar);
+        b.rects = ws.alloc_n<float>((size_t)np * mc * 6);
+        b.valid = ws.alloc_n<uint8_t>((size_t)np * mc);
+        OCRS_HIP(hipMemsetAsync(b.overflow, 0, np * sizeof(int32_t), st));
+        return b;
+    };
+    auto run_ccl = [&](const uint8_t* mask, int np, const k::CclBuffers& b, int mc, int64_t ar) {
+        {
+            StageScope sc(T, ST_CCL, st, 6);
+            k::ccl_label(mask, np, h, w, b, mc, st);
+        }
+        {
+            StageScope sc(T, ST_CONTOUR_RECTS, st, 3);
+            k::contour_rects(mask, np, h, w, b, mc, ar, /*expand*/ 3.0f, min_area, /*eps*/ 2.0f, st);
+        }
+    };
+    const k::CclBuffers b = alloc_ccl(N, max_comp, arena);
+    run_ccl(d_mask, N, b, max_comp, arena);
     // One round trip in the common case: the counts travel together with the first kSpec candidate rects of every
     // page (a page of text has a few hundred to ~1 500 components); only a page with more needs a second one.
     constexpr int kSpec = 2048;
@@ -138,14 +148,12 @@ void ocrs_engine::detect(const ocrs_page* const* pages, size_t n, std::vector<st
         ws.download(hv[i].data(), b.valid + (size_t)i * max_comp, spec);
     }
     ws.sync();
-    for (int i = 0; i < N; i++)
-        if (ovf[i] || counts[i] > max_comp)
-            fail(OCRS_ERR_CAPACITY, "text mask of page %d has too many components or border pixels (%d components)", i,
-                 counts[i]);
     rects_out->assign(n, {});
     bool more = false;
+    std::vector<int> big;   // pages whose component stage did not fit
     for (int i = 0; i < N; i++) {
         const int cnt = counts[i];
+        if (ovf[i] || cnt > max_comp) { big.push_back(i); continue; }
         if (cnt <= spec) continue;
         more = true;
         hr[i].resize((size_t)cnt * 6);
@@ -154,12 +162,156 @@ void ocrs_engine::detect(const ocrs_page* const* pages, size_t n, std::vector<st
         ws.download(hv[i].data(), b.valid + (size_t)i * max_comp, cnt);
     }
     if (more) ws.sync();
+    for (int i : big) {
+        // Worst case of an h x w mask: no more than px / 4 + O(h + w) 8-connected components can be pairwise
+        // separated, and a border walk enters a pixel at most once per direction (8 px points in total).
+        const int64_t mc64 = px / 4 + (int64_t)h + w + 16, ar_big = 8 * px + 64;
+        if (ar_big >= (int64_t)0x7fffffff)
+            fail(OCRS_ERR_CAPACITY, "text mask of page %d: %lld pixels exceed the 32-bit contour arena", i, (long long)px);
+        const int mc = (int)mc64;
+        const k::CclBuffers bb = alloc_ccl(1, mc, ar_big);
+        run_ccl(d_mask + (size_t)i * px, 1, bb, mc, ar_big);
+        int32_t cnt = 0, o = 0;
+        ws.download(&cnt, bb.n_roots, sizeof cnt);
+        ws.download(&o, bb.overflow, sizeof o);
+        ws.sync();
+        if (o || cnt > mc)
+            fail(OCRS_ERR_DEVICE, "internal: component stage of page %d overflowed its worst-case buffers (%d components)", i, cnt);
+        counts[i] = cnt;
+        hr[i].resize((size_t)cnt * 6);
+        hv[i].resize(cnt);
+        ws.download(hr[i].data(), bb.rects, hr[i].size() * sizeof(float));
+        ws.download(hv[i].data(), bb.valid, cnt);
+        ws.sync();
+    }
     for (int i = 0; i < N; i++) {
         auto& out = (*rects_out)[i];
         for (int c = 0; c < counts[i]; c++)
             if (hv[i][c]) out.push_back(RotatedRect::from_array(&hr[i][(size_t)c * 6]));
     }
     if (T) T->collect();
+}
+
+// ===========================================================================
+// Coalescing front ends (coalesce.hpp): concurrent small requests share one launch sequence
+// ===========================================================================
+namespace {
+
+// Runs `merged` for the whole batch; if that fails and the batch has several requests, every request is re-run
+// on its own so that an error reaches only the caller whose input caused it.
+template <class Req, class Merged, class Single>
+void run_batch(std::vector<Req*>& batch, Merged&& merged, Single&& single) {
+    try {
+        merged();
+        return;
+    } catch (...) {
+        if (batch.size() == 1) {
+            batch[0]->error = std::current_exception();
+            return;
+        }
+    }
+    for (Req* r : batch) {
+        try {
+            single(*r);
+        } catch (...) {
+            r->error = std::current_exception();
+        }
+    }
+}
+
+}  // namespace
+
+void ocrs_engine::init_coalescers() {
+    det_queue = std::make_unique<Coalescer<DetRequest>>(
+        [this](std::vector<DetRequest*>& batch) {
+            run_batch(
+                batch,
+                [&] {
+                    if (batch.size() == 1) { detect_now(batch[0]->pages, batch[0]->n, batch[0]->rects, nullptr); return; }
+                    std::vector<const ocrs_page*> pages;
+                    for (DetRequest* r : batch) pages.insert(pages.end(), r->pages, r->pages + r->n);
+                    std::vector<std::vector<RotatedRect>> rects;
+                    detect_now(pages.data(), pages.size(), &rects, nullptr);
+                    size_t at = 0;
+                    for (DetRequest* r : batch) {
+                        r->rects->assign(std::make_move_iterator(rects.begin() + at), std::make_move_iterator(rects.begin() + at + r->n));
+                        at += r->n;
+                    }
+                },
+                [&](DetRequest& r) { detect_now(r.pages, r.n, r.rects, nullptr); });
+        },
+        [](const DetRequest& a, const DetRequest& b) {   // one detection batch = pages of one size (detect_now checks it)
+            return a.pages[0]->h == b.pages[0]->h && a.pages[0]->w == b.pages[0]->w;
+        });
+    rec_queue = std::make_unique<Coalescer<RecRequest>>(
+        [this](std::vector<RecRequest*>& batch) {
+            run_batch(
+                batch,
+                [&] {
+                    if (batch.size() == 1) {
+                        RecRequest& r = *batch[0];
+                        recognize_now(r.pages, r.n_pages, *r.lines_per_page, r.steps, r.rec_lines, r.ctc_len);
+                        return;
+                    }
+                    std::vector<const ocrs_page*> pages;
+                    std::vector<std::vector<std::vector<RotatedRect>>> lpp;
+                    for (RecRequest* r : batch) {
+                        pages.insert(pages.end(), r->pages, r->pages + r->n_pages);
+                        lpp.insert(lpp.end(), r->lines_per_page->begin(), r->lines_per_page->end());
+                    }
+                    std::vector<std::vector<CtcStep>> steps;
+                    std::vector<RecLine> rl;
+                    std::vector<uint32_t> cl;
+                    recognize_now(pages.data(), pages.size(), lpp, &steps, &rl, &cl);
+                    size_t line0 = 0, page0 = 0;
+                    for (RecRequest* r : batch) {
+                        size_t nl = 0;
+                        for (const auto& pg : *r->lines_per_page) nl += pg.size();
+                        r->steps->assign(std::make_move_iterator(steps.begin() + line0), std::make_move_iterator(steps.begin() + line0 + nl));
+                        r->ctc_len->assign(cl.begin() + line0, cl.begin() + line0 + nl);
+                        r->rec_lines->assign(std::make_move_iterator(rl.begin() + line0), std::make_move_iterator(rl.begin() + line0 + nl));
+                        for (RecLine& l : *r->rec_lines) {   // back to the caller's numbering
+                            l.page -= page0;
+                            l.index -= line0;
+                        }
+                        line0 += nl;
+                        page0 += r->n_pages;
+                    }
+                },
+                [&](RecRequest& r) { recognize_now(r.pages, r.n_pages, *r.lines_per_page, r.steps, r.rec_lines, r.ctc_len); });
+        },
+        [](const RecRequest&, const RecRequest&) { return true; });   // lines of any pages share a ragged batch
+}
+
+void ocrs_engine::detect(const ocrs_page* const* pages, size_t n, std::vector<std::vector<RotatedRect>>* rects_out,
+                         float* host_map) const {
+    const int max_active = option(OPT_COALESCE);
+    const size_t max_pages = (size_t)std::max(1, option(OPT_COALESCE_PAGES));
+    // merged only where it cannot be observed: HIP executor (a caller's `trait Model` sees every run), rects only
+    if (max_active <= 0 || !det_queue || !rects_out || host_map || n == 0 || 2 * n > max_pages || !detection ||
+        detection->is_callback() || debug) {
+        detect_now(pages, n, rects_out, host_map);
+        return;
+    }
+    DetRequest r;
+    r.pages = pages; r.n = n; r.rects = rects_out; r.weight = n;
+    det_queue->submit(r, max_active, max_pages, option_long(OPT_COALESCE_WINDOW_US));
+}
+
+void ocrs_engine::recognize(const ocrs_page* const* pages, size_t n_pages,
+                            const std::vector<std::vector<std::vector<RotatedRect>>>& lines_per_page,
+                            std::vector<std::vector<CtcStep>>* steps_out, std::vector<RecLine>* rec_lines_out,
+                            std::vector<uint32_t>* ctc_len_out) const {
+    const int max_active = option(OPT_COALESCE);
+    const size_t max_pages = (size_t)std::max(1, option(OPT_COALESCE_PAGES));
+    if (max_active <= 0 || !rec_queue || n_pages == 0 || 2 * n_pages > max_pages || !recognition || recognition->is_callback()) {
+        recognize_now(pages, n_pages, lines_per_page, steps_out, rec_lines_out, ctc_len_out);
+        return;
+    }
+    RecRequest r;
+    r.pages = pages; r.n_pages = n_pages; r.lines_per_page = &lines_per_page;
+    r.steps = steps_out; r.rec_lines = rec_lines_out; r.ctc_len = ctc_len_out; r.weight = n_pages;
+    rec_queue->submit(r, max_active, max_pages, option_long(OPT_COALESCE_WINDOW_US));
 }
 
 // ===========================================================================
@@ -252,10 +404,10 @@ static double rec_pixel_budget() {
     return v > 0 ? (double)v : 2.0e9;
 }
 
-void ocrs_engine::recognize(const ocrs_page* const* pages, size_t n_pages,
-                            const std::vector<std::vector<std::vector<RotatedRect>>>& lines_per_page,
-                            std::vector<std::vector<CtcStep>>* steps_out, std::vector<RecLine>* rec_lines_out,
-                            std::vector<uint32_t>* ctc_len_out) const {
+void ocrs_engine::recognize_now(const ocrs_page* const* pages, size_t n_pages,
+                                const std::vector<std::vector<std::vector<RotatedRect>>>& lines_per_page,
+                                std::vector<std::vector<CtcStep>>* steps_out, std::vector<RecLine>* rec_lines_out,
+                                std::vector<uint32_t>* ctc_len_out) const {
     if (!recognition) fail(OCRS_ERR_MODEL_NOT_LOADED, "Recognition model not loaded");
     const uint32_t rec_h = rec_input_height();
     std::vector<RecLine> lines;
@@ -302,10 +454,7 @@ void ocrs_engine::recognize_lines(const ocrs_page* const* pages, size_t n_pages,
 
     // group by padded width (recognition.rs:430-446); std::map gives a deterministic order
     std::map<uint32_t, std::vector<size_t>> groups;
-    for (size_t i = 0; i < L; i++) {
-        if (lines[i].polygon.size() > 512) fail(OCRS_ERR_CAPACITY, "text line %zu has more than 128 words", i);
-        groups[lines[i].group_width].push_back(i);
-    }
+    for (size_t i = 0; i < L; i++) groups[lines[i].group_width].push_back(i);
 
     Workspace ws;
     hipStream_t st = ws.s();

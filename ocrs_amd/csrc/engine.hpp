@@ -4,13 +4,17 @@
 #include <string>
 #include <vector>
 
+#include <memory>
+
+#include "coalesce.hpp"
 #include "common.hpp"
 #include "geometry.hpp"
 #include "model.hpp"
 
 struct ocrs_page {  // OcrInput (lib.rs:125-128)
-    ocrs::DevBuf grey;  // [h, w] fp32 in [-0.5, 0.5]
+    ocrs::DevBuf grey;  // [h, w] fp32 in [-0.5, 0.5]; on the device of the engine that prepared it
     int h = 0, w = 0;
+    int device() const { return grey.device(); }
 };
 
 namespace ocrs {
@@ -36,9 +40,25 @@ struct RecLine {  // TextRecLine (recognition.rs:80-89) + owning page
     uint32_t group_width = 0;
 };
 
+// One caller's detection / recognition request while it waits in the engine's coalescer (coalesce.hpp).
+struct DetRequest : CoalescedBase {
+    const ocrs_page* const* pages = nullptr;
+    size_t n = 0;
+    std::vector<std::vector<geom::RotatedRect>>* rects = nullptr;
+};
+struct RecRequest : CoalescedBase {
+    const ocrs_page* const* pages = nullptr;
+    size_t n_pages = 0;
+    const std::vector<std::vector<std::vector<geom::RotatedRect>>>* lines_per_page = nullptr;
+    std::vector<std::vector<CtcStep>>* steps = nullptr;
+    std::vector<RecLine>* rec_lines = nullptr;
+    std::vector<uint32_t>* ctc_len = nullptr;
+};
+
 }  // namespace ocrs
 
 struct ocrs_engine {
+    int device = 0;   // the HIP device of its models (ocrs_engine_new); every call binds the calling thread to it
     const ocrs::ModelBase* detection = nullptr;
     const ocrs::ModelBase* recognition = nullptr;
     bool debug = false;
@@ -55,15 +75,26 @@ struct ocrs_engine {
 
     ocrs::StageTimers* tm() const { return timers.enabled ? &timers : nullptr; }
 
-    // detection.rs:104-200 over a batch of equally sized pages.
+    // detection.rs:104-200 over a batch of equally sized pages.  Small requests (fewer pages than half of option
+    // "coalesce_pages") that only want rects are merged with concurrent ones (coalesce.hpp); results are those of
+    // detect_now on the caller's pages alone.
     void detect(const ocrs_page* const* pages, size_t n, std::vector<std::vector<ocrs::geom::RotatedRect>>* rects,
                 float* host_map /* [n,h,w] or null */) const;
+    void detect_now(const ocrs_page* const* pages, size_t n, std::vector<std::vector<ocrs::geom::RotatedRect>>* rects,
+                    float* host_map) const;
 
-    // recognition.rs:404-540 over the lines of several pages.
+    // recognition.rs:404-540 over the lines of several pages; small requests are merged likewise.
     void recognize(const ocrs_page* const* pages, size_t n_pages,
                    const std::vector<std::vector<std::vector<ocrs::geom::RotatedRect>>>& lines_per_page,
                    std::vector<std::vector<ocrs::CtcStep>>* steps, std::vector<ocrs::RecLine>* rec_lines,
                    std::vector<uint32_t>* ctc_input_len) const;
+    void recognize_now(const ocrs_page* const* pages, size_t n_pages,
+                       const std::vector<std::vector<std::vector<ocrs::geom::RotatedRect>>>& lines_per_page,
+                       std::vector<std::vector<ocrs::CtcStep>>* steps, std::vector<ocrs::RecLine>* rec_lines,
+                       std::vector<uint32_t>* ctc_input_len) const;
+    void init_coalescers();
+    mutable std::unique_ptr<ocrs::Coalescer<ocrs::DetRequest>> det_queue;
+    mutable std::unique_ptr<ocrs::Coalescer<ocrs::RecRequest>> rec_queue;
     // one sub-request of `recognize` (within the activation budget); outputs indexed like `lines`
     void recognize_lines(const ocrs_page* const* pages, size_t n_pages, const std::vector<ocrs::RecLine>& lines,
                          std::vector<std::vector<ocrs::CtcStep>>* steps, std::vector<uint32_t>* ctc_input_len) const;

@@ -130,13 +130,14 @@ bool gru_step_fused(const float* gx, const float* wh, const float* bh, const flo
 // ---- kernels_gru.hip: all time steps of one bidirectional GRU layer in ONE persistent launch.
 // d_sync: gru_persistent_sync_words(M) words of scratch (zeroed by the call); its last word is non-zero
 // afterwards if a wait inside the kernel timed out.  Returns false (nothing launched) if the shape is not
-// supported (H, more than 4096 lines, Tmax beyond the LDS table): the caller then runs gru_step_fused per step.
+// supported (H, more than 4096 lines, Tmax beyond the LDS table, a device that cannot keep a whole group of clusters
+// resident): the caller then runs gru_step_fused per step.
 // gru_persistent_prepare marks every word of y "unwritten" (the kernel's hand-off protocol reads y as its own
 // flag); call it on a stream ordered before gru_persistent.
 size_t gru_persistent_sync_words(int M);
 bool gru_persistent_supported(int M, int Tmax, int64_t R, int H);
 bool gru_tile_plan(const int32_t* h_Tm, int M, int H, int* ncl, int16_t* tiles /* [512] */);  // host only: the deal of row tiles to waves
-void gru_persistent_prepare(float* y, int64_t R, int H, hipStream_t s);
+hipError_t gru_persistent_prepare(float* y, int64_t R, int H, hipStream_t s);
 // h_Tm: the same lengths as d_Tm on the host (descending) — the deal of row tiles to waves is computed from them.
 bool gru_persistent(const float* gx, const float* wh, const float* bh, float* y, const int32_t* d_Tm, const int32_t* d_off,
                     const int32_t* h_Tm, int64_t R, int M, int Tmax, int H, uint32_t* d_sync, hipStream_t s);

@@ -30,6 +30,8 @@
 // wants lane (row, kq) to hold h[row][4*s + kq]; rows are fetched as 16-byte pieces and turned by a
 // 4x4 transpose across the four 16-lane groups (v_permlane16_swap / v_permlane32_swap).
 #include <cstdlib>
+#include <map>
+#include <mutex>
 #include <vector>
 
 #include "common.hpp"
@@ -415,18 +417,14 @@ template <int H>
 __global__ void __launch_bounds__(256)
 gru_gates_kernel(GruParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds_w[];  // H*48 floats | off[Tmax+1] | exchange | abort
-    // ONE workgroup of this kernel per CU, through the register file: the clobber pushes the allocation past 256
-    // registers per lane, i.e. one wave per SIMD.  At its natural 117 registers the hardware puts two workgroups on a
-    // CU as soon as other requests' kernels occupy part of the chip; their six polling waves then kept that CU's
-    // memory pipeline so full that the awaited stores did not get through (waits of seconds, every run with 2+
-    // requests in flight, before await_state backed off).  With the back-off the shared placement works as well, but
-    // one workgroup per CU — what the general kernel's 299 registers impose anyway — is 5 % faster under load.
+    // ONE workgroup of this kernel per CU, enforced through the register file: the clobber pushes the allocation past
+    // 256 registers per lane, i.e. one wave per SIMD.  At its natural 117 registers the hardware puts two workgroups
+    // on a CU as soon as other requests' kernels occupy part of the chip; their six polling waves then re-issued the 17
+    // state loads back to back and kept that CU's memory pipeline so full that the awaited stores did not get through
+    // (waits of seconds in every run with 2+ requests in flight).  await_state now backs off, with which the shared
+    // placement works too; one workgroup per CU — what the general kernel's 299 registers impose anyway — stays
+    // because it measured 5 % faster under load.
     asm volatile("v_accvgpr_write_b32 a200, 0" ::: "a200");
-    // ONE workgroup of this kernel per CU, enforced through the register file: the clobber makes the allocation
-    // exceed 256 registers per lane, i.e. one wave per SIMD.  At its natural 117 registers two workgroups can share a
-    // CU, and in that placement (seen as soon as another request's kernels occupy part of the chip) waits for a peer
-    // workgroup's state timed out — every run with 2+ requests in flight, none with this line, none for the general
-    // kernel, whose 299 registers impose the same placement.  Cause not established; kept out by construction.
     constexpr int UB = H / 16;
     const int b = blockIdx.x;
     const int q = b >> 3;
@@ -558,18 +556,63 @@ static size_t gru_gates_lds_bytes(int H, int Tmax) {   // Wh slice | off table (
 size_t gru_persistent_sync_words(int) { return kMaxGrid + 1; }  // placement table + error word (last)
 
 // y -> all words "unwritten"; any stream that is ordered before the recurrence (it does not depend on gx)
-void gru_persistent_prepare(float* y, int64_t R, int H, hipStream_t s) {
-    if (R > 0) (void)hipMemsetAsync(y, 0xFF, (size_t)R * 2 * H * sizeof(float), s);
+hipError_t gru_persistent_prepare(float* y, int64_t R, int H, hipStream_t s) {
+    return R > 0 ? hipMemsetAsync(y, 0xFF, (size_t)R * 2 * H * sizeof(float), s) : hipSuccess;
+}
+
+// How many workgroups of the recurrence kernels the CURRENT device keeps resident at once: CUs x workgroups per CU
+// (hipOccupancyMaxActiveBlocksPerMultiprocessor for the kernel's registers and LDS), capped at one per CU — the
+// placement both kernels are built for.  Their workgroups wait for each other, so a launch is only safe when every
+// workgroup of the earliest unfinished group of clusters can be resident together.  With in-order dispatch that
+// holds iff the device holds one whole group (8 clusters x UB workgroups): the resident set is always the earliest
+// unfinished workgroups, and while the earliest unfinished group is not fully dispatched fewer than 8 * UB of its
+// workgroups hold slots, so the dispatcher still has room.  Devices / partitions with fewer slots get no plan and
+// the caller runs the per-step kernels instead.  Cached per device.
+static int gru_resident_capacity(int H, bool gates, size_t lds) {
+    static std::mutex mu;
+    static std::map<int, int> cache;   // key: device * 8 + (gates ? 4 : 0) + log-ish(H)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    const int key = dev * 8 + (gates ? 4 : 0) + (H == 256 ? 2 : H == 128 ? 1 : 0);
+    {
+        std::lock_guard<std::mutex> g(mu);
+        auto it = cache.find(key);
+        if (it != cache.end()) return it->second;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+    int per_cu = 0;
+    hipError_t e;
+    if (gates) {
+        e = H == 256 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gru_gates_kernel<256>, 256, lds)
+          : H == 128 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gru_gates_kernel<128>, 256, lds)
+                     : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gru_gates_kernel<64>, 256, lds);
+    } else {
+        e = H == 256 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gru_persistent_kernel<256>, 256, lds)
+          : H == 128 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gru_persistent_kernel<128>, 256, lds)
+                     : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gru_persistent_kernel<64>, 256, lds);
+    }
+    if (e != hipSuccess) { (void)hipGetLastError(); per_cu = 0; }
+    int cap = prop.multiProcessorCount * (per_cu > 0 ? 1 : 0);   // one workgroup per CU by design
+    if (const char* env = getenv("OCRS_GRU_BLOCKS")) { const int v = atoi(env); if (v > 0) cap = v < cap ? v : cap; }
+    std::lock_guard<std::mutex> g(mu);
+    cache[key] = cap;
+    return cap;
 }
 
 // Grid geometry: ncl clusters per direction (UB workgroups each); false if the shape is not supported.
-// Every workgroup of a cluster must be resident at once, so the grid stays at about one workgroup per CU (256),
-// two per CU for requests of more than 4 tiles per wave at that size (> 2048 lines at H = 256).
+// Every workgroup of a cluster must be resident at once, so the first wave of the grid stays within `max_blocks`
+// resident workgroups (the device's capacity, at most one per CU: 256 on MI355X); requests of more than 4 tiles per
+// wave at that size (> 2048 lines at H = 256) get twice the clusters, whose second half is dispatched as the first
+// finishes (see gru_resident_capacity for why that cannot deadlock).
 static bool gru_plan(int M, int Tmax, int H, int* ncl, int max_blocks = 256) {
     if (H != 256 && H != 128 && H != 64) return false;
     const int ntiles = (M + 15) / 16;
     const int UB = H / 16;
-    int max_ncl = max_blocks / UB / 2 >= 1 ? max_blocks / UB / 2 : 1;
+    max_blocks = max_blocks > 256 ? 256 : max_blocks;
+    max_blocks -= max_blocks % (8 * UB);                 // whole groups of 8 clusters
+    if (max_blocks < 8 * UB) return false;               // the device cannot hold one group of clusters
+    int max_ncl = max_blocks / UB / 2;
     if (ntiles > 16 * max_ncl) max_ncl *= 2;
     if (ntiles > 16 * max_ncl || 4 * max_ncl > kMaxSlots) return false;
     *ncl = (ntiles + 3) / 4 < max_ncl ? (ntiles + 3) / 4 : max_ncl;
@@ -616,30 +659,40 @@ static void gru_assign_tiles(const int32_t* h_Tm, int M, int ncl, int16_t* tiles
 // The deal gru_persistent would use for these (descending) line lengths: clusters per direction and, per wave slot
 // (cluster * 4 + wave), up to 4 row-tile indices, -1 = none.  Host only (tests).
 bool gru_tile_plan(const int32_t* h_Tm, int M, int H, int* ncl, int16_t* tiles /* [kMaxSlots * 4] */) {
-    if (M <= 0 || !gru_plan(M, h_Tm[0], H, ncl)) return false;
+    for (int i = 0; i < kMaxSlots * 4; i++) tiles[i] = -1;   // the whole buffer: slots beyond 4 * ncl stay "none"
+    if (M <= 0 || !gru_plan(M, h_Tm[0], H, ncl)) return false;   // (host only: planned for a 256-CU device)
     gru_assign_tiles(h_Tm, M, *ncl, tiles);
     return true;
 }
 
+static size_t gru_general_lds_bytes(int H, int Tmax) { return (size_t)H * 48 * sizeof(float) + ((size_t)Tmax + 1) * sizeof(int); }
+
 bool gru_persistent_supported(int M, int Tmax, int64_t R, int H) {
     int ncl;
+    if (H != 256 && H != 128 && H != 64) return false;
     // y is addressed through one buffer resource: < 4 GiB
-    return M > 0 && (uint64_t)R * 2 * H * sizeof(float) < (uint64_t(1) << 32) && gru_plan(M, Tmax, H, &ncl);
+    return M > 0 && (uint64_t)R * 2 * H * sizeof(float) < (uint64_t(1) << 32) &&
+           gru_plan(M, Tmax, H, &ncl, gru_resident_capacity(H, false, gru_general_lds_bytes(H, Tmax)));
 }
 
 // gate-per-wave kernel: every tile has a cluster of its own
 static bool gru_gates_plan(int M, int Tmax, int H, int* ncl) {
     if (H != 256 && H != 128 && H != 64) return false;
+    if (gru_gates_lds_bytes(H, Tmax) > 64 * 1024) return false;
     const int ntiles = (M + 15) / 16, UB = H / 16;
+    int cap = gru_resident_capacity(H, true, gru_gates_lds_bytes(H, Tmax));
+    cap = cap > 256 ? 256 : cap;
+    cap -= cap % (8 * UB);
+    if (cap < 8 * UB) return false;
     // One workgroup per CU, as for the general kernel: 256 / UB / 2 clusters per direction.  (Two workgroups per CU
     // ran 2-3 page requests 15-20 % faster when alone, but see the note on placement in gru_gates_kernel: requests
     // timed out as soon as several were in flight.  A multi-tile variant of this kernel for the 16-page request
     // was also built: 7.2 vs 4.6 ms per layer, the general kernel's three interleaved chains per wave use the
     // matrix cores better.)
-    const int max_ncl = 256 / UB / 2 >= 1 ? 256 / UB / 2 : 1;
+    const int max_ncl = cap / UB / 2;
     if (ntiles > max_ncl) return false;
     *ncl = ntiles;
-    return gru_gates_lds_bytes(H, Tmax) <= 64 * 1024;
+    return true;
 }
 
 bool gru_persistent(const float* gx, const float* wh, const float* bh, float* y, const int32_t* d_Tm, const int32_t* d_off,
@@ -659,7 +712,7 @@ bool gru_persistent(const float* gx, const float* wh, const float* bh, float* y,
             const int UBg = H / 16;
             const dim3 grid(8 * UBg * ((2 * g.ncl + 7) / 8));
             const size_t lds = gru_gates_lds_bytes(H, Tmax);
-            (void)hipMemsetAsync(d_sync, 0, gru_persistent_sync_words(M) * sizeof(uint32_t), s);
+            OCRS_HIP(hipMemsetAsync(d_sync, 0, gru_persistent_sync_words(M) * sizeof(uint32_t), s));
             if (H == 256) hipLaunchKernelGGL((gru_gates_kernel<256>), grid, dim3(256), lds, s, g);
             else if (H == 128) hipLaunchKernelGGL((gru_gates_kernel<128>), grid, dim3(256), lds, s, g);
             else hipLaunchKernelGGL((gru_gates_kernel<64>), grid, dim3(256), lds, s, g);
@@ -671,10 +724,9 @@ bool gru_persistent(const float* gx, const float* wh, const float* bh, float* y,
     p.place = d_sync;
     p.sync = d_sync + kMaxGrid;
     p.R = R; p.M = M; p.Tmax = Tmax;
+    if (H != 256 && H != 128 && H != 64) return false;
     const int UB = H / 16;
-    int max_blocks = 256;
-    if (const char* e = getenv("OCRS_GRU_BLOCKS")) max_blocks = atoi(e) > 0 ? atoi(e) : 256;
-    if (!gru_plan(M, Tmax, H, &p.ncl, max_blocks) && !gru_plan(M, Tmax, H, &p.ncl)) return false;
+    if (!gru_plan(M, Tmax, H, &p.ncl, gru_resident_capacity(H, false, gru_general_lds_bytes(H, Tmax)))) return false;
     gru_assign_tiles(h_Tm, M, p.ncl, p.tiles);
     p.prio = 3;
     if (const char* e = getenv("OCRS_GRU_PRIO")) p.prio = atoi(e);
@@ -684,8 +736,8 @@ bool gru_persistent(const float* gx, const float* wh, const float* bh, float* y,
     if (grid.x > (unsigned)kMaxGrid) return false;
     p.allow_local = option(OPT_GRU_LOCAL) != 0;
     p.scatter = option(OPT_GRU_SCATTER) != 0;
-    const size_t lds = (size_t)H * 48 * sizeof(float) + ((size_t)Tmax + 1) * sizeof(int);
-    (void)hipMemsetAsync(d_sync, 0, gru_persistent_sync_words(M) * sizeof(uint32_t), s);  // (y: gru_persistent_prepare)
+    const size_t lds = gru_general_lds_bytes(H, Tmax);
+    OCRS_HIP(hipMemsetAsync(d_sync, 0, gru_persistent_sync_words(M) * sizeof(uint32_t), s));  // (y: gru_persistent_prepare)
     if (H == 256) hipLaunchKernelGGL((gru_persistent_kernel<256>), grid, dim3(256), lds, s, p);
     else if (H == 128) hipLaunchKernelGGL((gru_persistent_kernel<128>), grid, dim3(256), lds, s, p);
     else hipLaunchKernelGGL((gru_persistent_kernel<64>), grid, dim3(256), lds, s, p);

@@ -7,7 +7,10 @@
 // polygon with the (at most two) source scanlines that row interpolates
 // between, into LDS; every output pixel then classifies its 4 source taps by
 // counting crossings (even-odd rule), gathers them from the page and
-// interpolates.  HBM-bound: reads the line's page pixels once (L2 serves the
+// interpolates.  The LDS lists hold CROSSINGS, not edges: a line polygon of
+// any number of words (4 vertices each, recognition.rs:29-55) crosses a
+// scanline a handful of times; a scanline with more than MAX_LDS_EDGES
+// crossings (a degenerate polygon) is handled by walking the edge list per tap.  HBM-bound: reads the line's page pixels once (L2 serves the
 // 2x row re-use), writes 4*out_w bytes per row.
 #include "kernels.hpp"
 
@@ -45,7 +48,7 @@ crop_lines_kernel(const float* const* __restrict__ pages, const int32_t* __restr
     const int out_w = ln.out_w;
     float* __restrict__ dst = batch + ln.out_off + (int64_t)oy * out_w;
     const float fill = -0.5f;
-    if (ln.bh <= 0 || ln.bw <= 0 || ln.poly_n > MAX_LDS_EDGES) {
+    if (ln.bh <= 0 || ln.bw <= 0) {
         for (int ox = threadIdx.x; ox < out_w; ox += blockDim.x) dst[ox] = fill;
         return;
     }
@@ -67,10 +70,25 @@ crop_lines_kernel(const float* const* __restrict__ pages, const int32_t* __restr
         if (ya > yb) { int t = ya; ya = yb; yb = t; t = xa; xa = xb; xb = t; }
         if (y < ya || y >= yb) continue;
         int slot = atomicAdd(&cnt[which], 1);
-        xs[which][slot] = edge_x_at(xa, ya, xb, yb, y);
+        if (slot < MAX_LDS_EDGES) xs[which][slot] = edge_x_at(xa, ya, xb, yb, y);
     }
     __syncthreads();
     const int m0 = cnt[0], m1 = cnt[1];
+    // crossings of scanline `which` at or left of x, straight from the edge list (same arithmetic as the staging loop)
+    auto crossings_direct = [&](int which, int x) {
+        const int y = ln.top + (which ? r1 : r0);
+        int c = 0;
+        for (int e = 0; e < ln.poly_n; e++) {
+            int ya = pv[2 * e], xa = pv[2 * e + 1];
+            const int e2 = e + 1 == ln.poly_n ? 0 : e + 1;
+            int yb = pv[2 * e2], xb = pv[2 * e2 + 1];
+            if (ya == yb) continue;
+            if (ya > yb) { int t = ya; ya = yb; yb = t; t = xa; xa = xb; xb = t; }
+            if (y < ya || y >= yb) continue;
+            c += edge_x_at(xa, ya, xb, yb, y) <= x ? 1 : 0;
+        }
+        return c;
+    };
     for (int ox = threadIdx.x; ox < out_w; ox += blockDim.x) {
         float v = fill;
         if (ox < ln.resized_w) {
@@ -86,7 +104,10 @@ crop_lines_kernel(const float* const* __restrict__ pages, const int32_t* __restr
                 const int y = ln.top + r, x = ln.left + c;
                 const int m = which ? m1 : m0;
                 int crossings = 0;
-                for (int kk = 0; kk < m; kk++) crossings += xs[which][kk] <= x ? 1 : 0;
+                if (m <= MAX_LDS_EDGES)
+                    for (int kk = 0; kk < m; kk++) crossings += xs[which][kk] <= x ? 1 : 0;
+                else
+                    crossings = crossings_direct(which, x);
                 float t = fill;
                 // page_index_rect.contains_point(in_p) && contains_point(out_p) (recognition.rs:100,112)
                 if ((crossings & 1) && y >= 0 && y <= ph - 1 && x >= 0 && x <= pw - 1 && r <= ph - 1 && c <= pw - 1)

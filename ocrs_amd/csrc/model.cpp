@@ -49,7 +49,7 @@ void CallbackModel::run(const float* input, const int64_t in_shape[4], std::vect
     *out_ndim = nd;
 }
 
-std::unique_ptr<HipModel> HipModel::load(const void* data, size_t len) {
+std::unique_ptr<HipModel> HipModel::load(const void* data, size_t len, int device) {
     if (len < sizeof(FileHeader)) fail(OCRS_ERR_IO, "model file too short");
     FileHeader hd;
     memcpy(&hd, data, sizeof hd);
@@ -144,6 +144,10 @@ std::unique_ptr<HipModel> HipModel::load(const void* data, size_t len) {
         }
         m->ops.push_back(op);
     }
+    // everything above is validation on the host (a malformed file fails before any device work); from here on
+    // the thread is bound to the device that will hold the weights
+    DeviceScope bind(device);
+    m->device = ctx().device;
     m->weights = DevBuf(slab.size() * sizeof(float));
     OCRS_HIP(hipMemcpy(m->weights.p, slab.data(), slab.size() * sizeof(float), hipMemcpyHostToDevice));
     const float* base = m->weights.as<float>();
@@ -363,7 +367,12 @@ float* HipModel::run_device(Workspace& ws, const float* d_in, int n, int h, int 
         const GraphOp& op = ops[i];
         const TensorShape a = shp[op.in0];
         const TensorShape o = shp[op.out];
+        // one stage per op, chosen once: detection graphs are one stage; recognition graphs switch at TOSEQ
         if (kind == 0) enter_stage(ST_DET_CNN);
+        else if (op.type == OP_GRU) enter_stage(ST_REC_GRU);
+        else if (op.type == OP_LINEAR || op.type == OP_LOGSOFTMAX) enter_stage(seen_seq ? ST_REC_HEAD : ST_REC_CONV);
+        else enter_stage(seen_seq ? ST_REC_GRU : ST_REC_CONV);
+        if (op.type == OP_TOSEQ) seen_seq = true;
         if (covered[i]) {
             for (int sl = 1; sl < (int)n_slots; sl++)   // any slot whose last reader this op was (incl. a skipped PADCAT's inputs)
                 if (last_use[sl] == (int)i && ptr[sl] && cap[sl]) {
@@ -439,10 +448,6 @@ float* HipModel::run_device(Workspace& ws, const float* d_in, int n, int h, int 
                 }
             }
         }
-        else if (op.type == OP_GRU) enter_stage(ST_REC_GRU);
-        else if (op.type == OP_LINEAR || op.type == OP_LOGSOFTMAX) enter_stage(seen_seq ? ST_REC_HEAD : ST_REC_CONV);
-        else enter_stage(seen_seq ? ST_REC_GRU : ST_REC_CONV);
-        if (op.type == OP_TOSEQ) seen_seq = true;
 
         const float* x = ptr[op.in0];
         float* y = nullptr;
@@ -872,10 +877,9 @@ int HipModel::run_recognition_packed(Workspace& ws, const std::vector<PackedGrou
     // to the request's own stream by events) and everything after it overlaps freely.
     float* X = nullptr;
     int C0 = 0;
-    static std::mutex heavy_phase;
     {
-        // all conv stacks go through ONE stream, in request order, without host waits
-        std::lock_guard<std::mutex> heavy(heavy_phase);
+        // all conv stacks of a device go through ONE stream, in request order, without host waits
+        std::lock_guard<std::mutex> heavy(ctx().heavy_phase);
         try {
             X = run_prefix_ragged(ws, heavy_stream(), groups, plan, h, ts, timers, &C0);
         } catch (...) {
@@ -922,36 +926,59 @@ int HipModel::run_recognition_packed(Workspace& ws, const std::vector<PackedGrou
             float* y = ws.alloc_n<float>((size_t)R * 2 * H);
             const bool fused = (H == 256 || H == 128 || H == 64);
             const bool persistent = fused && gru_mode() == GRU_PERSISTENT && k::gru_persistent_supported(M, plan.Tmax, R, H);
-            if (persistent) k::gru_persistent_prepare(y, R, H, st);  // "unwritten" marks; ahead of the input GEMM
+            if (persistent) OCRS_HIP(k::gru_persistent_prepare(y, R, H, st));  // "unwritten" marks; ahead of the input GEMM
             k::GemmDesc d{};
             d.A = cur; d.lda = I; d.B = op.aux0; d.ldb = 3 * H; d.bias = op.aux1; d.C = gx; d.ldc = 3 * H;
             d.M = (int)R; d.N = 3 * H; d.K = I; d.batch = 2;
             d.strideA = 0; d.strideB = (int64_t)I * 3 * H; d.strideBias = 3 * H; d.strideC = R * 3 * H;
             timed(KC_GEMM_GRU_INPUT, 2.0 * 2 * R * (double)d.N * d.K, 4.0 * ((double)R * I + 2.0 * R * d.N + 2.0 * d.K * d.N),
                   [&] { k::gemm(d, st); });
+            bool ran_persistent = false;
             if (persistent) {
                 // ONE launch for all Tmax steps of both directions (kernels_gru.hip).  Its workgroups wait on
                 // each other, so two such kernels must never be half-resident at the same time: every request's
-                // recurrences go through one process-wide stream (FIFO on the GPU, linked by events, no host wait).
+                // recurrences go through one stream per device (FIFO on the GPU, linked by events, no host wait).
                 uint32_t* d_sync = ws.alloc_n<uint32_t>(k::gru_persistent_sync_words(M));
                 double fl = 0.0;
                 for (int step = 0; step < plan.Tmax; step++) fl += 2.0 * 2 * plan.active[step] * 3.0 * H * H;
                 {
-                    static std::mutex rec_phase;
-                    std::lock_guard<std::mutex> g(rec_phase);
-                    hipStream_t rs = recurrent_stream();
+                    DeviceContext& dc = ctx();
+                    std::lock_guard<std::mutex> g(dc.rec_phase);
+                    hipStream_t rs = dc.recurrent_stream();
                     hipEvent_t ready = ws.make_event(), done = ws.make_event();
                     OCRS_HIP(hipEventRecord(ready, st));
                     OCRS_HIP(hipStreamWaitEvent(rs, ready, 0));
                     int ktok = timers ? timers->kbegin(KC_GEMM_GRU_HIDDEN, rs, fl, 4.0 * ((double)R * (2.0 * 3 * H + 2.0 * 2 * H) + 2.0 * 3 * H * H)) : -1;
-                    k::gru_persistent(gx, op.aux2, op.aux3, y, plan.d_Tm, plan.d_off, plan.h_Tm.data(), R, M, plan.Tmax, H, d_sync, rs);
+                    ran_persistent = k::gru_persistent(gx, op.aux2, op.aux3, y, plan.d_Tm, plan.d_off, plan.h_Tm.data(), R, M, plan.Tmax, H, d_sync, rs);
                     if (ktok >= 0) timers->end(ktok, rs);
-                    if (plan.h_status && gru_layer < 8) ws.download(plan.h_status + gru_layer, d_sync + k::gru_persistent_sync_words(M) - 1, sizeof(uint32_t), rs);
+                    if (ran_persistent && plan.h_status && gru_layer < 8)
+                        ws.download(plan.h_status + gru_layer, d_sync + k::gru_persistent_sync_words(M) - 1, sizeof(uint32_t), rs);
                     OCRS_HIP(hipEventRecord(done, rs));
                     OCRS_HIP(hipStreamWaitEvent(st, done, 0));
                 }
+            }
+            if (ran_persistent) {
+                // done
             } else if (fused) {
-                // one launch per time step: transposed, ping-ponged state            } else {
+                // One launch per time step (option gru_mode = 1, and shapes the persistent kernel has no plan for):
+                // hidden GEMM + gates in one kernel, transposed ping-ponged state hT[2 dirs][H][Mcap].
+                const int Mcap = (M + 3) & ~3;
+                float* hT0 = ws.alloc_n<float>((size_t)2 * H * Mcap);
+                float* hT1 = ws.alloc_n<float>((size_t)2 * H * Mcap);
+                OCRS_HIP(hipMemsetAsync(hT0, 0, (size_t)2 * H * Mcap * sizeof(float), st));
+                for (int step = 0; step < plan.Tmax; step++) {
+                    const int act = plan.active[step];
+                    if (act <= 0) break;
+                    const float* hin = (step & 1) ? hT1 : hT0;
+                    float* hout = (step & 1) ? hT0 : hT1;
+                    timed(KC_GEMM_GRU_HIDDEN, 2.0 * 2 * act * 3.0 * H * H,
+                          4.0 * 2 * ((double)act * H * 2 + (double)act * 3 * H + 3.0 * H * H + (double)act * H), [&] {
+                              if (!k::gru_step_fused(gx, op.aux2, op.aux3, hin, hout, y, plan.d_Tm, plan.d_off, R, Mcap, act, H, step, st))
+                                  fail(OCRS_ERR_RUN_FAILED, "model run failed: no fused GRU step kernel for hidden size %d", H);
+                          });
+                }
+            } else {
+                // any other hidden size: hidden GEMM and gate kernel as two launches per time step
                 float* gh = ws.alloc_n<float>((size_t)2 * M * 3 * H);
                 float* hs = ws.alloc_n<float>((size_t)2 * M * H);
                 OCRS_HIP(hipMemsetAsync(hs, 0, (size_t)2 * M * H * sizeof(float), st));

@@ -50,6 +50,7 @@ struct TensorShape {  // NHWC activations, or [T,N,C] sequences (n=T, h=N, w=1, 
 // What a caller-implemented model looks like to the engine (`trait Model`).
 struct ModelBase {
     virtual ~ModelBase() = default;
+    int device = -1;                            // HIP device that holds the weights (-1: none, a callback model)
     int64_t input_shape[4] = {-1, -1, -1, -1};  // NCHW, -1 = symbolic
     virtual bool is_callback() const = 0;
 };
@@ -71,7 +72,8 @@ struct HipModel : ModelBase {
     DevBuf weights;      // one slab: file blob + derived tensors
     bool is_callback() const override { return false; }
 
-    static std::unique_ptr<HipModel> load(const void* data, size_t len);
+    // device < 0: the process default (ocrs_set_device)
+    static std::unique_ptr<HipModel> load(const void* data, size_t len, int device = -1);
 
     // Shape inference for an input of n x h x w (C = 1); returns the output shape.
     TensorShape infer(int n, int h, int w, std::vector<TensorShape>* slots = nullptr) const;
