@@ -9,10 +9,15 @@ that are already resident in HBM:  prepare_input -> detect_words (CNN @ 800x600,
 threshold, components -> rects) -> find_text_lines (host) -> recognize_text
 (line crops, CRNN, greedy CTC) -> TextLines on the host.
 
-N > 1: one process per GPU.  Launched under `torch.distributed.run` the script is one rank; launched
-plainly as `python bench.py --gpus N` it re-executes itself under `torch.distributed.run` with N ranks on
-127.0.0.1.  Pages are sharded across ranks with no collective on the compute path (weak scaling: every rank
-owns `--pages` pages per step); the only exchange is the final result gather (RCCL all_gather).
+N > 1, two shapes (pages are independent units: no collective on the compute path in either; weak scaling —
+`--pages` pages per step per GPU):
+  * one process per GPU: launched under `torch.distributed.run` (as the driver does) the script is one rank; the only
+    exchange is the final result gather (RCCL all_gather through torch.distributed).  `--spawn-ranks` makes a plain
+    launch re-execute itself that way.
+  * ONE process driving N GPUs: a plain `python bench.py --gpus N` runs the engine group of the C ABI
+    (ocrs_engine_group_*): page i -> member i mod N, every member on its own host threads / streams, the packed
+    results gathered device to device with librccl's ncclAllGather (`--gather host` = through each member's own pinned
+    staging instead).  `--devices 0,0` puts several members on one GPU (a one-GPU box; the gather then uses the host).
 
 `--stream-pages P` is BASELINE.json configs[4]: P distinct pages (seeds 0..P-1), page i -> rank i mod N,
 processed in requests of `--pages` pages, every page resident in HBM before the timed region.
@@ -33,6 +38,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md "HBM3E peak BW" (spec)
+PEAK_FP32_VALU_TFLOPS = 157.3  # MI355X_MICROARCH.md "Peak FP32 (vector)": 256 CUs x 128 lanes x 2 (FMA) x 2.4 GHz
 # kernel classes of the detection CNN (HBM-bound: depthwise-separable U-Net)
 DETECTION_CLASSES = ("dwconv3x3", "gemm_pointwise_mfma", "gemm_convt_mfma", "pool", "padcat", "conv1x1_sigmoid",
                      "conv_direct")
@@ -64,6 +70,12 @@ def parse(argv=None):
     ap.add_argument("--profile-hint", action="store_true", help="print per-stage and per-kernel tables to stderr")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the detection-only (configs[1]), recognition-only (configs[2]) and host-pixels legs")
+    ap.add_argument("--spawn-ranks", action="store_true",
+                    help="N > 1 launched without a launcher: re-execute under torch.distributed.run with N ranks (one "
+                         "process per GPU) instead of driving the N GPUs from this process through the engine group")
+    ap.add_argument("--devices", type=str, default="",
+                    help="engine-group mode: comma-separated member devices (default 0..N-1; a device may repeat)")
+    ap.add_argument("--gather", choices=("auto", "host", "rccl"), default="auto", help="engine-group mode: result transport")
     ap.add_argument("--dist-selftest", action="store_true",
                     help="exercise only the multi-rank plumbing (spawn, rendezvous, page sharding, result gather, "
                          "reductions) with fake per-page results and no GPU: the CPU test of the N > 1 path")
@@ -80,7 +92,7 @@ def _free_port():
 
 def maybe_spawn(args, argv):
     """`python bench.py --gpus N` without a launcher: become N ranks (one per GPU) under torch.distributed.run."""
-    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ or not (args.spawn_ranks or args.dist_selftest):
         return
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
@@ -200,7 +212,7 @@ def main():
     torch.cuda.set_device(dev_index)
     red_dev = "cuda" if backend == "nccl" else "cpu"
 
-    from ocrs_amd import DimOrder, Model, OcrEngine, _lib, models, synth
+    from ocrs_amd import DimOrder, EngineGroup, Model, OcrEngine, _lib, models, synth
     from ocrs_amd import dist as D
 
     if not os.path.exists(_lib.LIB_PATH):
@@ -209,32 +221,52 @@ def main():
     L = _lib.lib()
     _lib.check(L.ocrs_set_device(dev_index))
 
-    det = Model.load_bytes(models.synthetic_detection_bytes())
-    rec = Model.load_bytes(models.synthetic_recognition_bytes())
-    engine = OcrEngine(detection_model=det, recognition_model=rec)
+    # ONE process, several GPUs: the engine group of the C ABI (a plain launch with --gpus N > 1)
+    group_mode = world == 1 and (args.gpus > 1 or bool(args.devices))
+    group = None
+    if group_mode:
+        devices = [int(x) for x in args.devices.split(",")] if args.devices else list(range(args.gpus))
+        group = EngineGroup(devices, models.synthetic_detection_bytes(), models.synthetic_recognition_bytes(), gather=args.gather)
+        engine = group.member(0)[0]     # stage / kernel timers: member 0's
+        G = len(devices)
+    else:
+        devices = [dev_index]
+        det = Model.load_bytes(models.synthetic_detection_bytes())
+        rec = Model.load_bytes(models.synthetic_recognition_bytes())
+        engine = OcrEngine(detection_model=det, recognition_model=rec)
+        G = 1
 
-    # ---- synthetic pages, resident in HBM before the timed region
+    # ---- synthetic pages, resident in HBM before the timed region (in group mode: page i on member i mod G's device)
     B, H, W = args.pages, 1024, 1024
     if args.stream_pages:
         my_ids = D.shard_pages(args.stream_pages, rank, world)            # page i -> rank i mod N
-        args.steps = max(1, -(-max(len(D.shard_pages(args.stream_pages, r, world)) for r in range(world)) // B))
+        args.steps = max(1, -(-max(len(D.shard_pages(args.stream_pages, r, world)) for r in range(world)) // (B * G)))
     else:
-        my_ids = [rank * B + i for i in range(B)]
+        my_ids = [rank * B + i for i in range(B * G)]
     host_pages = make_pages(my_ids, args.lines, synth)
     dptrs = []
-    for pg in host_pages:
+    for i, pg in enumerate(host_pages):
         p = C.c_void_p()
-        _lib.check(L.ocrs_device_malloc(C.c_size_t(pg.nbytes), C.byref(p)))
+        if group_mode:
+            _lib.check(L.ocrs_device_malloc_on(C.c_int(devices[i % G]), C.c_size_t(pg.nbytes), C.byref(p)))
+        else:
+            _lib.check(L.ocrs_device_malloc(C.c_size_t(pg.nbytes), C.byref(p)))
         _lib.check(L.ocrs_device_upload(p, pg.ctypes.data_as(C.c_void_p), C.c_size_t(pg.nbytes)))
         dptrs.append(p)
+    BG = B * G   # pages per step of this process
 
     def request_pages(k):
-        """device pointers of step k's pages: the same B pages every step, or the k-th slice of the stream"""
+        """device pointers of step k's pages: the same pages every step, or the k-th slice of the stream"""
         if not args.stream_pages:
             return dptrs
-        return dptrs[k * B:(k + 1) * B]
+        return dptrs[k * BG:(k + 1) * BG]
 
     def stage_a(k=0):  # prepare -> detect -> layout (GPU ~4 ms, then host)
+        if group_mode:
+            inputs = group.prepare_input_device_batch([p.value for p in request_pages(k)], np.uint8, DimOrder.Hwc, H, W, 3)
+            words = group.detect_words_batch(inputs)
+            rects, loffs, poffs = group.find_text_lines_batch_raw(words)
+            return inputs, words, (rects, loffs, poffs)
         inputs = [engine.prepare_input_device(p.value, np.uint8, DimOrder.Hwc, H, W, 3) for p in request_pages(k)]
         words = engine.detect_words_batch(inputs)
         rects, loffs, poffs = engine.find_text_lines_batch_raw(words)
@@ -242,13 +274,18 @@ def main():
 
     def stage_b(a):  # recognise (GPU) -> TextLines on the host
         inputs, words, (rects, loffs, poffs) = a
-        chars, coffs = engine.recognize_text_batch_raw(inputs, rects, loffs, poffs)
+        chars, coffs = (group or engine).recognize_text_batch_raw(inputs, rects, loffs, poffs)
         return words, (rects, loffs, poffs), (chars, coffs)
+
+    step_latency = []   # seconds per whole step (request latency), appended by every in-flight host thread
 
     def step(k=0):
         if args.stream_pages and not request_pages(k):
             return None
-        return stage_b(stage_a(k))
+        t = time.perf_counter()
+        out = stage_b(stage_a(k))
+        step_latency.append(time.perf_counter() - t)
+        return out
 
     from concurrent.futures import ThreadPoolExecutor
     pool = ThreadPoolExecutor(max_workers=1)
@@ -303,6 +340,7 @@ def main():
     engine.enable_timing(0 if args.no_kernel_timing else 2)
     engine.stage_times(reset=True)
     sync_all()
+    del step_latency[:]
     cpu0 = time.process_time()
     t0 = time.perf_counter()
     outs = run_steps(args.steps, collect=True)
@@ -329,7 +367,7 @@ def main():
             for li in range(int(poffs[i]), int(poffs[i + 1])):
                 a, b = int(coffs[li]), int(coffs[li + 1])
                 page_lines.append("".join(map(chr, codes[a:b])) if b > a else None)
-            local_payload[str(my_ids[si * B + i] if args.stream_pages else my_ids[i])] = page_lines
+            local_payload[str(my_ids[si * BG + i] if args.stream_pages else my_ids[i])] = page_lines
     gathered = D.gather_results(local_payload)
     elapsed, (n_pages_all, n_lines_all, n_words_all, n_chars_all) = reduce_over_ranks(
         elapsed, (n_pages, n_lines, n_words, n_chars), world, red_dev)
@@ -345,7 +383,7 @@ def main():
         "metric": "pages/sec end-to-end (1024x1024)",
         "value": round(value, 3),
         "unit": "pages/s",
-        "n_gpus": world,
+        "n_gpus": G if group_mode else world,
         "steps": args.steps,
         "warmup": args.warmup,
         "extra_untimed_settle_steps": settle_steps,
@@ -362,10 +400,15 @@ def main():
                         ", ~%d lines/page; prepare_input -> detect_words (U-Net @800x600 + threshold + components->rects) "
                         "-> find_text_lines (host) -> recognize_text (crops, CRNN, greedy CTC)" % args.lines,
             "pages_per_step_per_gpu": B,
+            "coalesce": ("concurrent small requests share launches (option coalesce = %s): %s" % (
+                os.environ.get("OCRS_COALESCE", "2"), json.dumps(engine.coalesce_stats()))),
             "lines_per_page": round(n_lines / max(n_pages, 1), 1),
             "words_per_page": round(n_words / max(n_pages, 1), 1),
             "weights": "seeded synthetic weights on the SURVEY.md §2.4 architectures (real ocrs weights unobtainable offline)",
-            "parallelism": "page-sharded, %d process(es) x 1 GPU, no data-path collective; result gather over %s" % (world, backend),
+            "parallelism": ("page-sharded, ONE process x %d GPUs (engine group of the C ABI, devices %s): page i -> member i mod %d, "
+                            "no data-path collective; result gather: %s" % (G, devices, G, json.dumps(group.last_gather())))
+                           if group_mode else
+                           "page-sharded, %d process(es) x 1 GPU, no data-path collective; result gather over %s" % (world, backend),
             "gru": "persistent kernel per layer" if os.environ.get("OCRS_GRU_MODE", "0") == "0" else "one launch per time step",
             "step_overlap": ("%d whole steps in flight (one host thread + HIP stream each); the conv stacks of all "
                              "requests run FIFO on one shared stream, the GRU recurrences on another, the host layout "
@@ -375,6 +418,9 @@ def main():
                              "stream) overlap recognition of step i; every step still does all of its work"),
         },
         "lines_per_s": round(n_lines_all / elapsed, 1),
+        "request_latency_ms": ({"p50": round(1e3 * float(np.percentile(step_latency, 50)), 2),
+                                "p99": round(1e3 * float(np.percentile(step_latency, 99)), 2),
+                                "pages_per_request": BG, "requests_in_flight": max(1, args.inflight)} if step_latency else None),
         "host_cpu_cores_busy_per_gpu": round(host_cpu_s / elapsed, 2),
         "host_cores_budget_per_rank": per_rank_cores,
         "chars_last_step": len(last[2][0]),
@@ -441,7 +487,7 @@ def main():
                 print("stage %-18s %8.3f ms/step" % (k, v[0] / args.steps), file=sys.stderr)
 
     # ---- extra legs named by BASELINE.json (rank 0, N=1 only; not part of `value`)
-    if world == 1 and not args.no_extras:
+    if world == 1 and not group_mode and not args.no_extras:
         result["extras"] = extra_legs(engine, dptrs, host_pages, H, W, synth, np, DimOrder, sync_all, args)
         if "roofline_detection" in result["extras"]:
             result["roofline_detection"] = result["extras"].pop("roofline_detection")
@@ -449,7 +495,7 @@ def main():
             result["value_incl_h2d"] = result["extras"]["value_incl_h2d"]
 
     # ---- CPU baseline: the oracle on the host cores, bounded sample (rank 0, N=1 only)
-    if world == 1 and not args.no_cpu_baseline and not args.stream_pages:
+    if world == 1 and not group_mode and not args.no_cpu_baseline and not args.stream_pages:
         words, (rects, loffs, poffs), (chars, coffs) = last
         gpu_text = []
         for i in range(min(args.cpu_pages, B)):
@@ -484,6 +530,20 @@ def pmc_traffic(kernel_class):
     return None
 
 
+def detection_traffic():
+    """HBM-side bytes one 8-page detection request moves, summed over EVERY kernel of the stack, from the newest
+    committed PMC summary of the detection-only loop (profiles/*_det_pmc.json: per kernel launches and bytes per launch,
+    plus the number of requests the profiled loop ran).  None if there is no such summary."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_det_pmc.json")), reverse=True):
+        d = json.load(open(f))
+        req = d.get("_meta", {}).get("requests")
+        rows = [r for k, r in d.items() if k != "_meta"]
+        if req and rows:
+            return round(sum(r["hbm_bytes_per_launch"] * r["launches"] for r in rows) / req)
+    return None
+
+
 def extra_legs(engine, dptrs, host_pages, H, W, synth, np, DimOrder, sync_all, args):
     out = {}
     # configs[1]: detection only — 8 synthetic 1024x1024 pages, CNN forward + threshold + components -> rects
@@ -511,6 +571,35 @@ def extra_legs(engine, dptrs, host_pages, H, W, synth, np, DimOrder, sync_all, a
     out["detection_only_pages_per_s"] = round(reps * len(inputs) / dt, 1)
     out["detection_only_config"] = "8 pages per request, 3 requests in flight, %d requests timed, %d word rects per request" % (
         reps, sum(len(w) for w in words[0]))
+    # The reference's own call pattern (ocrs-cli/src/main.rs:420-446; recognition.rs:465-485): ONE page per call,
+    # concurrency from host threads.  12 threads, each running prepare_input -> detect_words -> find_text_lines ->
+    # recognize_text on one page at a time through the one-page entry points; inside the engine concurrent small
+    # requests share launches (option "coalesce"; the bits of every call are those of the call alone).
+    def one_page(i):
+        t = time.perf_counter()
+        inp = engine.prepare_input_device(dptrs[i % len(dptrs)].value, np.uint8, DimOrder.Hwc, H, W, 3)
+        w1 = engine.detect_words_batch([inp])
+        r1, lo1, po1 = engine.find_text_lines_batch_raw(w1)
+        ch1, _ = engine.recognize_text_batch_raw([inp], r1, lo1, po1)
+        return time.perf_counter() - t, len(ch1)
+    threads, n_req = 12, 360
+    with ThreadPoolExecutor(threads) as pool:
+        list(pool.map(one_page, range(3 * threads)))
+        sync_all()
+        c0 = engine.coalesce_stats()
+        t0 = time.perf_counter()
+        lat = list(pool.map(one_page, range(n_req)))
+        sync_all()
+        dt = time.perf_counter() - t0
+        c1 = engine.coalesce_stats()
+    lat_ms = np.array([x[0] for x in lat]) * 1e3
+    out["single_page_api"] = {
+        "pages_per_s": round(n_req / dt, 1), "threads_in_flight": threads, "requests": n_req,
+        "latency_ms": {"p50": round(float(np.percentile(lat_ms, 50)), 2), "p99": round(float(np.percentile(lat_ms, 99)), 2)},
+        "merged_batches": {k: [c1[k][0] - c0[k][0], c1[k][1] - c0[k][1]] for k in c1},
+        "how": "one page per call from 12 host threads (the reference's call pattern); merged_batches = [batches run, "
+               "calls they carried] per stage inside the engine",
+    }
     # roofline of the detection CNN stack (the stack north_star names; depthwise-separable => HBM-bound):
     # algorithmic bytes of its layers (from the loaded graph) over the summed duration of its kernels
     if not args.no_kernel_timing:
@@ -524,14 +613,19 @@ def extra_legs(engine, dptrs, host_pages, H, W, synth, np, DimOrder, sync_all, a
         ms = sum(v["ms"] for v in ks.values())
         by = sum(v["bytes"] for v in ks.values())
         if ms > 0:
-            tr = [pmc_traffic(k) for k in ks]
+            n_launch = sum(v["launches"] for v in ks.values()) // 3
+            fl = sum(v["flops"] for v in ks.values())
             out["roofline_detection"] = {
-                "bound": "hbm", "kernel": "detection CNN stack (%d launches per 8-page batch: %s)" % (
-                    sum(v["launches"] for v in ks.values()) // 3, ", ".join(sorted(ks))),
+                "bound": "hbm", "kernel": "detection CNN stack (%d launches per 8-page batch: %s)" % (n_launch, ", ".join(sorted(ks))),
                 "achieved": round(by / ms / 1e6, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                 "frac": round(by / ms / 1e6 / PEAK_HBM_GBS, 4),
                 "ms_per_8_pages": round(ms / 3, 4), "algorithmic_bytes_per_page": round(by / 3 / len(inputs)),
-                "traffic": None if not any(tr) else sum(t["hbm_bytes_per_launch"] for t in tr if t),
+                # the fused blocks are VALU / MFMA work on LDS tiles, not bandwidth: the arithmetic rate beside the byte rate
+                "algorithmic_gflop_per_page": round(fl / 3 / len(inputs) / 1e9, 3),
+                "achieved_tflops": round(fl / ms / 1e9, 2),
+                "frac_of_fp32_vector_peak": round(fl / ms / 1e9 / PEAK_FP32_VALU_TFLOPS, 4),
+                "traffic": detection_traffic(),
+                "traffic_unit": "bytes per 8-page request, summed over every kernel of the stack (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE passes of tools/det_bench.py)",
                 "per_class_ms_per_8_pages": {k: round(v["ms"] / 3, 4) for k, v in sorted(ks.items(), key=lambda kv: -kv[1]["ms"])}}
     # configs[2]: recognition only — 2048 line crops of 64x256 (padded to 300 by the engine exactly as
     # recognition.rs:437 does), CRNN forward + greedy CTC, batched.  The crops are stacked into one tall
@@ -647,8 +741,9 @@ _CPU_W = {}
 
 
 def _cpu_worker_run(task):
-    """One page through the oracle in a worker process (CPU only; layout through the product's host C++, which is host
-    code in both paths).  task = (backend, page or None for the warm-up, threads)."""
+    """One page through the oracle in a worker process (CPU only; layout through the product's host C++ — "layout
+    shared with the product" in the JSON — cross-checked against oracle/layout.py by _cpu_layout_check).
+    task = (backend, page or None for the warm-up, threads)."""
     backend, page, threads = task
     import ctypes as C
     import numpy as np
@@ -684,38 +779,46 @@ def _cpu_worker_run(task):
 
 
 def cpu_baseline(pages, engine, gpu_text, np):
-    """The CPU restatement (oracle/) timed on this box's host cores on a bounded sample of the same pages.
-      * `exact` back-end (the C fmaf-chain restatement of the networks, OpenMP over all budgeted threads), the sampled
+    """The CPU restatement (oracle/) timed on this box's host cores — ALL physical cores (os.cpu_count() // 2; RTen's
+    policy is a pool of the physical cores, CHANGELOG.md:78-89) — on a bounded sample of the same pages.
+      * `exact` back-end (the C fmaf-chain restatement of the networks, OpenMP over all physical cores), the sampled
         pages one after the other: this is the checker — `text_match` says that the text the GPU path decoded for these
         pages equals, line for line, what it decodes (the bit-exact parity proper is tests/test_gpu_bench_scale.py);
       * `torch` back-end (PyTorch-CPU fp32 convolutions / ATen GRU — what a native CPU runtime such as RTen does),
         run the way a CPU deployment would use the box: W worker processes x T threads covering the same cores, one
-        page per worker at a time (a single page cannot keep 32+ threads busy: the reference's recognition works in
+        page per worker at a time (a single page cannot keep 100+ threads busy: the reference's recognition works in
         chunks of <= 20 lines).  `value` is the best of the legs.
-    C for image ops, contours, crops and CTC in all legs; layout analysis through the product's host C++ (it is host
-    code in both paths).  Reported next to the GPU number; it is not the target."""
+    C for image ops, contours, crops and CTC in all legs.  Layout analysis is SHARED with the product (its host C++,
+    which is host code in both paths) inside the timed legs; the oracle's own layout (oracle/layout.py) is run on the
+    sampled pages outside the timing and must give the same lines (`layout_checked_against_oracle`).
+    Reported next to the GPU number; it is not the target."""
     import multiprocessing as mp
-    cores = int(os.environ["OMP_NUM_THREADS"])
-    # leg 1: exact, sequential, all threads (in this process)
-    t0 = time.perf_counter()
-    _cpu_worker_run(("exact", None, cores))
-    texts_e, n_lines = [], 0
-    t0 = time.perf_counter()
-    for pg in pages:
-        _, t, nl = _cpu_worker_run(("exact", pg, cores))
-        texts_e.append(t)
-        n_lines += nl
-    dt_e = time.perf_counter() - t0
+    from concurrent.futures import ProcessPoolExecutor
+    cores = max(1, (os.cpu_count() or 2) // 2)
+    ctx = mp.get_context("spawn")
+    # leg 1: exact, sequential, all physical cores (own process: the OpenMP pool size is fixed when the library loads)
+    texts_e, n_lines, dt_e, layout_ok = [], 0, 0.0, None
+    with ProcessPoolExecutor(1, mp_context=ctx, initializer=_cpu_worker_init, initargs=(cores,)) as pool:
+        pool.submit(_cpu_worker_run, ("exact", None, cores)).result(timeout=600)
+        t0 = time.perf_counter()
+        for pg in pages:
+            _, t, nl = pool.submit(_cpu_worker_run, ("exact", pg, cores)).result(timeout=900)
+            texts_e.append(t)
+            n_lines += nl
+        dt_e = time.perf_counter() - t0
+        try:
+            layout_ok = all(pool.submit(_cpu_layout_check, pg).result(timeout=900) for pg in pages[:1])
+        except Exception as e:
+            print("cpu_baseline: layout cross-check failed to run: %r" % (e,), file=sys.stderr)
     # leg 2: torch, W workers x T threads
     T = 4 if cores >= 8 else max(1, cores // 2)
-    W = max(1, cores // T)
+    W = max(1, min(cores // T, 32))
     rate_t, n_pages_t, dt_t = 0.0, 0, 0.0
     lines_t = 0
     try:
-        from concurrent.futures import ProcessPoolExecutor
         # (an executor rather than mp.Pool: a worker that dies while starting breaks the pool loudly instead of being
         # respawned for ever; every wait below is bounded)
-        with ProcessPoolExecutor(W, mp_context=mp.get_context("spawn"), initializer=_cpu_worker_init, initargs=(T,)) as pool:
+        with ProcessPoolExecutor(W, mp_context=ctx, initializer=_cpu_worker_init, initargs=(T,)) as pool:
             for f in [pool.submit(_cpu_worker_run, ("torch", None, T)) for _ in range(W)]:   # import + warm-up everywhere
                 f.result(timeout=300)
             t0 = time.perf_counter()
@@ -732,16 +835,46 @@ def cpu_baseline(pages, engine, gpu_text, np):
     lines_equal = sum(sum(1 for x, y in zip(a, b) if x == y) for a, b in zip(texts_e, gpu_text))
     rate_e = len(pages) / dt_e
     best_t = rate_t >= rate_e
-    return {"value": round(max(rate_e, rate_t), 4), "unit": "pages/s", "cores": cores, "kind": "port",
+    return {"value": round(max(rate_e, rate_t), 4), "unit": "pages/s", "cores": cores if not best_t else W * T, "kind": "port",
+            "host_logical_cpus": os.cpu_count(),
             "lines_per_s": round((lines_t / dt_t) if best_t and dt_t > 0 else n_lines / dt_e, 2),
             "backend": "torch" if best_t else "exact",
             "pages_per_s_by_backend": {"exact": round(rate_e, 4), "torch": round(rate_t, 4)},
             "text_match": lines_total > 0 and lines_equal == lines_total,
             "text_lines_equal": "%d/%d" % (lines_equal, lines_total),
-            "sample": "full pipeline on the oracle (C image/contour/crop/CTC, host C++ layout). exact: %d of the same synthetic "
-                      "1024x1024 pages one after the other, networks = C fmaf-chain restatement, %d threads, %.1f s.  torch: "
-                      "%d pages (the same ones, repeated) on %d worker processes x %d threads, networks = PyTorch-CPU fp32, "
-                      "%.1f s" % (len(pages), cores, dt_e, n_pages_t, W, T, dt_t)}
+            "layout_checked_against_oracle": layout_ok,
+            "sample": "full pipeline on the oracle (C image/contour/crop/CTC; layout shared with the product: its host C++ runs "
+                      "inside both timed legs, oracle/layout.py cross-checks it outside the timing). exact: %d of the same "
+                      "synthetic 1024x1024 pages one after the other, networks = C fmaf-chain restatement, %d threads (all "
+                      "physical cores), %.1f s.  torch: %d pages (the same ones, repeated) on %d worker processes x %d "
+                      "threads, networks = PyTorch-CPU fp32, %.1f s" % (len(pages), cores, dt_e, n_pages_t, W, T, dt_t)}
+
+
+def _cpu_layout_check(page):
+    """oracle/layout.py (the restatement of layout_analysis.rs) against the product's host C++ layout on the words the
+    oracle detects on `page`: the same lines, the same order.  Outside any timing."""
+    import ctypes as C
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    from oracle import layout as OL
+    from oracle import pipeline as OP
+    from oracle.nn import OracleGraph, OracleModel
+    from ocrs_amd import _lib, models
+    ora = _CPU_W.get("exact") or OP.OcrEngine(detection_model=OracleModel(OracleGraph(models.synthetic_detection_bytes()), "exact"))
+    inp = ora.prepare_input(OP.ImageSource.from_tensor(page, "hwc"))
+    words = ora.detect_words(inp)
+    mine = [[tuple(float(v) for v in w.to_array()) for w in line] for line in OL.find_text_lines(words)]
+    a = np.ascontiguousarray(np.array([w.to_array() for w in words], np.float32).reshape(-1, 6))
+    L = _lib.lib()
+    lr, lo, nl = C.POINTER(C.c_float)(), C.POINTER(C.c_size_t)(), C.c_size_t(0)
+    _lib.check(L.ocrs_engine_find_text_lines(None, None, a.ctypes.data_as(C.POINTER(C.c_float)), C.c_size_t(len(a)),
+                                             C.byref(lr), C.byref(lo), C.byref(nl)))
+    offs = [lo[i] for i in range(nl.value + 1)]
+    flat = np.ctypeslib.as_array(lr, shape=(max(len(a), 1) * 6,))[: len(a) * 6].reshape(-1, 6).copy()
+    L.ocrs_buffer_free(lr)
+    L.ocrs_buffer_free(lo)
+    theirs = [[tuple(float(v) for v in r) for r in flat[offs[i]:offs[i + 1]]] for i in range(nl.value)]
+    return mine == theirs
 
 
 if __name__ == "__main__":

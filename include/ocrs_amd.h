@@ -83,6 +83,14 @@ OCRS_API ocrs_status ocrs_ctc_beam_search(const float* logp, int t, int c, uint3
 OCRS_API ocrs_status ocrs_gru_tile_plan(const int32_t* lengths_desc, size_t n_lines, int hidden, int32_t* n_clusters,
                                         int16_t* tiles);
 
+/* Test hook (host only, no GPU work) for the request coalescer behind the one-page entry points (option "coalesce"):
+ * n_threads callers submit requests_per_thread requests each (of two incompatible kinds, weights 1..2 pages); request
+ * ids divisible by fail_every (> 0) fail.  out = {batches run, requests carried, errors delivered to their callers,
+ * requests that were run twice / not at all / got a wrong result or shared a batch with the other kind, largest batch
+ * in pages}. */
+OCRS_API ocrs_status ocrs_coalescer_selftest(int n_threads, int requests_per_thread, int max_active, int max_pages,
+                                             long window_us, int fail_every, uint64_t out[5]);
+
 /* Process-wide integer tuning options (no reference counterpart: RTen's equivalents are compile-time).
  * Each also reads its initial value from the environment variable OCRS_<NAME IN CAPITALS>.
  *   "gru_mode"        0 = one persistent kernel per GRU layer (default), 1 = one launch per time step
@@ -387,6 +395,9 @@ OCRS_API ocrs_status ocrs_engine_stage_times(ocrs_engine* e, double* ms, uint64_
  * figures of DESIGN.md §6 summed over the launches. */
 /* Restrict per-launch kernel timing to the classes whose bit is set (default: all). */
 OCRS_API ocrs_status ocrs_engine_set_kernel_timing_mask(ocrs_engine* e, uint32_t mask);
+/* Request coalescing (option "coalesce"): {merged batches run, caller requests they carried} per stage since the engine
+ * was created.  requests > batches means calls of different host threads shared launches. */
+OCRS_API ocrs_status ocrs_engine_coalesce_stats(const ocrs_engine* e, uint64_t detect[2], uint64_t recognize[2]);
 OCRS_API int ocrs_kernel_class_count(void);
 OCRS_API const char* ocrs_kernel_class_name(int cls);
 OCRS_API ocrs_status ocrs_engine_kernel_stats(ocrs_engine* e, double* ms, uint64_t* launches, double* flops,

@@ -14,7 +14,7 @@ from . import _lib
 from ._lib import OcrsError, check, lib
 
 __all__ = ["OcrEngine", "OcrEngineParams", "ImageSource", "ImageSourceError", "DimOrder", "DecodeMethod", "Model",
-           "OcrInput", "TextLine", "TextWord", "TextChar", "OcrsError", "DEFAULT_ALPHABET"]
+           "OcrInput", "TextLine", "TextWord", "TextChar", "OcrsError", "DEFAULT_ALPHABET", "EngineGroup"]
 
 # lib.rs:34 (with the EUR sign the comment at lib.rs:33 asks for)
 DEFAULT_ALPHABET = " 0123456789!\"#$%&'()*+,-./:;<=>?@[\\]^_`{|}~€ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz"
@@ -88,10 +88,20 @@ class Model:
         return Model(h)
 
     @staticmethod
-    def load_bytes(buf):
+    def load_bytes(buf, device=None):
+        """device=None: the process default (ocrs_set_device); an int places the weights on that HIP device."""
         h = C.c_void_p()
-        check(lib().ocrs_model_load_bytes(C.c_char_p(bytes(buf)), C.c_size_t(len(buf)), C.byref(h)))
+        if device is None:
+            check(lib().ocrs_model_load_bytes(C.c_char_p(bytes(buf)), C.c_size_t(len(buf)), C.byref(h)))
+        else:
+            check(lib().ocrs_model_load_bytes_on_device(C.c_char_p(bytes(buf)), C.c_size_t(len(buf)), C.c_int(int(device)),
+                                                        C.byref(h)))
         return Model(h)
+
+    def device(self):
+        d = C.c_int(-1)
+        check(lib().ocrs_model_device(self._h, C.byref(d)))
+        return d.value
 
     @staticmethod
     def from_callable(input_shape, fn):
@@ -293,6 +303,27 @@ class OcrEngine:
         p.allowed_chars = params.allowed_chars.encode("utf-8") if params.allowed_chars is not None else None
         self._h = C.c_void_p()
         check(lib().ocrs_engine_new(C.byref(p), C.byref(self._h)))
+
+    @classmethod
+    def _borrowed(cls, handle, keep):
+        """An engine owned by somebody else (an EngineGroup member): same methods, never freed here."""
+        self = cls.__new__(cls)
+        self._params = None
+        self._h = handle
+        self._keep = keep
+        self._owned = False
+        return self
+
+    def device(self):
+        d = C.c_int(-1)
+        check(lib().ocrs_engine_device(self._h, C.byref(d)))
+        return d.value
+
+    def coalesce_stats(self):
+        """{stage: (merged batches run, caller requests they carried)} — ocrs_engine_coalesce_stats."""
+        det, rec = (C.c_uint64 * 2)(), (C.c_uint64 * 2)()
+        check(lib().ocrs_engine_coalesce_stats(self._h, det, rec))
+        return {"detect": (int(det[0]), int(det[1])), "recognize": (int(rec[0]), int(rec[1]))}
 
     # ---- lib.rs:183-187
     def prepare_input(self, image):
@@ -533,8 +564,141 @@ class OcrEngine:
 
     def __del__(self):
         try:
-            if self._h:
+            if self._h and getattr(self, "_owned", True):
                 lib().ocrs_engine_free(self._h)
+            self._h = None
+        except Exception:
+            pass
+
+
+def _chars_from_c(chars, coffs, nl):
+    co = np.ctypeslib.as_array(coffs, shape=(nl + 1,)).astype(np.uintp)
+    total = int(co[nl])
+    dt = np.dtype([("ch", np.uint32), ("top", np.int32), ("left", np.int32), ("bottom", np.int32), ("right", np.int32)])
+    if total:
+        buf = (C.c_char * (total * dt.itemsize)).from_address(C.addressof(chars.contents))
+        arr = np.frombuffer(buf, dtype=dt, count=total).copy()
+    else:
+        arr = np.zeros(0, dt)
+    lib().ocrs_buffer_free(chars)
+    lib().ocrs_buffer_free(coffs)
+    return arr, co
+
+
+class EngineGroup:
+    """Several GPUs behind one handle in one process (include/ocrs_amd.h "engine group"): page i of a call goes to
+    member i mod G.  `devices` may repeat a device (members then share it; the gather uses the host transport)."""
+
+    GATHER = {"auto": 0, "host": 1, "rccl": 2}
+
+    def __init__(self, devices, detection_bytes=None, recognition_bytes=None, debug=False, decode_method=DecodeMethod.Greedy,
+                 alphabet=None, allowed_chars=None, gather="auto"):
+        p = _lib.GroupParams()
+        self._det = bytes(detection_bytes) if detection_bytes is not None else None
+        self._rec = bytes(recognition_bytes) if recognition_bytes is not None else None
+        p.detection_model = C.cast(C.c_char_p(self._det), C.c_void_p) if self._det else None
+        p.detection_model_len = len(self._det) if self._det else 0
+        p.recognition_model = C.cast(C.c_char_p(self._rec), C.c_void_p) if self._rec else None
+        p.recognition_model_len = len(self._rec) if self._rec else 0
+        self._devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+        p.devices = self._devs
+        p.n_devices = len(devices)
+        p.debug = 1 if debug else 0
+        p.decode_method = 0 if decode_method[0] == "greedy" else 1
+        p.beam_width = decode_method[1]
+        p.alphabet = alphabet.encode("utf-8") if alphabet is not None else None
+        p.allowed_chars = allowed_chars.encode("utf-8") if allowed_chars is not None else None
+        p.gather = self.GATHER[gather]
+        self._h = C.c_void_p()
+        check(lib().ocrs_engine_group_new(C.byref(p), C.byref(self._h)))
+        self.devices = [int(d) for d in devices]
+
+    def __len__(self):
+        n = C.c_size_t(0)
+        check(lib().ocrs_engine_group_size(self._h, C.byref(n)))
+        return n.value
+
+    def member(self, i):
+        """(OcrEngine view of member i, its device)"""
+        e, d = C.c_void_p(), C.c_int(-1)
+        check(lib().ocrs_engine_group_member(self._h, C.c_size_t(i), C.byref(e), C.byref(d)))
+        return OcrEngine._borrowed(e, self), d.value
+
+    def last_gather(self):
+        t, b, why = C.c_int(0), C.c_size_t(0), C.c_char_p()
+        check(lib().ocrs_group_last_gather(self._h, C.byref(t), C.byref(b), C.byref(why)))
+        return {"transport": {0: None, 1: "host", 2: "rccl"}[t.value], "bytes": b.value,
+                "why_host": (why.value or b"").decode()}
+
+    def prepare_input_batch(self, images, order=DimOrder.Hwc):
+        """images: equally shaped numpy arrays (host)."""
+        arrs = [np.ascontiguousarray(a) for a in images]
+        a0 = arrs[0]
+        if order == DimOrder.Hwc:
+            h, w, c = a0.shape
+        else:
+            c, h, w = a0.shape
+        n = len(arrs)
+        ptrs = (C.c_void_p * n)(*[a.ctypes.data for a in arrs])
+        out = (C.c_void_p * n)()
+        check(lib().ocrs_group_prepare_input_batch(self._h, ptrs, C.c_size_t(n), 0 if a0.dtype == np.uint8 else 1, order, h, w, c, out))
+        return [OcrInput(C.c_void_p(out[i])) for i in range(n)]
+
+    def prepare_input_device_batch(self, d_ptrs, dtype, order, h, w, c):
+        n = len(d_ptrs)
+        ptrs = (C.c_void_p * n)(*d_ptrs)
+        out = (C.c_void_p * n)()
+        check(lib().ocrs_group_prepare_input_device_batch(self._h, ptrs, C.c_size_t(n), 0 if dtype == np.uint8 else 1, order,
+                                                          h, w, c, out))
+        return [OcrInput(C.c_void_p(out[i])) for i in range(n)]
+
+    def detect_words_batch(self, inputs):
+        n = len(inputs)
+        pages = (C.c_void_p * n)(*[i._h for i in inputs])
+        rects = C.POINTER(C.c_float)()
+        offs = (C.c_size_t * (n + 1))()
+        check(lib().ocrs_group_detect_words_batch(self._h, pages, C.c_size_t(n), C.byref(rects), offs))
+        total = offs[n]
+        flat = np.ctypeslib.as_array(rects, shape=(max(total, 1) * 6,))[: total * 6].reshape(-1, 6).copy()
+        lib().ocrs_buffer_free(rects)
+        return [flat[offs[i]:offs[i + 1]] for i in range(n)]
+
+    def find_text_lines_batch_raw(self, words_per_page):
+        return self.member(0)[0].find_text_lines_batch_raw(words_per_page)   # host work: any engine handle serves
+
+    def recognize_text_batch_raw(self, inputs, rects, line_offsets, page_line_offsets):
+        n = len(inputs)
+        pages = (C.c_void_p * n)(*[i._h for i in inputs])
+        rects = np.ascontiguousarray(rects, np.float32)
+        lo = np.ascontiguousarray(line_offsets, np.uintp)
+        po = np.ascontiguousarray(page_line_offsets, np.uintp)
+        nl = len(lo) - 1
+        chars = C.POINTER(_lib.TextCharC)()
+        coffs = C.POINTER(C.c_size_t)()
+        check(lib().ocrs_group_recognize_text_batch(
+            self._h, pages, C.c_size_t(n), po.ctypes.data_as(C.POINTER(C.c_size_t)),
+            rects.ctypes.data_as(C.POINTER(C.c_float)), lo.ctypes.data_as(C.POINTER(C.c_size_t)), C.c_size_t(nl),
+            C.byref(chars), C.byref(coffs)))
+        return _chars_from_c(chars, coffs, nl)
+
+    def gather(self, payloads):
+        """payloads: one bytes object per member -> (concatenation through the group's transport, offsets)."""
+        g = len(self)
+        assert len(payloads) == g
+        bufs = [C.create_string_buffer(bytes(p), max(len(p), 1)) for p in payloads]
+        ptrs = (C.c_void_p * g)(*[C.addressof(b) for b in bufs])
+        sizes = (C.c_size_t * g)(*[len(p) for p in payloads])
+        out = C.c_void_p()
+        offs = (C.c_size_t * (g + 1))()
+        check(lib().ocrs_group_gather(self._h, ptrs, sizes, C.byref(out), offs))
+        data = C.string_at(out, offs[g])
+        lib().ocrs_buffer_free(out)
+        return data, [int(offs[i]) for i in range(g + 1)]
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().ocrs_engine_group_free(self._h)
                 self._h = None
         except Exception:
             pass

@@ -25,6 +25,13 @@ class EngineParams(C.Structure):
                 ("allowed_chars", C.c_char_p)]
 
 
+class GroupParams(C.Structure):
+    _fields_ = [("detection_model", C.c_void_p), ("detection_model_len", C.c_size_t), ("recognition_model", C.c_void_p),
+                ("recognition_model_len", C.c_size_t), ("devices", C.POINTER(C.c_int)), ("n_devices", C.c_size_t),
+                ("debug", C.c_int), ("decode_method", C.c_int), ("beam_width", C.c_uint32), ("alphabet", C.c_char_p),
+                ("allowed_chars", C.c_char_p), ("gather", C.c_int)]
+
+
 class RunOptions(C.Structure):
     _fields_ = [("timing", C.c_int)]
 
@@ -58,7 +65,7 @@ DECLARED_SYMBOLS = [
     "ocrs_get_device", "ocrs_model_load_file_on_device", "ocrs_model_load_bytes_on_device", "ocrs_model_device", "ocrs_engine_device",
     "ocrs_engine_group_new", "ocrs_engine_group_free", "ocrs_engine_group_size", "ocrs_engine_group_member", "ocrs_group_deal",
     "ocrs_group_prepare_input_batch", "ocrs_group_prepare_input_device_batch", "ocrs_group_detect_words_batch",
-    "ocrs_group_recognize_text_batch", "ocrs_group_gather", "ocrs_group_last_gather", "ocrs_device_malloc_on",
+    "ocrs_group_recognize_text_batch", "ocrs_group_gather", "ocrs_group_last_gather", "ocrs_device_malloc_on", "ocrs_engine_coalesce_stats", "ocrs_coalescer_selftest",
 ]
 
 _lib = None
@@ -78,7 +85,7 @@ def lib():
         L.ocrs_stage_name.restype = C.c_char_p
         L.ocrs_kernel_class_name.restype = C.c_char_p
         L.ocrs_buffer_free.argtypes = [C.c_void_p]
-        for name in ("ocrs_model_free", "ocrs_engine_free", "ocrs_page_free"):
+        for name in ("ocrs_model_free", "ocrs_engine_free", "ocrs_page_free", "ocrs_engine_group_free"):
             getattr(L, name).argtypes = [C.c_void_p]
             getattr(L, name).restype = None
         _lib = L

@@ -54,6 +54,55 @@ ocrs_status ocrs_gru_tile_plan(const int32_t* lengths_desc, size_t n_lines, int 
     });
 }
 
+// Host-only test hook for coalesce.hpp (the engine's queues need a GPU to be driven through the ABI).
+ocrs_status ocrs_coalescer_selftest(int n_threads, int requests_per_thread, int max_active, int max_pages, long window_us,
+                                    int fail_every, uint64_t out[5]) {
+    return guarded([&] {
+        if (!out || n_threads < 1 || requests_per_thread < 1 || max_pages < 1) fail(OCRS_ERR_INVALID_ARGUMENT, "bad argument");
+        struct TReq : CoalescedBase { int id = 0, kind = 0; long result = 0; int runs = 0; };
+        std::atomic<uint64_t> max_batch_pages{0}, mixed{0};
+        Coalescer<TReq> q(
+            [&](std::vector<TReq*>& batch) {
+                uint64_t w = 0;
+                for (TReq* r : batch) { w += r->weight; if (r->kind != batch[0]->kind) mixed++; }
+                uint64_t prev = max_batch_pages.load();
+                while (w > prev && !max_batch_pages.compare_exchange_weak(prev, w)) {}
+                std::this_thread::sleep_for(std::chrono::microseconds(300));   // the "GPU work" of a batch
+                for (TReq* r : batch) {
+                    r->runs++;
+                    if (fail_every > 0 && r->id % fail_every == 0) {
+                        try { fail(OCRS_ERR_INVALID_ARGUMENT, "request %d is bad", r->id); } catch (...) { r->error = std::current_exception(); }
+                    } else {
+                        r->result = 3L * r->id + 1;
+                    }
+                }
+            },
+            [](const TReq& a, const TReq& b) { return a.kind == b.kind; });
+        std::atomic<uint64_t> wrong{0}, errors{0};
+        std::vector<std::thread> th;
+        for (int t = 0; t < n_threads; t++)
+            th.emplace_back([&, t] {
+                for (int k = 0; k < requests_per_thread; k++) {
+                    TReq r;
+                    r.id = t * requests_per_thread + k + 1;
+                    r.kind = r.id % 2;
+                    r.weight = 1 + (size_t)(r.id % 3 == 0);
+                    try {
+                        q.submit(r, max_active, (size_t)max_pages, window_us);
+                        if (r.runs != 1 || r.result != 3L * r.id + 1 || (fail_every > 0 && r.id % fail_every == 0)) wrong++;
+                    } catch (const Error& e) {
+                        errors++;
+                        if (r.runs != 1 || !(fail_every > 0 && r.id % fail_every == 0)) wrong++;
+                    }
+                }
+            });
+        for (auto& t : th) t.join();
+        uint64_t batches = 0, reqs = 0;
+        q.stats(&batches, &reqs);
+        out[0] = batches; out[1] = reqs; out[2] = errors.load(); out[3] = wrong.load() + mixed.load(); out[4] = max_batch_pages.load();
+    });
+}
+
 ocrs_status ocrs_ctc_beam_search(const float* logp, int t, int c, uint32_t width, int impl, uint32_t** labels,
                                  uint32_t** positions, size_t* n) {
     return guarded([&] {
@@ -627,6 +676,14 @@ ocrs_status ocrs_engine_set_kernel_timing_mask(ocrs_engine* e, uint32_t mask) {
     return guarded_on(e ? e->device : -1, [&] {
         if (!e) fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
         e->timers.kernel_mask = mask;
+    });
+}
+ocrs_status ocrs_engine_coalesce_stats(const ocrs_engine* e, uint64_t detect[2], uint64_t recognize[2]) {
+    return guarded([&] {
+        if (!e || !detect || !recognize) fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
+        detect[0] = detect[1] = recognize[0] = recognize[1] = 0;
+        if (e->det_queue) e->det_queue->stats(&detect[0], &detect[1]);
+        if (e->rec_queue) e->rec_queue->stats(&recognize[0], &recognize[1]);
     });
 }
 int ocrs_kernel_class_count(void) { return KC_COUNT; }

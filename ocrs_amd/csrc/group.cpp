@@ -224,19 +224,15 @@ ocrs_status ocrs_engine_group_new(const ocrs_group_params* params, ocrs_engine_g
             ep.beam_width = params->beam_width;
             ep.alphabet = params->alphabet;
             ep.allowed_chars = params->allowed_chars;
-            if (!mem.detection && !mem.recognition) {   // no weights to pin the engine to its device: bind explicitly
-                DeviceScope bind(mem.device);
-                mem.engine = make_engine(ep);
-                mem.engine->device = mem.device;
-            } else {
-                mem.engine = make_engine(ep);
-            }
+            mem.engine = make_engine(ep);
+            mem.engine->device = mem.device;   // (an engine without weights has nothing else to pin it to its device)
         }
         if (params->gather == OCRS_GATHER_HOST) {
             g->why_host = "host transport requested";
         } else if (!distinct) {
             g->why_host = "a device appears more than once in the group: RCCL refuses such a communicator";
-            if (params->gather == OCRS_GATHER_RCCL) { /* documented fallback, reported by ocrs_group_last_gather */ }
+        } else if (params->gather == OCRS_GATHER_AUTO && params->n_devices == 1) {
+            g->why_host = "one member: nothing to gather";
         } else {
             std::vector<int> devs;
             for (const auto& mem : g->members) devs.push_back(mem.device);

@@ -299,7 +299,7 @@ def test_gru_tile_plan_covers_every_tile_once_and_balances(lib, n_lines):
     ntiles = (n_lines + 15) // 16
     assert 1 <= ncl <= (8 if ntiles <= 128 else 16)
     used = tiles[: 4 * 4 * ncl].reshape(-1, 4)
-    assert np.all(tiles[4 * 4 * ncl:] == -1) or np.all(tiles[4 * 4 * ncl:] <= -1)
+    assert np.all(tiles[4 * 4 * ncl:] == -1)                   # the whole 512-entry buffer is initialised
     flat = used[used >= 0]
     assert sorted(flat.tolist()) == list(range(ntiles))
     tl = [int(lengths[16 * k]) for k in range(ntiles)]
@@ -319,3 +319,54 @@ def test_gru_tile_plan_rejects_what_the_kernel_cannot_hold(lib):
     assert _gru_plan(lib, np.full(4097, 50, np.int32))[0] == 9      # OCRS_ERR_CAPACITY: > 4096 lines at H = 256
     assert _gru_plan(lib, np.full(64, 50, np.int32), hidden=96)[0] == 9  # unsupported hidden size
     assert _gru_plan(lib, [10, 20])[0] == 1                  # OCRS_ERR_INVALID_ARGUMENT: not descending
+
+
+# ---------------------------------------------------------------- request coalescer (coalesce.hpp), host only
+@pytest.mark.parametrize("threads,max_active,window_us", [(1, 2, 300), (12, 2, 300), (12, 1, 0), (24, 3, 2000)])
+def test_coalescer_runs_every_request_once_and_merges_under_load(lib, threads, max_active, window_us):
+    """The leader/follower queue behind the one-page entry points (ocrs-cli/src/main.rs:420-446 is one page per call):
+    every request runs exactly once with its own result, requests of incompatible kinds never share a batch, a batch
+    stays within the page budget, errors reach exactly their callers, and with many callers batches carry several
+    requests."""
+    out = (C.c_uint64 * 5)()
+    per = 40
+    st = lib.ocrs_coalescer_selftest(threads, per, max_active, 8, C.c_long(window_us), 7, out)
+    assert st == 0, lib.ocrs_last_error()
+    batches, reqs, errors, wrong, max_pages = [int(v) for v in out]
+    n = threads * per
+    assert reqs == n and wrong == 0
+    assert errors == len([i for i in range(1, n + 1) if i % 7 == 0])
+    assert max_pages <= 8
+    if threads == 1:
+        assert batches == n            # a lone caller is never delayed into a batch
+    else:
+        assert batches < n             # concurrent callers share batches
+
+
+# ---------------------------------------------------------------- engine group: dealing and packing (host side)
+def test_group_deals_pages_round_robin(lib):
+    for n, g in [(0, 1), (7, 3), (16, 8), (5, 8), (10000, 8)]:
+        mo = (C.c_size_t * max(n, 1))()
+        pp = (C.c_size_t * g)()
+        assert lib.ocrs_group_deal(C.c_size_t(n), C.c_size_t(g), mo, pp) == 0
+        assert [mo[i] for i in range(n)] == [i % g for i in range(n)]          # SURVEY §8d config 5
+        assert [pp[m] for m in range(g)] == [len(range(m, n, g)) for m in range(g)]
+    assert lib.ocrs_group_deal(C.c_size_t(4), C.c_size_t(0), None, None) == 1
+
+
+def test_group_host_gather_concatenates_member_payloads_in_member_order(lib):
+    """A group without models needs no GPU: the host transport of the result gather packs the members' payloads in
+    member order with their boundaries (the RCCL transport must deliver the same bytes: tests/test_gpu_r3.py)."""
+    from ocrs_amd import EngineGroup
+    g = EngineGroup([0, 0, 0], gather="host")
+    assert len(g) == 3 and [g.member(i)[1] for i in range(3)] == [0, 0, 0]
+    rng = np.random.default_rng(1)
+    payloads = [rng.integers(0, 256, n, dtype=np.uint8).tobytes() for n in (24 * 7, 0, 4096 + 5)]
+    data, offs = g.gather(payloads)
+    assert data == b"".join(payloads) and offs == [0, 168, 168, 168 + 4101]
+    lg = g.last_gather()
+    assert lg["transport"] == "host" and lg["bytes"] == len(data) and lg["why_host"]
+    g2 = EngineGroup([0, 0], gather="rccl")       # RCCL asked for, impossible with a repeated device: host, and says why
+    assert g2.gather([b"a", b"bc"])[0] == b"abc" and "more than once" in g2.last_gather()["why_host"]
+    with pytest.raises(ocrs_amd.OcrsError):
+        EngineGroup([], gather="host")

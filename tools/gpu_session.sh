@@ -1,6 +1,6 @@
 #!/bin/bash
 # One gpurun call = one session: tools/gpu_session.sh <tag> <section>...   (outputs under gpurun_out/<tag>/)
-# Sections: tests_new tests_all ab lat serial16 det detprof full multi stream conc prof pmc
+# Sections: tests_new tests_r3 tests_all ab lat serial16 det detprof detpmc full multi group stream stream10k conc single prof pmc
 set -u
 export TMPDIR=/tmp
 TAG=$1; shift
@@ -17,6 +17,7 @@ f, label = sys.argv[1], sys.argv[2]
 try:
     d = json.loads([l for l in open(f).read().splitlines() if l.startswith("{")][-1])
     rl = d.get("rooflines", {})
+    if "request_latency_ms" in d and d["request_latency_ms"]: print("   request latency:", d["request_latency_ms"])
     print("%s: %.1f pages/s, %.2f ms/step, host cores %.2f | %s" % (label, d["value"], d["ms_per_step"], d.get("host_cpu_cores_busy_per_gpu", 0),
           ", ".join("%s %.3f (%.2f ms x %.1f)" % (k.replace("gemm_", "").replace("_mfma", ""), v["frac"], v["avg_launch_ms"], v["launches_per_step"]) for k, v in rl.items())))
     st = d.get("stages_ms_per_step")
@@ -32,6 +33,8 @@ for sec in "$@"; do
 case $sec in
 tests_new)
   say "== bench-scale tests"; timeout 900 python -m pytest tests/test_gpu_bench_scale.py -x -q > $OUT/test_bench_scale.log 2>&1; say "rc=$?"; tail -4 $OUT/test_bench_scale.log | tee -a $S;;
+tests_r3)
+  say "== round-3 tests (group, coalescing, capacity fall-backs, recurrence fall-backs)"; timeout 1200 python -m pytest tests/test_gpu_r3.py -x -q > $OUT/test_r3.log 2>&1; say "rc=$?"; tail -15 $OUT/test_r3.log | tee -a $S;;
 tests_all)
   say "== full GPU suite"; timeout 1500 python -m pytest tests -m gpu -x -q > $OUT/test_gpu_all.log 2>&1; say "rc=$?"; tail -4 $OUT/test_gpu_all.log | tee -a $S;;
 ab)
@@ -70,6 +73,40 @@ multi)
   OCRS_DIST_BACKEND=gloo timeout 600 python bench.py --gpus 2 --steps 8 --warmup 4 --pages 8 --settle-s 0 --no-cpu-baseline --no-extras > $OUT/bench_2rank.json 2> $OUT/bench_2rank.err; say "rc=$?"; jsum $OUT/bench_2rank.json "2 ranks/1 GPU"; tail -3 $OUT/bench_2rank.err | cut -c1-300 | tee -a $S
   say "== 2 ranks, RCCL backend on one GPU (may be refused by RCCL: informational)"
   timeout 300 python bench.py --gpus 2 --steps 4 --warmup 2 --pages 8 --settle-s 0 --no-cpu-baseline --no-extras > $OUT/bench_2rank_rccl.json 2> $OUT/bench_2rank_rccl.err; say "rc=$?"; jsum $OUT/bench_2rank_rccl.json "2 ranks RCCL"; tail -2 $OUT/bench_2rank_rccl.err | cut -c1-300 | tee -a $S;;
+group)
+  say "== engine group in ONE process: 2 members on this one GPU (devices 0,0; host gather), 8 pages per member per step"
+  timeout 600 python bench.py --gpus 2 --devices 0,0 --steps 12 --warmup 6 --pages 8 --settle-s 0 > $OUT/bench_group00.json 2> $OUT/bench_group00.err; say "rc=$?"; jsum $OUT/bench_group00.json "group [0,0]"; tail -2 $OUT/bench_group00.err | cut -c1-300 | tee -a $S
+  say "== engine group of one member with the RCCL gather (ncclCommInitAll on one device)"
+  timeout 600 python bench.py --devices 0 --gather rccl --steps 12 --warmup 6 --settle-s 0 > $OUT/bench_group0_rccl.json 2> $OUT/bench_group0_rccl.err; say "rc=$?"; jsum $OUT/bench_group0_rccl.json "group [0] rccl"; tail -2 $OUT/bench_group0_rccl.err | cut -c1-300 | tee -a $S
+  python - $OUT/bench_group0_rccl.json <<'PY' | tee -a $S
+import json, sys
+try:
+    d = json.loads([l for l in open(sys.argv[1]).read().splitlines() if l.startswith("{")][-1]); print("   ", d["config"]["parallelism"][:300])
+except Exception as e: print("parse failed", e)
+PY
+  ;;
+single)
+  say "== the reference's call pattern: one page per call, 12 / 24 host threads; coalescing on (default) and off"
+  for a in "2 12" "0 12" "2 24" "3 24"; do
+    set -- $a
+    OCRS_COALESCE=$1 timeout 300 python bench.py --pages 1 --inflight $2 --steps 360 --warmup 36 --settle-s 1 --no-cpu-baseline --no-extras > $OUT/bench_single_c$1_i$2.json 2> $OUT/bench_single_c$1_i$2.err; rc=$?
+    say "coalesce=$1 inflight=$2 rc=$rc"; jsum $OUT/bench_single_c$1_i$2.json "coalesce=$1 inflight=$2"
+    python - $OUT/bench_single_c$1_i$2.json <<'PY' | tee -a $S
+import json, sys
+try:
+    d = json.loads([l for l in open(sys.argv[1]).read().splitlines() if l.startswith("{")][-1]); print("    latency", d.get("request_latency_ms"), d["config"].get("coalesce", "")[-120:])
+except Exception as e: print("parse failed", e)
+PY
+  done;;
+stream10k)
+  say "== configs[4] as stated: 10 000 distinct pages on 1 GPU (31 GB resident)"; timeout 1500 python bench.py --stream-pages 10000 --warmup 4 --no-cpu-baseline --no-extras > $OUT/bench_stream10k.json 2> $OUT/bench_stream10k.err; say "rc=$?"; jsum $OUT/bench_stream10k.json "stream 10k"; tail -2 $OUT/bench_stream10k.err | cut -c1-300 | tee -a $S;;
+detpmc)
+  say "== PMC passes of the detection-only loop (FETCH_SIZE, WRITE_SIZE): bytes per 8-page request over every kernel"
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $ROOT/$OUT/detpmc -o fetch -- python $ROOT/tools/det_bench.py 10 > $ROOT/$OUT/detpmc_fetch.log 2>&1); say "fetch rc=$?"
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $ROOT/$OUT/detpmc -o write -- python $ROOT/tools/det_bench.py 10 > $ROOT/$OUT/detpmc_write.log 2>&1); say "write rc=$?"
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE -d $ROOT/$OUT/detpmc -o mfma -- python $ROOT/tools/det_bench.py 10 > $ROOT/$OUT/detpmc_mfma.log 2>&1); say "mfma rc=$?"
+  python tools/pmc_summary.py $OUT/detpmc $OUT/${TAG}_det_pmc_hbm.txt $OUT/${TAG}_det_pmc.json 13 > /dev/null 2>$OUT/detpmc_summary.err; head -30 $OUT/${TAG}_det_pmc_hbm.txt | cut -c1-200 | tee -a $S
+  find $OUT/detpmc -size +30M -delete;;
 stream)
   say "== configs[4] stream mode on 1 GPU: 512 distinct pages"; timeout 900 python bench.py --stream-pages 512 --warmup 4 --no-cpu-baseline --no-extras > $OUT/bench_stream512.json 2> $OUT/bench_stream512.err; say "rc=$?"; jsum $OUT/bench_stream512.json "stream 512";;
 prof)

@@ -33,7 +33,7 @@ def load(path):
     return out, launches, dur
 
 
-def main(prefix, out_txt, out_json):
+def main(prefix, out_txt, out_json, requests=None):
     fetch, lf, df = load(prefix + "/fetch_results.db")
     write, lw, dw = load(prefix + "/write_results.db")
     mfma, lm, dm = load(prefix + "/mfma_results.db")
@@ -67,9 +67,12 @@ def main(prefix, out_txt, out_json):
             "%.1f" % (100 * r["mfma_pipe_util"]) if r["mfma_pipe_util"] is not None else "-",
             "%.2f" % r["shader_clock_ghz"] if r["shader_clock_ghz"] is not None else "-"))
     open(out_txt, "w").write("\n".join(lines) + "\n")
-    json.dump({r["kernel"]: r for r in rows}, open(out_json, "w"), indent=1)
+    table = {r["kernel"]: r for r in rows}
+    if requests:   # how many requests the profiled loop ran (bench.py detection_traffic divides the summed bytes by it)
+        table["_meta"] = {"requests": int(requests)}
+    json.dump(table, open(out_json, "w"), indent=1)
     print("\n".join(lines[:14]))
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2], sys.argv[3])
+    main(sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else None)
