@@ -104,6 +104,8 @@ OCRS_API ocrs_status ocrs_coalescer_selftest(int n_threads, int requests_per_thr
  *                     as consecutive sub-requests (default 0 = 2e9, sized for the activation memory of one GPU)
  *   "gru_gates"       1 = requests small enough that every 16-line row tile gets its own cluster of workgroups run the
  *                     gate-per-wave recurrence kernel (default), 0 = always the general persistent kernel
+ *   "gru_gates_pack"  2 = the gate-per-wave kernel also takes requests of up to twice the row tiles by running two workgroups
+ *                     per CU (default 1: one workgroup per CU)
  *   "gemm_nfast"      1 = dense GEMMs run the column tiles of a row tile side by side on one XCD (default), 0 = column
  *                     tile on the grid's y axis
  *   "gru_scatter"     test knob: 1 = spread every cluster over all XCDs (exercises the write-through path), default 0

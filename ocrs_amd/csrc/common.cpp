@@ -52,7 +52,11 @@ DeviceContext& ctx() {
 DeviceScope::DeviceScope(int device) : prev_(t_ctx) {
     DeviceContext& c = device_context(device < 0 ? default_device() : device);
     // always: other code on this thread (torch, the caller) may have switched the thread's device between our calls
-    OCRS_HIP(hipSetDevice(c.device));
+    const hipError_t e = hipSetDevice(c.device);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();   // HIP keeps the failure as the thread's "last error": do not leave it for a later, unrelated check
+        fail(OCRS_ERR_DEVICE, "cannot bind to HIP device %d: %s", c.device, hipGetErrorString(e));
+    }
     t_ctx = &c;
 }
 
@@ -237,6 +241,7 @@ const OptDef kOptDefs[OPT_COUNT] = {
     {"coalesce", "OCRS_COALESCE", 2},                   // merged batches of small requests in flight per engine and stage (0 = no merging)
     {"coalesce_pages", "OCRS_COALESCE_PAGES", 16},      // pages per merged batch; requests of half that size or more run on their own
     {"coalesce_window_us", "OCRS_COALESCE_WINDOW_US", 300},  // how long a would-be leader lets the queue fill while other batches run
+    {"gru_gates_pack", "OCRS_GRU_GATES_PACK", 1},       // gate-per-wave GRU kernel: 2 = two workgroups per CU for requests of twice the row tiles
 };
 std::atomic<long> g_opts[OPT_COUNT];
 std::once_flag g_opts_once;

@@ -288,7 +288,7 @@ void ocrs_engine::detect(const ocrs_page* const* pages, size_t n, std::vector<st
     const int max_active = option(OPT_COALESCE);
     const size_t max_pages = (size_t)std::max(1, option(OPT_COALESCE_PAGES));
     // merged only where it cannot be observed: HIP executor (a caller's `trait Model` sees every run), rects only
-    if (max_active <= 0 || !det_queue || !rects_out || host_map || n == 0 || 2 * n > max_pages || !detection ||
+    if (max_active <= 0 || !det_queue || !rects_out || host_map || n == 0 || 2 * n >= max_pages || !detection ||
         detection->is_callback() || debug) {
         detect_now(pages, n, rects_out, host_map);
         return;
@@ -304,7 +304,7 @@ void ocrs_engine::recognize(const ocrs_page* const* pages, size_t n_pages,
                             std::vector<uint32_t>* ctc_len_out) const {
     const int max_active = option(OPT_COALESCE);
     const size_t max_pages = (size_t)std::max(1, option(OPT_COALESCE_PAGES));
-    if (max_active <= 0 || !rec_queue || n_pages == 0 || 2 * n_pages > max_pages || !recognition || recognition->is_callback()) {
+    if (max_active <= 0 || !rec_queue || n_pages == 0 || 2 * n_pages >= max_pages || !recognition || recognition->is_callback()) {
         recognize_now(pages, n_pages, lines_per_page, steps_out, rec_lines_out, ctc_len_out);
         return;
     }
@@ -469,8 +469,8 @@ void ocrs_engine::recognize_lines(const ocrs_page* const* pages, size_t n_pages,
     }
     const float** d_pages = ws.alloc_n<const float*>(n_pages);
     int32_t* d_hw = ws.alloc_n<int32_t>(2 * n_pages);
-    OCRS_HIP(hipMemcpyAsync(d_pages, hp.data(), n_pages * sizeof(float*), hipMemcpyHostToDevice, st));
-    OCRS_HIP(hipMemcpyAsync(d_hw, hhw.data(), hhw.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    ws.upload(d_pages, hp.data(), n_pages * sizeof(float*));
+    ws.upload(d_hw, hhw.data(), hhw.size() * sizeof(int32_t));
 
     const bool callback = recognition->is_callback();
     const uint8_t* d_excl = has_excluded ? d_excluded.as<uint8_t>() : nullptr;
@@ -519,14 +519,15 @@ void ocrs_engine::recognize_lines(const ocrs_page* const* pages, size_t n_pages,
         if (descs.empty()) return;
         k::LineDesc* d_descs = ws.alloc_n<k::LineDesc>(descs.size());
         int32_t* d_poly = ws.alloc_n<int32_t>(poly.size());
-        OCRS_HIP(hipMemcpyAsync(d_descs, descs.data(), descs.size() * sizeof(k::LineDesc), hipMemcpyHostToDevice, st));
-        OCRS_HIP(hipMemcpyAsync(d_poly, poly.data(), poly.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+        // host temporaries travel through the workspace's pinned staging: real asynchronous copies, no host wait here
+        ws.upload(d_descs, descs.data(), descs.size() * sizeof(k::LineDesc));
+        ws.upload(d_poly, poly.data(), poly.size() * sizeof(int32_t));
         float* d_all = ws.alloc_n<float>((size_t)off);
         {
             StageScope sc(T, ST_LINE_CROP, st);
             k::crop_lines(d_pages, d_hw, d_descs, d_poly, (int)descs.size(), (int)rec_h, d_all, st);
         }
-        ws.sync();  // descs/poly are host temporaries
+        if (callback) ws.sync();   // the callback path reads the crops back right away
         for (Chunk& ch : chunks) ch.ptr = d_all + ch.off;
     }
     auto chunk_ptr = [](const Chunk& ch) { return ch.ptr; };
@@ -770,7 +771,12 @@ void ocrs_engine::recognize_lines(const ocrs_page* const* pages, size_t n_pages,
         };
         Sub sub_long, sub_short;
         if (split) {
-            launch(first_long, chunks.size(), ws_long, sub_long);  // the crops were produced on `st` and are already synced
+            {   // the crops were produced on `st`: the long lines' stream starts after them
+                hipEvent_t crops = ws.make_event();
+                OCRS_HIP(hipEventRecord(crops, st));
+                OCRS_HIP(hipStreamWaitEvent(ws_long.s(), crops, 0));
+            }
+            launch(first_long, chunks.size(), ws_long, sub_long);
             launch(0, first_long, ws, sub_short);
             ws_long.sync();
             ws.sync();

@@ -413,7 +413,7 @@ __device__ __forceinline__ f32x4 gate_chain(int lane, const float (&w)[H / 4], c
     return acc;
 }
 
-template <int H>
+template <int H, bool PACK2>
 __global__ void __launch_bounds__(256)
 gru_gates_kernel(GruParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds_w[];  // H*48 floats | off[Tmax+1] | exchange | abort
@@ -423,8 +423,9 @@ gru_gates_kernel(GruParams p) {
     // state loads back to back and kept that CU's memory pipeline so full that the awaited stores did not get through
     // (waits of seconds in every run with 2+ requests in flight).  await_state now backs off, with which the shared
     // placement works too; one workgroup per CU — what the general kernel's 299 registers impose anyway — stays
-    // because it measured 5 % faster under load.
-    asm volatile("v_accvgpr_write_b32 a200, 0" ::: "a200");
+    // because it measured 5 % faster under load.  PACK2 (option "gru_gates_pack" = 2) drops the clobber: two workgroups
+    // per CU, i.e. room for twice the row tiles (requests of up to ~3 pages) at this kernel's shorter step.
+    if (!PACK2) asm volatile("v_accvgpr_write_b32 a200, 0" ::: "a200");
     constexpr int UB = H / 16;
     const int b = blockIdx.x;
     const int q = b >> 3;
@@ -584,9 +585,9 @@ static int gru_resident_capacity(int H, bool gates, size_t lds) {
     int per_cu = 0;
     hipError_t e;
     if (gates) {
-        e = H == 256 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gru_gates_kernel<256>, 256, lds)
-          : H == 128 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gru_gates_kernel<128>, 256, lds)
-                     : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gru_gates_kernel<64>, 256, lds);
+        e = H == 256 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gru_gates_kernel<256, false>, 256, lds)
+          : H == 128 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gru_gates_kernel<128, false>, 256, lds)
+                     : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gru_gates_kernel<64, false>, 256, lds);
     } else {
         e = H == 256 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gru_persistent_kernel<256>, 256, lds)
           : H == 128 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gru_persistent_kernel<128>, 256, lds)
@@ -675,8 +676,8 @@ bool gru_persistent_supported(int M, int Tmax, int64_t R, int H) {
            gru_plan(M, Tmax, H, &ncl, gru_resident_capacity(H, false, gru_general_lds_bytes(H, Tmax)));
 }
 
-// gate-per-wave kernel: every tile has a cluster of its own
-static bool gru_gates_plan(int M, int Tmax, int H, int* ncl) {
+// gate-per-wave kernel: every tile has a cluster of its own.  *pack = workgroups per CU the launch relies on.
+static bool gru_gates_plan(int M, int Tmax, int H, int* ncl, int* pack) {
     if (H != 256 && H != 128 && H != 64) return false;
     if (gru_gates_lds_bytes(H, Tmax) > 64 * 1024) return false;
     const int ntiles = (M + 15) / 16, UB = H / 16;
@@ -684,13 +685,19 @@ static bool gru_gates_plan(int M, int Tmax, int H, int* ncl) {
     cap = cap > 256 ? 256 : cap;
     cap -= cap % (8 * UB);
     if (cap < 8 * UB) return false;
-    // One workgroup per CU, as for the general kernel: 256 / UB / 2 clusters per direction.  (Two workgroups per CU
-    // ran 2-3 page requests 15-20 % faster when alone, but see the note on placement in gru_gates_kernel: requests
-    // timed out as soon as several were in flight.  A multi-tile variant of this kernel for the 16-page request
-    // was also built: 7.2 vs 4.6 ms per layer, the general kernel's three interleaved chains per wave use the
-    // matrix cores better.)
+    // One workgroup per CU, as for the general kernel: cap / UB / 2 clusters per direction (8 at H = 256 on MI355X:
+    // one page).  With option "gru_gates_pack" = 2 requests of up to twice that run two workgroups per CU (117
+    // registers, two fit): 2-3 page requests then keep this kernel's 4.6 us step instead of the general kernel's
+    // 6.6 us lone-tile step.  (Packed placement once made waits time out under concurrency — pollers saturating the
+    // CU's memory pipeline — which await_state's back-off cured; see gru_gates_kernel.  A multi-tile variant of this
+    // kernel for the 16-page request was also built: 7.2 vs 4.6 ms per layer, the general kernel's three interleaved
+    // chains per wave use the matrix cores better.)
     const int max_ncl = cap / UB / 2;
-    if (ntiles > max_ncl) return false;
+    *pack = 1;
+    if (ntiles > max_ncl) {
+        if (option(OPT_GRU_GATES_PACK) < 2 || ntiles > 2 * max_ncl) return false;
+        *pack = 2;
+    }
     *ncl = ntiles;
     return true;
 }
@@ -700,7 +707,8 @@ bool gru_persistent(const float* gx, const float* wh, const float* bh, float* y,
     if (M <= 0) return true;
     if (option(OPT_GRU_GATES)) {
         GruParams g{};
-        if (gru_gates_plan(M, Tmax, H, &g.ncl)) {
+        int pack = 1;
+        if (gru_gates_plan(M, Tmax, H, &g.ncl, &pack)) {
             g.gx = gx; g.wh = wh; g.bh = bh; g.y = y; g.Tm = d_Tm; g.off = d_off;
             g.place = d_sync;
             g.sync = d_sync + kMaxGrid;
@@ -713,9 +721,15 @@ bool gru_persistent(const float* gx, const float* wh, const float* bh, float* y,
             const dim3 grid(8 * UBg * ((2 * g.ncl + 7) / 8));
             const size_t lds = gru_gates_lds_bytes(H, Tmax);
             OCRS_HIP(hipMemsetAsync(d_sync, 0, gru_persistent_sync_words(M) * sizeof(uint32_t), s));
-            if (H == 256) hipLaunchKernelGGL((gru_gates_kernel<256>), grid, dim3(256), lds, s, g);
-            else if (H == 128) hipLaunchKernelGGL((gru_gates_kernel<128>), grid, dim3(256), lds, s, g);
-            else hipLaunchKernelGGL((gru_gates_kernel<64>), grid, dim3(256), lds, s, g);
+            if (pack == 2) {
+                if (H == 256) hipLaunchKernelGGL((gru_gates_kernel<256, true>), grid, dim3(256), lds, s, g);
+                else if (H == 128) hipLaunchKernelGGL((gru_gates_kernel<128, true>), grid, dim3(256), lds, s, g);
+                else hipLaunchKernelGGL((gru_gates_kernel<64, true>), grid, dim3(256), lds, s, g);
+            } else {
+                if (H == 256) hipLaunchKernelGGL((gru_gates_kernel<256, false>), grid, dim3(256), lds, s, g);
+                else if (H == 128) hipLaunchKernelGGL((gru_gates_kernel<128, false>), grid, dim3(256), lds, s, g);
+                else hipLaunchKernelGGL((gru_gates_kernel<64, false>), grid, dim3(256), lds, s, g);
+            }
             return true;
         }
     }

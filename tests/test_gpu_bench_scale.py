@@ -263,6 +263,7 @@ def test_gru_modes_give_identical_bits(engine):
     rng = np.random.default_rng(0)
     short = [l[: max(1, int(rng.integers(1, len(l) + 1)))] for l in lines[:40]]   # ragged: prefixes of lines
     req = lines + short
+    req2 = lines + short + lines[:70]      # 9-16 row tiles: the packed gate-per-wave kernel's range (mode 7)
     cinp, crects, n = _crops_request(engine)
     cl = np.arange(n + 1, dtype=np.uintp)
     res = {}
@@ -272,12 +273,14 @@ def test_gru_modes_give_identical_bits(engine):
         # placement census must then choose write-through by itself)
         # 4 = without the gate-per-wave kernel (gru_gates 0): the one-page request then runs on the general kernel;
         # 5, 6 = the gate-per-wave kernel with forced write-through / scattered clusters
-        for mode in (0, 1, 2, 3, 4, 5, 6):
+        # 7 = gate-per-wave kernel packed two workgroups per CU (gru_gates_pack 2): applies to requests of 9-16 row tiles
+        for mode in (0, 1, 2, 3, 4, 5, 6, 7):
+            _lib.set_option("gru_gates_pack", 2 if mode == 7 else 1)
             _lib.set_option("gru_mode", 1 if mode == 1 else 0)
             _lib.set_option("gru_local", 0 if mode in (2, 5) else 1)
             _lib.set_option("gru_scatter", 1 if mode in (3, 6) else 0)
             _lib.set_option("gru_gates", 0 if mode in (2, 3, 4) else 1)
-            a = engine.recognize_text(inp, req)
+            a = engine.recognize_text(inp, req) + engine.recognize_text(inp, req2)
             b = engine.recognize_text_batch_raw([cinp], crects, cl, np.array([0, n], dtype=np.uintp))
             res[mode] = ([(str(t), [c.rect for c in t.chars()]) if t else None for t in a], b)
     finally:
@@ -285,7 +288,8 @@ def test_gru_modes_give_identical_bits(engine):
         _lib.set_option("gru_local", 1)
         _lib.set_option("gru_scatter", 0)
         _lib.set_option("gru_gates", 1)
-    for mode in (1, 2, 3, 4, 5, 6):
+        _lib.set_option("gru_gates_pack", 1)
+    for mode in (1, 2, 3, 4, 5, 6, 7):
         assert res[0][0] == res[mode][0], mode
         assert np.array_equal(res[0][1][0], res[mode][1][0]) and np.array_equal(res[0][1][1], res[mode][1][1]), mode
     assert sum(1 for t in res[0][0] if t) > 80

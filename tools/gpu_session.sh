@@ -86,18 +86,25 @@ except Exception as e: print("parse failed", e)
 PY
   ;;
 single)
-  say "== the reference's call pattern: one page per call, 12 / 24 host threads; coalescing on (default) and off"
-  for a in "2 12" "0 12" "2 24" "3 24"; do
-    set -- $a
-    OCRS_COALESCE=$1 timeout 300 python bench.py --pages 1 --inflight $2 --steps 360 --warmup 36 --settle-s 1 --no-cpu-baseline --no-extras > $OUT/bench_single_c$1_i$2.json 2> $OUT/bench_single_c$1_i$2.err; rc=$?
-    say "coalesce=$1 inflight=$2 rc=$rc"; jsum $OUT/bench_single_c$1_i$2.json "coalesce=$1 inflight=$2"
-    python - $OUT/bench_single_c$1_i$2.json <<'PY' | tee -a $S
+  say "== the reference's call pattern: one page per call from N host threads; coalescing variants (env | inflight)"
+  while IFS='|' read -r envs infl; do
+    [ -z "$infl" ] && continue
+    tag=$(echo "$envs$infl" | tr -c 'A-Za-z0-9' '_')
+    env $envs timeout 300 python bench.py --pages 1 --inflight $infl --steps 360 --warmup 36 --settle-s 1 --no-cpu-baseline --no-extras > $OUT/bench_single_$tag.json 2> $OUT/bench_single_$tag.err; rc=$?
+    say "[$envs] inflight=$infl rc=$rc"; jsum $OUT/bench_single_$tag.json "[$envs] inflight=$infl"
+    [ $rc -ne 0 ] && tail -2 $OUT/bench_single_$tag.err | cut -c1-300 | tee -a $S
+    python - $OUT/bench_single_$tag.json <<'PY' | tee -a $S
 import json, sys
 try:
-    d = json.loads([l for l in open(sys.argv[1]).read().splitlines() if l.startswith("{")][-1]); print("    latency", d.get("request_latency_ms"), d["config"].get("coalesce", "")[-120:])
+    d = json.loads([l for l in open(sys.argv[1]).read().splitlines() if l.startswith("{")][-1]); print("    ", d["config"].get("coalesce", "")[-100:])
 except Exception as e: print("parse failed", e)
 PY
-  done;;
+  done <<EOF_SINGLE
+${SINGLE_CASES:-OCRS_COALESCE=2|12
+OCRS_COALESCE=0|12
+OCRS_COALESCE=2|24}
+EOF_SINGLE
+  ;;
 stream10k)
   say "== configs[4] as stated: 10 000 distinct pages on 1 GPU (31 GB resident)"; timeout 1500 python bench.py --stream-pages 10000 --warmup 4 --no-cpu-baseline --no-extras > $OUT/bench_stream10k.json 2> $OUT/bench_stream10k.err; say "rc=$?"; jsum $OUT/bench_stream10k.json "stream 10k"; tail -2 $OUT/bench_stream10k.err | cut -c1-300 | tee -a $S;;
 detpmc)
