@@ -242,6 +242,7 @@ const OptDef kOptDefs[OPT_COUNT] = {
     {"coalesce_pages", "OCRS_COALESCE_PAGES", 16},      // pages per merged batch; requests of half that size or more run on their own
     {"coalesce_window_us", "OCRS_COALESCE_WINDOW_US", 300},  // how long a would-be leader lets the queue fill while other batches run
     {"gru_gates_pack", "OCRS_GRU_GATES_PACK", 1},       // gate-per-wave GRU kernel: 2 = two workgroups per CU for requests of twice the row tiles
+    {"conv_occupancy", "OCRS_CONV_OCCUPANCY", 4},       // recognition conv blocks per CU: 4 (fastest alone), 3 leaves room for other requests' small kernels
 };
 std::atomic<long> g_opts[OPT_COUNT];
 std::once_flag g_opts_once;

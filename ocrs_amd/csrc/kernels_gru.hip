@@ -721,7 +721,8 @@ bool gru_persistent(const float* gx, const float* wh, const float* bh, float* y,
             const dim3 grid(8 * UBg * ((2 * g.ncl + 7) / 8));
             const size_t lds = gru_gates_lds_bytes(H, Tmax);
             OCRS_HIP(hipMemsetAsync(d_sync, 0, gru_persistent_sync_words(M) * sizeof(uint32_t), s));
-            if (pack == 2) {
+            static const bool lean = getenv("OCRS_GRU_GATES_LEAN") != nullptr;   // experiment: 117 registers also for pack 1
+            if (pack == 2 || lean) {
                 if (H == 256) hipLaunchKernelGGL((gru_gates_kernel<256, true>), grid, dim3(256), lds, s, g);
                 else if (H == 128) hipLaunchKernelGGL((gru_gates_kernel<128, true>), grid, dim3(256), lds, s, g);
                 else hipLaunchKernelGGL((gru_gates_kernel<64, true>), grid, dim3(256), lds, s, g);
