@@ -40,8 +40,8 @@ PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md "HBM3E peak BW" (spec)
 PEAK_FP32_VALU_TFLOPS = 157.3  # MI355X_MICROARCH.md "Peak FP32 (vector)": 256 CUs x 128 lanes x 2 (FMA) x 2.4 GHz
 # kernel classes of the detection CNN (HBM-bound: depthwise-separable U-Net)
-DETECTION_CLASSES = ("dwconv3x3", "gemm_pointwise_mfma", "gemm_convt_mfma", "pool", "padcat", "conv1x1_sigmoid",
-                     "conv_direct")
+DETECTION_CLASSES = ("det_fused_block", "dwconv3x3", "gemm_pointwise_mfma", "gemm_convt_mfma", "pool", "padcat",
+                     "conv1x1_sigmoid", "conv_direct")
 MFMA_CLASSES = ("gemm_conv3x3_mfma", "gemm_gru_input_mfma", "gemm_gru_hidden_mfma", "gemm_linear_mfma")
 
 
@@ -626,6 +626,10 @@ def extra_legs(engine, dptrs, host_pages, H, W, synth, np, DimOrder, sync_all, a
                 "algorithmic_gflop_per_page": round(fl / 3 / len(inputs) / 1e9, 3),
                 "achieved_tflops": round(fl / ms / 1e9, 2),
                 "frac_of_fp32_vector_peak": round(fl / ms / 1e9 / PEAK_FP32_VALU_TFLOPS, 4),
+                # how much of the stack's arithmetic is dense contraction work executed on the matrix cores (pointwise convs and
+                # ConvTransposes: per-op MFMA GEMMs at the deep levels, MFMA variants of the fused blocks where the contraction
+                # fills the 16-row tile); the rest — depthwise 3x3, and the 8-channel pointwise convs at full resolution — is VALU
+                "mfma_share_of_flops": round(sum(v["mfma_flops"] for v in ks.values()) / max(fl, 1.0), 4),
                 "traffic": detection_traffic(),
                 "traffic_unit": "bytes per 8-page request, summed over every kernel of the stack (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE passes of tools/det_bench.py)",
                 "per_class_ms_per_8_pages": {k: round(v["ms"] / 3, 4) for k, v in sorted(ks.items(), key=lambda kv: -kv[1]["ms"])}}

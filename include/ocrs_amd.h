@@ -96,6 +96,9 @@ OCRS_API ocrs_status ocrs_coalescer_selftest(int n_threads, int requests_per_thr
  *   "gru_mode"        0 = one persistent kernel per GRU layer (default), 1 = one launch per time step
  *   "det_fuse"        1 = fused LDS-tiled DoubleConv blocks of the detection U-Net where they win (default),
  *                     2 = for every block shape that has a fused kernel, 0 = per-op kernels only
+ *   "det_mfma"        fused detection blocks: 1 = their pointwise convolutions and ConvTranspose run on MFMA where the
+ *                     contraction fills the 16-row tile (>= 16 mid channels; default), 2 = in every fused block,
+ *                     0 = thread-per-pixel VALU kernels only
  *   "layout_threads"  host threads ocrs_engine_find_text_lines_batch may use (0 = automatic)
  *   "beam_gpu"        1 = DecodeMethod::BeamSearch runs on the GPU (default), 0 = on the host (threaded over lines)
  *   "gru_local"       persistent GRU kernel: 1 = a cluster of workgroups that finds itself on one XCD hands its state
@@ -106,6 +109,7 @@ OCRS_API ocrs_status ocrs_coalescer_selftest(int n_threads, int requests_per_thr
  *                     gate-per-wave recurrence kernel (default), 0 = always the general persistent kernel
  *   "gru_gates_pack"  2 = the gate-per-wave kernel also takes requests of up to twice the row tiles by running two workgroups
  *                     per CU (default 1: one workgroup per CU)
+ *   "conv_occupancy"  recognition 3x3 conv blocks per CU: 4 (default) or 3
  *   "gemm_nfast"      1 = dense GEMMs run the column tiles of a row tile side by side on one XCD (default), 0 = column
  *                     tile on the grid's y axis
  *   "gru_scatter"     test knob: 1 = spread every cluster over all XCDs (exercises the write-through path), default 0
@@ -404,6 +408,10 @@ OCRS_API int ocrs_kernel_class_count(void);
 OCRS_API const char* ocrs_kernel_class_name(int cls);
 OCRS_API ocrs_status ocrs_engine_kernel_stats(ocrs_engine* e, double* ms, uint64_t* launches, double* flops,
                                               double* bytes, int reset);
+/* Per class, the part of `flops` that ran on the matrix cores (all of it for the gemm_*_mfma classes; the pointwise
+ * convolutions and ConvTranspose of a fused detection block when its MFMA variant ran).  Call BEFORE a resetting
+ * ocrs_engine_kernel_stats. */
+OCRS_API ocrs_status ocrs_engine_kernel_mfma_flops(ocrs_engine* e, double* mfma_flops);
 
 #ifdef __cplusplus
 }

@@ -551,8 +551,11 @@ class OcrEngine:
         cnt = (C.c_uint64 * n)()
         fl = (C.c_double * n)()
         by = (C.c_double * n)()
+        mf = (C.c_double * n)()
+        check(lib().ocrs_engine_kernel_mfma_flops(self._h, mf))
         check(lib().ocrs_engine_kernel_stats(self._h, ms, cnt, fl, by, 1 if reset else 0))
-        return {lib().ocrs_kernel_class_name(i).decode(): dict(ms=ms[i], launches=int(cnt[i]), flops=fl[i], bytes=by[i])
+        return {lib().ocrs_kernel_class_name(i).decode(): dict(ms=ms[i], launches=int(cnt[i]), flops=fl[i], bytes=by[i],
+                                                               mfma_flops=mf[i])
                 for i in range(n)}
 
     def stage_times(self, reset=True):

@@ -702,6 +702,13 @@ ocrs_status ocrs_engine_kernel_stats(ocrs_engine* e, double* ms, uint64_t* launc
         if (reset) e->timers.reset();
     });
 }
+ocrs_status ocrs_engine_kernel_mfma_flops(ocrs_engine* e, double* mfma_flops) {
+    return guarded_on(e ? e->device : -1, [&] {
+        if (!e || !mfma_flops) fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
+        e->timers.collect();
+        for (int i = 0; i < KC_COUNT; i++) mfma_flops[i] = e->timers.kmfma[i];
+    });
+}
 int ocrs_stage_count(void) { return ST_COUNT; }
 const char* ocrs_stage_name(int stage) { return stage >= 0 && stage < ST_COUNT ? kStageNames[stage] : ""; }
 ocrs_status ocrs_engine_stage_times(ocrs_engine* e, double* ms, uint64_t* launches, int reset) {

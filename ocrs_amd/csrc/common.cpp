@@ -72,7 +72,8 @@ const char* const kStageNames[ST_COUNT] = {
 const char* const kKernelClassNames[KC_COUNT] = {
     "gemm_conv3x3_mfma", "gemm_pointwise_mfma", "gemm_convt_mfma", "gemm_gru_input_mfma", "gemm_gru_hidden_mfma",
     "gemm_linear_mfma",  "dwconv3x3",           "conv_direct",     "pool",                "padcat",
-    "conv1x1_sigmoid",   "gru_gates",           "logsoftmax_argmax", "other"};
+    "conv1x1_sigmoid",   "gru_gates",           "logsoftmax_argmax", "other",
+    "det_fused_block"};
 
 // ---------------------------------------------------------------- DevicePool
 static size_t round_size(size_t n) {
@@ -243,6 +244,7 @@ const OptDef kOptDefs[OPT_COUNT] = {
     {"coalesce_window_us", "OCRS_COALESCE_WINDOW_US", 300},  // how long a would-be leader lets the queue fill while other batches run
     {"gru_gates_pack", "OCRS_GRU_GATES_PACK", 1},       // gate-per-wave GRU kernel: 2 = two workgroups per CU for requests of twice the row tiles
     {"conv_occupancy", "OCRS_CONV_OCCUPANCY", 4},       // recognition conv blocks per CU: 4 (fastest alone), 3 leaves room for other requests' small kernels
+    {"det_mfma", "OCRS_DET_MFMA", 1},                   // fused detection blocks: pointwise convs on MFMA where the contraction fills the tile (1), everywhere (2), never (0)
 };
 std::atomic<long> g_opts[OPT_COUNT];
 std::once_flag g_opts_once;
@@ -323,15 +325,16 @@ hipEvent_t StageTimers::get_event() {
 
 int StageTimers::begin(int stage, hipStream_t s, uint64_t n_launches) {
     if (!enabled) return -1;
-    Pending p{stage, get_event(), get_event(), n_launches, false, 0.0, 0.0};
+    Pending p{stage, get_event(), get_event(), n_launches, false, 0.0, 0.0, 0.0};
     OCRS_HIP(hipEventRecord(p.a, s));
     pending().push_back(p);
     return (int)pending().size() - 1;
 }
 
-int StageTimers::kbegin(int cls, hipStream_t s, double flops, double bytes) {
+int StageTimers::kbegin(int cls, hipStream_t s, double flops, double bytes, double mfma_flops) {
     if (!enabled || !kernels_enabled || !((kernel_mask >> cls) & 1u)) return -1;
-    Pending p{cls, get_event(), get_event(), 1, true, flops, bytes};
+    if (mfma_flops < 0.0) mfma_flops = cls <= KC_GEMM_LINEAR ? flops : 0.0;   // the gemm_*_mfma classes
+    Pending p{cls, get_event(), get_event(), 1, true, flops, bytes, mfma_flops};
     OCRS_HIP(hipEventRecord(p.a, s));
     pending().push_back(p);
     return (int)pending().size() - 1;
@@ -346,12 +349,12 @@ void StageTimers::end(int token, hipStream_t s) {
 void StageTimers::collect() {
     auto& pd = pending();
     if (pd.empty()) return;
-    double lms[ST_COUNT] = {0}, lkms[KC_COUNT] = {0}, lkf[KC_COUNT] = {0}, lkb[KC_COUNT] = {0};
+    double lms[ST_COUNT] = {0}, lkms[KC_COUNT] = {0}, lkf[KC_COUNT] = {0}, lkb[KC_COUNT] = {0}, lkm[KC_COUNT] = {0};
     uint64_t ln[ST_COUNT] = {0}, lkn[KC_COUNT] = {0};
     for (auto& p : pd) {
         float t = 0.f;
         if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&t, p.a, p.b) == hipSuccess) {
-            if (p.kernel) { lkms[p.stage] += t; lkn[p.stage] += 1; lkf[p.stage] += p.flops; lkb[p.stage] += p.bytes; }
+            if (p.kernel) { lkms[p.stage] += t; lkn[p.stage] += 1; lkf[p.stage] += p.flops; lkb[p.stage] += p.bytes; lkm[p.stage] += p.mfma; }
             else { lms[p.stage] += t; ln[p.stage] += p.n; }
         }
         free_events().push_back(p.a);
@@ -360,13 +363,13 @@ void StageTimers::collect() {
     pd.clear();
     std::lock_guard<std::mutex> g(mu);
     for (int i = 0; i < ST_COUNT; i++) { ms[i] += lms[i]; launches[i] += ln[i]; }
-    for (int i = 0; i < KC_COUNT; i++) { kms[i] += lkms[i]; klaunches[i] += lkn[i]; kflops[i] += lkf[i]; kbytes[i] += lkb[i]; }
+    for (int i = 0; i < KC_COUNT; i++) { kms[i] += lkms[i]; klaunches[i] += lkn[i]; kflops[i] += lkf[i]; kbytes[i] += lkb[i]; kmfma[i] += lkm[i]; }
 }
 
 void StageTimers::reset() {
     std::lock_guard<std::mutex> g(mu);
     for (int i = 0; i < ST_COUNT; i++) { ms[i] = 0; launches[i] = 0; }
-    for (int i = 0; i < KC_COUNT; i++) { kms[i] = 0; klaunches[i] = 0; kflops[i] = 0; kbytes[i] = 0; }
+    for (int i = 0; i < KC_COUNT; i++) { kms[i] = 0; klaunches[i] = 0; kflops[i] = 0; kbytes[i] = 0; kmfma[i] = 0; }
 }
 
 }  // namespace ocrs

@@ -140,7 +140,7 @@ inline hipStream_t recurrent_stream() { return ctx().recurrent_stream(); }
 // Process-wide tuning options (ocrs_set_option; initial value from the environment variable OCRS_<NAME>).
 // Integer-valued, looked up by name; unknown names are rejected by the ABI.
 enum Option { OPT_GRU_MODE = 0, OPT_DET_FUSE, OPT_LAYOUT_THREADS, OPT_BEAM_GPU, OPT_GRU_LOCAL, OPT_GRU_SCATTER, OPT_REC_MAX_PIXELS, OPT_GEMM_NFAST, OPT_GRU_GATES,
-              OPT_COALESCE, OPT_COALESCE_PAGES, OPT_COALESCE_WINDOW_US, OPT_GRU_GATES_PACK, OPT_CONV_OCCUPANCY, OPT_COUNT };
+              OPT_COALESCE, OPT_COALESCE_PAGES, OPT_COALESCE_WINDOW_US, OPT_GRU_GATES_PACK, OPT_CONV_OCCUPANCY, OPT_DET_MFMA, OPT_COUNT };
 enum { GRU_PERSISTENT = 0, GRU_STEP = 1 };
 int option(Option o);
 long option_long(Option o);
@@ -234,7 +234,7 @@ extern const char* const kStageNames[ST_COUNT];
 enum KernelClass {
     KC_GEMM_CONV3X3 = 0, KC_GEMM_POINTWISE, KC_GEMM_CONVT, KC_GEMM_GRU_INPUT, KC_GEMM_GRU_HIDDEN, KC_GEMM_LINEAR,
     KC_DWCONV3X3, KC_CONV_DIRECT, KC_POOL, KC_PADCAT, KC_CONV1X1_SIGMOID, KC_GRU_GATES, KC_LOGSOFTMAX_ARGMAX,
-    KC_OTHER, KC_COUNT
+    KC_OTHER, KC_DET_BLOCK, KC_COUNT
 };
 extern const char* const kKernelClassNames[KC_COUNT];
 
@@ -249,12 +249,14 @@ struct StageTimers {
     uint64_t klaunches[KC_COUNT] = {0};
     double kflops[KC_COUNT] = {0};
     double kbytes[KC_COUNT] = {0};
-    struct Pending { int stage; hipEvent_t a, b; uint64_t n; bool kernel; double flops, bytes; };
+    double kmfma[KC_COUNT] = {0};   // the part of kflops that ran on the matrix cores
+    struct Pending { int stage; hipEvent_t a, b; uint64_t n; bool kernel; double flops, bytes, mfma; };
     // Pending events are per host thread (an API call runs on one thread and collects its own
     // events after draining its stream), so concurrent calls never wait on each other's events.
     static std::vector<Pending>& pending();
     int begin(int stage, hipStream_t s, uint64_t n_launches);  // returns token (-1 when disabled)
-    int kbegin(int cls, hipStream_t s, double flops, double bytes);
+    // mfma_flops < 0: all of `flops` for the MFMA GEMM classes, none for the others
+    int kbegin(int cls, hipStream_t s, double flops, double bytes, double mfma_flops = -1.0);
     void end(int token, hipStream_t s);
     void collect();  // after a stream sync
     void reset();

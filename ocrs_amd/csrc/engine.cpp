@@ -122,11 +122,11 @@ void ocrs_engine::detect_now(const ocrs_page* const* pages, size_t n, std::vecto
     };
     auto run_ccl = [&](const uint8_t* mask, int np, const k::CclBuffers& b, int mc, int64_t ar) {
         {
-            StageScope sc(T, ST_CCL, st, 6);
+            StageScope sc(T, ST_CCL, st, 4);
             k::ccl_label(mask, np, h, w, b, mc, st);
         }
         {
-            StageScope sc(T, ST_CONTOUR_RECTS, st, 3);
+            StageScope sc(T, ST_CONTOUR_RECTS, st, 2);
             k::contour_rects(mask, np, h, w, b, mc, ar, /*expand*/ 3.0f, min_area, /*eps*/ 2.0f, st);
         }
     };

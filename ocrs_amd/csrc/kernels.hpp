@@ -30,8 +30,8 @@ struct CclBuffers {
     int32_t* row_offsets; // [n, h]
     int32_t* n_roots;     // [n]  external components per page
     int32_t* roots;       // [n, max_comp]  raster-ordered start pixels
-    int32_t* lengths;     // [n, max_comp]  contour lengths
-    int32_t* offsets;     // [n, max_comp]  arena offsets (exclusive scan of lengths)
+    int32_t* lengths;     // [n, max_comp]  (unused since r3: lengths are found by the contour kernel itself)
+    int32_t* offsets;     // [n]            per-page bump counter of the contour arena
     int32_t* overflow;    // [n]  set if a capacity was exceeded
     uint32_t* pts;        // [n, arena]  packed (y << 16 | x) contour points
     uint32_t* tmp;        // [n, 4 * arena]  per component: simplified | sorted | hull (2x) scratch
@@ -96,9 +96,10 @@ struct DoubleConvArgs {
 };
 // true if a fused kernel exists for the shape (cs skip channels, cx ConvT input channels or 0, ...) at this
 // fuse level (option "det_fuse": 1 = the shapes where fusion wins, 2 = every shape that has a kernel);
-// launches it when `launch` is set.
+// launches it when `launch` is set.  *on_mfma: the block's pointwise convs / ConvTranspose run on the matrix cores
+// (option "det_mfma").
 bool double_conv_fused(const DoubleConvArgs& a, int cs, int cx, int cmid, int cout, bool pool, bool final_conv, int fuse_level,
-                       bool launch, hipStream_t s);
+                       bool launch, hipStream_t s, bool* on_mfma = nullptr);
 void maxpool(const float* x, int n, int h, int w, int c, int kh, int kw, float* y, hipStream_t s);
 void avgpool(const float* x, int n, int h, int w, int c, int kh, int kw, float* y, hipStream_t s);
 void padcat(const float* skip, int n, int sh, int sw, int cs, const float* x, int h, int w, int cx, float* y,

@@ -13,11 +13,12 @@
 //       * a background component touching the image frame flattens to -1, so a
 //         component is an OUTERMOST one (RetrievalMode::External) iff the
 //         background pixel left of its root is frame-connected (or x == 0).
-//  2. Ordered compaction of the external roots (row counts -> scan -> write).
+//  2. Ordered compaction of the external roots (row counts -> write; a row's
+//     block sums the counts of the rows above itself).
 //  3. Border following from each root.  The walk only tests pixels for
-//     non-zero, so it needs the binary mask, not Suzuki's marks.  Two passes:
-//     count (one lane per component), scan, then write + simplify + rectangle
-//     with one wavefront per component.
+//     non-zero, so it needs the binary mask, not Suzuki's marks.  One
+//     wavefront per component: count walk, atomic bump of the page's contour
+//     arena, write walk + simplify + rectangle.
 // Everything here is integer/byte work or latency-bound geometry on a 1 MiB
 // mask that lives in L2: there is no MFMA-shaped computation in this stage.
 #include "kernels.hpp"
@@ -113,8 +114,11 @@ ccl_flatten_kernel(int32_t* __restrict__ labels, int64_t total_per_page, int n_p
     }
 }
 
+// A root needs no flattened labels: L[p] == p holds for roots of the forest as it is after the merge pass, and only
+// for the (few thousand) root pixels is the left neighbour's component looked up — so the separate pass that
+// compressed every path of every pixel (46 us per 8 pages) is gone.
 __device__ __forceinline__ bool is_external_root(const uint8_t* m, const int32_t* L, int w, int p, int x) {
-    return m[p] && L[p] == p && (x == 0 || L[p - 1] < 0);
+    return m[p] && L[p] == p && (x == 0 || uf_find(L, p - 1) < 0);
 }
 
 // One block per (row, page).
@@ -136,51 +140,36 @@ count_roots_kernel(const uint8_t* __restrict__ mask, const int32_t* __restrict__
     if (threadIdx.x == 0) row_counts[n * h + y] = red[0];
 }
 
-// Exclusive scan of `count` ints per page (one block per page), total -> totals[n].
-__global__ void __launch_bounds__(256)
-scan_kernel(const int32_t* __restrict__ in, int32_t* __restrict__ out, int32_t* __restrict__ totals,
-            const int32_t* __restrict__ counts_per_page, int stride, int fixed_count, int cap,
-            int32_t* __restrict__ overflow) {
-    const int n = blockIdx.x;
-    const int count = counts_per_page ? min(counts_per_page[n], stride) : fixed_count;
-    const int32_t* src = in + (int64_t)n * stride;
-    int32_t* dst = out + (int64_t)n * stride;
-    __shared__ int part[256];
-    __shared__ int carry;
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    for (int base = 0; base < count; base += 256) {
-        int i = base + threadIdx.x;
-        int v = i < count ? src[i] : 0;
-        part[threadIdx.x] = v;
-        __syncthreads();
-        for (int off = 1; off < 256; off <<= 1) {
-            int t = (int)threadIdx.x >= off ? part[threadIdx.x - off] : 0;
-            __syncthreads();
-            part[threadIdx.x] += t;
-            __syncthreads();
-        }
-        if (i < count) dst[i] = carry + part[threadIdx.x] - v;
-        __syncthreads();
-        if (threadIdx.x == 255) carry += part[255];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        if (totals) totals[n] = carry;
-        if (cap > 0 && carry > cap && overflow) overflow[n] = 1;
-    }
-}
-
+// One block per (row, page).  The row's first slot = number of roots in the rows above (summed here from the row
+// counts: no separate scan launch); the block of the last row also publishes the page's total.
 __global__ void __launch_bounds__(256)
 write_roots_kernel(const uint8_t* __restrict__ mask, const int32_t* __restrict__ labels, int h, int w,
-                   const int32_t* __restrict__ row_offsets, int32_t* __restrict__ roots, int max_comp) {
+                   const int32_t* __restrict__ row_counts, int32_t* __restrict__ roots, int32_t* __restrict__ n_roots,
+                   int32_t* __restrict__ overflow, int max_comp) {
     const int y = blockIdx.x, n = blockIdx.y;
     const uint8_t* m = mask + (int64_t)n * h * w;
     const int32_t* L = labels + (int64_t)n * h * w;
     __shared__ int wave_cnt[4];
+    __shared__ int red[256];
     __shared__ int base;
-    if (threadIdx.x == 0) base = row_offsets[n * h + y];
+    int above = 0;
+    for (int i = threadIdx.x; i < y; i += blockDim.x) above += row_counts[n * h + i];
+    red[threadIdx.x] = above;
     __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        base = red[0];
+        if (y == h - 1) {
+            const int total = red[0] + row_counts[n * h + y];
+            n_roots[n] = total;
+            if (total > max_comp) overflow[n] = 1;
+        }
+    }
+    __syncthreads();
+    if (row_counts[n * h + y] == 0) return;   // (uniform) most rows of a page start no component
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     for (int x0 = 0; x0 < w; x0 += 256) {
         int x = x0 + threadIdx.x;
@@ -204,14 +193,9 @@ void ccl_label(const uint8_t* d_mask, int n, int h, int w, const CclBuffers& b, 
     dim3 grid((w + 255) / 256, h, n);
     hipLaunchKernelGGL(ccl_init_kernel, grid, dim3(256), 0, s, d_mask, b.labels, h, w);
     hipLaunchKernelGGL(ccl_merge_kernel, grid, dim3(256), 0, s, d_mask, b.labels, h, w);
-    int64_t total = (int64_t)h * w;
-    int fgrid = (int)((total * n + 255) / 256 < 8192 ? (total * n + 255) / 256 : 8192);
-    hipLaunchKernelGGL(ccl_flatten_kernel, dim3(fgrid), dim3(256), 0, s, b.labels, total, n);
     hipLaunchKernelGGL(count_roots_kernel, dim3(h, n), dim3(256), 0, s, d_mask, b.labels, h, w, b.row_counts);
-    hipLaunchKernelGGL(scan_kernel, dim3(n), dim3(256), 0, s, b.row_counts, b.row_offsets, b.n_roots,
-                       (const int32_t*)nullptr, h, h, max_comp, b.overflow);
-    hipLaunchKernelGGL(write_roots_kernel, dim3(h, n), dim3(256), 0, s, d_mask, b.labels, h, w, b.row_offsets,
-                       b.roots, max_comp);
+    hipLaunchKernelGGL(write_roots_kernel, dim3(h, n), dim3(256), 0, s, d_mask, b.labels, h, w, b.row_counts, b.roots,
+                       b.n_roots, b.overflow, max_comp);
 }
 
 // ---------------------------------------------------------------------------
@@ -221,50 +205,10 @@ void ccl_label(const uint8_t* d_mask, int n, int h, int w, const CclBuffers& b, 
 __device__ __forceinline__ int dir_dy(int d) { return (int)((0xA901u >> (2 * d)) & 3u) - 1; }  // {0,-1,-1,-1,0,1,1,1}+1
 __device__ __forceinline__ int dir_dx(int d) { return (int)((0x1A90u >> (2 * d)) & 3u) - 1; }  // {-1,-1,0,1,1,1,0,-1}+1
 
-template <bool WRITE>
-__device__ int trace_border(const uint8_t* __restrict__ m, int h, int w, int sy, int sx, uint32_t* out) {
-    // the 8 neighbours of (y, x) as a bit mask (bit d = direction d is foreground), fetched with 8 INDEPENDENT byte
-    // loads: a step of the walk costs one memory latency instead of one per neighbour examined
-    auto neighbours = [&](int y, int x) -> unsigned {
-        unsigned mk = 0;
-#pragma unroll
-        for (int d = 0; d < 8; d++) {
-            const int yy = y + dir_dy(d), xx = x + dir_dx(d);
-            const bool in = (unsigned)yy < (unsigned)h && (unsigned)xx < (unsigned)w;
-            const uint8_t v = m[in ? yy * w + xx : 0];
-            mk |= (in && v != 0) ? (1u << d) : 0u;
-        }
-        return mk;
-    };
-    const unsigned nb0 = neighbours(sy, sx);
-    if (nb0 == 0) {
-        if (WRITE) out[0] = ((uint32_t)sy << 16) | (uint32_t)sx;
-        return 1;
-    }
-    const int first = __ffs((int)nb0) - 1;  // 3.1: clockwise from W = lowest set direction
-    const int i1 = sy + dir_dy(first), j1 = sx + dir_dx(first);
-    int i3 = sy, j3 = sx, d0 = first, n = 0;
-    unsigned nb = nb0;
-    for (;;) {
-        int i4 = i3, j4 = j3, dn = d0;
-#pragma unroll
-        for (int s = 1; s <= 8; s++) {  // 3.3: counter-clockwise from the element after (i2,j2)
-            const int d = (d0 - s) & 7;
-            if ((nb >> d) & 1u) { i4 = i3 + dir_dy(d); j4 = j3 + dir_dx(d); dn = d; break; }
-        }
-        if (WRITE) out[n] = ((uint32_t)i3 << 16) | (uint32_t)j3;
-        n++;
-        if (i4 == sy && j4 == sx && i3 == i1 && j3 == j1) break;  // 3.5
-        i3 = i4; j3 = j4;
-        d0 = (dn + 4) & 7;  // the pixel we came from, seen from the new current pixel
-        nb = neighbours(i3, j3);
-    }
-    return n;
-}
-
-// The same walk by a whole wavefront: lane d < 8 fetches neighbour d, a ballot gives the mask, the walk state is
+// The walk by a whole wavefront: lane d < 8 fetches neighbour d, a ballot gives the mask, the walk state is
 // wave-uniform (scalar registers).  One memory latency and a handful of scalar instructions per border pixel —
 // a single lane running trace_border pays the issue latency of every instruction of the step.
+template <bool WRITE>
 __device__ int trace_border_wave(const uint8_t* __restrict__ m, int h, int w, int sy, int sx, uint32_t* out, int lane) {
     const int ldy = dir_dy(lane & 7), ldx = dir_dx(lane & 7);
     auto neighbours = [&](int y, int x) -> unsigned {
@@ -275,7 +219,7 @@ __device__ int trace_border_wave(const uint8_t* __restrict__ m, int h, int w, in
     };
     const unsigned nb0 = neighbours(sy, sx);
     if (nb0 == 0) {
-        if (lane == 0) out[0] = ((uint32_t)sy << 16) | (uint32_t)sx;
+        if (WRITE && lane == 0) out[0] = ((uint32_t)sy << 16) | (uint32_t)sx;
         return 1;
     }
     const int first = __ffs((int)nb0) - 1;
@@ -296,7 +240,7 @@ __device__ int trace_border_wave(const uint8_t* __restrict__ m, int h, int w, in
             dn = d0;
         }
         if (rot) { i4 = i3 + dir_dy(dn); j4 = j3 + dir_dx(dn); }
-        if (lane == 0) out[n] = ((uint32_t)i3 << 16) | (uint32_t)j3;
+        if (WRITE && lane == 0) out[n] = ((uint32_t)i3 << 16) | (uint32_t)j3;
         n++;
         if (i4 == sy && j4 == sx && i3 == i1 && j3 == j1) break;
         i3 = i4; j3 = j4;
@@ -304,18 +248,6 @@ __device__ int trace_border_wave(const uint8_t* __restrict__ m, int h, int w, in
         nb = neighbours(i3, j3);
     }
     return n;
-}
-
-__global__ void __launch_bounds__(64)
-trace_count_kernel(const uint8_t* __restrict__ mask, int h, int w, const int32_t* __restrict__ n_roots,
-                   const int32_t* __restrict__ roots, int32_t* __restrict__ lengths, int max_comp) {
-    const int n = blockIdx.y;
-    const int cnt = min(n_roots[n], max_comp);
-    const uint8_t* m = mask + (int64_t)n * h * w;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += gridDim.x * blockDim.x) {
-        int r = roots[(int64_t)n * max_comp + i];
-        lengths[(int64_t)n * max_comp + i] = trace_border<false>(m, h, w, r / w, r % w, nullptr);
-    }
 }
 
 // ---- geometry restated from rten-imageproc ------------
@@ -349,30 +281,42 @@ __device__ __forceinline__ float cross3(P2 o, P2 a, P2 b) {
 // One wavefront (= one 64-thread block) per component.
 __global__ void __launch_bounds__(64)
 contour_rect_kernel(const uint8_t* __restrict__ mask, int h, int w, const int32_t* __restrict__ n_roots,
-                    const int32_t* __restrict__ roots, const int32_t* __restrict__ lengths,
-                    const int32_t* __restrict__ offsets, const int32_t* __restrict__ overflow,
+                    const int32_t* __restrict__ roots, int32_t* __restrict__ arena_top, int32_t* __restrict__ overflow,
                     uint32_t* __restrict__ pts_all, uint32_t* __restrict__ tmp_all, uint8_t* __restrict__ keep_all,
                     float* __restrict__ rects, uint8_t* __restrict__ valid, int max_comp, int64_t arena,
                     float expand, float min_area, float eps) {
     const int page = blockIdx.y;
-    if (overflow[page]) return;
-    const int cnt = min(n_roots[page], max_comp);
+    if (n_roots[page] > max_comp) return;    // the page's component stage is re-run with larger buffers (engine.cpp)
+    const int cnt = n_roots[page];
     const uint8_t* m = mask + (int64_t)page * h * w;
     const int lane = threadIdx.x;
     for (int ci = blockIdx.x; ci < cnt; ci += gridDim.x) {
         const int64_t slot = (int64_t)page * max_comp + ci;
-        const int n = lengths[slot];
-        const int64_t off = (int64_t)page * arena + offsets[slot];
+        const int root = roots[slot];
+        // ---- 0. length of the border (the same wave-cooperative walk, nothing written), then this component's
+        // piece of the page's arena: an atomic bump (placement order is irrelevant — results are indexed by slot).
+        // r2 ran a separate count kernel (one lane per component) + a scan launch for this.
+        const int n = trace_border_wave<false>(m, h, w, root / w, root % w, nullptr, lane);
+        int off32 = 0;
+        if (lane == 0) off32 = atomicAdd(&arena_top[page], n);
+        off32 = __builtin_amdgcn_readfirstlane(off32);
+        if ((int64_t)off32 + n > arena) {
+            if (lane == 0) {
+                overflow[page] = 1;
+                valid[slot] = 0;
+            }
+            continue;
+        }
+        const int64_t off = (int64_t)page * arena + off32;
         uint32_t* pts = pts_all + off;
         uint8_t* keep = keep_all + off;
         // three scratch regions per component: simplified / sorted / hull (<= 2m + 2)
-        uint32_t* simp = tmp_all + (int64_t)page * arena * 4 + (int64_t)offsets[slot] * 4;
+        uint32_t* simp = tmp_all + (int64_t)page * arena * 4 + (int64_t)off32 * 4;
         uint32_t* sorted = simp + n;
         uint32_t* hull = sorted + n;  // 2n words
-        const int root = roots[slot];
 
         // ---- 1. border following (serial by nature): lane 0 writes the points
-        trace_border_wave(m, h, w, root / w, root % w, pts, lane);
+        trace_border_wave<true>(m, h, w, root / w, root % w, pts, lane);
         for (int k = lane; k < n; k += 64) keep[k] = 0;
         WAVE_SYNC();
 
@@ -548,13 +492,10 @@ contour_rect_kernel(const uint8_t* __restrict__ mask, int h, int w, const int32_
 
 void contour_rects(const uint8_t* d_mask, int n, int h, int w, const CclBuffers& b, int max_comp, int64_t arena,
                    float expand, float min_area, float eps, hipStream_t s) {
-    hipLaunchKernelGGL(trace_count_kernel, dim3(64, n), dim3(64), 0, s, d_mask, h, w, b.n_roots, b.roots, b.lengths,
-                       max_comp);
-    hipLaunchKernelGGL(scan_kernel, dim3(n), dim3(256), 0, s, b.lengths, b.offsets, (int32_t*)nullptr, b.n_roots,
-                       max_comp, 0, (int)(arena < 0x7fffffff ? arena : 0x7fffffff), b.overflow);
-    hipLaunchKernelGGL(contour_rect_kernel, dim3(2048, n), dim3(64), 0, s, d_mask, h, w, b.n_roots, b.roots, b.lengths,
-                       b.offsets, b.overflow, b.pts, b.tmp, b.keep, b.rects, b.valid, max_comp, arena, expand, min_area,
-                       eps);
+    // b.offsets[0..n) serves as the per-page arena bump counter (zeroed here); b.lengths is unused since r3
+    (void)hipMemsetAsync(b.offsets, 0, (size_t)n * sizeof(int32_t), s);
+    hipLaunchKernelGGL(contour_rect_kernel, dim3(2048, n), dim3(64), 0, s, d_mask, h, w, b.n_roots, b.roots, b.offsets,
+                       b.overflow, b.pts, b.tmp, b.keep, b.rects, b.valid, max_comp, arena, expand, min_area, eps);
 }
 
 }  // namespace k

@@ -354,8 +354,8 @@ float* HipModel::run_device(Workspace& ws, const float* d_in, int n, int h, int 
     };
     bool seen_seq = false;
     // per-launch kernel timing (only when the engine asked for it)
-    auto timed = [&](int cls, double flops, double bytes, auto&& launch) {
-        int tok = timers ? timers->kbegin(cls, st, flops, bytes) : -1;
+    auto timed = [&](int cls, double flops, double bytes, auto&& launch, double mfma_flops = -1.0) {
+        int tok = timers ? timers->kbegin(cls, st, flops, bytes, mfma_flops) : -1;
         launch();
         if (tok >= 0) timers->end(tok, st);
     };
@@ -433,9 +433,14 @@ float* HipModel::run_device(Workspace& ws, const float* d_in, int n, int h, int 
                     const int cin = d1.cin;
                     const double fl = 2.0 * px * (9.0 * cin + (double)cin * b.cmid + 9.0 * b.cmid + (double)b.cmid * b.cout +
                                                   (b.fin >= 0 ? b.cout : 0)) + 2.0 * px * (b.convt >= 0 ? (double)b.cx * b.cs : 0.0);
-                    timed(KC_DWCONV3X3, fl, 4.0 * (px * b.cs + px1 * b.cx + out_floats), [&] {
+                    // of which dense contractions (pointwise convs, ConvTranspose) — on the matrix cores if the block's MFMA variant runs
+                    const double fl_dense = 2.0 * px * ((double)cin * b.cmid + (double)b.cmid * b.cout) +
+                                            2.0 * px * (b.convt >= 0 ? (double)b.cx * b.cs : 0.0);
+                    bool on_mfma = false;
+                    k::double_conv_fused(k::DoubleConvArgs{}, b.cs, b.cx, b.cmid, b.cout, b.pool >= 0, b.fin >= 0, det_fuse, false, nullptr, &on_mfma);
+                    timed(KC_DET_BLOCK, fl, 4.0 * (px * b.cs + px1 * b.cx + out_floats), [&] {
                         k::double_conv_fused(da, b.cs, b.cx, b.cmid, b.cout, b.pool >= 0, b.fin >= 0, det_fuse, true, st);
-                    });
+                    }, on_mfma ? fl_dense : 0.0);
                     for (int q = b.first + 1; q <= b.last; q++) covered[q] = 1;
                     for (int sl = 1; sl < (int)n_slots; sl++)
                         if (last_use[sl] == (int)i && ptr[sl] && cap[sl]) {

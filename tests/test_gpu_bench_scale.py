@@ -311,13 +311,19 @@ def test_fused_double_conv_blocks_equal_unfused_and_oracle(in_hw, depths):
     try:
         _lib.set_option("det_fuse", 0)
         ref = model.run(x)
-        _lib.set_option("det_fuse", 2)   # every block shape that has a fused kernel
-        got2 = model.run(x)
-        _lib.set_option("det_fuse", 1)   # the default: only the shapes where fusion wins
-        got = model.run(x)
+        outs = {}
+        for mfma in (2, 1, 0):               # r3: pointwise convs of the fused blocks on MFMA: all blocks / default mix / none
+            _lib.set_option("det_mfma", mfma)
+            _lib.set_option("det_fuse", 2)   # every block shape that has a fused kernel
+            outs[(mfma, 2)] = model.run(x)
+            _lib.set_option("det_fuse", 1)   # the default: only the shapes where fusion wins
+            outs[(mfma, 1)] = model.run(x)
     finally:
         _lib.set_option("det_fuse", 1)
+        _lib.set_option("det_mfma", 1)
+    got = outs[(1, 1)]   # the defaults
     assert got.shape == ref.shape == (3, 1) + in_hw
-    assert np.array_equal(got, ref) and np.array_equal(got2, ref)
+    for key, o in outs.items():
+        assert np.array_equal(o, ref), key
     if in_hw[0] <= 256:
         assert np.array_equal(got, OracleGraph(dbuf).run_exact(x))
