@@ -110,6 +110,9 @@ OCRS_API ocrs_status ocrs_coalescer_selftest(int n_threads, int requests_per_thr
  *   "gru_gates_pack"  2 = the gate-per-wave kernel also takes requests of up to twice the row tiles by running two workgroups
  *                     per CU (default 1: one workgroup per CU)
  *   "conv_occupancy"  recognition 3x3 conv blocks per CU: 4 (default) or 3
+ *   "gru_background"  1 = requests too large for one row tile per cluster run the recurrence on the lean multi-tile
+ *                     gate-per-wave kernel (a third of the general kernel's registers: conv stacks of other requests keep
+ *                     three blocks per CU beside it; slower on its own), default 0
  *   "gemm_nfast"      1 = dense GEMMs run the column tiles of a row tile side by side on one XCD (default), 0 = column
  *                     tile on the grid's y axis
  *   "gru_scatter"     test knob: 1 = spread every cluster over all XCDs (exercises the write-through path), default 0

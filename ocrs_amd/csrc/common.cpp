@@ -245,6 +245,8 @@ const OptDef kOptDefs[OPT_COUNT] = {
     {"gru_gates_pack", "OCRS_GRU_GATES_PACK", 1},       // gate-per-wave GRU kernel: 2 = two workgroups per CU for requests of twice the row tiles
     {"conv_occupancy", "OCRS_CONV_OCCUPANCY", 4},       // recognition conv blocks per CU: 4 (fastest alone), 3 leaves room for other requests' small kernels
     {"det_mfma", "OCRS_DET_MFMA", 1},                   // fused detection blocks: pointwise convs on MFMA where the contraction fills the tile (1), everywhere (2), never (0)
+    {"gru_background", "OCRS_GRU_BACKGROUND", 0},       // requests beyond the gate-per-wave kernel's size: 1 = lean multi-tile gate-per-wave kernel (small footprint, slower alone)
+    {"gx_heavy", "OCRS_GX_HEAVY", 0},                   // GRU input projections of large requests on the shared conv-stack stream (serialised with the conv stacks)
 };
 std::atomic<long> g_opts[OPT_COUNT];
 std::once_flag g_opts_once;

@@ -64,6 +64,7 @@ struct GruParams {
     int scatter;         // 1: clusters deliberately spread over the XCDs (OCRS_GRU_SCATTER=1; tests the census)
     int16_t tiles[kMaxSlots * 4];  // row tiles of wave slot (cluster-in-direction * 4 + wave), longest first; -1 = none
     uint32_t spin_limit;
+    int lazy;            // background kernel: wait this many x 1024 clocks before every re-read (its waits are whole rounds long)
 };
 
 // Hand-off accesses to y: 16-byte raw-buffer loads/stores with the sc1 (agent-scope) cache bit — the store is
@@ -170,6 +171,7 @@ template <int H>
 __device__ __forceinline__ bool await_state(const GruParams& p, __amdgpu_buffer_rsrc_t y, int ub, int kq, Loaded<H>& L) {
     for (uint32_t spins = 0; !state_ready<H>(L); spins++) {
         __builtin_amdgcn_s_sleep(2);
+        for (int z = 0; z < p.lazy; z++) __builtin_amdgcn_s_sleep(16);
         // Back off when the wait is a long one (a peer workgroup not resident yet, or held up): a re-read costs 17
         // line fetches per lane group, and a CU whose pollers re-issue them back to back can keep its own memory
         // pipeline so full that the store everybody is waiting for does not get through (seen with two workgroups
@@ -548,6 +550,203 @@ gru_gates_kernel(GruParams p) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// r3: the gate-per-wave layout for LARGE requests, as a background kernel.
+//
+// The general kernel above is built to finish a layer as fast as possible: three interleaved MFMA chains per wave,
+// the next item's 17 loads in flight under them, 299 registers — one wave per SIMD, and while it is resident a CU has
+// room for ONE block of another request's conv stack instead of four (conv3x3 0.79 of the MFMA peak alone, 0.63-0.67
+// live).  The recurrence is 9 % of a step's arithmetic; the conv stacks are 79 %.  This kernel trades the
+// recurrence's own speed for its footprint: the gate-per-wave roles of gru_gates_kernel (117 registers: it fits in
+// the register space of ONE conv wave per SIMD, so a CU keeps three conv blocks beside it), no second register set —
+// a wave's load and hand-off latencies are filled by the conv waves it shares the SIMD with — and SEVERAL row tiles
+// per cluster, stepped round-robin (tile j's state of step s - 1 has a whole round of the other tiles to arrive).
+//   waves 0..2 (gate r, z, n) per item (tile j, step s): previous state of the tile (polled) -> transposes ->
+//              64-MFMA chain of their gate -> accumulators to LDS (two exchange buffers, used alternately) -> barrier
+//   wave 3:    gx of the item (prefetched one item ahead), previous state of its own 4 units (read back from y) ->
+//              barrier -> gates from LDS -> sigma / tanh -> store
+// One barrier per item: the gate waves reach item i + 2 (same exchange buffer as item i) only through the barrier of
+// item i + 1, which wave 3 enters after it has read item i's accumulators.
+// Same arithmetic per output as every other path (tests compare the bits).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kMultiTiles = 16;   // row tiles per cluster
+
+template <int H>
+__global__ void __launch_bounds__(256)
+gru_gates_multi_kernel(GruParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds_w[];  // H*48 floats | off[Tmax+1] | 2 x exchange | tile tables | abort
+    constexpr int UB = H / 16;
+    const int b = blockIdx.x;
+    const int q = b >> 3;
+    const int ub = p.scatter ? b % UB : q % UB;
+    const int cid = p.scatter ? b / UB : (q / UB) * 8 + (b & 7);
+    if (cid >= 2 * p.ncl) return;
+    const int dir = cid & 1, cl = cid >> 1;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i16 = lane & 15, kq = lane >> 4;
+    uint32_t xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
+    if (tid == 0) __hip_atomic_store((gu32*)p.place + cid * UB + ub, xcc + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const float* __restrict__ whd = p.wh + (int64_t)dir * H * 3 * H;
+    const float* __restrict__ bhd = p.bh + (int64_t)dir * 3 * H;
+    const int j0 = ub * 16;
+    for (int i = tid; i < H * 12; i += 256) {   // Wh slice -> LDS, layout as in gru_persistent_kernel
+        const int k = i / 12, qq = i - k * 12;
+        const int g = qq >> 2, c4 = (qq & 3) * 4;
+        const float4 v = *reinterpret_cast<const float4*>(whd + (int64_t)k * 3 * H + g * H + j0 + c4);
+        const int blk = k >> 4, e = (k >> 2) & 3, kk = k & 3;
+        float* dst = &lds_w[(((g * (H / 16) + blk) * 64) + kk * 16 + c4) * 4 + e];
+        dst[0] = v.x; dst[4] = v.y; dst[8] = v.z; dst[12] = v.w;
+    }
+    int* off_l = reinterpret_cast<int*>(lds_w + H * 48);
+    for (int i = tid; i <= p.Tmax; i += 256) off_l[i] = p.off[i];
+    f32x4* xch = reinterpret_cast<f32x4*>(lds_w + H * 48 + (((p.Tmax + 1) + 3) & ~3));   // [2][3][64]
+    int* tm_l = reinterpret_cast<int*>(xch + 2 * 3 * 64);      // [kMultiTiles][16] lengths of the tiles' rows
+    int* tile_l = tm_l + kMultiTiles * 16;                      // [kMultiTiles] tile index (-1: none)
+    int* abort_w = tile_l + kMultiTiles;
+    if (tid == 0) *abort_w = 0;
+    for (int i = tid; i < kMultiTiles * 16; i += 256) {
+        const int t = p.tiles[cl * kMultiTiles + (i >> 4)];
+        const int m = t * 16 + (i & 15);
+        tm_l[i] = (t >= 0 && m < p.M) ? p.Tm[m] : 0;
+        if ((i & 15) == 0) tile_l[i >> 4] = t;
+    }
+    __syncthreads();
+    if (p.prio >= 3) __builtin_amdgcn_s_setprio(3);
+    else if (p.prio == 2) __builtin_amdgcn_s_setprio(2);
+    else if (p.prio == 1) __builtin_amdgcn_s_setprio(1);
+    if (tm_l[0] <= 0) return;                     // (lists are sorted by length: an empty first tile = an empty cluster)
+    bool local;
+    {   // placement census, part 2 (see gru_persistent_kernel)
+        const gu32* pl = (const gu32*)p.place + cid * UB;
+        uint32_t v = xcc + 1u;
+        for (uint32_t spins = 0;; spins++) {
+            if (lane < UB) v = __hip_atomic_load(pl + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!__any(v == 0u)) break;
+            __builtin_amdgcn_s_sleep(8);
+            if (spins >= p.spin_limit) {
+                __hip_atomic_store((gu32*)p.sync, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *abort_w = 1;
+                break;
+            }
+        }
+        local = !__any(v != xcc + 1u) && p.allow_local;
+    }
+    const __amdgpu_buffer_rsrc_t yb = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)(uint32_t)(p.R * 2 * H * sizeof(float)), 0x00020000);
+    // item iterator, identical in all four waves: (step s, list position j); tile j is live at step s iff its longest
+    // row (row 0 of the tile) is longer than s; lists are sorted by length, so the live tiles of a step are a prefix
+    auto tile_T = [&](int j) { return j < kMultiTiles ? tm_l[j * 16] : 0; };
+    auto advance = [&](int& s, int& j) -> bool {   // false: no further item
+        if (tile_T(j + 1) > s) { j++; return true; }
+        if (tile_T(0) > s + 1) { s++; j = 0; return true; }
+        return false;
+    };
+    int s = 0, j = 0, it = 0;
+    if (wave < 3) {
+        const f32x4 bias = *reinterpret_cast<const f32x4*>(bhd + wave * H + j0 + kq * 4);
+        Loaded<H> L;
+        const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+        L.gr = L.gz = L.gn = zero;
+        L.out_off = 0;
+        for (;;) {
+            const int tm = tm_l[j * 16 + i16];
+            const int m = tile_l[j] * 16 + i16;
+            L.active = tm > s;
+            L.has_prev = L.active && s > 0;
+            L.hp = zero;
+#pragma unroll
+            for (int jj = 0; jj < H / 16; jj++) L.h[jj] = zero;
+            L.prev_off = L.has_prev ? (uint32_t)((((int64_t)off_l[dir ? tm - s : s - 1] + m) * 2 * H + dir * H) * sizeof(float)) : 0u;
+            issue_state<H>(yb, ub, kq, L);
+            if (!await_state<H>(p, yb, ub, kq, L)) *abort_w = 1;
+            float w[H / 4];
+#pragma unroll
+            for (int jj = 0; jj < H / 16; jj++) transpose4(L.h[jj], &w[4 * jj]);
+            xch[(it & 1) * 192 + wave * 64 + lane] = gate_chain<H>(lane, w, lds_w, wave, bias);
+            __syncthreads();
+            if (*abort_w) return;
+            it++;
+            if (!advance(s, j)) return;
+        }
+    } else {
+        struct Gx { f32x4 gr, gz, gn, hp; uint32_t out_off; bool active; };
+        // gx of an item + the previous state of this lane's own 4 units (its own store of one round earlier, read back
+        // with the hand-off's bypassing load; polled like any other state word, although it has long landed)
+        auto fetch = [&](int ss, int jj, Gx& g) {
+            const int tm = tm_l[jj * 16 + i16];
+            const int m = tile_l[jj] * 16 + i16;
+            g.active = tm > ss;
+            const int t = dir ? tm - 1 - ss : ss;
+            const int64_t row = g.active ? (int64_t)off_l[t] + m : 0;
+            g.out_off = (uint32_t)((row * 2 * H + dir * H + ub * 16 + kq * 4) * sizeof(float));
+            const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+            g.gr = g.gz = g.gn = g.hp = zero;
+            if (g.active) {
+                const float* gp = p.gx + ((int64_t)dir * p.R + row) * 3 * H + ub * 16 + kq * 4;
+                g.gr = *reinterpret_cast<const f32x4*>(gp);
+                g.gz = *reinterpret_cast<const f32x4*>(gp + H);
+                g.gn = *reinterpret_cast<const f32x4*>(gp + 2 * H);
+                if (ss > 0) {
+                    const uint32_t po = (uint32_t)((((int64_t)off_l[dir ? tm - ss : ss - 1] + m) * 2 * H + dir * H + ub * 16 + kq * 4) * sizeof(float));
+                    g.hp = load_bypass(yb, po);
+                    // re-read while any word is still unwritten (bounded; cannot really happen: see above)
+                    for (uint32_t spins = 0; spins < 4096u; spins++) {
+                        unsigned mx = 0;
+#pragma unroll
+                        for (int e = 0; e < 4; e++) mx = max(mx, __float_as_uint(g.hp[e]));
+                        if (mx != kUnwritten) break;
+                        __builtin_amdgcn_s_sleep(4);
+                        g.hp = load_bypass(yb, po);
+                    }
+                }
+            }
+        };
+        auto finish = [&](const Gx& g) {   // after the item's barrier: gates from the exchange buffer, store
+            GateAcc a;
+            const f32x4* x = xch + (it & 1) * 192;
+            a.r = x[lane]; a.z = x[64 + lane]; a.n = x[128 + lane];
+            f32x4 hn;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const float rg = sigmoidf_sl(g.gr[r] + a.r[r]);
+                const float zg = sigmoidf_sl(g.gz[r] + a.z[r]);
+                const float ng = tanhf_sl(fmaf(rg, a.n[r], g.gn[r]));
+                const float hv = fmaf(zg, g.hp[r] - ng, ng);
+                hn[r] = __float_as_uint(hv) == kUnwritten ? __uint_as_float(0x7FC00000u) : hv;
+            }
+            const uint32_t o = g.active ? g.out_off : 0xFFFFFFF0u;
+            if (local) store_local(yb, o, hn);
+            else store_through(yb, o, hn);
+        };
+        Gx ga, gb;
+        fetch(0, 0, ga);
+        // two register sets used alternately, as in the general kernel (copying one would wait for loads in flight)
+        auto step = [&](Gx& cur, Gx& nxt) -> bool {   // false: done / aborted
+            int ns = s, nj = j;
+            const bool have_next = advance(ns, nj);
+            // the next item's gx may be fetched now; its hp only if it belongs to ANOTHER tile (this item's own store is
+            // the previous state of the same tile's next step) — with one tile in the list it is fetched after the store
+            const bool same_tile = have_next && nj == j;
+            if (have_next && !same_tile) fetch(ns, nj, nxt);
+            __syncthreads();
+            if (*abort_w) return false;
+            finish(cur);
+            it++;
+            if (!have_next) return false;
+            if (same_tile) fetch(ns, nj, nxt);
+            s = ns; j = nj;
+            return true;
+        };
+        for (;;) {
+            if (!step(ga, gb)) return;
+            if (!step(gb, ga)) return;
+        }
+    }
+}
+
 }  // namespace
 
 constexpr int kMaxGrid = 4096;
@@ -702,6 +901,44 @@ static bool gru_gates_plan(int M, int Tmax, int H, int* ncl, int* pack) {
     return true;
 }
 
+
+// ---- background (lean) recurrence for large requests: gru_gates_multi_kernel --------------------------------------
+static size_t gru_multi_lds_bytes(int H, int Tmax) {
+    return (size_t)H * 48 * sizeof(float) + (size_t)(((Tmax + 1) + 3) & ~3) * sizeof(int) + 2 * 3 * 64 * 16 +
+           (size_t)kMultiTiles * 16 * sizeof(int) + (size_t)kMultiTiles * sizeof(int) + 16;
+}
+
+// ncl clusters per direction, up to kMultiTiles row tiles each.
+static bool gru_multi_plan(int M, int Tmax, int H, int* ncl) {
+    if (H != 256 && H != 128 && H != 64) return false;
+    if (gru_multi_lds_bytes(H, Tmax) > 64 * 1024) return false;
+    const int ntiles = (M + 15) / 16, UB = H / 16;
+    int cap = gru_resident_capacity(H, true, gru_multi_lds_bytes(H, Tmax));
+    cap = cap > 256 ? 256 : cap;
+    cap -= cap % (8 * UB);
+    if (cap < 8 * UB) return false;
+    const int max_ncl = cap / UB / 2;
+    if (ntiles > kMultiTiles * max_ncl || max_ncl * kMultiTiles > kMaxSlots * 4) return false;
+    *ncl = ntiles < max_ncl ? ntiles : max_ncl;
+    return true;
+}
+
+// Tiles (longest first) to the cluster with the least work so far (work = sum of the tiles' lengths: a cluster
+// steps its tiles one after the other); every list ends up sorted by length.
+static void gru_assign_multi(const int32_t* h_Tm, int M, int ncl, int16_t* tiles) {
+    const int ntiles = (M + 15) / 16;
+    for (int i = 0; i < kMaxSlots * 4; i++) tiles[i] = -1;
+    std::vector<int64_t> load(ncl, 0);
+    std::vector<int> cnt(ncl, 0);
+    for (int k = 0; k < ntiles; k++) {
+        int best = -1;
+        for (int c = 0; c < ncl; c++)
+            if (cnt[c] < kMultiTiles && (best < 0 || load[c] < load[best])) best = c;
+        tiles[best * kMultiTiles + cnt[best]++] = (int16_t)k;
+        load[best] += h_Tm[k * 16];
+    }
+}
+
 bool gru_persistent(const float* gx, const float* wh, const float* bh, float* y, const int32_t* d_Tm, const int32_t* d_off,
                     const int32_t* h_Tm, int64_t R, int M, int Tmax, int H, uint32_t* d_sync, hipStream_t s) {
     if (M <= 0) return true;
@@ -731,6 +968,30 @@ bool gru_persistent(const float* gx, const float* wh, const float* bh, float* y,
                 else if (H == 128) hipLaunchKernelGGL((gru_gates_kernel<128, false>), grid, dim3(256), lds, s, g);
                 else hipLaunchKernelGGL((gru_gates_kernel<64, false>), grid, dim3(256), lds, s, g);
             }
+            return true;
+        }
+    }
+    if (option(OPT_GRU_BACKGROUND)) {
+        GruParams g{};
+        if (gru_multi_plan(M, Tmax, H, &g.ncl)) {
+            g.gx = gx; g.wh = wh; g.bh = bh; g.y = y; g.Tm = d_Tm; g.off = d_off;
+            g.place = d_sync;
+            g.sync = d_sync + kMaxGrid;
+            g.R = R; g.M = M; g.Tmax = Tmax;
+            g.prio = 3;
+            if (const char* e = getenv("OCRS_GRU_BG_PRIO")) g.prio = atoi(e);
+            if (const char* e = getenv("OCRS_GRU_BG_LAZY")) g.lazy = atoi(e);
+            g.spin_limit = 1u << 21;
+            g.allow_local = option(OPT_GRU_LOCAL) != 0;
+            g.scatter = option(OPT_GRU_SCATTER) != 0;
+            gru_assign_multi(h_Tm, M, g.ncl, g.tiles);
+            const int UBg = H / 16;
+            const dim3 grid(8 * UBg * ((2 * g.ncl + 7) / 8));
+            const size_t lds = gru_multi_lds_bytes(H, Tmax);
+            OCRS_HIP(hipMemsetAsync(d_sync, 0, gru_persistent_sync_words(M) * sizeof(uint32_t), s));
+            if (H == 256) hipLaunchKernelGGL((gru_gates_multi_kernel<256>), grid, dim3(256), lds, s, g);
+            else if (H == 128) hipLaunchKernelGGL((gru_gates_multi_kernel<128>), grid, dim3(256), lds, s, g);
+            else hipLaunchKernelGGL((gru_gates_multi_kernel<64>), grid, dim3(256), lds, s, g);
             return true;
         }
     }

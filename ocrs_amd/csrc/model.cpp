@@ -1,6 +1,7 @@
 #include "model.hpp"
 
 #include <cstdio>
+#include <functional>
 #include <map>
 #include <mutex>
 
@@ -647,7 +648,8 @@ float* HipModel::run_device(Workspace& ws, const float* d_in, int n, int h, int 
 // Ragged recognition batch
 // ---------------------------------------------------------------------------
 float* HipModel::run_prefix_ragged(Workspace& ws, hipStream_t exec, const std::vector<PackedGroup>& groups,
-                                   const PackedPlan& plan, int h, int ts, StageTimers* timers, int* feat_c) const {
+                                   const PackedPlan& plan, int h, int ts, StageTimers* timers, int* feat_c,
+                                   const std::function<void()>& before_launch) const {
     // supported stack: CONV 3x3 (Cin == 1 directly followed by MAXPOOL 2x2, or Cin % 32 == 0), MAXPOOL, AVGPOOL,
     // each consuming the previous op's output
     const int G = (int)groups.size();
@@ -750,6 +752,7 @@ float* HipModel::run_prefix_ragged(Workspace& ws, hipStream_t exec, const std::v
     int32_t* d32 = ws.alloc_n<int32_t>(meta32.size());
     ws.upload(d64, meta64.data(), meta64.size() * sizeof(int64_t));
     ws.upload(d32, meta32.data(), meta32.size() * sizeof(int32_t));
+    if (before_launch) before_launch();   // everything above is host work and uploads on the request's own stream
     if (exec != ws.s()) {  // inputs (crops, plan, metadata) were produced on the request's stream
         hipEvent_t ready = ws.make_event();
         OCRS_HIP(hipEventRecord(ready, ws.s()));
@@ -883,10 +886,18 @@ int HipModel::run_recognition_packed(Workspace& ws, const std::vector<PackedGrou
     float* X = nullptr;
     int C0 = 0;
     {
-        // all conv stacks of a device go through ONE stream, in request order, without host waits
-        std::lock_guard<std::mutex> heavy(ctx().heavy_phase);
+        // all conv stacks of a device go through ONE stream, in request order.  The lock is taken by the hook, i.e. after
+        // the request's geometry has been worked out and its metadata uploads are queued.  With option "gx_heavy" the
+        // hook first waits (on the host) until everything the conv stack reads — crops, metadata — is on the device: a
+        // conv stack whose inputs are late would stall the shared stream for every request behind it, and under a
+        // saturating conv stack of another request small kernels and copies ARE late (they wait for CU slots).
+        std::unique_lock<std::mutex> heavy(ctx().heavy_phase, std::defer_lock);
+        const bool wait_inputs = option(OPT_GX_HEAVY) != 0;
         try {
-            X = run_prefix_ragged(ws, heavy_stream(), groups, plan, h, ts, timers, &C0);
+            X = run_prefix_ragged(ws, heavy_stream(), groups, plan, h, ts, timers, &C0, [&] {
+                if (wait_inputs) ws.stream.sync();
+                heavy.lock();
+            });
         } catch (...) {
             // Kernels of this request may already be queued on the shared stream, reading and writing scratch
             // that ~Workspace hands back to the pool after draining only the request's OWN stream: make that
@@ -931,13 +942,34 @@ int HipModel::run_recognition_packed(Workspace& ws, const std::vector<PackedGrou
             float* y = ws.alloc_n<float>((size_t)R * 2 * H);
             const bool fused = (H == 256 || H == 128 || H == 64);
             const bool persistent = fused && gru_mode() == GRU_PERSISTENT && k::gru_persistent_supported(M, plan.Tmax, R, H);
-            if (persistent) OCRS_HIP(k::gru_persistent_prepare(y, R, H, st));  // "unwritten" marks; ahead of the input GEMM
+            const bool gx_on_heavy = option(OPT_GX_HEAVY) && R >= 4096;
+            if (persistent && !gx_on_heavy) OCRS_HIP(k::gru_persistent_prepare(y, R, H, st));  // "unwritten" marks; ahead of the input GEMM
             k::GemmDesc d{};
             d.A = cur; d.lda = I; d.B = op.aux0; d.ldb = 3 * H; d.bias = op.aux1; d.C = gx; d.ldc = 3 * H;
             d.M = (int)R; d.N = 3 * H; d.K = I; d.batch = 2;
             d.strideA = 0; d.strideB = (int64_t)I * 3 * H; d.strideBias = 3 * H; d.strideC = R * 3 * H;
-            timed(KC_GEMM_GRU_INPUT, 2.0 * 2 * R * (double)d.N * d.K, 4.0 * ((double)R * I + 2.0 * R * d.N + 2.0 * d.K * d.N),
-                  [&] { k::gemm(d, st); });
+            const double gx_flops = 2.0 * 2 * R * (double)d.N * d.K, gx_bytes = 4.0 * ((double)R * I + 2.0 * R * d.N + 2.0 * d.K * d.N);
+            if (gx_on_heavy) {
+                // The input projections are MFMA-bound like the conv stacks: run them on the device's conv-stack stream,
+                // one after the other with the conv stacks of all requests, instead of beside them.  A projection whose
+                // input is not ready would block that stream for everybody, so the host waits for its input first (layer
+                // 1: the request's own conv stack, already queued there; layer 2: the first layer's recurrence).
+                if (gru_layer > 0) ws.stream.sync();
+                DeviceContext& dc = ctx();
+                std::lock_guard<std::mutex> heavy(dc.heavy_phase);
+                hipStream_t hs = dc.heavy_stream();
+                hipEvent_t ready = ws.make_event(), done = ws.make_event();
+                OCRS_HIP(hipEventRecord(ready, st));
+                OCRS_HIP(hipStreamWaitEvent(hs, ready, 0));
+                if (persistent) OCRS_HIP(k::gru_persistent_prepare(y, R, H, hs));   // (a fill kernel: it too would wait for CU slots elsewhere)
+                int gtok = timers ? timers->kbegin(KC_GEMM_GRU_INPUT, hs, gx_flops, gx_bytes) : -1;
+                k::gemm(d, hs);
+                if (gtok >= 0) timers->end(gtok, hs);
+                OCRS_HIP(hipEventRecord(done, hs));
+                OCRS_HIP(hipStreamWaitEvent(st, done, 0));
+            } else {
+                timed(KC_GEMM_GRU_INPUT, gx_flops, gx_bytes, [&] { k::gemm(d, st); });
+            }
             bool ran_persistent = false;
             if (persistent) {
                 // ONE launch for all Tmax steps of both directions (kernels_gru.hip).  Its workgroups wait on

@@ -1,6 +1,7 @@
 // Fixed-graph HIP executor: the MI355X replacement for `rten::Model`
 // behind `trait Model` (ocrs/src/model.rs:6-41).
 #pragma once
+#include <functional>
 #include <memory>
 #include <string>
 #include <vector>
@@ -115,8 +116,11 @@ struct HipModel : ModelBase {
     // Conv stack (ops [0, ts)) over all groups at once; writes packed feature rows.  Returns
     // nullptr if the stack has an op the ragged kernels do not cover.
     // Kernels are launched on `exec` (which may differ from ws.s(); the caller links the two with events).
+    // before_launch: called once after the host-side planning and the metadata uploads, before the first launch on `exec`
+    // (the caller takes the shared stream's lock there).
     float* run_prefix_ragged(Workspace& ws, hipStream_t exec, const std::vector<PackedGroup>& groups,
-                             const PackedPlan& plan, int h, int ts, StageTimers* timers, int* feat_c) const;
+                             const PackedPlan& plan, int h, int ts, StageTimers* timers, int* feat_c,
+                             const std::function<void()>& before_launch = nullptr) const;
 };
 
 }  // namespace ocrs

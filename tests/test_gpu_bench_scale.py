@@ -274,10 +274,13 @@ def test_gru_modes_give_identical_bits(engine):
         # 4 = without the gate-per-wave kernel (gru_gates 0): the one-page request then runs on the general kernel;
         # 5, 6 = the gate-per-wave kernel with forced write-through / scattered clusters
         # 7 = gate-per-wave kernel packed two workgroups per CU (gru_gates_pack 2): applies to requests of 9-16 row tiles
-        for mode in (0, 1, 2, 3, 4, 5, 6, 7):
+        # 8 = the background (lean, multi-tile gate-per-wave) kernel for requests beyond one tile per cluster; 9 = the same
+        #     with forced write-through hand-offs
+        for mode in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9):
             _lib.set_option("gru_gates_pack", 2 if mode == 7 else 1)
+            _lib.set_option("gru_background", 1 if mode in (8, 9) else 0)
             _lib.set_option("gru_mode", 1 if mode == 1 else 0)
-            _lib.set_option("gru_local", 0 if mode in (2, 5) else 1)
+            _lib.set_option("gru_local", 0 if mode in (2, 5, 9) else 1)
             _lib.set_option("gru_scatter", 1 if mode in (3, 6) else 0)
             _lib.set_option("gru_gates", 0 if mode in (2, 3, 4) else 1)
             a = engine.recognize_text(inp, req) + engine.recognize_text(inp, req2)
@@ -289,7 +292,8 @@ def test_gru_modes_give_identical_bits(engine):
         _lib.set_option("gru_scatter", 0)
         _lib.set_option("gru_gates", 1)
         _lib.set_option("gru_gates_pack", 1)
-    for mode in (1, 2, 3, 4, 5, 6, 7):
+        _lib.set_option("gru_background", 0)
+    for mode in (1, 2, 3, 4, 5, 6, 7, 8, 9):
         assert res[0][0] == res[mode][0], mode
         assert np.array_equal(res[0][1][0], res[mode][1][0]) and np.array_equal(res[0][1][1], res[mode][1][1]), mode
     assert sum(1 for t in res[0][0] if t) > 80
