@@ -99,6 +99,11 @@ OCRS_API ocrs_status ocrs_coalescer_selftest(int n_threads, int requests_per_thr
  *   "det_mfma"        fused detection blocks: 1 = their pointwise convolutions and ConvTranspose run on MFMA where the
  *                     contraction fills the 16-row tile (>= 16 mid channels; default), 2 = in every fused block,
  *                     0 = thread-per-pixel VALU kernels only
+ *   "det_heavy"       the detection stage's kernels run on the device's shared conv-stack stream (queued between other
+ *                     requests' conv stacks, at full speed) instead of on the call's own stream (beside them, every one of its
+ *                     ~50 launches waiting for CU slots): 1 = for requests of fewer than 8 pages (default), 2 = always, 0 = never
+ *   "gx_heavy"        1 = the GRU input projections of large requests run on that stream too (every MFMA-bound class then
+ *                     runs at its alone speed, the throughput is the same or slightly lower), default 0
  *   "layout_threads"  host threads ocrs_engine_find_text_lines_batch may use (0 = automatic)
  *   "beam_gpu"        1 = DecodeMethod::BeamSearch runs on the GPU (default), 0 = on the host (threaded over lines)
  *   "gru_local"       persistent GRU kernel: 1 = a cluster of workgroups that finds itself on one XCD hands its state

@@ -247,6 +247,7 @@ const OptDef kOptDefs[OPT_COUNT] = {
     {"det_mfma", "OCRS_DET_MFMA", 1},                   // fused detection blocks: pointwise convs on MFMA where the contraction fills the tile (1), everywhere (2), never (0)
     {"gru_background", "OCRS_GRU_BACKGROUND", 0},       // requests beyond the gate-per-wave kernel's size: 1 = lean multi-tile gate-per-wave kernel (small footprint, slower alone)
     {"gx_heavy", "OCRS_GX_HEAVY", 0},                   // GRU input projections of large requests on the shared conv-stack stream (serialised with the conv stacks)
+    {"det_heavy", "OCRS_DET_HEAVY", 1},                 // detection kernels on the shared conv-stack stream: 1 = requests of fewer than 8 pages, 2 = all
 };
 std::atomic<long> g_opts[OPT_COUNT];
 std::once_flag g_opts_once;

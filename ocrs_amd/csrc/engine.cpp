@@ -36,17 +36,43 @@ void ocrs_engine::detect_now(const ocrs_page* const* pages, size_t n, std::vecto
     Workspace ws;
     hipStream_t st = ws.s();
     StageTimers* T = tm();
+    // Option "det_heavy": a small request's kernels go through the device's conv-stack stream instead of its own.
+    // Beside other requests' conv stacks the ~50 short dependent launches of this stage each wait for CU slots between
+    // 0.5 ms-long conv blocks (detect_words 0.8 ms alone, 14 ms with a dozen one-page requests in flight); queued
+    // BETWEEN the conv stacks they run at full speed and wait once, for at most one (short: small requests) conv stack.
+    const int det_heavy = option(OPT_DET_HEAVY);
+    const bool on_heavy = !detection->is_callback() && rects_out && !host_map && !debug &&
+                          (det_heavy >= 2 || (det_heavy == 1 && n < 8));
+    hipStream_t ex = on_heavy ? heavy_stream() : st;       // where the kernels run; copies stay on st
+    std::unique_lock<std::mutex> heavy(ctx().heavy_phase, std::defer_lock);
+    auto leave_heavy = [&](bool ok) {   // st continues after everything queued on the shared stream
+        if (!on_heavy || !heavy.owns_lock()) return;
+        hipEvent_t e = nullptr;
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess) {
+            ws.events.push_back(e);
+            if (hipEventRecord(e, ex) != hipSuccess || hipStreamWaitEvent(st, e, 0) != hipSuccess) (void)hipStreamSynchronize(ex);
+        } else {
+            (void)hipStreamSynchronize(ex);
+        }
+        heavy.unlock();
+        (void)ok;
+    };
 
     // page pointer table
     std::vector<const float*> hp(n);
     for (size_t i = 0; i < n; i++) hp[i] = pages[i]->grey.as<float>();
     const float** d_ptrs = ws.alloc_n<const float*>(n);
-    OCRS_HIP(hipMemcpyAsync(d_ptrs, hp.data(), n * sizeof(float*), hipMemcpyHostToDevice, st));
+    ws.upload(d_ptrs, hp.data(), n * sizeof(float*));
 
     float* d_in = ws.alloc_n<float>((size_t)N * in_h * in_w);
+    if (on_heavy) {
+        ws.stream.sync();     // inputs on the device before anything enters the shared stream (nothing there may wait)
+        heavy.lock();
+    }
+    try {
     {
-        StageScope sc(T, ST_RESIZE_IN, st);
-        k::resize_pages_to_model(d_ptrs, N, h, w, vh, vw, d_in, in_h, in_w, st);
+        StageScope sc(T, ST_RESIZE_IN, ex);
+        k::resize_pages_to_model(d_ptrs, N, h, w, vh, vw, d_in, in_h, in_w, ex);
     }
 
     const float* d_prob = nullptr;
@@ -73,7 +99,7 @@ void ocrs_engine::detect_now(const ocrs_page* const* pages, size_t n, std::vecto
     } else {
         const auto* hm = static_cast<const HipModel*>(detection);
         TensorShape os;
-        d_prob = hm->run_device(ws, d_in, N, in_h, in_w, &os, T, nullptr, nullptr, true, debug);
+        d_prob = hm->run_device(ws, d_in, N, in_h, in_w, &os, T, nullptr, nullptr, true, debug, -1, on_heavy ? ex : nullptr);
         if (os.n != N || os.h != in_h || os.w != in_w || os.c != 1)
             fail(OCRS_ERR_WRONG_OUTPUT, "model output had unexpected type or shape: detection output [%d,%d,%d,%d]", os.n,
                  os.c, os.h, os.w);
@@ -84,12 +110,13 @@ void ocrs_engine::detect_now(const ocrs_page* const* pages, size_t n, std::vecto
     uint8_t* d_mask = ws.alloc_n<uint8_t>((size_t)N * h * w);
     float* d_map = host_map ? ws.alloc_n<float>((size_t)N * h * w) : nullptr;
     {
-        StageScope sc(T, ST_RESIZE_THRESH, st);
-        k::resize_threshold(d_prob, N, in_h, in_w, sh, sw, text_threshold, d_mask, d_map, h, w, st);
+        StageScope sc(T, ST_RESIZE_THRESH, ex);
+        k::resize_threshold(d_prob, N, in_h, in_w, sh, sw, text_threshold, d_mask, d_map, h, w, ex);
     }
     if (host_map)
         ws.download(host_map, d_map, (size_t)N * h * w * sizeof(float));
     if (!rects_out) {
+        leave_heavy(true);
         ws.sync();
         if (T) T->collect();
         return;
@@ -102,7 +129,7 @@ void ocrs_engine::detect_now(const ocrs_page* const* pages, size_t n, std::vecto
     // component stage re-run on its own with buffers for the worst case — below.
     const int max_comp = (int)std::min<int64_t>(65536, px / 2 + 16);
     const int64_t arena = 2 * px + 64;
-    auto alloc_ccl = [&](int np, int mc, int64_t ar) {
+    auto alloc_ccl = [&](int np, int mc, int64_t ar, hipStream_t cs) {
         k::CclBuffers b{};
         b.labels = ws.alloc_n<int32_t>((size_t)np * px);
         b.row_counts = ws.alloc_n<int32_t>((size_t)np * h);
@@ -117,21 +144,22 @@ void ocrs_engine::detect_now(const ocrs_page* const* pages, size_t n, std::vecto
         b.keep = ws.alloc_n<uint8_t>((size_t)np * ar);
         b.rects = ws.alloc_n<float>((size_t)np * mc * 6);
         b.valid = ws.alloc_n<uint8_t>((size_t)np * mc);
-        OCRS_HIP(hipMemsetAsync(b.overflow, 0, np * sizeof(int32_t), st));
+        OCRS_HIP(hipMemsetAsync(b.overflow, 0, np * sizeof(int32_t), cs));
         return b;
     };
-    auto run_ccl = [&](const uint8_t* mask, int np, const k::CclBuffers& b, int mc, int64_t ar) {
+    auto run_ccl = [&](const uint8_t* mask, int np, const k::CclBuffers& b, int mc, int64_t ar, hipStream_t cs) {
         {
-            StageScope sc(T, ST_CCL, st, 4);
-            k::ccl_label(mask, np, h, w, b, mc, st);
+            StageScope sc(T, ST_CCL, cs, 4);
+            k::ccl_label(mask, np, h, w, b, mc, cs);
         }
         {
-            StageScope sc(T, ST_CONTOUR_RECTS, st, 2);
-            k::contour_rects(mask, np, h, w, b, mc, ar, /*expand*/ 3.0f, min_area, /*eps*/ 2.0f, st);
+            StageScope sc(T, ST_CONTOUR_RECTS, cs, 2);
+            k::contour_rects(mask, np, h, w, b, mc, ar, /*expand*/ 3.0f, min_area, /*eps*/ 2.0f, cs);
         }
     };
-    const k::CclBuffers b = alloc_ccl(N, max_comp, arena);
-    run_ccl(d_mask, N, b, max_comp, arena);
+    const k::CclBuffers b = alloc_ccl(N, max_comp, arena, ex);
+    run_ccl(d_mask, N, b, max_comp, arena, ex);
+    leave_heavy(true);
     // One round trip in the common case: the counts travel together with the first kSpec candidate rects of every
     // page (a page of text has a few hundred to ~1 500 components); only a page with more needs a second one.
     constexpr int kSpec = 2048;
@@ -169,8 +197,8 @@ void ocrs_engine::detect_now(const ocrs_page* const* pages, size_t n, std::vecto
         if (ar_big >= (int64_t)0x7fffffff)
             fail(OCRS_ERR_CAPACITY, "text mask of page %d: %lld pixels exceed the 32-bit contour arena", i, (long long)px);
         const int mc = (int)mc64;
-        const k::CclBuffers bb = alloc_ccl(1, mc, ar_big);
-        run_ccl(d_mask + (size_t)i * px, 1, bb, mc, ar_big);
+        const k::CclBuffers bb = alloc_ccl(1, mc, ar_big, st);
+        run_ccl(d_mask + (size_t)i * px, 1, bb, mc, ar_big, st);
         int32_t cnt = 0, o = 0;
         ws.download(&cnt, bb.n_roots, sizeof cnt);
         ws.download(&o, bb.overflow, sizeof o);
@@ -188,6 +216,10 @@ void ocrs_engine::detect_now(const ocrs_page* const* pages, size_t n, std::vecto
         auto& out = (*rects_out)[i];
         for (int c = 0; c < counts[i]; c++)
             if (hv[i][c]) out.push_back(RotatedRect::from_array(&hr[i][(size_t)c * 6]));
+    }
+    } catch (...) {
+        leave_heavy(false);   // scratch of this call may still be in use on the shared stream: st waits for it before ~Workspace drains st
+        throw;
     }
     if (T) T->collect();
 }

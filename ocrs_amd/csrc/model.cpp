@@ -297,14 +297,14 @@ double HipModel::flops(int n, int h, int w) const {
 
 float* HipModel::run_device(Workspace& ws, const float* d_in, int n, int h, int w, TensorShape* out_shape,
                             StageTimers* timers, const uint8_t* d_excluded, int32_t* d_labels, bool want_logp,
-                            bool print_timing, int stop_before) const {
+                            bool print_timing, int stop_before, hipStream_t exec) const {
     std::vector<TensorShape> shp;
     TensorShape out = infer(n, h, w, &shp);
     const size_t n_run = stop_before >= 0 ? (size_t)stop_before : ops.size();
     const uint32_t ret_slot = stop_before >= 0 ? (uint32_t)ops[stop_before].in0 : out_slot;
     if (stop_before >= 0) out = shp[ret_slot];
     if (out_shape) *out_shape = out;
-    hipStream_t st = ws.s();
+    hipStream_t st = exec ? exec : ws.s();
 
     // liveness: last op index that reads each slot
     std::vector<int> last_use(n_slots, -1);

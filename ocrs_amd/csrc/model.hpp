@@ -87,7 +87,8 @@ struct HipModel : ModelBase {
     // stop_before >= 0: execute only ops [0, stop_before) and return that op's input tensor.
     float* run_device(Workspace& ws, const float* d_in, int n, int h, int w, TensorShape* out_shape,
                       StageTimers* timers, const uint8_t* d_excluded = nullptr, int32_t* d_labels = nullptr,
-                      bool want_logp = true, bool print_timing = false, int stop_before = -1) const;
+                      bool want_logp = true, bool print_timing = false, int stop_before = -1,
+                      hipStream_t exec = nullptr /* launch here instead of on ws's stream (the caller links the two) */) const;
 
     // ---- ragged recognition batch (all width groups of a request at once) ----
     // The graph must be: <conv stack> TOSEQ GRU* LINEAR LOGSOFTMAX.  Returns the index

@@ -70,9 +70,9 @@ full)
   say "== default bench with every leg (extras, cpu baseline)"; timeout 900 python bench.py > $OUT/bench_full.json 2> $OUT/bench_full.err; say "rc=$?"; jsum $OUT/bench_full.json "default";;
 multi)
   say "== 2 ranks on this one GPU (gloo, ranks share the device): exercises the self-spawn + gather path"
-  OCRS_DIST_BACKEND=gloo timeout 600 python bench.py --gpus 2 --steps 8 --warmup 4 --pages 8 --settle-s 0 --no-cpu-baseline --no-extras > $OUT/bench_2rank.json 2> $OUT/bench_2rank.err; say "rc=$?"; jsum $OUT/bench_2rank.json "2 ranks/1 GPU"; tail -3 $OUT/bench_2rank.err | cut -c1-300 | tee -a $S
+  OCRS_DIST_BACKEND=gloo timeout 600 python bench.py --gpus 2 --spawn-ranks --steps 8 --warmup 4 --pages 8 --settle-s 0 --no-cpu-baseline --no-extras > $OUT/bench_2rank.json 2> $OUT/bench_2rank.err; say "rc=$?"; jsum $OUT/bench_2rank.json "2 ranks/1 GPU"; tail -3 $OUT/bench_2rank.err | cut -c1-300 | tee -a $S
   say "== 2 ranks, RCCL backend on one GPU (may be refused by RCCL: informational)"
-  timeout 300 python bench.py --gpus 2 --steps 4 --warmup 2 --pages 8 --settle-s 0 --no-cpu-baseline --no-extras > $OUT/bench_2rank_rccl.json 2> $OUT/bench_2rank_rccl.err; say "rc=$?"; jsum $OUT/bench_2rank_rccl.json "2 ranks RCCL"; tail -2 $OUT/bench_2rank_rccl.err | cut -c1-300 | tee -a $S;;
+  timeout 300 python bench.py --gpus 2 --spawn-ranks --steps 4 --warmup 2 --pages 8 --settle-s 0 --no-cpu-baseline --no-extras > $OUT/bench_2rank_rccl.json 2> $OUT/bench_2rank_rccl.err; say "rc=$?"; jsum $OUT/bench_2rank_rccl.json "2 ranks RCCL"; tail -2 $OUT/bench_2rank_rccl.err | cut -c1-300 | tee -a $S;;
 group)
   say "== engine group in ONE process: 2 members on this one GPU (devices 0,0; host gather), 8 pages per member per step"
   timeout 600 python bench.py --gpus 2 --devices 0,0 --steps 12 --warmup 6 --pages 8 --settle-s 0 > $OUT/bench_group00.json 2> $OUT/bench_group00.err; say "rc=$?"; jsum $OUT/bench_group00.json "group [0,0]"; tail -2 $OUT/bench_group00.err | cut -c1-300 | tee -a $S
