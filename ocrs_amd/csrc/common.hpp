@@ -310,6 +310,14 @@ struct Workspace {
         downloads.push_back(Download{pin, h_dst, bytes});
         OCRS_HIP(hipMemcpyAsync(pin, d_src, bytes, hipMemcpyDeviceToHost, st ? st : stream.get()));
     }
+    // strided device -> host: `rows` pieces of `width` bytes, `d_pitch` apart on the device, packed on the host; handed
+    // over like download()
+    void download_2d(void* h_dst, const void* d_src, size_t d_pitch, size_t width, size_t rows, hipStream_t st = nullptr) {
+        if (!width || !rows) return;
+        void* pin = hpool.alloc(width * rows);
+        downloads.push_back(Download{pin, h_dst, width * rows});
+        OCRS_HIP(hipMemcpy2DAsync(pin, width, d_src, d_pitch, width, rows, hipMemcpyDeviceToHost, st ? st : stream.get()));
+    }
     hipStream_t s() const { return stream.get(); }
     void* alloc(size_t bytes) { bufs.emplace_back(bytes ? bytes : 4); return bufs.back().p; }
     template <class T> T* alloc_n(size_t n) { return static_cast<T*>(alloc(n * sizeof(T))); }

@@ -167,15 +167,19 @@ void ocrs_engine::detect_now(const ocrs_page* const* pages, size_t n, std::vecto
     std::vector<int32_t> counts(N), ovf(N);
     std::vector<std::vector<float>> hr(N);
     std::vector<std::vector<uint8_t>> hv(N);
+    std::vector<float> hr_all((size_t)N * spec * 6);
+    std::vector<uint8_t> hv_all((size_t)N * spec);
     ws.download(counts.data(), b.n_roots, N * sizeof(int32_t));
     ws.download(ovf.data(), b.overflow, N * sizeof(int32_t));
-    for (int i = 0; i < N; i++) {
-        hr[i].resize((size_t)spec * 6);
-        hv[i].resize(spec);
-        ws.download(hr[i].data(), b.rects + (size_t)i * max_comp * 6, hr[i].size() * sizeof(float));
-        ws.download(hv[i].data(), b.valid + (size_t)i * max_comp, spec);
-    }
+    // the first `spec` candidates of every page in ONE strided copy per array (r2: two copies per page — each a blit
+    // kernel that waits for CU slots like any other)
+    ws.download_2d(hr_all.data(), b.rects, (size_t)max_comp * 6 * sizeof(float), (size_t)spec * 6 * sizeof(float), N);
+    ws.download_2d(hv_all.data(), b.valid, (size_t)max_comp, (size_t)spec, N);
     ws.sync();
+    for (int i = 0; i < N; i++) {
+        hr[i].assign(hr_all.begin() + (size_t)i * spec * 6, hr_all.begin() + (size_t)(i + 1) * spec * 6);
+        hv[i].assign(hv_all.begin() + (size_t)i * spec, hv_all.begin() + (size_t)(i + 1) * spec);
+    }
     rects_out->assign(n, {});
     bool more = false;
     std::vector<int> big;   // pages whose component stage did not fit

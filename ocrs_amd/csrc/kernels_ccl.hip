@@ -208,8 +208,9 @@ __device__ __forceinline__ int dir_dx(int d) { return (int)((0x1A90u >> (2 * d))
 // The walk by a whole wavefront: lane d < 8 fetches neighbour d, a ballot gives the mask, the walk state is
 // wave-uniform (scalar registers).  One memory latency and a handful of scalar instructions per border pixel —
 // a single lane running trace_border pays the issue latency of every instruction of the step.
+// WRITE: points go to out[0 .. cap) (LDS or global); the return value is the full length either way.
 template <bool WRITE>
-__device__ int trace_border_wave(const uint8_t* __restrict__ m, int h, int w, int sy, int sx, uint32_t* out, int lane) {
+__device__ int trace_border_wave(const uint8_t* __restrict__ m, int h, int w, int sy, int sx, uint32_t* out, int cap, int lane) {
     const int ldy = dir_dy(lane & 7), ldx = dir_dx(lane & 7);
     auto neighbours = [&](int y, int x) -> unsigned {
         const int yy = y + ldy, xx = x + ldx;
@@ -219,7 +220,7 @@ __device__ int trace_border_wave(const uint8_t* __restrict__ m, int h, int w, in
     };
     const unsigned nb0 = neighbours(sy, sx);
     if (nb0 == 0) {
-        if (WRITE && lane == 0) out[0] = ((uint32_t)sy << 16) | (uint32_t)sx;
+        if (WRITE && lane == 0 && cap > 0) out[0] = ((uint32_t)sy << 16) | (uint32_t)sx;
         return 1;
     }
     const int first = __ffs((int)nb0) - 1;
@@ -240,7 +241,7 @@ __device__ int trace_border_wave(const uint8_t* __restrict__ m, int h, int w, in
             dn = d0;
         }
         if (rot) { i4 = i3 + dir_dy(dn); j4 = j3 + dir_dx(dn); }
-        if (WRITE && lane == 0) out[n] = ((uint32_t)i3 << 16) | (uint32_t)j3;
+        if (WRITE && lane == 0 && n < cap) out[n] = ((uint32_t)i3 << 16) | (uint32_t)j3;
         n++;
         if (i4 == sy && j4 == sx && i3 == i1 && j3 == j1) break;
         i3 = i4; j3 = j4;
@@ -278,6 +279,70 @@ __device__ __forceinline__ float cross3(P2 o, P2 a, P2 b) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   \
     } while (0)
 
+// Ramer-Douglas-Peucker on the closed polyline p[0..n] (p[n] = p[0]) + ordered gather of the kept points into `simp`;
+// returns their number.  Stack-free: each round walks the current kept points in order and splits every not-yet-final
+// segment once.  keep: 0 = dropped, 1 = kept, 2 = kept and the segment starting here is final.  The surviving set does
+// not depend on the order in which segments are split.  Index n (the duplicated start) is implicit: always kept.
+// (forceinline: called once with LDS and once with global pointers; each copy gets its own address space.)
+__device__ __forceinline__ int rdp_gather(const uint32_t* pts, uint8_t* keep, int n, float eps, uint32_t* simp, int lane) {
+    for (int k = lane; k < n; k += 64) keep[k] = 0;
+    WAVE_SYNC();
+    if (lane == 0) keep[0] = 1;
+    WAVE_SYNC();
+    bool changed = true;
+    while (changed) {
+        changed = false;
+        int lo = 0;
+        while (lo < n) {
+            // next kept index after lo (or n)
+            int hi = n;
+            for (int base = lo + 1; base < n; base += 64) {
+                int k = base + lane;
+                unsigned long long bal = __ballot(k < n && keep[k] != 0);
+                if (bal) { hi = base + __ffsll((long long)bal) - 1; break; }
+            }
+            const bool final_seg = keep[lo] == 2;
+            if (!final_seg) {
+                const P2 a = unpack_pt(pts[lo]);
+                const P2 b = unpack_pt(pts[hi == n ? 0 : hi]);
+                float maxd = 0.0f;
+                int maxi = -1;
+                for (int k = lo + 1 + lane; k < hi; k += 64) {
+                    float d = seg_distance(a, b, unpack_pt(pts[k]));
+                    if (d > maxd) { maxd = d; maxi = k; }
+                }
+                // wave arg-max, ties -> smallest index (first maximum)
+                for (int o = 32; o > 0; o >>= 1) {
+                    float od = __shfl_xor(maxd, o);
+                    int oi = __shfl_xor(maxi, o);
+                    bool take = (oi >= 0) && (maxi < 0 || od > maxd || (od == maxd && oi < maxi));
+                    if (take) { maxd = od; maxi = oi; }
+                }
+                if (maxi >= 0 && maxd > eps) {
+                    if (lane == 0) keep[maxi] = 1;
+                    changed = true;
+                } else {
+                    if (lane == 0) keep[lo] = 2;
+                }
+            }
+            lo = hi;
+        }
+        WAVE_SYNC();
+    }
+    int mcount = 0;
+    for (int base = 0; base < n; base += 64) {
+        int k = base + lane;
+        bool kp = k < n && keep[k] != 0;
+        unsigned long long bal = __ballot(kp);
+        if (kp) simp[mcount + __popcll(bal & ((1ull << lane) - 1))] = pts[k];
+        mcount += __popcll(bal);
+    }
+    WAVE_SYNC();
+    return mcount;
+}
+
+constexpr int kWalkBuf = 4096;   // border points buffered in LDS by the contour kernel (16 KB per 64-thread block)
+
 // One wavefront (= one 64-thread block) per component.
 __global__ void __launch_bounds__(64)
 contour_rect_kernel(const uint8_t* __restrict__ mask, int h, int w, const int32_t* __restrict__ n_roots,
@@ -293,10 +358,13 @@ contour_rect_kernel(const uint8_t* __restrict__ mask, int h, int w, const int32_
     for (int ci = blockIdx.x; ci < cnt; ci += gridDim.x) {
         const int64_t slot = (int64_t)page * max_comp + ci;
         const int root = roots[slot];
-        // ---- 0. length of the border (the same wave-cooperative walk, nothing written), then this component's
-        // piece of the page's arena: an atomic bump (placement order is irrelevant — results are indexed by slot).
-        // r2 ran a separate count kernel (one lane per component) + a scan launch for this.
-        const int n = trace_border_wave<false>(m, h, w, root / w, root % w, nullptr, lane);
+        // ---- 0/1. border following (serial by nature; wave-cooperative: one memory latency per border pixel).  ONE walk:
+        // the points go to an LDS buffer, the length is known at the end, the component then takes its piece of the
+        // page's arena with an atomic bump (placement order is irrelevant — results are indexed by slot) and the buffer
+        // is copied there with coalesced stores.  Only a border longer than the buffer is walked a second time, straight
+        // into the arena.  (r2: a separate count kernel, one lane per component, + a scan launch + the write walk.)
+        __shared__ uint32_t walk[kWalkBuf];
+        const int n = trace_border_wave<true>(m, h, w, root / w, root % w, walk, kWalkBuf, lane);
         int off32 = 0;
         if (lane == 0) off32 = atomicAdd(&arena_top[page], n);
         off32 = __builtin_amdgcn_readfirstlane(off32);
@@ -305,6 +373,7 @@ contour_rect_kernel(const uint8_t* __restrict__ mask, int h, int w, const int32_
                 overflow[page] = 1;
                 valid[slot] = 0;
             }
+            WAVE_SYNC();
             continue;
         }
         const int64_t off = (int64_t)page * arena + off32;
@@ -314,71 +383,19 @@ contour_rect_kernel(const uint8_t* __restrict__ mask, int h, int w, const int32_
         uint32_t* simp = tmp_all + (int64_t)page * arena * 4 + (int64_t)off32 * 4;
         uint32_t* sorted = simp + n;
         uint32_t* hull = sorted + n;  // 2n words
-
-        // ---- 1. border following (serial by nature): lane 0 writes the points
-        trace_border_wave<true>(m, h, w, root / w, root % w, pts, lane);
-        for (int k = lane; k < n; k += 64) keep[k] = 0;
-        WAVE_SYNC();
-
-        // ---- 2. Ramer-Douglas-Peucker on the closed polyline p[0..n] (p[n] = p[0]).
-        // Stack-free: each round walks the current kept points in order and splits
-        // every not-yet-final segment once.  keep: 0 = dropped, 1 = kept, 2 = kept and
-        // the segment starting here is final.  The surviving set does not depend on
-        // the order in which segments are split.
-        // index n (the duplicated start) is implicit: always kept.
-        if (lane == 0) keep[0] = 1;
-        WAVE_SYNC();
-        bool changed = true;
-        while (changed) {
-            changed = false;
-            int lo = 0;
-            while (lo < n) {
-                // next kept index after lo (or n)
-                int hi = n;
-                for (int base = lo + 1; base < n; base += 64) {
-                    int k = base + lane;
-                    unsigned long long bal = __ballot(k < n && keep[k] != 0);
-                    if (bal) { hi = base + __ffsll((long long)bal) - 1; break; }
-                }
-                const bool final_seg = keep[lo] == 2;
-                if (!final_seg) {
-                    const P2 a = unpack_pt(pts[lo]);
-                    const P2 b = unpack_pt(pts[hi == n ? 0 : hi]);
-                    float maxd = 0.0f;
-                    int maxi = -1;
-                    for (int k = lo + 1 + lane; k < hi; k += 64) {
-                        float d = seg_distance(a, b, unpack_pt(pts[k]));
-                        if (d > maxd) { maxd = d; maxi = k; }
-                    }
-                    // wave arg-max, ties -> smallest index (first maximum)
-                    for (int o = 32; o > 0; o >>= 1) {
-                        float od = __shfl_xor(maxd, o);
-                        int oi = __shfl_xor(maxi, o);
-                        bool take = (oi >= 0) && (maxi < 0 || od > maxd || (od == maxd && oi < maxi));
-                        if (take) { maxd = od; maxi = oi; }
-                    }
-                    if (maxi >= 0 && maxd > eps) {
-                        if (lane == 0) keep[maxi] = 1;
-                        changed = true;
-                    } else {
-                        if (lane == 0) keep[lo] = 2;
-                    }
-                }
-                lo = hi;
-            }
+        WAVE_SYNC();   // lane 0's LDS writes visible to the wave
+        // ---- 2/3. simplify (RDP) and gather the kept points.  The border stays in LDS when it fits the walk buffer
+        // (one LDS latency per access in the chains of dependent reads below instead of one L2 round trip); a longer
+        // one is walked again, straight into the arena, and simplified from there.
+        int mcount;
+        if (n <= kWalkBuf) {
+            __shared__ uint8_t keep_l[kWalkBuf];
+            mcount = rdp_gather(walk, keep_l, n, eps, simp, lane);
+        } else {
+            trace_border_wave<true>(m, h, w, root / w, root % w, pts, n, lane);
             WAVE_SYNC();
+            mcount = rdp_gather(pts, keep, n, eps, simp, lane);
         }
-
-        // ---- 3. ordered gather of the simplified polygon
-        int mcount = 0;
-        for (int base = 0; base < n; base += 64) {
-            int k = base + lane;
-            bool kp = k < n && keep[k] != 0;
-            unsigned long long bal = __ballot(kp);
-            if (kp) simp[mcount + __popcll(bal & ((1ull << lane) - 1))] = pts[k];
-            mcount += __popcll(bal);
-        }
-        WAVE_SYNC();
 
         // ---- 4. rank sort by (x, y) (index breaks ties) for the monotone chain
         for (int i = lane; i < mcount; i += 64) {

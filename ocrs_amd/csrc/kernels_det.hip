@@ -330,6 +330,7 @@ void launch_dc(const DoubleConvArgs& a0, hipStream_t s) {
 // =====================================================================================================================
 template <int CS_, int CX_, int CMID_, int COUT_, int TH_, int TW_, bool POOL_, bool FINAL_>
 struct McCfg {
+    static constexpr int NT = 512;                        // threads per workgroup: one tile's phases are short, more waves hide their latencies
     static constexpr int CS = CS_, CX = CX_, CMID = CMID_, COUT = COUT_, TH = TH_, TW = TW_;
     static constexpr bool POOL = POOL_, FINAL = FINAL_, DEC = CX_ > 0;
     static constexpr int CU = DEC ? CS_ : 0;
@@ -361,11 +362,11 @@ template <int K> __device__ __forceinline__ constexpr int ch_of(int n) { return 
 // channel block.
 template <int K, int P, int S_IN, int S_OUT>
 __device__ __forceinline__ void dw_stage(const float* __restrict__ src, int srcw, float* __restrict__ dst, int rows, int cols,
-                                         const float* __restrict__ sw, bool relu, int tid) {
+                                         const float* __restrict__ sw, bool relu, int tid, int nt) {
     constexpr int NB = K / 4;
     const int ns = (cols + P - 1) / P;
     const int items = rows * ns * NB;
-    for (int it = tid; it < items; it += 256) {
+    for (int it = tid; it < items; it += nt) {
         const int blk = it % NB;
         const int t2 = it / NB;
         const int strip = t2 % ns, r = t2 / ns;
@@ -424,8 +425,9 @@ __device__ __forceinline__ void load_b(const float* __restrict__ p, float (&b)[K
 }
 
 template <class Cfg>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(Cfg::NT)
 double_conv_mfma_kernel(DoubleConvArgs a) {
+    constexpr int NT = Cfg::NT, NW = Cfg::NT / 64;
     constexpr int CS = Cfg::CS, CX = Cfg::CX, CU = Cfg::CU, CIN = Cfg::CIN, CMID = Cfg::CMID, COUT = Cfg::COUT;
     constexpr int TH = Cfg::TH, TW = Cfg::TW, SA = Cfg::SA, SD1 = Cfg::SD1, SC = Cfg::SC, SD2 = Cfg::SD2, SE = Cfg::SE, SX = Cfg::SX;
     constexpr int R0H = Cfg::R0H, R0W = Cfg::R0W, R1H = Cfg::R1H, R1W = Cfg::R1W, LH = Cfg::LH, LW = Cfg::LW;
@@ -448,12 +450,12 @@ double_conv_mfma_kernel(DoubleConvArgs a) {
     const int h = a.h, w = a.w;
 
     // ---------------- depthwise weights -> LDS (permuted)
-    for (int i = tid; i < 10 * CIN; i += 256) {
+    for (int i = tid; i < 10 * CIN; i += NT) {
         const int t = i / CIN, n = i - t * CIN;
         const int c = Cfg::ONE ? 0 : ch_of<Cfg::ONE ? 4 : CIN>(n);
         sW1[i] = t < 9 ? a.wd1[t * CIN + c] : a.bd1[c];
     }
-    for (int i = tid; i < 10 * CMID; i += 256) {
+    for (int i = tid; i < 10 * CMID; i += NT) {
         const int t = i / CMID, n = i - t * CMID;
         const int c = ch_of<CMID>(n);
         sW2[i] = t < 9 ? a.wd2[t * CMID + c] : a.bd2[c];
@@ -463,7 +465,7 @@ double_conv_mfma_kernel(DoubleConvArgs a) {
     float* sA = sU;
     const float* __restrict__ skip = a.skip + (int64_t)img * h * w * CS;
     if constexpr (Cfg::ONE) {
-        for (int p = tid; p < NPIX0; p += 256) {
+        for (int p = tid; p < NPIX0; p += NT) {
             const int gy = Y0 - 2 + p / R0W, gx = X0 - 2 + p % R0W;
             float v = 0.f;
             if ((unsigned)gy < (unsigned)h && (unsigned)gx < (unsigned)w) v = skip[(int64_t)gy * w + gx];
@@ -471,7 +473,7 @@ double_conv_mfma_kernel(DoubleConvArgs a) {
         }
     } else {
         constexpr int Q = CS / 4;
-        for (int i = tid; i < NPIX0 * Q; i += 256) {
+        for (int i = tid; i < NPIX0 * Q; i += NT) {
             const int p = i / Q, c4 = i - p * Q;
             const int gy = Y0 - 2 + p / R0W, gx = X0 - 2 + p % R0W;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -487,7 +489,7 @@ double_conv_mfma_kernel(DoubleConvArgs a) {
         const int ly0 = floor_div2(Y0 - 2 - pyo), lx0 = floor_div2(X0 - 2 - pxo);
         const float* __restrict__ x1 = a.x1 + (int64_t)img * a.h1 * a.w1 * CX;
         constexpr int QX = CX / 4, NLOW = LH * LW;
-        for (int i = tid; i < NLOW * QX; i += 256) {               // low-res region -> sX, permuted for the B operand
+        for (int i = tid; i < NLOW * QX; i += NT) {               // low-res region -> sX, permuted for the B operand
             const int p = i / QX, c4 = i - p * QX;
             const int ly = ly0 + p / LW, lx = lx0 + p % LW;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -496,7 +498,7 @@ double_conv_mfma_kernel(DoubleConvArgs a) {
 #pragma unroll
             for (int e = 0; e < 4; e++) sX[p * SX + ch_pos<CX>(c4 * 4 + e)] = v[e];
         }
-        for (int i = tid; i < NPIX0 * CU; i += 256) {             // the `up` channels default to zero
+        for (int i = tid; i < NPIX0 * CU; i += NT) {             // the `up` channels default to zero
             const int p = i / CU, c = i - p * CU;
             sA[p * SA + ch_pos<CIN>(CS + c)] = 0.f;
         }
@@ -515,7 +517,7 @@ double_conv_mfma_kernel(DoubleConvArgs a) {
             for (int r = 0; r < 4; r++) biast[g][r] = a.bt[(16 * g + 4 * kq + r) % CU];
         }
         __syncthreads();
-        for (int pg = wave; pg * 16 < NLOW; pg += 4) {
+        for (int pg = wave; pg * 16 < NLOW; pg += NW) {
             const int p = pg * 16 + i16;
             const int pc = p < NLOW ? p : NLOW - 1;
             float b[KSX];
@@ -546,7 +548,7 @@ double_conv_mfma_kernel(DoubleConvArgs a) {
     if constexpr (Cfg::ONE) {
         // one input channel: no contraction — thread per pixel, outputs straight into sC's permuted order
         float* sCt = sV;   // (sA is still being read: build sC in V, copy is not needed — stage 2 reads from V)
-        for (int p = tid; p < NPIX1; p += 256) {
+        for (int p = tid; p < NPIX1; p += NT) {
             const int ry = p / R1W, rx = p - ry * R1W;
             const int gy = Y0 - 1 + ry, gx = X0 - 1 + rx;
             float* dst = &sCt[p * SC];
@@ -570,7 +572,7 @@ double_conv_mfma_kernel(DoubleConvArgs a) {
         sC = sCt;
     } else {
         float* sD1 = sV;
-        dw_stage<CIN, P, SA, SD1>(sA, R0W, sD1, R1H, R1W, sW1, a.relu_d1 != 0, tid);
+        dw_stage<CIN, P, SA, SD1>(sA, R0W, sD1, R1H, R1W, sW1, a.relu_d1 != 0, tid, NT);
         // A operand (W1^T) and bias of this lane's rows, for all k-steps: rows are output channels in sC's permuted order
         constexpr int KS = CIN / 4, NG = (CMID + 15) / 16;
         float aw[NG][KS];
@@ -588,7 +590,7 @@ double_conv_mfma_kernel(DoubleConvArgs a) {
             }
         }
         __syncthreads();   // sD1 complete, sA dead
-        for (int pg = wave; pg * 16 < NPIX1; pg += 4) {
+        for (int pg = wave; pg * 16 < NPIX1; pg += NW) {
             const int p = pg * 16 + i16;
             const int pc = p < NPIX1 ? p : NPIX1 - 1;
             float b[KS];
@@ -614,7 +616,7 @@ double_conv_mfma_kernel(DoubleConvArgs a) {
 
     // ---------------- stage 2: dw2 (VALU) -> sD2, pw2 (MFMA) -> registers -> HBM (+ final conv / pool staging)
     float* sD2 = Cfg::ONE ? sU : sV;    // (ONE: sC lives in V, sA in U is dead)
-    dw_stage<CMID, P, SC, SD2>(sC, R1W, sD2, TH, TW, sW2, a.relu_d2 != 0, tid);
+    dw_stage<CMID, P, SC, SD2>(sC, R1W, sD2, TH, TW, sW2, a.relu_d2 != 0, tid, NT);
     constexpr int KS2 = CMID / 4, NG2 = (COUT + 15) / 16;
     float aw2[NG2][KS2];
     f32x4 bias2[NG2];
@@ -629,7 +631,7 @@ double_conv_mfma_kernel(DoubleConvArgs a) {
     __syncthreads();       // sD2 complete, sC dead
     float* __restrict__ yimg = a.y + (int64_t)img * h * w * (Cfg::FINAL ? 1 : COUT);
     float* sE = Cfg::ONE ? sV : sU;     // pool staging: a region that is dead by now (ONE: sC in V is dead after dw2; else sC in U)
-    for (int pg = wave; pg * 16 < NPIX2; pg += 4) {
+    for (int pg = wave; pg * 16 < NPIX2; pg += NW) {
         const int p = pg * 16 + i16;    // NPIX2 is a multiple of 16
         float b[KS2];
         load_b<KS2>(sD2 + p * SD2 + kq * KS2, b);
@@ -682,7 +684,7 @@ double_conv_mfma_kernel(DoubleConvArgs a) {
         const int ph = h / 2, pw = w / 2;
         float* __restrict__ pimg = a.ypool + (int64_t)img * ph * pw * COUT;
         constexpr int Q = COUT / 4;
-        for (int i = tid; i < (TH / 2) * (TW / 2) * Q; i += 256) {
+        for (int i = tid; i < (TH / 2) * (TW / 2) * Q; i += NT) {
             const int pp = i / Q, c4 = i - pp * Q;
             const int py = pp / (TW / 2), px = pp - py * (TW / 2);
             const int gy = Y0 / 2 + py, gx = X0 / 2 + px;
@@ -714,7 +716,7 @@ void launch_mc(const DoubleConvArgs& a0, hipStream_t s) {
         return true;
     }();
     (void)attr_set;
-    hipLaunchKernelGGL((double_conv_mfma_kernel<Cfg>), dim3(grid), dim3(256), Cfg::LDS_BYTES, s, a);
+    hipLaunchKernelGGL((double_conv_mfma_kernel<Cfg>), dim3(grid), dim3(Cfg::NT), Cfg::LDS_BYTES, s, a);
 }
 
 }  // namespace
@@ -722,18 +724,16 @@ void launch_mc(const DoubleConvArgs& a0, hipStream_t s) {
 // Shapes with a fused kernel: (skip channels, ConvT input channels or 0, mid, out, pool, final).
 bool double_conv_fused(const DoubleConvArgs& a, int cs, int cx, int cmid, int cout, bool pool, bool final_conv, int fuse_level,
                        bool launch, hipStream_t s, bool* on_mfma) {
-    // option "det_mfma": pointwise convs (and the ConvTranspose) of the fused blocks on the matrix cores
-    // (double_conv_mfma_kernel).  1 (default) = where the contraction fills the 16-row MFMA tile, i.e. blocks with
-    // >= 16 mid channels (encoder levels 1-2, decoder level 1: 47 vs 54, 33 vs 46, 167 vs 211 us per 8 pages); the two
-    // full-resolution blocks contract into 8 channels — half of every tile idle at the VALU's own FLOP rate — and stay
-    // on the round-2 thread-per-pixel kernels (decoder level 0: 354 vs 263 us on MFMA).  2 = every block on MFMA,
-    // 3 = also the C = 32 levels as fused blocks, 0 = no MFMA in fused blocks.  Same bits in every mode.
+    // option "det_mfma": 1 (default) = the fused blocks' pointwise convs and ConvTranspose run on the matrix cores
+    // (double_conv_mfma_kernel, 512 threads per tile), 0 = the round-2 thread-per-pixel kernels, 2 = additionally the
+    // C = 32 levels run as fused MFMA blocks instead of per-op kernels.  Same bits in every mode.  Per 8 pages, MFMA vs
+    // VALU kernel: encoder levels 0-2 96 / 47 / 35 vs 109 / 54 / 46 us, decoder level 1 140 vs 211, level 0 256 vs 263.
     const int mode = option(OPT_DET_MFMA);
 #define OCRS_DC(CS, CX, CM, CO, TH, TW, P, F)                                                   \
     if (cs == CS && cx == CX && cmid == CM && cout == CO && pool == P && final_conv == F) {      \
-        if (on_mfma) *on_mfma = mode >= 2 || (mode == 1 && CM >= 16);                            \
+        if (on_mfma) *on_mfma = mode >= 1;                                                       \
         if (launch) {                                                                            \
-            if (mode >= 2 || (mode == 1 && CM >= 16)) launch_mc<McCfg<CS, CX, CM, CO, TH, TW, P, F>>(a, s); \
+            if (mode >= 1) launch_mc<McCfg<CS, CX, CM, CO, TH, TW, P, F>>(a, s);                  \
             else launch_dc<DcCfg<CS, CX, CM, CO, TH, TW, P, F>>(a, s);                            \
         }                                                                                        \
         return true;                                                                             \
@@ -750,7 +750,7 @@ bool double_conv_fused(const DoubleConvArgs& a, int cs, int cx, int cmid, int co
     OCRS_DC(8, 16, 8, 8, 8, 32, false, true)
     OCRS_DC(8, 16, 8, 8, 8, 32, false, false)
     OCRS_DC(16, 32, 16, 16, 8, 16, false, false)
-    if (fuse_level >= 2 || (fuse_level >= 1 && mode >= 3)) {   // every shape that has a kernel
+    if (fuse_level >= 2 || (fuse_level >= 1 && mode >= 2)) {   // every shape that has a kernel
         OCRS_DC(32, 0, 32, 32, 8, 16, true, false)
         OCRS_DC(32, 32, 32, 32, 8, 16, false, false)
         OCRS_DC(32, 64, 32, 32, 8, 16, false, false)

@@ -316,7 +316,7 @@ def test_fused_double_conv_blocks_equal_unfused_and_oracle(in_hw, depths):
         _lib.set_option("det_fuse", 0)
         ref = model.run(x)
         outs = {}
-        for mfma in (2, 1, 0):               # r3: pointwise convs of the fused blocks on MFMA: all blocks / default mix / none
+        for mfma in (2, 1, 0):               # r3: pointwise convs of the fused blocks on MFMA: + C = 32 levels / default / none
             _lib.set_option("det_mfma", mfma)
             _lib.set_option("det_fuse", 2)   # every block shape that has a fused kernel
             outs[(mfma, 2)] = model.run(x)

@@ -268,7 +268,11 @@ def test_masks_with_more_components_than_the_scratch_holds():
     dots[500:520, 40:900] = 1
     noise = (rng.random((h, w)) < 0.3).astype(np.uint8)
     dense = (rng.random((h, w)) < 0.12).astype(np.uint8)   # the density with the most components per pixel
-    for name, mask in (("dots", dots), ("noise30", noise), ("noise12", dense)):
+    comb = np.zeros((h, w), np.uint8)    # ONE component whose border (~38 000 points) is far longer than the contour
+    comb[100:104, 20:1000] = 1           # kernel's LDS walk buffer (4 096): the walk is then repeated straight into the arena
+    comb[104:200, 20:1000:4] = 1
+    comb[300:500, 300:700] = 1           # and an ordinary blob next to it
+    for name, mask in (("dots", dots), ("noise30", noise), ("noise12", dense), ("comb", comb)):
         box["prob"] = mask.astype(np.float32)
         got = gpu.detect_words(inp)
         exp = rects_of(ora.detect_words(page))
