@@ -26,6 +26,14 @@
 namespace ocrs {
 namespace k {
 
+// barrier + LDS / memory visibility inside a one-wavefront workgroup
+#define WAVE_SYNC()                                              \
+    do {                                                         \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   \
+        __builtin_amdgcn_s_barrier();                            \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   \
+    } while (0)
+
 // ---------------------------------------------------------------------------
 // Union-find helpers (labels are page-local linear indices; -1 = frame).
 // ---------------------------------------------------------------------------
@@ -208,15 +216,53 @@ __device__ __forceinline__ int dir_dx(int d) { return (int)((0x1A90u >> (2 * d))
 // The walk by a whole wavefront: lane d < 8 fetches neighbour d, a ballot gives the mask, the walk state is
 // wave-uniform (scalar registers).  One memory latency and a handful of scalar instructions per border pixel —
 // a single lane running trace_border pays the issue latency of every instruction of the step.
+// The walk reads the mask through a WINDOW of it in LDS (kWinH rows x kWinW bytes, loaded by the whole wave with
+// coalesced 16-byte loads, zeros outside the image): one LDS latency per border pixel instead of one L2 round trip,
+// and a reload — one global latency — only when the walk leaves the window (a word-sized blob fits one; a 600-pixel
+// text line takes ~10).  The window is re-centred on the current pixel when that happens.
+constexpr int kWinW = 128, kWinH = 32;
+
+__device__ __forceinline__ void load_window(const uint8_t* __restrict__ m, int h, int w, int wy0, int wx0, uint8_t* win, int lane) {
+    // lane -> (row = lane / 2, 64-byte half of the row)
+    const int r = lane >> 1, y = wy0 + r, x0 = wx0 + 64 * (lane & 1);
+    uint8_t* dst = win + r * kWinW + 64 * (lane & 1);
+    if ((unsigned)y < (unsigned)h && x0 >= 0 && x0 + 64 <= w) {
+        const uint8_t* src = m + (int64_t)y * w + x0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            uint4 v;
+            __builtin_memcpy(&v, src + 16 * q, 16);   // (the address is byte-aligned only: the compiler picks the load width)
+            *reinterpret_cast<uint4*>(dst + 16 * q) = v;
+        }
+    } else {
+        for (int i = 0; i < 64; i++) {
+            const int x = x0 + i;
+            dst[i] = ((unsigned)y < (unsigned)h && (unsigned)x < (unsigned)w) ? m[(int64_t)y * w + x] : (uint8_t)0;
+        }
+    }
+}
+
 // WRITE: points go to out[0 .. cap) (LDS or global); the return value is the full length either way.
+// win: kWinW * kWinH bytes of LDS.
 template <bool WRITE>
-__device__ int trace_border_wave(const uint8_t* __restrict__ m, int h, int w, int sy, int sx, uint32_t* out, int cap, int lane) {
+__device__ int trace_border_wave(const uint8_t* __restrict__ m, int h, int w, int sy, int sx, uint32_t* out, int cap,
+                                 uint8_t* win, int lane) {
     const int ldy = dir_dy(lane & 7), ldx = dir_dx(lane & 7);
+    // the component lies below and to both sides of its raster-first pixel
+    int wy0 = sy - 1, wx0 = sx - kWinW / 2;
+    load_window(m, h, w, wy0, wx0, win, lane);
+    WAVE_SYNC();
     auto neighbours = [&](int y, int x) -> unsigned {
+        if (y - 1 < wy0 || y + 1 >= wy0 + kWinH || x - 1 < wx0 || x + 1 >= wx0 + kWinW) {   // (wave-uniform)
+            WAVE_SYNC();
+            wy0 = y - kWinH / 2;
+            wx0 = x - kWinW / 2;
+            load_window(m, h, w, wy0, wx0, win, lane);
+            WAVE_SYNC();
+        }
         const int yy = y + ldy, xx = x + ldx;
-        const bool in = lane < 8 && (unsigned)yy < (unsigned)h && (unsigned)xx < (unsigned)w;
-        const uint8_t v = m[in ? yy * w + xx : 0];
-        return (unsigned)(__ballot(in && v != 0) & 0xffull);
+        const uint8_t v = win[(yy - wy0) * kWinW + (xx - wx0)];    // zeros outside the image
+        return (unsigned)(__ballot(lane < 8 && v != 0) & 0xffull);
     };
     const unsigned nb0 = neighbours(sy, sx);
     if (nb0 == 0) {
@@ -272,19 +318,12 @@ __device__ __forceinline__ float cross3(P2 o, P2 a, P2 b) {
     return (a.x - o.x) * (b.y - o.y) - (a.y - o.y) * (b.x - o.x);
 }
 
-#define WAVE_SYNC()                                              \
-    do {                                                         \
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   \
-        __builtin_amdgcn_s_barrier();                            \
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   \
-    } while (0)
 
-// Ramer-Douglas-Peucker on the closed polyline p[0..n] (p[n] = p[0]) + ordered gather of the kept points into `simp`;
-// returns their number.  Stack-free: each round walks the current kept points in order and splits every not-yet-final
+// Ramer-Douglas-Peucker on the closed polyline p[0..n] (p[n] = p[0]): marks the kept points, returns their number.  Stack-free: each round walks the current kept points in order and splits every not-yet-final
 // segment once.  keep: 0 = dropped, 1 = kept, 2 = kept and the segment starting here is final.  The surviving set does
 // not depend on the order in which segments are split.  Index n (the duplicated start) is implicit: always kept.
 // (forceinline: called once with LDS and once with global pointers; each copy gets its own address space.)
-__device__ __forceinline__ int rdp_gather(const uint32_t* pts, uint8_t* keep, int n, float eps, uint32_t* simp, int lane) {
+__device__ __forceinline__ int rdp_mark(const uint32_t* pts, uint8_t* keep, int n, float eps, int lane) {
     for (int k = lane; k < n; k += 64) keep[k] = 0;
     WAVE_SYNC();
     if (lane == 0) keep[0] = 1;
@@ -329,6 +368,16 @@ __device__ __forceinline__ int rdp_gather(const uint32_t* pts, uint8_t* keep, in
         }
         WAVE_SYNC();
     }
+    int mcount = 0;   // how many points survive
+    for (int base = 0; base < n; base += 64) {
+        int k = base + lane;
+        mcount += __popcll(__ballot(k < n && keep[k] != 0));
+    }
+    return mcount;
+}
+
+// ordered gather of the kept points
+__device__ __forceinline__ void gather_kept(const uint32_t* pts, const uint8_t* keep, int n, uint32_t* simp, int lane) {
     int mcount = 0;
     for (int base = 0; base < n; base += 64) {
         int k = base + lane;
@@ -338,10 +387,121 @@ __device__ __forceinline__ int rdp_gather(const uint32_t* pts, uint8_t* keep, in
         mcount += __popcll(bal);
     }
     WAVE_SYNC();
-    return mcount;
 }
 
-constexpr int kWalkBuf = 4096;   // border points buffered in LDS by the contour kernel (16 KB per 64-thread block)
+// Steps 4-6 for one component: rank sort of the simplified polygon, convex hull, minimum-area rectangle (+ expand,
+// area test).  simp / sorted / hull: scratch of m, m and 2 m words (LDS for small polygons, the arena otherwise);
+// forceinline so that each call site keeps its pointers' address space.
+__device__ __forceinline__ void hull_rect(const uint32_t* simp, uint32_t* sorted, uint32_t* hull, int mcount, int* s_hn,
+                                          float expand, float min_area, float* rr, uint8_t* valid_out, int lane) {
+    // ---- 4. rank sort by (x, y) (index breaks ties) for the monotone chain
+    for (int i = lane; i < mcount; i += 64) {
+        uint32_t pi = simp[i];
+        uint32_t key_i = ((pi & 0xffffu) << 16) | (pi >> 16);
+        int rank = 0;
+        for (int j = 0; j < mcount; j++) {
+            uint32_t pj = simp[j];
+            uint32_t key_j = ((pj & 0xffffu) << 16) | (pj >> 16);
+            rank += (key_j < key_i || (key_j == key_i && j < i)) ? 1 : 0;
+        }
+        sorted[rank] = pi;
+    }
+    WAVE_SYNC();
+
+    // ---- 5. convex hull (Andrew monotone chain, duplicates and collinear points dropped)
+    if (lane == 0) {
+        int un = 0;  // dedupe in place
+        for (int i = 0; i < mcount; i++)
+            if (un == 0 || sorted[i] != sorted[un - 1]) sorted[un++] = sorted[i];
+        int kk = 0;
+        if (un <= 2) {
+            for (int i = 0; i < un; i++) hull[kk++] = sorted[i];
+        } else {
+            for (int i = 0; i < un; i++) {
+                P2 c = unpack_pt(sorted[i]);
+                while (kk >= 2 && cross3(unpack_pt(hull[kk - 2]), unpack_pt(hull[kk - 1]), c) <= 0.0f) kk--;
+                hull[kk++] = sorted[i];
+            }
+            int lower = kk + 1;
+            for (int i = un - 2; i >= 0; i--) {
+                P2 c = unpack_pt(sorted[i]);
+                while (kk >= lower && cross3(unpack_pt(hull[kk - 2]), unpack_pt(hull[kk - 1]), c) <= 0.0f) kk--;
+                hull[kk++] = sorted[i];
+            }
+            kk -= 1;
+        }
+        *s_hn = kk;
+    }
+    WAVE_SYNC();
+    const int hn = *s_hn;
+
+    // ---- 6. minimum-area rectangle: exhaustive search over hull edges
+    float best_area = 3.40282347e+38f;
+    int best_e = -1;
+    for (int e = lane; e < hn; e += 64) {
+        P2 a = unpack_pt(hull[e]), b = unpack_pt(hull[e + 1 == hn ? 0 : e + 1]);
+        float ex = b.x - a.x, ey = b.y - a.y;
+        float len = sqrtf(ex * ex + ey * ey);
+        float parx = ex / len, pary = ey / len;
+        float perx = -pary, pery = parx;
+        float min_par = 3.40282347e+38f, max_par = -3.40282347e+38f, max_perp = -3.40282347e+38f;
+        for (int q = 0; q < hn; q++) {
+            P2 c = unpack_pt(hull[q]);
+            float dx = c.x - a.x, dy = c.y - a.y;
+            float pp = parx * dx + pary * dy;
+            float qq = perx * dx + pery * dy;
+            min_par = pp < min_par ? pp : min_par;
+            max_par = pp > max_par ? pp : max_par;
+            max_perp = qq > max_perp ? qq : max_perp;
+        }
+        float area = max_perp * (max_par - min_par);
+        if (area < best_area) { best_area = area; best_e = e; }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        float oa = __shfl_xor(best_area, o);
+        int oe = __shfl_xor(best_e, o);
+        bool take = (oe >= 0) && (best_e < 0 || oa < best_area || (oa == best_area && oe < best_e));
+        if (take) { best_area = oa; best_e = oe; }
+    }
+    if (lane == 0) {
+        uint8_t ok = 0;
+        if (best_e >= 0) {
+            const int e = best_e;
+            P2 a = unpack_pt(hull[e]), b = unpack_pt(hull[e + 1 == hn ? 0 : e + 1]);
+            float ex = b.x - a.x, ey = b.y - a.y;
+            float len = sqrtf(ex * ex + ey * ey);
+            float parx = ex / len, pary = ey / len;
+            float perx = -pary, pery = parx;
+            float min_par = 3.40282347e+38f, max_par = -3.40282347e+38f, max_perp = -3.40282347e+38f;
+            for (int q = 0; q < hn; q++) {
+                P2 c = unpack_pt(hull[q]);
+                float dx = c.x - a.x, dy = c.y - a.y;
+                float pp = parx * dx + pary * dy;
+                float qq = perx * dx + pery * dy;
+                min_par = pp < min_par ? pp : min_par;
+                max_par = pp > max_par ? pp : max_par;
+                max_perp = qq > max_perp ? qq : max_perp;
+            }
+            float height = max_perp;
+            float width = max_par - min_par;
+            float along = min_par + width / 2.0f;
+            float half_h = height / 2.0f;
+            float ul = sqrtf(perx * perx + pery * pery);
+            rr[0] = a.x + along * parx + half_h * perx;
+            rr[1] = a.y + along * pary + half_h * pery;
+            rr[2] = perx / ul;
+            rr[3] = pery / ul;
+            float ew = width + 2.0f * expand, eh = height + 2.0f * expand;
+            rr[4] = ew;
+            rr[5] = eh;
+            ok = (ew * eh >= min_area) ? 1 : 0;
+        }
+        *valid_out = ok;
+    }
+}
+
+constexpr int kSmallPoly = 64;   // simplified polygons up to this size keep their sort / hull scratch in LDS
+constexpr int kWalkBuf = 1024;   // border points buffered in LDS by the contour kernel: LDS per 64-thread block stays near 10 KB, i.e. ~15 components in flight per CU — the stage is bound by one wave's instruction latencies, so concurrency matters more than where the data sits
 
 // One wavefront (= one 64-thread block) per component.
 __global__ void __launch_bounds__(64)
@@ -364,7 +524,8 @@ contour_rect_kernel(const uint8_t* __restrict__ mask, int h, int w, const int32_
         // is copied there with coalesced stores.  Only a border longer than the buffer is walked a second time, straight
         // into the arena.  (r2: a separate count kernel, one lane per component, + a scan launch + the write walk.)
         __shared__ uint32_t walk[kWalkBuf];
-        const int n = trace_border_wave<true>(m, h, w, root / w, root % w, walk, kWalkBuf, lane);
+        __shared__ __attribute__((aligned(16))) uint8_t win[kWinW * kWinH];
+        const int n = trace_border_wave<true>(m, h, w, root / w, root % w, walk, kWalkBuf, win, lane);
         int off32 = 0;
         if (lane == 0) off32 = atomicAdd(&arena_top[page], n);
         off32 = __builtin_amdgcn_readfirstlane(off32);
@@ -387,121 +548,27 @@ contour_rect_kernel(const uint8_t* __restrict__ mask, int h, int w, const int32_
         // ---- 2/3. simplify (RDP) and gather the kept points.  The border stays in LDS when it fits the walk buffer
         // (one LDS latency per access in the chains of dependent reads below instead of one L2 round trip); a longer
         // one is walked again, straight into the arena, and simplified from there.
+        __shared__ uint8_t keep_l[kWalkBuf];
         int mcount;
         if (n <= kWalkBuf) {
-            __shared__ uint8_t keep_l[kWalkBuf];
-            mcount = rdp_gather(walk, keep_l, n, eps, simp, lane);
+            mcount = rdp_mark(walk, keep_l, n, eps, lane);
         } else {
-            trace_border_wave<true>(m, h, w, root / w, root % w, pts, n, lane);
+            trace_border_wave<true>(m, h, w, root / w, root % w, pts, n, win, lane);
             WAVE_SYNC();
-            mcount = rdp_gather(pts, keep, n, eps, simp, lane);
+            mcount = rdp_mark(pts, keep, n, eps, lane);
         }
 
-        // ---- 4. rank sort by (x, y) (index breaks ties) for the monotone chain
-        for (int i = lane; i < mcount; i += 64) {
-            uint32_t pi = simp[i];
-            uint32_t key_i = ((pi & 0xffffu) << 16) | (pi >> 16);
-            int rank = 0;
-            for (int j = 0; j < mcount; j++) {
-                uint32_t pj = simp[j];
-                uint32_t key_j = ((pj & 0xffffu) << 16) | (pj >> 16);
-                rank += (key_j < key_i || (key_j == key_i && j < i)) ? 1 : 0;
-            }
-            sorted[rank] = pi;
-        }
-        WAVE_SYNC();
-
-        // ---- 5. convex hull (Andrew monotone chain, duplicates and collinear points dropped)
+        // ---- 4-6. hull and rectangle; polygons of up to kSmallPoly points (all but pathological ones) in LDS scratch
         __shared__ int s_hn;
-        if (lane == 0) {
-            int un = 0;  // dedupe in place
-            for (int i = 0; i < mcount; i++)
-                if (un == 0 || sorted[i] != sorted[un - 1]) sorted[un++] = sorted[i];
-            int kk = 0;
-            if (un <= 2) {
-                for (int i = 0; i < un; i++) hull[kk++] = sorted[i];
-            } else {
-                for (int i = 0; i < un; i++) {
-                    P2 c = unpack_pt(sorted[i]);
-                    while (kk >= 2 && cross3(unpack_pt(hull[kk - 2]), unpack_pt(hull[kk - 1]), c) <= 0.0f) kk--;
-                    hull[kk++] = sorted[i];
-                }
-                int lower = kk + 1;
-                for (int i = un - 2; i >= 0; i--) {
-                    P2 c = unpack_pt(sorted[i]);
-                    while (kk >= lower && cross3(unpack_pt(hull[kk - 2]), unpack_pt(hull[kk - 1]), c) <= 0.0f) kk--;
-                    hull[kk++] = sorted[i];
-                }
-                kk -= 1;
-            }
-            s_hn = kk;
-        }
-        WAVE_SYNC();
-        const int hn = s_hn;
-
-        // ---- 6. minimum-area rectangle: exhaustive search over hull edges
-        float best_area = 3.40282347e+38f;
-        int best_e = -1;
-        for (int e = lane; e < hn; e += 64) {
-            P2 a = unpack_pt(hull[e]), b = unpack_pt(hull[e + 1 == hn ? 0 : e + 1]);
-            float ex = b.x - a.x, ey = b.y - a.y;
-            float len = sqrtf(ex * ex + ey * ey);
-            float parx = ex / len, pary = ey / len;
-            float perx = -pary, pery = parx;
-            float min_par = 3.40282347e+38f, max_par = -3.40282347e+38f, max_perp = -3.40282347e+38f;
-            for (int q = 0; q < hn; q++) {
-                P2 c = unpack_pt(hull[q]);
-                float dx = c.x - a.x, dy = c.y - a.y;
-                float pp = parx * dx + pary * dy;
-                float qq = perx * dx + pery * dy;
-                min_par = pp < min_par ? pp : min_par;
-                max_par = pp > max_par ? pp : max_par;
-                max_perp = qq > max_perp ? qq : max_perp;
-            }
-            float area = max_perp * (max_par - min_par);
-            if (area < best_area) { best_area = area; best_e = e; }
-        }
-        for (int o = 32; o > 0; o >>= 1) {
-            float oa = __shfl_xor(best_area, o);
-            int oe = __shfl_xor(best_e, o);
-            bool take = (oe >= 0) && (best_e < 0 || oa < best_area || (oa == best_area && oe < best_e));
-            if (take) { best_area = oa; best_e = oe; }
-        }
-        if (lane == 0) {
-            uint8_t ok = 0;
-            float* rr = rects + slot * 6;
-            if (best_e >= 0) {
-                const int e = best_e;
-                P2 a = unpack_pt(hull[e]), b = unpack_pt(hull[e + 1 == hn ? 0 : e + 1]);
-                float ex = b.x - a.x, ey = b.y - a.y;
-                float len = sqrtf(ex * ex + ey * ey);
-                float parx = ex / len, pary = ey / len;
-                float perx = -pary, pery = parx;
-                float min_par = 3.40282347e+38f, max_par = -3.40282347e+38f, max_perp = -3.40282347e+38f;
-                for (int q = 0; q < hn; q++) {
-                    P2 c = unpack_pt(hull[q]);
-                    float dx = c.x - a.x, dy = c.y - a.y;
-                    float pp = parx * dx + pary * dy;
-                    float qq = perx * dx + pery * dy;
-                    min_par = pp < min_par ? pp : min_par;
-                    max_par = pp > max_par ? pp : max_par;
-                    max_perp = qq > max_perp ? qq : max_perp;
-                }
-                float height = max_perp;
-                float width = max_par - min_par;
-                float along = min_par + width / 2.0f;
-                float half_h = height / 2.0f;
-                float ul = sqrtf(perx * perx + pery * pery);
-                rr[0] = a.x + along * parx + half_h * perx;
-                rr[1] = a.y + along * pary + half_h * pery;
-                rr[2] = perx / ul;
-                rr[3] = pery / ul;
-                float ew = width + 2.0f * expand, eh = height + 2.0f * expand;
-                rr[4] = ew;
-                rr[5] = eh;
-                ok = (ew * eh >= min_area) ? 1 : 0;
-            }
-            valid[slot] = ok;
+        if (mcount <= kSmallPoly) {
+            __shared__ uint32_t simp_l[kSmallPoly], sorted_l[kSmallPoly], hull_l[2 * kSmallPoly + 2];
+            if (n <= kWalkBuf) gather_kept(walk, keep_l, n, simp_l, lane);
+            else gather_kept(pts, keep, n, simp_l, lane);
+            hull_rect(simp_l, sorted_l, hull_l, mcount, &s_hn, expand, min_area, rects + slot * 6, valid + slot, lane);
+        } else {
+            if (n <= kWalkBuf) gather_kept(walk, keep_l, n, simp, lane);
+            else gather_kept(pts, keep, n, simp, lane);
+            hull_rect(simp, sorted, hull, mcount, &s_hn, expand, min_area, rects + slot * 6, valid + slot, lane);
         }
         WAVE_SYNC();
     }
