@@ -96,8 +96,8 @@ OCRS_API ocrs_status ocrs_coalescer_selftest(int n_threads, int requests_per_thr
  *   "gru_mode"        0 = one persistent kernel per GRU layer (default), 1 = one launch per time step
  *   "det_fuse"        1 = fused LDS-tiled DoubleConv blocks of the detection U-Net where they win (default),
  *                     2 = for every block shape that has a fused kernel, 0 = per-op kernels only
- *   "det_mfma"        fused detection blocks: 1 = their pointwise convolutions and ConvTranspose run on MFMA (default),
- *                     0 = thread-per-pixel VALU kernels, 2 = additionally the 32-channel levels run as fused MFMA blocks
+ *   "det_mfma"        1 = DoubleConv blocks of the detection U-Net (8 to 32 channels) run as fused launches with their
+ *                     pointwise convolutions and ConvTranspose on MFMA (default), 0 = thread-per-pixel VALU kernels
  *   "det_heavy"       the detection stage's kernels run on the device's shared conv-stack stream (queued between other
  *                     requests' conv stacks, at full speed) instead of on the call's own stream (beside them, every one of its
  *                     ~50 launches waiting for CU slots): 1 = for requests of fewer than 8 pages (default), 2 = always, 0 = never

@@ -244,7 +244,7 @@ const OptDef kOptDefs[OPT_COUNT] = {
     {"coalesce_window_us", "OCRS_COALESCE_WINDOW_US", 300},  // how long a would-be leader lets the queue fill while other batches run
     {"gru_gates_pack", "OCRS_GRU_GATES_PACK", 1},       // gate-per-wave GRU kernel: 2 = two workgroups per CU for requests of twice the row tiles
     {"conv_occupancy", "OCRS_CONV_OCCUPANCY", 4},       // recognition conv blocks per CU: 4 (fastest alone), 3 leaves room for other requests' small kernels
-    {"det_mfma", "OCRS_DET_MFMA", 1},                   // fused detection blocks: pointwise convs + ConvTranspose on MFMA (1), also the C = 32 levels as fused blocks (2), VALU kernels (0)
+    {"det_mfma", "OCRS_DET_MFMA", 1},                   // fused detection blocks: pointwise convs + ConvTranspose on MFMA, all block shapes incl. the 32-channel levels (1); VALU kernels (0)
     {"gru_background", "OCRS_GRU_BACKGROUND", 0},       // requests beyond the gate-per-wave kernel's size: 1 = lean multi-tile gate-per-wave kernel (small footprint, slower alone)
     {"gx_heavy", "OCRS_GX_HEAVY", 0},                   // GRU input projections of large requests on the shared conv-stack stream (serialised with the conv stacks)
     {"det_heavy", "OCRS_DET_HEAVY", 1},                 // detection kernels on the shared conv-stack stream: 1 = requests of fewer than 8 pages, 2 = all

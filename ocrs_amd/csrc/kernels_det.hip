@@ -724,10 +724,11 @@ void launch_mc(const DoubleConvArgs& a0, hipStream_t s) {
 // Shapes with a fused kernel: (skip channels, ConvT input channels or 0, mid, out, pool, final).
 bool double_conv_fused(const DoubleConvArgs& a, int cs, int cx, int cmid, int cout, bool pool, bool final_conv, int fuse_level,
                        bool launch, hipStream_t s, bool* on_mfma) {
-    // option "det_mfma": 1 (default) = the fused blocks' pointwise convs and ConvTranspose run on the matrix cores
-    // (double_conv_mfma_kernel, 512 threads per tile), 0 = the round-2 thread-per-pixel kernels, 2 = additionally the
-    // C = 32 levels run as fused MFMA blocks instead of per-op kernels.  Same bits in every mode.  Per 8 pages, MFMA vs
-    // VALU kernel: encoder levels 0-2 96 / 47 / 35 vs 109 / 54 / 46 us, decoder level 1 140 vs 211, level 0 256 vs 263.
+    // option "det_mfma": 1 (default) = the pointwise convs and ConvTransposes of every block shape listed below run on
+    // the matrix cores (double_conv_mfma_kernel, 512 threads per tile) — including the 32-channel levels, which as
+    // thread-per-pixel blocks lost to the per-op kernels and as MFMA blocks win (detection-only +4 %); 0 = the round-2
+    // thread-per-pixel kernels for the shapes `fuse_level` selects.  Same bits in every mode.  Per 8 pages, MFMA vs VALU
+    // kernel: encoder levels 0-2 96 / 47 / 35 vs 109 / 54 / 46 us, decoder level 1 140 vs 211, level 0 256 vs 263.
     const int mode = option(OPT_DET_MFMA);
 #define OCRS_DC(CS, CX, CM, CO, TH, TW, P, F)                                                   \
     if (cs == CS && cx == CX && cmid == CM && cout == CO && pool == P && final_conv == F) {      \
@@ -750,7 +751,7 @@ bool double_conv_fused(const DoubleConvArgs& a, int cs, int cx, int cmid, int co
     OCRS_DC(8, 16, 8, 8, 8, 32, false, true)
     OCRS_DC(8, 16, 8, 8, 8, 32, false, false)
     OCRS_DC(16, 32, 16, 16, 8, 16, false, false)
-    if (fuse_level >= 2 || (fuse_level >= 1 && mode >= 2)) {   // every shape that has a kernel
+    if (fuse_level >= 2 || (fuse_level >= 1 && mode >= 1)) {   // every shape that has a kernel
         OCRS_DC(32, 0, 32, 32, 8, 16, true, false)
         OCRS_DC(32, 32, 32, 32, 8, 16, false, false)
         OCRS_DC(32, 64, 32, 32, 8, 16, false, false)
