@@ -17,6 +17,7 @@
 #include <rccl/rccl.h>
 
 #include <atomic>
+#include <system_error>
 #include <thread>
 
 #include "abi_util.hpp"
@@ -76,7 +77,11 @@ void for_each_member(const ocrs_engine_group* g, const std::vector<char>& has_wo
     for (size_t m = 0; m < G; m++) {
         if (!has_work[m]) continue;
         if (mine == G) { mine = m; continue; }
-        th.emplace_back(body, m);
+        try {
+            th.emplace_back(body, m);
+        } catch (const std::system_error&) {   // no thread to be had: this member's share runs here, after the others were started
+            body(m);
+        }
     }
     if (mine < G) body(mine);
     for (auto& t : th) t.join();
