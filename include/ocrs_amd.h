@@ -114,6 +114,8 @@ OCRS_API ocrs_status ocrs_coalescer_selftest(int n_threads, int requests_per_thr
  *   "gru_gates_pack"  2 = the gate-per-wave kernel also takes requests of up to twice the row tiles by running two workgroups
  *                     per CU (default 1: one workgroup per CU)
  *   "conv_occupancy"  recognition 3x3 conv blocks per CU: 4 (default) or 3
+ *   "conv_flat"       recognition 3x3 convs: the 128-pixel patches tile a width group's strip of images side by side
+ *                     (1, default: only a group's last patch is ragged) or every image on its own (0); same bits
  *   "gru_background"  1 = requests too large for one row tile per cluster run the recurrence on the lean multi-tile
  *                     gate-per-wave kernel (a third of the general kernel's registers: conv stacks of other requests keep
  *                     three blocks per CU beside it; slower on its own), default 0

@@ -171,6 +171,13 @@ struct RaggedView {          // device pointers live in one metadata upload; pas
     int ntiles128, ntiles256;
     const int32_t* toff2d;   // [G+1] cumulative TH x TW patch counts (conv3x3_ragged), TH = 128 / tw
     int ntiles2d, tw;
+    // the same with the patches tiling the whole group's strip of images (flat column = img * Wp + x; Wp = W, or W
+    // rounded up to even in the *_flat2 table of a layer whose epilogue pools horizontally)
+    const int32_t* toff2d_flat;
+    const int32_t* toff2d_flat2;
+    int ntiles2d_flat, ntiles2d_flat2;
+    int64_t max_tile_px_;    // most pixels in the images one flat tile touches (host)
+    int min_w;               // narrowest image at this layer (host)
     int64_t pixels;          // total pixels (host)
     int max_w;               // widest image at this layer (host)
 };

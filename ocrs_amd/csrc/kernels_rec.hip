@@ -241,7 +241,10 @@ constexpr int RG_BM = 128, RG_BK = OCRS_CONV_BK, RG_LDA = RG_BM + 1;
 #ifndef OCRS_ABL
 #define OCRS_ABL 0  // ablation builds (tools/conv_ablation.sh; results are WRONG on purpose): 1 no barriers,
 #endif              // 2 no global loads, 4 no LDS writes
-template <int BN, int TW, int PH, int PW>
+// FLAT: the patches of a group tile the strip of ALL its images side by side (flat column c = img * Wp + x, Wp = W
+// rounded up to PW) instead of each image on its own, so only the last patch of a GROUP is ragged, not the last
+// patch of every image (group widths are multiples of 50: W / 4 = 87, 112, 137 ... wasted 7 % of the MFMA rows).
+template <int BN, int TW, int PH, int PW, bool FLAT>
 __global__ void __launch_bounds__(256, OCRS_CONV_WAVES)
 conv3x3_ragged_kernel(const float* __restrict__ X, RaggedView rv, int cin, const float* __restrict__ Bw,
                       const float* __restrict__ bias, int cout, int relu, float* __restrict__ Y,
@@ -256,14 +259,30 @@ conv3x3_ragged_kernel(const float* __restrict__ X, RaggedView rv, int cin, const
     const int half = lane >> 5, l31 = lane & 31;
     const int wm = wave >> 1, wn = wave & 1;
     const int gtile = xcd_remap(blockIdx.x, gridDim.x);
-    const int g = find_group(rv.toff2d, rv.G, gtile);
-    const int tile = gtile - rv.toff2d[g];
+    const int32_t* __restrict__ toff = FLAT ? (PW == 2 ? rv.toff2d_flat2 : rv.toff2d_flat) : rv.toff2d;
+    const int g = find_group(toff, rv.G, gtile);
+    const int tile = gtile - toff[g];
     const int H = rv.H, W = rv.W[g];
-    const int tiles_w = (W + TW - 1) / TW, tiles_h = H / TH;
-    const int cb = tile % tiles_w;
-    const int t2 = tile / tiles_w;
-    const int rb = t2 % tiles_h, img = t2 / tiles_h;
-    const int y0 = rb * TH, x0 = cb * TW;
+    const int tiles_h = H / TH;
+    // FLAT: column strip of the whole group; the tile starts in image img0 at column xf0 and may run into the next ones
+    const int Wp = FLAT ? (PW == 2 ? (W + 1) & ~1 : W) : W;
+    const int nimg = FLAT ? rv.n[g] : 1;
+    int rb, img, x0, span = 1;
+    if (FLAT) {
+        rb = tile % tiles_h;
+        const int c0 = (tile / tiles_h) * TW;
+        img = c0 / Wp;
+        x0 = c0 - img * Wp;
+        span = min(nimg - img, (x0 + TW - 1) / Wp + 1);
+    } else {
+        const int tiles_w = (W + TW - 1) / TW;
+        const int cb = tile % tiles_w;
+        const int t2 = tile / tiles_w;
+        rb = t2 % tiles_h;
+        img = t2 / tiles_h;
+        x0 = cb * TW;
+    }
+    const int y0 = rb * TH;
     const int n0 = blockIdx.y * BN;
     const float* __restrict__ A = X + (rv.poff[g] + (int64_t)img * H * W) * cin;
     const int K = 9 * cin;
@@ -281,9 +300,14 @@ conv3x3_ragged_kernel(const float* __restrict__ X, RaggedView rv, int cin, const
 #pragma unroll
     for (int j = 0; j < AV; j++) {
         const int m = ar + AROWS * j;
-        const int py = y0 + m / TW, px = x0 + m % TW;
+        const int py = y0 + m / TW;
+        int px = x0 + m % TW, ir = 0;   // FLAT: column px of image img + ir
+        if (FLAT) {
+#pragma unroll
+            for (int q = 0; q < 3; q++) { const bool nx = px >= Wp; px -= nx ? Wp : 0; ir += nx; }  // Wp >= 11 (host)
+        }
         unsigned mk = 0;
-        if (px < W) {  // a column past the image contributes nothing (its outputs are never stored)
+        if (px < W && ir < span) {  // a column past the image contributes nothing (its outputs are never stored)
 #pragma unroll
             for (int t9 = 0; t9 < 9; t9++) {
                 const int iy = py + t9 / 3 - 1, ix = px + t9 % 3 - 1;
@@ -291,7 +315,7 @@ conv3x3_ragged_kernel(const float* __restrict__ X, RaggedView rv, int cin, const
             }
         }
         amask[j] = mk;
-        aoff[j] = (py * W + min(px, W - 1)) * cin + akq * 4;
+        aoff[j] = ((min(ir, span - 1) * H + py) * W + min(px, W - 1)) * cin + akq * 4;
     }
     constexpr int BV = RG_BK * BN / 4 / 256;
     // A is fetched from global memory a full 128-byte line (32 channels) per pixel at a time — two
@@ -301,8 +325,8 @@ conv3x3_ragged_kernel(const float* __restrict__ X, RaggedView rv, int cin, const
     // Buffer loads: the hardware range check returns 0.0f for the out-of-image taps (their lanes get an
     // offset beyond num_records), so the load is unconditional and needs neither a branch nor a select.
     const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(A), /*stride*/ 0, (int)((int64_t)H * W * cin * sizeof(float)), 0x00020000);
-    constexpr int OOB = 0x40000000;  // 1 GiB: past any image (an image is at most H * W * cin * 4 < 2^30 bytes)
+        const_cast<float*>(A), /*stride*/ 0, (int)((int64_t)span * H * W * cin * sizeof(float)), 0x00020000);
+    constexpr int OOB = 0x40000000;  // 1 GiB: past any tile's images (span * H * W * cin * 4 < 2^30 bytes, checked by the host)
     auto load_a_pair = [&](int k0) {  // chunks k0 and k0 + RG_BK (same tap: cin % (2*RG_BK) == 0)
         const int tap = k0 / cin;
         const int ci0 = k0 - tap * cin;
@@ -404,6 +428,21 @@ conv3x3_ragged_kernel(const float* __restrict__ X, RaggedView rv, int cin, const
     const int Ho = H / PH, Wo = W / PW;
     float* __restrict__ C = Y + (out_poff[g] + (int64_t)img * Ho * Wo) * cout;
     auto act = [&](float v) { return relu ? (v > 0.0f ? v : 0.0f) : v; };
+    // FLAT: a lane's accumulator rows cover NX distinct patch columns (tx = q & (TW - 1) below); their image, column and
+    // validity are worked out once: xo_off[jx] = element offset of (image, pooled column) from C, or -1.
+    constexpr int NX = TW == 16 ? 8 : 16;
+    int xo_off[FLAT ? NX : 1];
+    if (FLAT) {
+#pragma unroll
+        for (int jx = 0; jx < NX; jx++) {
+            if (PW == 2 && (jx & 1)) { xo_off[jx] = -1; continue; }
+            const int q = (jx & 3) + 8 * (jx >> 2) + 4 * half;
+            int x = x0 + (TW == 32 ? q : (q & 15)), ir = 0;
+#pragma unroll
+            for (int k = 0; k < 3; k++) { const bool nx = x >= Wp; x -= nx ? Wp : 0; ir += nx; }
+            xo_off[jx] = (x + (PW - 1) < W && ir < span) ? (ir * Ho * Wo + x / PW) * cout : -1;
+        }
+    }
 #pragma unroll
     for (int t = 0; t < NTW; t++) {
         const int col = n0 + wn * (BN / 2) + t * 32 + l31;
@@ -419,7 +458,7 @@ conv3x3_ragged_kernel(const float* __restrict__ X, RaggedView rv, int cin, const
                 const int ty = TW == 32 ? 2 * wm + i : 4 * wm + 2 * i + (r >> 3);
                 const int tx = TW == 32 ? q : (q & 15);
                 const int x = x0 + tx;
-                if (x + (PW - 1) >= W) continue;
+                if (FLAT ? xo_off[TW == 16 ? (r & 7) : r] < 0 : x + (PW - 1) >= W) continue;
                 constexpr int VI = (PH == 2 && TW == 32) ? 1 : 0;   // partner's i offset
                 constexpr int VR = (PH == 2 && TW == 16) ? 8 : 0;   // partner's r offset
                 float m = act(acc[i][t][r]);
@@ -428,8 +467,9 @@ conv3x3_ragged_kernel(const float* __restrict__ X, RaggedView rv, int cin, const
                     { const float v = act(acc[(i + VI) & 1][t][(r + VR) & 15]); m = v > m ? v : m; }
                     if (PW == 2) { const float v = act(acc[(i + VI) & 1][t][(r + VR + 1) & 15]); m = v > m ? v : m; }
                 }
-                const int yo = (y0 + ty) / PH, xo = x / PW;
-                C[((int64_t)yo * Wo + xo) * cout + col] = m;
+                const int yo = (y0 + ty) / PH;
+                if (FLAT) C[xo_off[TW == 16 ? (r & 7) : r] + yo * Wo * cout + col] = m;
+                else C[((int64_t)yo * Wo + x / PW) * cout + col] = m;
             }
         }
     }
@@ -444,9 +484,13 @@ bool conv3x3_ragged(const float* x, const RaggedView& rv, int cin, const float* 
     if ((ph == 2 || pw == 2) && !relu) return false;  // the fused pool assumes ReLU'd (non-negative, NaN-free order) inputs
     if (rv.tw != 32 && rv.tw != 16) return false;
     if (rv.H % (RG_BM / rv.tw) != 0) return false;
-    // A is addressed through a buffer descriptor per image with 32-bit byte offsets (OOB marker at 1 GiB)
-    if ((int64_t)rv.H * rv.max_w * cin * (int64_t)sizeof(float) >= (int64_t)1 << 30) return false;
-    if (rv.ntiles2d <= 0) return true;
+    // flat tiling: 32-bit element offsets inside a tile's images, at most three image borders per patch row
+    const bool flat = option(OPT_CONV_FLAT) != 0 && rv.min_w >= 11 &&
+                      rv.max_tile_px_ * std::max(cin, cout) * (int64_t)sizeof(float) < (int64_t)1 << 30;
+    // A is addressed through a buffer descriptor per tile (its images) with 32-bit byte offsets (OOB marker at 1 GiB)
+    if (!flat && (int64_t)rv.H * rv.max_w * cin * (int64_t)sizeof(float) >= (int64_t)1 << 30) return false;
+    const int ntiles = flat ? (pw == 2 ? rv.ntiles2d_flat2 : rv.ntiles2d_flat) : rv.ntiles2d;
+    if (ntiles <= 0) return true;
     const bool n64 = cout <= 64;
     size_t lds = (size_t)(2 * RG_BK * RG_LDA + 2 * RG_BK * (n64 ? 64 : 128)) * sizeof(float);
     // Four of these blocks fill every SIMD's register file (4 waves x 128 VGPRs) for ~0.5 ms at a time: a small
@@ -455,15 +499,19 @@ bool conv3x3_ragged(const float* x, const RaggedView& rv, int cin, const float* 
     // requests).  Option "conv_occupancy" = 3 pads the LDS request so that three blocks fit per CU: a quarter of
     // each SIMD's registers stays free for whatever else is queued, at 3-4 % of this kernel's own rate.
     if (option(OPT_CONV_OCCUPANCY) == 3) lds = std::max<size_t>(lds, 53 * 1024);
-    const dim3 grid(rv.ntiles2d, (cout + (n64 ? 63 : 127)) / (n64 ? 64 : 128));
-#define OCRS_LAUNCH_CONV(BN_, TW_, PH_, PW_)                                                                        \
-    hipLaunchKernelGGL((conv3x3_ragged_kernel<BN_, TW_, PH_, PW_>), grid, dim3(256), lds, s, x, rv, cin, wt, bias, cout, \
-                       relu, y, out.poff)
-#define OCRS_DISPATCH_POOL(BN_, TW_)                                   \
-    do {                                                               \
-        if (ph == 1) OCRS_LAUNCH_CONV(BN_, TW_, 1, 1);                 \
-        else if (pw == 1) OCRS_LAUNCH_CONV(BN_, TW_, 2, 1);            \
-        else OCRS_LAUNCH_CONV(BN_, TW_, 2, 2);                         \
+    const dim3 grid(ntiles, (cout + (n64 ? 63 : 127)) / (n64 ? 64 : 128));
+#define OCRS_LAUNCH_CONV(BN_, TW_, PH_, PW_)                                                                            \
+    do {                                                                                                                \
+        if (flat) hipLaunchKernelGGL((conv3x3_ragged_kernel<BN_, TW_, PH_, PW_, true>), grid, dim3(256), lds, s, x, rv, \
+                                     cin, wt, bias, cout, relu, y, out.poff);                                           \
+        else hipLaunchKernelGGL((conv3x3_ragged_kernel<BN_, TW_, PH_, PW_, false>), grid, dim3(256), lds, s, x, rv,     \
+                                cin, wt, bias, cout, relu, y, out.poff);                                                \
+    } while (0)
+#define OCRS_DISPATCH_POOL(BN_, TW_)                              \
+    do {                                                          \
+        if (ph == 1) OCRS_LAUNCH_CONV(BN_, TW_, 1, 1);            \
+        else if (pw == 1) OCRS_LAUNCH_CONV(BN_, TW_, 2, 1);       \
+        else OCRS_LAUNCH_CONV(BN_, TW_, 2, 2);                    \
     } while (0)
     if (n64) {
         if (rv.tw == 32) OCRS_DISPATCH_POOL(64, 32); else OCRS_DISPATCH_POOL(64, 16);

@@ -703,7 +703,7 @@ float* HipModel::run_prefix_ragged(Workspace& ws, hipStream_t exec, const std::v
     // layout of the metadata blob per geometry: W[G] | toff128[G+1] | toff256[G+1] | poff[G+1] (int64)
     std::vector<int32_t> meta32;
     std::vector<int64_t> meta64;
-    struct GeoOff { size_t w, t128, t256, t32, t16, p; int nt128, nt256, nt32, nt16; int64_t pixels; };
+    struct GeoOff { size_t w, t128, t256, t32, t16, p, f32[2], f16[2]; int nt128, nt256, nt32, nt16, nf32[2], nf16[2]; int64_t pixels; };
     std::vector<GeoOff> goff;
     const size_t n_at = 0;
     meta32.insert(meta32.end(), nvec.begin(), nvec.end());
@@ -721,6 +721,9 @@ float* HipModel::run_prefix_ragged(Workspace& ws, hipStream_t exec, const std::v
         int32_t a128 = 0, a256 = 0, a32 = 0, a16 = 0;
         int64_t px = 0;
         std::vector<int32_t> t256{0}, t32{0}, t16{0};  // t32 / t16: 4 x 32 and 8 x 16 pixel patches (conv3x3_ragged)
+        // the same patches over the group's whole strip of images; [1]: image widths rounded up to even
+        std::vector<int32_t> f32[2] = {{0}, {0}}, f16[2] = {{0}, {0}};
+        int32_t af32[2] = {0, 0}, af16[2] = {0, 0};
         std::vector<int64_t> pv{0};
         meta32.push_back(0);
         for (int g = 0; g < G; g++) {
@@ -729,6 +732,13 @@ float* HipModel::run_prefix_ragged(Workspace& ws, hipStream_t exec, const std::v
             a256 += (int32_t)((rows + 255) / 256);
             a32 += nvec[g] * (ge.H / 4) * ((ge.W[g] + 31) / 32);
             a16 += nvec[g] * (ge.H / 8) * ((ge.W[g] + 15) / 16);
+            for (int e = 0; e < 2; e++) {
+                const int64_t cols = (int64_t)nvec[g] * (e ? (ge.W[g] + 1) & ~1 : ge.W[g]);
+                af32[e] += (int32_t)((ge.H / 4) * ((cols + 31) / 32));
+                af16[e] += (int32_t)((ge.H / 8) * ((cols + 15) / 16));
+                f32[e].push_back(af32[e]);
+                f16[e].push_back(af16[e]);
+            }
             px += rows;
             meta32.push_back(a128);
             t256.push_back(a256);
@@ -743,6 +753,13 @@ float* HipModel::run_prefix_ragged(Workspace& ws, hipStream_t exec, const std::v
         o.t16 = meta32.size();
         meta32.insert(meta32.end(), t16.begin(), t16.end());
         o.nt32 = a32; o.nt16 = a16;
+        for (int e = 0; e < 2; e++) {
+            o.f32[e] = meta32.size();
+            meta32.insert(meta32.end(), f32[e].begin(), f32[e].end());
+            o.f16[e] = meta32.size();
+            meta32.insert(meta32.end(), f16[e].begin(), f16[e].end());
+            o.nf32[e] = af32[e]; o.nf16[e] = af16[e];
+        }
         o.p = meta64.size();
         meta64.insert(meta64.end(), pv.begin(), pv.end());
         o.nt128 = a128; o.nt256 = a256; o.pixels = px;
@@ -771,6 +788,17 @@ float* HipModel::run_prefix_ragged(Workspace& ws, hipStream_t exec, const std::v
         v.tw = use16 ? 16 : 32;
         v.toff2d = d32 + (use16 ? goff[gi].t16 : goff[gi].t32);
         v.ntiles2d = use16 ? goff[gi].nt16 : goff[gi].nt32;
+        v.toff2d_flat = d32 + (use16 ? goff[gi].f16[0] : goff[gi].f32[0]);
+        v.toff2d_flat2 = d32 + (use16 ? goff[gi].f16[1] : goff[gi].f32[1]);
+        v.ntiles2d_flat = use16 ? goff[gi].nf16[0] : goff[gi].nf32[0];
+        v.ntiles2d_flat2 = use16 ? goff[gi].nf16[1] : goff[gi].nf32[1];
+        v.max_tile_px_ = 0;
+        v.min_w = INT32_MAX;
+        for (int g = 0; g < G; g++) {
+            const int64_t w = geos[gi].W[g], span = std::min<int64_t>(nvec[g], (v.tw - 1 + w - 1) / w + 1);
+            v.max_tile_px_ = std::max(v.max_tile_px_, span * geos[gi].H * w);
+            v.min_w = std::min(v.min_w, (int)w);
+        }
         return v;
     };
 

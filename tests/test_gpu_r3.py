@@ -374,3 +374,32 @@ def test_recurrence_paths_by_hidden_size_and_mode(hidden):
     else:
         assert gates0 == 0 and hid0 == 2                 # persistent: one launch per GRU layer
         assert gates1 == 0 and hid1 > 2 * 20             # fused step kernel: one launch per time step and layer
+
+
+# ------------------------------------------------------------------ conv patches spanning several images of a width group
+def test_narrow_lines_sharing_conv_patches():
+    """Width groups of 50 / 100 / 150 px with many lines each: at the conv layers the images are 25 / 12 (50 / 25,
+    75 / 37) columns wide, so one 16- or 32-column patch of `conv3x3_ragged` covers two to three images of the
+    group's strip, odd widths included (the pooled layer pads each image to an even width).  Same tokens and boxes
+    as the oracle, and the same with every image tiled on its own (conv_flat = 0)."""
+    rbuf, gpu, ora = _small_rec_engine(64)
+    px = synth.synthetic_page(12, 460, 760, lines=10, columns=1)
+    inp = gpu.prepare_input(ImageSource.from_tensor(px, DimOrder.Hwc))
+    oin = ora.prepare_input(OP.ImageSource.from_tensor(px, "hwc"))
+    lines = []
+    for i in range(23):  # resized widths 38..48 -> 50, 80..96 -> 100, 120..144 -> 150 at height 64
+        ww = (12, 15, 25, 30, 40, 45)[i % 6]
+        lines.append([RotatedRect.new((np.float32(20 + 30 * (i % 20) + ww / 2), np.float32(30 + 18 * i)),
+                                      (np.float32(0.0), np.float32(1.0)), np.float32(ww), np.float32(20.0))])
+    exp = ora.recognize_text(oin, lines)
+    assert sum(1 for t in exp if t is not None and len(t.chars)) >= 10
+    try:
+        for flat in (1, 0):
+            _lib.set_option("conv_flat", flat)
+            got = gpu.recognize_text(inp, [rects_of(l) for l in lines])
+            for a, b in zip(got, exp):
+                assert (a is None) == (b is None)
+                if a is not None:
+                    assert str(a) == str(b) and [c.rect for c in a.chars()] == [c.rect.tlbr() for c in b.chars]
+    finally:
+        _lib.set_option("conv_flat", 1)
