@@ -33,3 +33,14 @@ _lib.check(L.ocrs_device_synchronize())
 dt = time.perf_counter() - t0
 print("det_fuse=%s: %.1f pages/s (%.3f ms per 8 pages), %d words on page 0" % (
     os.environ.get("OCRS_DET_FUSE", "1"), reps * 8 / dt, 1e3 * dt / reps, len(words[0])))
+if os.environ.get("DET_BENCH_INFLIGHT"):
+    from concurrent.futures import ThreadPoolExecutor
+    k = int(os.environ["DET_BENCH_INFLIGHT"])
+    with ThreadPoolExecutor(k) as pool:
+        list(pool.map(lambda _: eng.detect_words_batch(inputs), range(k)))
+        _lib.check(L.ocrs_device_synchronize())
+        t0 = time.perf_counter()
+        list(pool.map(lambda _: eng.detect_words_batch(inputs), range(3 * reps)))
+        _lib.check(L.ocrs_device_synchronize())
+        dt = time.perf_counter() - t0
+    print("%d requests in flight: %.1f pages/s" % (k, 3 * reps * 8 / dt))
