@@ -176,6 +176,8 @@ struct RaggedView {          // device pointers live in one metadata upload; pas
     const int32_t* toff2d_flat;
     const int32_t* toff2d_flat2;
     int ntiles2d_flat, ntiles2d_flat2;
+    const int32_t* toff2d_gap;   // 8 x 16 patches over the strip with >= 1 empty column between images (conv12_fused_ragged)
+    int ntiles2d_gap;
     int64_t max_tile_px_;    // most pixels in the images one flat tile touches (host)
     int min_w;               // narrowest image at this layer (host)
     int64_t pixels;          // total pixels (host)
@@ -187,6 +189,9 @@ void pool_ragged(const float* x, const RaggedView& in, int c, int kh, int kw, bo
                  hipStream_t s);
 void to_seq_packed_ragged(const float* x, const RaggedView& in, int c, const int32_t* d_pos, const int32_t* d_off,
                           float* y, hipStream_t s);
+// conv1 (Cin = 1) + ReLU + pool 2x2 + conv2 + ReLU + pool 2x2 in one launch; false = not this shape (run the two ops)
+bool conv12_fused_ragged(const float* x, const RaggedView& in0, const RaggedView& mid, const float* w1, const float* b1,
+                         int c1, const float* w2, const float* b2, int c2, float* y, const RaggedView& out, hipStream_t s);
 // returns false if the shape is not supported (caller falls back to the per-group path)
 bool conv3x3_ragged(const float* x, const RaggedView& rv, int cin, const float* wt, const float* bias, int cout, int relu,
                     int ph, int pw, float* y, const RaggedView& out, hipStream_t s);

@@ -475,6 +475,205 @@ conv3x3_ragged_kernel(const float* __restrict__ X, RaggedView rv, int cin, const
     }
 }
 
+// ---------------------------------------------------------------------------
+// conv1 (Cin = 1) + ReLU + MaxPool 2x2 + conv2 (32 -> 64) + ReLU + MaxPool 2x2 in ONE kernel (round 3).
+// conv1's pooled output (2.9 GB for a 16-page request) was written once and read back nine times, tap by tap, by
+// conv2, and conv1 itself is a VALU kernel that the stream carrying the conv stacks has to wait for (1.4 ms alone,
+// 2.4 ms live).  Here a block computes conv1 for the 10 x 18 positions its 8 x 16 patch of conv2 outputs needs — on
+// the VALU, into an LDS tile [position][32 channels] — and conv2's MFMA loop takes its A operand straight from that
+// tile (no global A loads, no register staging, no ds_write commits); only conv2's weights stream through LDS as
+// before.  The conv1 work of a block (41 % more positions than the patch has: the halo) overlaps the MFMA phase of
+// the three other blocks on the CU.
+// Numerics: conv1 = the fmaf chain of conv1_relu_pool_ragged_kernel, position by position; conv2 = the k-ascending
+// MFMA chain of conv3x3_ragged_kernel from acc = bias (k = tap * 32 + channel); zero padding of conv2 = tile entries
+// of positions outside the image are 0.  The patches tile the group's strip of images with at least one empty column
+// between two images (flat column = image * Wg + x, Wg = W + 1 rounded up to even), so that a position is either a
+// pixel of ONE image or padding for both of its neighbours.
+// ---------------------------------------------------------------------------
+constexpr int F12_MID = 32, F12_COUT = 64, F12_TW = 16, F12_TH = 8, F12_HW = F12_TW + 2, F12_HH = F12_TH + 2;
+constexpr int F12_NPOS = F12_HH * F12_HW;          // 180 halo positions
+constexpr int F12_LD = F12_MID + 1;                // tile row stride (floats): consecutive positions -> consecutive banks
+constexpr size_t F12_LDS = (size_t)(F12_NPOS * F12_LD + 2 * RG_BK * F12_COUT) * sizeof(float);
+
+__global__ void __launch_bounds__(256, OCRS_CONV_WAVES)
+conv12_fused_kernel(const float* __restrict__ X0, RaggedView in0, RaggedView mid, const float* __restrict__ w1,
+                    const float* __restrict__ b1, const float* __restrict__ Bw, const float* __restrict__ bias,
+                    float* __restrict__ Y, const int64_t* __restrict__ out_poff) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int BN = F12_COUT, TW = F12_TW, TH = F12_TH, LD = F12_LD;
+    float* T = lds;                                  // [NPOS][LD]
+    float* Bs = lds + F12_NPOS * LD;                 // [2][RG_BK][BN]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int gtile = xcd_remap(blockIdx.x, gridDim.x);
+    const int g = find_group(mid.toff2d_gap, mid.G, gtile);
+    const int tile = gtile - mid.toff2d_gap[g];
+    const int H = mid.H, W = mid.W[g];               // conv2's input geometry (after conv1's pool)
+    const int H0 = in0.H, W0 = in0.W[g];             // the line images
+    const int tiles_h = H / TH;
+    const int Wg = (W + 2) & ~1;
+    const int nimg = mid.n[g];
+    const int rb = tile % tiles_h;
+    const int c0 = (tile / tiles_h) * TW;
+    const int img = c0 / Wg;
+    const int x0 = c0 - img * Wg;
+    const int span = min(nimg - img, (x0 + TW - 1) / Wg + 1);
+    const int y0 = rb * TH;
+
+    // ---- conv2 weights: first chunk on its way while conv1 runs
+    constexpr int BV = RG_BK * BN / 4 / 256;         // 1
+    static_assert(BV == 1, "one float4 of B per thread and chunk");
+    const int boff = (tid / (BN / 4)) * BN + (tid % (BN / 4)) * 4;
+    auto load_b = [&](int k0, int buf) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Bw + (int64_t)k0 * BN + boff),
+                                         (__attribute__((address_space(3))) void*)(Bs + buf * RG_BK * BN + wave * 256), 16, 0, 0);
+    };
+    load_b(0, 0);
+
+    // ---- stage 1: conv1 + ReLU + pool for the halo positions -> T.  Item = (position, 4 channels); a thread keeps
+    // its channel quad (256 % 8 == 0) and with it 9 x 4 weights + 4 biases in registers.
+    {
+        const int q = tid & 7;
+        float wq[9][4], bq[4];
+#pragma unroll
+        for (int t = 0; t < 9; t++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) wq[t][c] = w1[t * F12_MID + 4 * q + c];
+#pragma unroll
+        for (int c = 0; c < 4; c++) bq[c] = b1[4 * q + c];
+        const float* __restrict__ xg = X0 + in0.poff[g];
+        for (int p = tid >> 3; p < F12_NPOS; p += 32) {
+            const int hy = p / F12_HW, hx = p - hy * F12_HW;
+            const int y = y0 - 1 + hy;
+            int x = x0 - 1 + hx, ir = 0;
+#pragma unroll
+            for (int k = 0; k < 3; k++) { const bool nx = x >= Wg; x -= nx ? Wg : 0; ir += nx; }   // W >= 11 (host)
+            float m[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            if ((unsigned)y < (unsigned)H && x >= 0 && x < W && ir < span) {
+                const float* xi = xg + (int64_t)(img + ir) * H0 * W0;
+                float pt[4][4];
+                const int iy0 = 2 * y - 1, ix0 = 2 * x - 1;
+                if (iy0 >= 0 && iy0 + 3 < H0 && ix0 >= 0 && ix0 + 3 < W0) {
+                    const float* pp = xi + (int64_t)iy0 * W0 + ix0;
+#pragma unroll
+                    for (int a = 0; a < 4; a++)
+#pragma unroll
+                        for (int b = 0; b < 4; b++) pt[a][b] = pp[a * W0 + b];
+                } else {
+#pragma unroll
+                    for (int a = 0; a < 4; a++)
+#pragma unroll
+                        for (int b = 0; b < 4; b++) {
+                            const int iy = iy0 + a, ix = ix0 + b;
+                            pt[a][b] = ((unsigned)iy < (unsigned)H0 && (unsigned)ix < (unsigned)W0) ? xi[(int64_t)iy * W0 + ix] : 0.0f;
+                        }
+                }
+#pragma unroll
+                for (int py = 0; py < 2; py++)
+#pragma unroll
+                    for (int px = 0; px < 2; px++) {
+                        float acc[4];
+#pragma unroll
+                        for (int c = 0; c < 4; c++) acc[c] = bq[c];
+#pragma unroll
+                        for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+                            for (int kx = 0; kx < 3; kx++) {
+                                const float xv = pt[py + ky][px + kx];
+#pragma unroll
+                                for (int c = 0; c < 4; c++) acc[c] = fmaf(xv, wq[ky * 3 + kx][c], acc[c]);
+                            }
+#pragma unroll
+                        for (int c = 0; c < 4; c++) {
+                            const float v = acc[c] > 0.0f ? acc[c] : 0.0f;
+                            if (py == 0 && px == 0) m[c] = v;
+                            else m[c] = v > m[c] ? v : m[c];
+                        }
+                    }
+            }
+            float* t = T + p * LD + 4 * q;
+            t[0] = m[0]; t[1] = m[1]; t[2] = m[2]; t[3] = m[3];
+        }
+    }
+
+    // ---- stage 2: conv2 on the matrix cores, A from the tile
+    f32x16 acc[2];
+    {
+        const int col = wn * 32 + l31;
+        const float bv = bias[col];
+#pragma unroll
+        for (int r = 0; r < 16; r++) { acc[0][r] = bv; acc[1][r] = bv; }
+    }
+    // GEMM row m = wm * 64 + i * 32 + l31 is patch pixel (m / 16, m % 16); its tap (ky, kx), channel c sits at
+    // T[((m / 16 + ky) * 18 + m % 16 + kx) * LD + c]
+    int abase[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int m = wm * 64 + i * 32 + l31;
+        abase[i] = ((m / TW) * F12_HW + (m % TW)) * LD + half;
+    }
+    __syncthreads();     // T complete, B chunk 0 landed (the barrier's vmcnt(0))
+    constexpr int NCH = 9 * F12_MID / RG_BK;          // 18 chunks of 16
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+        if (c + 1 < NCH) load_b((c + 1) * RG_BK, (c + 1) & 1);
+        const int tap = (c * RG_BK) / F12_MID, ch0 = (c * RG_BK) % F12_MID;
+        const int toff = ((tap / 3) * F12_HW + tap % 3) * LD + ch0;
+        const float* b = Bs + (c & 1) * RG_BK * BN + wn * 32 + l31;
+#pragma unroll
+        for (int kp = 0; kp < RG_BK / 2; kp++) {
+            const float a0 = T[abase[0] + toff + 2 * kp], a1 = T[abase[1] + toff + 2 * kp];
+            const float bt = b[(2 * kp + half) * BN];
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bt, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bt, acc[1], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: ReLU + MaxPool 2x2 in registers (accumulator row r <-> patch pixel as in conv3x3_ragged_kernel,
+    // TW = 16: ty = 4 wm + 2 i + (r >> 3), tx = (r & 3) + 8 ((r >> 2) & 1) + 4 half), store the pooled pixel
+    const int Ho = H / 2, Wo = W / 2;
+    float* __restrict__ C = Y + (out_poff[g] + (int64_t)img * Ho * Wo) * BN;
+    auto act = [&](float v) { return v > 0.0f ? v : 0.0f; };
+    const int col = wn * 32 + l31;
+    int xo_off[8];
+#pragma unroll
+    for (int jx = 0; jx < 8; jx++) {
+        if (jx & 1) { xo_off[jx] = -1; continue; }
+        int x = x0 + (jx & 3) + 8 * (jx >> 2) + 4 * half, ir = 0;
+#pragma unroll
+        for (int k = 0; k < 3; k++) { const bool nx = x >= Wg; x -= nx ? Wg : 0; ir += nx; }
+        xo_off[jx] = (x + 1 < W && ir < span) ? (ir * Ho * Wo + x / 2) * BN : -1;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int r = 0; r < 8; r += 2) {
+            if (xo_off[r & 7] < 0) continue;
+            float m = act(acc[i][r]);
+            { const float v = act(acc[i][r + 1]); m = v > m ? v : m; }
+            { const float v = act(acc[i][r + 8]); m = v > m ? v : m; }
+            { const float v = act(acc[i][r + 9]); m = v > m ? v : m; }
+            const int yo = (y0 + 4 * wm + 2 * i) / 2;
+            C[xo_off[r & 7] + yo * Wo * BN + col] = m;
+        }
+}
+
+bool conv12_fused_ragged(const float* x, const RaggedView& in0, const RaggedView& mid, const float* w1, const float* b1,
+                         int c1, const float* w2, const float* b2, int c2, float* y, const RaggedView& out, hipStream_t s) {
+    // x == nullptr: only asks whether the shape has this kernel
+    if (option(OPT_CONV12_FUSE) == 0) return false;
+    if (c1 != F12_MID || c2 != F12_COUT || mid.H % F12_TH != 0 || in0.H != 2 * mid.H || out.H * 2 != mid.H) return false;
+    if (mid.min_w < 11 || mid.ntiles2d_gap <= 0) return false;
+    // 32-bit element offsets inside the images one patch touches
+    if (mid.max_tile_px_ * 4 * (int64_t)sizeof(float) >= (int64_t)1 << 30 ||
+        mid.max_tile_px_ * F12_COUT * (int64_t)sizeof(float) >= (int64_t)1 << 30) return false;
+    if (!x) return true;
+    hipLaunchKernelGGL(conv12_fused_kernel, dim3(mid.ntiles2d_gap), dim3(256), F12_LDS, s, x, in0, mid, w1, b1, w2, b2, y, out.poff);
+    return true;
+}
+
 // rv carries the 2-D tiling of the INPUT geometry (toff2d / ntiles2d / tw); `out` is the geometry after the
 // fused pool (== rv when ph == pw == 1).  Returns false if the shape is not supported.
 bool conv3x3_ragged(const float* x, const RaggedView& rv, int cin, const float* wt, const float* bias, int cout, int relu,

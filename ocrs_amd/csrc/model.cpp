@@ -703,7 +703,7 @@ float* HipModel::run_prefix_ragged(Workspace& ws, hipStream_t exec, const std::v
     // layout of the metadata blob per geometry: W[G] | toff128[G+1] | toff256[G+1] | poff[G+1] (int64)
     std::vector<int32_t> meta32;
     std::vector<int64_t> meta64;
-    struct GeoOff { size_t w, t128, t256, t32, t16, p, f32[2], f16[2]; int nt128, nt256, nt32, nt16, nf32[2], nf16[2]; int64_t pixels; };
+    struct GeoOff { size_t w, t128, t256, t32, t16, p, f32[2], f16[2], gap; int nt128, nt256, nt32, nt16, nf32[2], nf16[2], ngap; int64_t pixels; };
     std::vector<GeoOff> goff;
     const size_t n_at = 0;
     meta32.insert(meta32.end(), nvec.begin(), nvec.end());
@@ -724,6 +724,8 @@ float* HipModel::run_prefix_ragged(Workspace& ws, hipStream_t exec, const std::v
         // the same patches over the group's whole strip of images; [1]: image widths rounded up to even
         std::vector<int32_t> f32[2] = {{0}, {0}}, f16[2] = {{0}, {0}};
         int32_t af32[2] = {0, 0}, af16[2] = {0, 0};
+        std::vector<int32_t> tgap{0};   // 8 x 16 patches, images one empty column (at least) apart (conv12_fused_ragged)
+        int32_t agap = 0;
         std::vector<int64_t> pv{0};
         meta32.push_back(0);
         for (int g = 0; g < G; g++) {
@@ -732,6 +734,8 @@ float* HipModel::run_prefix_ragged(Workspace& ws, hipStream_t exec, const std::v
             a256 += (int32_t)((rows + 255) / 256);
             a32 += nvec[g] * (ge.H / 4) * ((ge.W[g] + 31) / 32);
             a16 += nvec[g] * (ge.H / 8) * ((ge.W[g] + 15) / 16);
+            agap += (int32_t)((ge.H / 8) * (((int64_t)nvec[g] * ((ge.W[g] + 2) & ~1) + 15) / 16));
+            tgap.push_back(agap);
             for (int e = 0; e < 2; e++) {
                 const int64_t cols = (int64_t)nvec[g] * (e ? (ge.W[g] + 1) & ~1 : ge.W[g]);
                 af32[e] += (int32_t)((ge.H / 4) * ((cols + 31) / 32));
@@ -753,6 +757,9 @@ float* HipModel::run_prefix_ragged(Workspace& ws, hipStream_t exec, const std::v
         o.t16 = meta32.size();
         meta32.insert(meta32.end(), t16.begin(), t16.end());
         o.nt32 = a32; o.nt16 = a16;
+        o.gap = meta32.size();
+        meta32.insert(meta32.end(), tgap.begin(), tgap.end());
+        o.ngap = agap;
         for (int e = 0; e < 2; e++) {
             o.f32[e] = meta32.size();
             meta32.insert(meta32.end(), f32[e].begin(), f32[e].end());
@@ -792,6 +799,8 @@ float* HipModel::run_prefix_ragged(Workspace& ws, hipStream_t exec, const std::v
         v.toff2d_flat2 = d32 + (use16 ? goff[gi].f16[1] : goff[gi].f32[1]);
         v.ntiles2d_flat = use16 ? goff[gi].nf16[0] : goff[gi].nf32[0];
         v.ntiles2d_flat2 = use16 ? goff[gi].nf16[1] : goff[gi].nf32[1];
+        v.toff2d_gap = d32 + goff[gi].gap;
+        v.ntiles2d_gap = geos[gi].H % 8 == 0 ? goff[gi].ngap : 0;
         v.max_tile_px_ = 0;
         v.min_w = INT32_MAX;
         for (int g = 0; g < G; g++) {
@@ -819,6 +828,29 @@ float* HipModel::run_prefix_ragged(Workspace& ws, hipStream_t exec, const std::v
         const k::RaggedView vin = view(i);
         float* y = nullptr;
         size_t ybytes = 0;
+        // conv1 + pool + conv2 + pool in one kernel where the shapes allow (kernels_rec.hip: conv12_fused_ragged)
+        if (op.type == OP_CONV && op.cin == 1 && i + 3 < ts && ops[i + 2].type == OP_CONV && ops[i + 2].cin == op.cout &&
+            ops[i + 2].relu && ops[i + 3].type == OP_MAXPOOL && ops[i + 3].kh == 2 && ops[i + 3].kw == 2) {
+            const GraphOp& op2 = ops[i + 2];
+            const k::RaggedView vmid = view(i + 2), vout = view(i + 4);
+            bool ok = k::conv12_fused_ragged(nullptr, vin, vmid, nullptr, nullptr, op.cout, nullptr, nullptr, op2.cout, nullptr, vout, st);
+            float* y2 = ok ? get((size_t)vout.pixels * op2.cout) : nullptr;
+            if (ok) {
+                // counted as conv2's launch with conv2's FLOPs (the matrix-core work); conv1's VALU work rides along
+                timed(KC_GEMM_CONV3X3, 2.0 * vmid.pixels * 9.0 * op2.cin * op2.cout,
+                      4.0 * (vin.pixels + vout.pixels * op2.cout) + 4.0 * op2.wcount[0],
+                      [&] { k::conv12_fused_ragged(cur, vin, vmid, op.w[0], op.w[1], op.cout, op2.w[0], op2.w[1], op2.cout, y2, vout, st); });
+                y = y2;
+                ybytes = (size_t)vout.pixels * op2.cout * sizeof(float);
+                curC = op2.cout;
+                i += 3;
+                if (prev_buf) spare.emplace_back(prev_buf, prev_bytes);
+                prev_buf = y;
+                prev_bytes = ybytes;
+                cur = y;
+                continue;
+            }
+        }
         if (op.type == OP_CONV && op.cin == 1) {
             const k::RaggedView vout = view(i + 2);  // after the fused MaxPool 2x2
             ybytes = (size_t)vout.pixels * op.cout * sizeof(float);

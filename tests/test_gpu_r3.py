@@ -381,7 +381,8 @@ def test_narrow_lines_sharing_conv_patches():
     """Width groups of 50 / 100 / 150 px with many lines each: at the conv layers the images are 25 / 12 (50 / 25,
     75 / 37) columns wide, so one 16- or 32-column patch of `conv3x3_ragged` covers two to three images of the
     group's strip, odd widths included (the pooled layer pads each image to an even width).  Same tokens and boxes
-    as the oracle, and the same with every image tiled on its own (conv_flat = 0)."""
+    as the oracle, and the same with every image tiled on its own (conv_flat = 0) and with the first two convs as
+    separate kernels (conv12_fuse = 0)."""
     rbuf, gpu, ora = _small_rec_engine(64)
     px = synth.synthetic_page(12, 460, 760, lines=10, columns=1)
     inp = gpu.prepare_input(ImageSource.from_tensor(px, DimOrder.Hwc))
@@ -394,8 +395,10 @@ def test_narrow_lines_sharing_conv_patches():
     exp = ora.recognize_text(oin, lines)
     assert sum(1 for t in exp if t is not None and len(t.chars)) >= 10
     try:
-        for flat in (1, 0):
+        # conv12_fuse: conv1 + pool + conv2 + pool as one kernel (its patches leave an empty column between images)
+        for flat, fuse12 in ((1, 1), (0, 1), (1, 0), (0, 0)):
             _lib.set_option("conv_flat", flat)
+            _lib.set_option("conv12_fuse", fuse12)
             got = gpu.recognize_text(inp, [rects_of(l) for l in lines])
             for a, b in zip(got, exp):
                 assert (a is None) == (b is None)
@@ -403,3 +406,4 @@ def test_narrow_lines_sharing_conv_patches():
                     assert str(a) == str(b) and [c.rect for c in a.chars()] == [c.rect.tlbr() for c in b.chars]
     finally:
         _lib.set_option("conv_flat", 1)
+        _lib.set_option("conv12_fuse", 1)
