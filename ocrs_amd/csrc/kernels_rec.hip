@@ -490,10 +490,17 @@ conv3x3_ragged_kernel(const float* __restrict__ X, RaggedView rv, int cin, const
 // between two images (flat column = image * Wg + x, Wg = W + 1 rounded up to even), so that a position is either a
 // pixel of ONE image or padding for both of its neighbours.
 // ---------------------------------------------------------------------------
+#ifndef OCRS_F12_ABL
+#define OCRS_F12_ABL 0   // ablation builds (tools/conv12_ablation.sh; wrong results on purpose): 1 no conv1 stage, 2 no weight loads, 4 an eighth of the MFMAs
+#endif
 constexpr int F12_MID = 32, F12_COUT = 64, F12_TW = 16, F12_TH = 8, F12_HW = F12_TW + 2, F12_HH = F12_TH + 2;
 constexpr int F12_NPOS = F12_HH * F12_HW;          // 180 halo positions
 constexpr int F12_LD = F12_MID + 1;                // tile row stride (floats): consecutive positions -> consecutive banks
-constexpr size_t F12_LDS = (size_t)(F12_NPOS * F12_LD + 2 * RG_BK * F12_COUT) * sizeof(float);
+#ifndef OCRS_F12_BK
+#define OCRS_F12_BK 16   // 32 (half the barriers, four blocks per CU instead of five) measured the same
+#endif
+constexpr int F12_BK = OCRS_F12_BK;                // K chunk of conv2's weight stream (one barrier per chunk)
+constexpr size_t F12_LDS = (size_t)(F12_NPOS * F12_LD + 2 * F12_BK * F12_COUT) * sizeof(float);
 
 __global__ void __launch_bounds__(256, OCRS_CONV_WAVES)
 conv12_fused_kernel(const float* __restrict__ X0, RaggedView in0, RaggedView mid, const float* __restrict__ w1,
@@ -502,7 +509,7 @@ conv12_fused_kernel(const float* __restrict__ X0, RaggedView in0, RaggedView mid
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int BN = F12_COUT, TW = F12_TW, TH = F12_TH, LD = F12_LD;
     float* T = lds;                                  // [NPOS][LD]
-    float* Bs = lds + F12_NPOS * LD;                 // [2][RG_BK][BN]
+    float* Bs = lds + F12_NPOS * LD;                 // [2][F12_BK][BN]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
     const int wm = wave >> 1, wn = wave & 1;
@@ -522,12 +529,13 @@ conv12_fused_kernel(const float* __restrict__ X0, RaggedView in0, RaggedView mid
     const int y0 = rb * TH;
 
     // ---- conv2 weights: first chunk on its way while conv1 runs
-    constexpr int BV = RG_BK * BN / 4 / 256;         // 1
-    static_assert(BV == 1, "one float4 of B per thread and chunk");
+    constexpr int BV = F12_BK * BN / 4 / 256;        // float4 of B per thread and chunk
     const int boff = (tid / (BN / 4)) * BN + (tid % (BN / 4)) * 4;
     auto load_b = [&](int k0, int buf) {
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Bw + (int64_t)k0 * BN + boff),
-                                         (__attribute__((address_space(3))) void*)(Bs + buf * RG_BK * BN + wave * 256), 16, 0, 0);
+#pragma unroll
+        for (int j = 0; j < BV; j++)   // chunk element idx = tid + 256 j lands at float 4 idx (row-major [k][BN])
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Bw + (int64_t)(k0 + 16 * j) * BN + boff),
+                                             (__attribute__((address_space(3))) void*)(Bs + buf * F12_BK * BN + wave * 256 + 1024 * j), 16, 0, 0);
     };
     load_b(0, 0);
 
@@ -543,7 +551,7 @@ conv12_fused_kernel(const float* __restrict__ X0, RaggedView in0, RaggedView mid
 #pragma unroll
         for (int c = 0; c < 4; c++) bq[c] = b1[4 * q + c];
         const float* __restrict__ xg = X0 + in0.poff[g];
-        for (int p = tid >> 3; p < F12_NPOS; p += 32) {
+        for (int p = tid >> 3; p < ((OCRS_F12_ABL & 1) ? 0 : F12_NPOS); p += 32) {
             const int hy = p / F12_HW, hx = p - hy * F12_HW;
             const int y = y0 - 1 + hy;
             int x = x0 - 1 + hx, ir = 0;
@@ -614,15 +622,16 @@ conv12_fused_kernel(const float* __restrict__ X0, RaggedView in0, RaggedView mid
         abase[i] = ((m / TW) * F12_HW + (m % TW)) * LD + half;
     }
     __syncthreads();     // T complete, B chunk 0 landed (the barrier's vmcnt(0))
-    constexpr int NCH = 9 * F12_MID / RG_BK;          // 18 chunks of 16
+    constexpr int NCH = 9 * F12_MID / F12_BK;         // chunks (F12_BK divides 32: a chunk stays inside one tap)
+    static_assert(F12_MID % F12_BK == 0 && F12_BK % 16 == 0, "chunk size");
 #pragma unroll
     for (int c = 0; c < NCH; c++) {
-        if (c + 1 < NCH) load_b((c + 1) * RG_BK, (c + 1) & 1);
-        const int tap = (c * RG_BK) / F12_MID, ch0 = (c * RG_BK) % F12_MID;
+        if (c + 1 < NCH && !(OCRS_F12_ABL & 2)) load_b((c + 1) * F12_BK, (c + 1) & 1);
+        const int tap = (c * F12_BK) / F12_MID, ch0 = (c * F12_BK) % F12_MID;
         const int toff = ((tap / 3) * F12_HW + tap % 3) * LD + ch0;
-        const float* b = Bs + (c & 1) * RG_BK * BN + wn * 32 + l31;
+        const float* b = Bs + (c & 1) * F12_BK * BN + wn * 32 + l31;
 #pragma unroll
-        for (int kp = 0; kp < RG_BK / 2; kp++) {
+        for (int kp = 0; kp < ((OCRS_F12_ABL & 4) ? 1 : F12_BK / 2); kp++) {
             const float a0 = T[abase[0] + toff + 2 * kp], a1 = T[abase[1] + toff + 2 * kp];
             const float bt = b[(2 * kp + half) * BN];
             acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bt, acc[0], 0, 0, 0);
