@@ -117,8 +117,6 @@ OCRS_API ocrs_status ocrs_coalescer_selftest(int n_threads, int requests_per_thr
  *   "conv12_fuse"     the first two recognition convs and their 2x2 pools (1 -> 32 -> 64 channels) run as one kernel
  *                     (1, default): conv1 is computed into an LDS tile per patch and conv2's matrix-core loop reads
  *                     its operand there; 0 = two kernels with the 32-channel tensor in HBM between them.  Same bits.
- *   "det_persist"     workgroups per CU of the fused detection blocks, each walking several tiles (default 2;
- *                     0 = one workgroup per tile)
  *   "conv_flat"       recognition 3x3 convs: the 128-pixel patches tile a width group's strip of images side by side
  *                     (1, default: only a group's last patch is ragged) or every image on its own (0); same bits
  *   "gru_background"  1 = requests too large for one row tile per cluster run the recurrence on the lean multi-tile

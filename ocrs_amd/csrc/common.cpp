@@ -249,7 +249,6 @@ const OptDef kOptDefs[OPT_COUNT] = {
     {"gx_heavy", "OCRS_GX_HEAVY", 0},                   // GRU input projections of large requests on the shared conv-stack stream (serialised with the conv stacks)
     {"det_heavy", "OCRS_DET_HEAVY", 1},                 // detection kernels on the shared conv-stack stream: 1 = requests of fewer than 8 pages, 2 = all
     {"conv_flat", "OCRS_CONV_FLAT", 1},                 // recognition 3x3 convs: patches tile a width group's whole strip of images (0: every image on its own)
-    {"det_persist", "OCRS_DET_PERSIST", 2},             // fused detection blocks: workgroups per CU, each walking several tiles (0 = one workgroup per tile)
     {"conv12_fuse", "OCRS_CONV12_FUSE", 1},             // first two recognition convs (+ their pools) in one kernel: conv1 into LDS, conv2's MFMA operand from there
 };
 std::atomic<long> g_opts[OPT_COUNT];

@@ -440,16 +440,14 @@ double_conv_mfma_kernel(DoubleConvArgs a) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int i16 = lane & 15, kq = lane >> 4;
+    const int nblk = gridDim.x;
+    const int per_xcd = (nblk + 7) / 8;
+    const int lin = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (lin >= a.n * a.tiles_y * a.tiles_x) return;
+    const int img = lin / (a.tiles_y * a.tiles_x);
+    const int trem = lin - img * (a.tiles_y * a.tiles_x);
+    const int Y0 = (trem / a.tiles_x) * TH, X0 = (trem % a.tiles_x) * TW;
     const int h = a.h, w = a.w;
-    // Tiles of one XCD are consecutive (halo rows and columns shared through its L2).  A workgroup walks its XCD's
-    // range with the stride of the XCD's workgroups: option "det_persist" = workgroups per CU (default 2, what fits),
-    // so the depthwise weights are staged once per workgroup and the tail of a launch is one tile, not one wave of
-    // workgroups (detection alone: +7 %).
-    const int total = a.n * a.tiles_y * a.tiles_x;
-    const int tiles_per_xcd = (total + 7) / 8, wgs_per_xcd = gridDim.x >> 3;
-    const int xcd_end = min(total, ((int)(blockIdx.x & 7) + 1) * tiles_per_xcd);
-    int lin = (blockIdx.x & 7) * tiles_per_xcd + (blockIdx.x >> 3);
-    if (lin >= xcd_end) return;
 
     // ---------------- depthwise weights -> LDS (permuted)
     for (int i = tid; i < 10 * CIN; i += NT) {
@@ -463,10 +461,6 @@ double_conv_mfma_kernel(DoubleConvArgs a) {
         sW2[i] = t < 9 ? a.wd2[t * CMID + c] : a.bd2[c];
     }
 
-  for (;; ) {
-    const int img = lin / (a.tiles_y * a.tiles_x);
-    const int trem = lin - img * (a.tiles_y * a.tiles_x);
-    const int Y0 = (trem / a.tiles_x) * TH, X0 = (trem % a.tiles_x) * TW;
     // ---------------- stage 0: input region -> sA (zeros outside the image)
     float* sA = sU;
     const float* __restrict__ skip = a.skip + (int64_t)img * h * w * CS;
@@ -706,10 +700,6 @@ double_conv_mfma_kernel(DoubleConvArgs a) {
             *reinterpret_cast<f32x4*>(pimg + ((int64_t)gy * pw + gx) * COUT + c4 * 4) = m;
         }
     }
-    lin += wgs_per_xcd;
-    if (lin >= xcd_end) break;
-    __syncthreads();   // the next tile's stage 0 overwrites what this tile's last stage still reads
-  }
 }
 
 template <class Cfg>
@@ -718,9 +708,7 @@ void launch_mc(const DoubleConvArgs& a0, hipStream_t s) {
     a.tiles_y = (a.h + Cfg::TH - 1) / Cfg::TH;
     a.tiles_x = (a.w + Cfg::TW - 1) / Cfg::TW;
     const int tiles = a.n * a.tiles_y * a.tiles_x;
-    int grid = ((tiles + 7) / 8) * 8;
-    const int per_cu = option(OPT_DET_PERSIST);   // workgroups per CU that walk the tiles; 0 = one workgroup per tile
-    if (per_cu > 0) grid = std::min(grid, ctx().cu_count() * per_cu / 8 * 8);
+    const int grid = ((tiles + 7) / 8) * 8;
     static bool attr_set = [] {
         if (Cfg::LDS_BYTES > 64 * 1024)
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&double_conv_mfma_kernel<Cfg>),
