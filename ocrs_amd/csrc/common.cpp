@@ -197,6 +197,9 @@ hipStream_t DeviceContext::heavy_stream() {
         // the recurrence in one persistent launch per layer that reason is gone.  The GPU is work-conserving — every
         // combination of stream priorities measured the same 256-259 pages/s — but here the dominant kernels are
         // stretched least by what runs beside them: 9.9-10.4 ms per launch against 11.2-11.4.)
+        // Round 3, OCRS_HEAVY_LOW=1 again: +0.8 % on the 16-page bench (eight of eight ABAB pairs) — and 2-8 pages/s instead
+        // of 180 for one-page calls from 12 threads (detect latencies of seconds): with the queue at the lowest priority its
+        // kernels starve as long as any other request has something queued.  The switch stays an experiment.
         DeviceScope bind(device);
         int least = 0, greatest = 0;
         OCRS_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
