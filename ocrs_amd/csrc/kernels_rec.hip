@@ -19,6 +19,7 @@ namespace k {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // Workgroup b runs on XCD b % 8 (observed; used for speed only).  Neighbouring tiles share
 // im2col rows, so give each XCD a contiguous range of tiles: their re-reads then hit that
@@ -543,13 +544,15 @@ conv12_fused_kernel(const float* __restrict__ X0, RaggedView in0, RaggedView mid
     // its channel quad (256 % 8 == 0) and with it 9 x 4 weights + 4 biases in registers.
     {
         const int q = tid & 7;
-        float wq[9][4], bq[4];
+        // channel pairs as 2-vectors: v_pk_fma_f32 (two IEEE fmas per instruction; the compiler packs the stand-alone
+        // conv1 kernel by itself, not this loop)
+        f32x2 wq[9][2], bq[2];
 #pragma unroll
         for (int t = 0; t < 9; t++)
 #pragma unroll
-            for (int c = 0; c < 4; c++) wq[t][c] = w1[t * F12_MID + 4 * q + c];
+            for (int c = 0; c < 2; c++) wq[t][c] = f32x2{w1[t * F12_MID + 4 * q + 2 * c], w1[t * F12_MID + 4 * q + 2 * c + 1]};
 #pragma unroll
-        for (int c = 0; c < 4; c++) bq[c] = b1[4 * q + c];
+        for (int c = 0; c < 2; c++) bq[c] = f32x2{b1[4 * q + 2 * c], b1[4 * q + 2 * c + 1]};
         const float* __restrict__ xg = X0 + in0.poff[g];
         for (int p = tid >> 3; p < ((OCRS_F12_ABL & 1) ? 0 : F12_NPOS); p += 32) {
             const int hy = p / F12_HW, hx = p - hy * F12_HW;
@@ -557,7 +560,7 @@ conv12_fused_kernel(const float* __restrict__ X0, RaggedView in0, RaggedView mid
             int x = x0 - 1 + hx, ir = 0;
 #pragma unroll
             for (int k = 0; k < 3; k++) { const bool nx = x >= Wg; x -= nx ? Wg : 0; ir += nx; }   // W >= 11 (host)
-            float m[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            f32x2 m[2] = {f32x2{0.0f, 0.0f}, f32x2{0.0f, 0.0f}};
             if ((unsigned)y < (unsigned)H && x >= 0 && x < W && ir < span) {
                 const float* xi = xg + (int64_t)(img + ir) * H0 * W0;
                 float pt[4][4];
@@ -581,27 +584,30 @@ conv12_fused_kernel(const float* __restrict__ X0, RaggedView in0, RaggedView mid
                 for (int py = 0; py < 2; py++)
 #pragma unroll
                     for (int px = 0; px < 2; px++) {
-                        float acc[4];
-#pragma unroll
-                        for (int c = 0; c < 4; c++) acc[c] = bq[c];
+                        f32x2 acc[2] = {bq[0], bq[1]};
 #pragma unroll
                         for (int ky = 0; ky < 3; ky++)
 #pragma unroll
                             for (int kx = 0; kx < 3; kx++) {
-                                const float xv = pt[py + ky][px + kx];
+                                const float xs = pt[py + ky][px + kx];
+                                const f32x2 xv = f32x2{xs, xs};
 #pragma unroll
-                                for (int c = 0; c < 4; c++) acc[c] = fmaf(xv, wq[ky * 3 + kx][c], acc[c]);
+                                for (int c = 0; c < 2; c++) acc[c] = __builtin_elementwise_fma(xv, wq[ky * 3 + kx][c], acc[c]);
                             }
+                        // max over the window of ReLU(v) = ReLU(max over the window of v): the largest positive value
+                        // (equal values have equal bits) or +0; v_max_f32 ignores a NaN operand exactly as
+                        // "v > m ? v : m" from m = ReLU(.) does; an all-NaN window ends as NaN > 0 ? . : 0 = +0.
 #pragma unroll
-                        for (int c = 0; c < 4; c++) {
-                            const float v = acc[c] > 0.0f ? acc[c] : 0.0f;
-                            if (py == 0 && px == 0) m[c] = v;
-                            else m[c] = v > m[c] ? v : m[c];
-                        }
+                        for (int c = 0; c < 2; c++) m[c] = (py == 0 && px == 0) ? acc[c] : __builtin_elementwise_max(acc[c], m[c]);
                     }
+#pragma unroll
+                for (int c = 0; c < 2; c++) {
+                    m[c].x = m[c].x > 0.0f ? m[c].x : 0.0f;
+                    m[c].y = m[c].y > 0.0f ? m[c].y : 0.0f;
+                }
             }
             float* t = T + p * LD + 4 * q;
-            t[0] = m[0]; t[1] = m[1]; t[2] = m[2]; t[3] = m[3];
+            t[0] = m[0].x; t[1] = m[0].y; t[2] = m[1].x; t[3] = m[1].y;
         }
     }
 
@@ -660,10 +666,7 @@ conv12_fused_kernel(const float* __restrict__ X0, RaggedView in0, RaggedView mid
 #pragma unroll
         for (int r = 0; r < 8; r += 2) {
             if (xo_off[r & 7] < 0) continue;
-            float m = act(acc[i][r]);
-            { const float v = act(acc[i][r + 1]); m = v > m ? v : m; }
-            { const float v = act(acc[i][r + 8]); m = v > m ? v : m; }
-            { const float v = act(acc[i][r + 9]); m = v > m ? v : m; }
+            const float m = act(__builtin_fmaxf(__builtin_fmaxf(acc[i][r], acc[i][r + 1]), __builtin_fmaxf(acc[i][r + 8], acc[i][r + 9])));
             const int yo = (y0 + 4 * wm + 2 * i) / 2;
             C[xo_off[r & 7] + yo * Wo * BN + col] = m;
         }
