@@ -741,8 +741,9 @@ bool double_conv_fused(const DoubleConvArgs& a, int cs, int cx, int cmid, int co
     }
     // Shapes where one fused launch beats the per-op kernels (rocprofv3, 8 pages of 800x600, profiles/r2_det_*):
     // encoder level 0 107 us vs 202, level 1 54 vs 93, level 2 46 vs 48; decoder level 0 268 vs 531, level 1 210 vs 208.
-    // Deeper levels (C >= 32 on <= 200x150 pixels) are thread-per-pixel VALU chains on few tiles and lose
-    // (decoder level 2: 322 us vs ~120, level 3: 200 vs ~90; encoder level 3: 40 vs 31), so they stay per-op.
+    // The 32-channel levels (<= 200x150 pixels) lost as thread-per-pixel VALU blocks (decoder level 2: 322 us vs ~120,
+    // level 3: 200 vs ~90; encoder level 3: 40 vs 31) and win as MFMA blocks (round 3): with det_mfma they are fused at
+    // fuse level 1 as well (the last three shapes below); the 64-256-channel levels stay per-op.
     // encoder blocks (input -> skip [+ pooled])
     OCRS_DC(1, 0, 8, 8, 16, 32, true, false)
     OCRS_DC(8, 0, 16, 16, 8, 32, true, false)
