@@ -370,3 +370,15 @@ def test_group_host_gather_concatenates_member_payloads_in_member_order(lib):
     assert g2.gather([b"a", b"bc"])[0] == b"abc" and "more than once" in g2.last_gather()["why_host"]
     with pytest.raises(ocrs_amd.OcrsError):
         EngineGroup([], gather="host")
+
+
+def test_every_option_of_the_library_is_documented_in_the_header():
+    """ocrs_set_option names: the table in common.cpp and the comment block of include/ocrs_amd.h list the same options."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "ocrs_amd", "csrc", "common.cpp")).read()
+    names = re.findall(r'\{"([a-z0-9_]+)",\s*"OCRS_[A-Z0-9_]+",', src)
+    assert len(names) >= 19
+    hdr = open(os.path.join(root, "include", "ocrs_amd.h")).read()
+    missing = [n for n in names if '"%s"' % n not in hdr]
+    assert not missing, missing
