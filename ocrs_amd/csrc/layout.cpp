@@ -1,7 +1,12 @@
 // Layout analysis: words -> lines in reading order.  Host side by design
 // (O(n^2) on ~600 rects, branchy, sub-millisecond) — mirrors
 // ocrs/src/layout_analysis.rs:19-233 and layout_analysis/empty_rects.rs:47-229.
+#include <emmintrin.h>
+
 #include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <new>
 #include <functional>
 #include <memory>
 
@@ -22,7 +27,8 @@ namespace {
 // partitions are never popped once the 80 separators are found.
 //
 // The search pops ~48 000 partitions for a 700-word page, so its inner loops are laid out for the host's
-// caches (21 -> 14 ms per 700-word page on the build host, results identical — the sequence of pushes and pops is unchanged):
+// caches (21 -> 14 ms per 700-word page on the build host in round 2, 14 -> 10 in round 3; results identical — the sequence of
+// pushes and pops is unchanged):
 // heap entries are 8 bytes (score, id) with a branch-free child choice; obstacle lists are indices
 // appended to one arena by a branch-free filter over structure-of-arrays obstacle coordinates; payloads are
 // written once and read once.
@@ -38,19 +44,24 @@ struct HeapEntry {
 
 class RustBinaryHeap {
   public:
-    explicit RustBinaryHeap(size_t reserve) { data_.reserve(reserve); }
+    // Entry i lives at slot i + 1 of a 64-byte aligned buffer: the eight great-grandchildren of any node (entries
+    // 8 p + 7 .. 8 p + 14) are then exactly one cache line, which sift_down_to_bottom prefetches two levels ahead.
+    explicit RustBinaryHeap(size_t reserve) { grow(std::max<size_t>(reserve, 64)); }
+    ~RustBinaryHeap() { std::free(base_); }
+    RustBinaryHeap(const RustBinaryHeap&) = delete;
+    RustBinaryHeap& operator=(const RustBinaryHeap&) = delete;
     void push(HeapEntry e) {
-        data_.push_back(e);
-        sift_up(0, data_.size() - 1);
+        if (size_ == cap_) grow(cap_ * 2);
+        d_[size_++] = e;
+        sift_up(0, size_ - 1);
     }
-    bool empty() const { return data_.empty(); }
-    uint32_t top_id() const { return data_[0].id; }   // the entry the next pop returns unless a higher score is pushed first
+    bool empty() const { return size_ == 0; }
+    uint32_t top_id() const { return d_[0].id; }   // the entry the next pop returns unless a higher score is pushed first
     bool pop(HeapEntry& out) {
-        if (data_.empty()) return false;
-        HeapEntry item = data_.back();
-        data_.pop_back();
-        if (!data_.empty()) {
-            std::swap(item, data_[0]);
+        if (size_ == 0) return false;
+        HeapEntry item = d_[--size_];
+        if (size_ != 0) {
+            std::swap(item, d_[0]);
             sift_down_to_bottom(0);
         }
         out = item;
@@ -58,9 +69,21 @@ class RustBinaryHeap {
     }
 
   private:
+    void grow(size_t cap) {
+        const size_t bytes = ((cap + 1) * sizeof(HeapEntry) + 63) / 64 * 64;
+        HeapEntry* nb = static_cast<HeapEntry*>(std::aligned_alloc(64, bytes));
+        if (!nb) throw std::bad_alloc();
+        if (base_) {
+            std::memcpy(nb + 1, d_, size_ * sizeof(HeapEntry));
+            std::free(base_);
+        }
+        base_ = nb;
+        d_ = nb + 1;
+        cap_ = cap;
+    }
     // f32::total_cmp on scores that are never NaN here
     size_t sift_up(size_t start, size_t pos) {
-        HeapEntry* d = data_.data();
+        HeapEntry* d = d_;
         const HeapEntry elt = d[pos];
         while (pos > start) {
             const size_t parent = (pos - 1) / 2;
@@ -72,12 +95,15 @@ class RustBinaryHeap {
         return pos;
     }
     void sift_down_to_bottom(size_t pos) {
-        HeapEntry* d = data_.data();
-        const size_t end = data_.size();
+        HeapEntry* d = d_;
+        const size_t end = size_;
         const size_t start = pos;
         const HeapEntry elt = d[pos];
         size_t child = 2 * pos + 1;
         while (end >= 2 && child <= end - 2) {
+            // on its way to L1 two levels before the walk needs it (the heap is ~0.5 MB; without this every level
+            // below the ninth is an L2 round trip)
+            if (8 * pos + 7 < end) __builtin_prefetch(d + 8 * pos + 7);
             child += (size_t)(d[child].score <= d[child + 1].score);  // the greater child; the right one on a tie
             d[pos] = d[child];
             pos = child;
@@ -90,7 +116,9 @@ class RustBinaryHeap {
         d[pos] = elt;
         sift_up(start, pos);
     }
-    std::vector<HeapEntry> data_;
+    HeapEntry* base_ = nullptr;
+    HeapEntry* d_ = nullptr;
+    size_t size_ = 0, cap_ = 0;
 };
 
 // empty_rects.rs:80-138 + FilterRectIter (:184-221) + take(n)
@@ -103,11 +131,13 @@ std::vector<Rect> max_empty_rects_filtered(const std::vector<Rect>& obstacles_in
         return ca.x != cb.x ? ca.x < cb.x : ca.y < cb.y;
     });
     const size_t n_obs = obstacles.size();
-    // obstacle coordinates as four arrays (the filter below reads them by index; they stay in L1)
-    std::vector<int32_t> ol(n_obs), ot(n_obs), orr(n_obs), ob(n_obs);
-    for (size_t i = 0; i < n_obs; i++) {
-        ol[i] = obstacles[i].left; ot[i] = obstacles[i].top; orr[i] = obstacles[i].right; ob[i] = obstacles[i].bottom;
-    }
+    // obstacle coordinates as one 16-byte record each (left, top, -right, -bottom): the filter below tests a record
+    // against a partition with ONE vector compare — (left, top, -right, -bottom) < (b.right, b.bottom, -b.left, -b.top) in
+    // all four lanes <=> the rects intersect — and the 11 KB of records stay in L1
+    struct alignas(16) Quad { int32_t v[4]; };
+    std::vector<Quad> oq(n_obs);
+    for (size_t i = 0; i < n_obs; i++)
+        oq[i] = Quad{{obstacles[i].left, obstacles[i].top, -obstacles[i].right, -obstacles[i].bottom}};
     typedef uint32_t Idx;
     // index arena: every materialised obstacle list is appended here; partitions refer to slices.
     // Grown geometrically by hand so that the filter loop can store without a capacity check.
@@ -143,10 +173,12 @@ std::vector<Rect> max_empty_rects_filtered(const std::vector<Rect>& obstacles_in
             const Idx* src = arena.data() + part.obs_off;
             Idx* dst = arena.data() + arena_n;
             size_t k = 0;
+            const __m128i bound = _mm_set_epi32(-b.top, -b.left, b.bottom, b.right);
             for (uint32_t q = 0; q < part.obs_len; q++) {   // branch-free filter: store always, advance if it intersects
                 const Idx idx = src[q];
                 dst[k] = idx;
-                k += (size_t)((int)(ol[idx] < b.right) & (int)(orr[idx] > b.left) & (int)(ot[idx] < b.bottom) & (int)(ob[idx] > b.top));
+                const __m128i lt = _mm_cmplt_epi32(_mm_load_si128(reinterpret_cast<const __m128i*>(oq[idx].v)), bound);
+                k += (size_t)(_mm_movemask_ps(_mm_castsi128_ps(lt)) == 0xF);
             }
             my_off = (uint32_t)arena_n;
             my_len = (uint32_t)k;
@@ -210,6 +242,17 @@ std::vector<std::vector<RotatedRect>> group_into_lines(const std::vector<Rotated
         ws.push_back(w);
     }
     std::stable_sort(ws.begin(), ws.end(), [](const WordInfo& a, const WordInfo& b) { return a.left_i < b.left_i; });
+    // Pruning of the candidate scan below (the scan is the reference's: every remaining word, in sorted order; what is
+    // skipped provably fails or cannot win): a candidate needs cx > last.cx, and cx < left_i + 1 + max half-width, so the
+    // scan may start at the first word with left_i > last.cx - 1 - max half-width; and cx_i >= left_i, so once a best
+    // candidate is known no word with left_i > its key can beat it (ties keep the first minimum anyway).
+    std::vector<int32_t> lefts(ws.size());
+    float max_half = 0.0f;
+    for (size_t i = 0; i < ws.size(); i++) {
+        lefts[i] = ws[i].left_i;
+        max_half = std::max(max_half, ws[i].rect.cx - ws[i].rect.bounding_rect().left);
+    }
+    const bool prune = std::isfinite(max_half);
 
     const float overlap_threshold = 5.0f;
     const float max_h_overlap = 5.0f;
@@ -227,7 +270,16 @@ std::vector<std::vector<RotatedRect>> group_into_lines(const std::vector<Rotated
             const WordInfo& last = ws[last_i];
             long best = -1;
             int32_t best_key = 0;
-            for (size_t i = first_unused; i < ws.size(); i++) {  // remaining rects keep their sorted order
+            size_t scan_from = first_unused;
+            if (prune) {
+                const double lo = std::floor((double)last.rect.cx - 2.0 - (double)max_half);
+                if (lo > (double)INT32_MIN) {
+                    const int32_t lo_i = lo >= (double)INT32_MAX ? INT32_MAX : (int32_t)lo;
+                    scan_from = std::max(scan_from, (size_t)(std::lower_bound(lefts.begin(), lefts.end(), lo_i) - lefts.begin()));
+                }
+            }
+            for (size_t i = scan_from; i < ws.size(); i++) {  // remaining rects keep their sorted order
+                if (prune && best >= 0 && lefts[i] > best_key) break;
                 if (used[i]) continue;
                 const WordInfo& w = ws[i];
                 if (!(w.rect.cx > last.rect.cx)) continue;
