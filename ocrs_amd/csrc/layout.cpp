@@ -57,6 +57,8 @@ class RustBinaryHeap {
     }
     bool empty() const { return size_ == 0; }
     uint32_t top_id() const { return d_[0].id; }   // the entry the next pop returns unless a higher score is pushed first
+    size_t size() const { return size_; }
+    uint32_t id_at(size_t pos) const { return d_[pos].id; }   // pos < size(): entries 1 and 2 are the candidates for the pop after next
     bool pop(HeapEntry& out) {
         if (size_ == 0) return false;
         HeapEntry item = d_[--size_];
@@ -163,6 +165,15 @@ std::vector<Rect> max_empty_rects_filtered(const std::vector<Rect>& obstacles_in
         const bool have_top = !queue.empty();
         const uint32_t top = have_top ? queue.top_id() : 0;
         if (have_top) __builtin_prefetch(&store[top]);
+        if (queue.size() > 2) {   // one of these two is the top after the next pop: its payload is then already here
+            __builtin_prefetch(&store[queue.id_at(1)]);
+            __builtin_prefetch(&store[queue.id_at(2)]);
+        }
+        if (have_top) {           // ... so the likely next partition's obstacle slice can be requested a whole iteration ahead
+            const Idx* nx = arena.data() + store[top].obs_off;
+            __builtin_prefetch(nx);
+            __builtin_prefetch(nx + 16);
+        }
         // materialise this partition's obstacle list (the root keeps every obstacle, as in the reference)
         uint32_t my_off, my_len;
         if (he.id == 0 && have_root) {
@@ -206,11 +217,6 @@ std::vector<Rect> max_empty_rects_filtered(const std::vector<Rect>& obstacles_in
                 sr.is_empty())
                 continue;
             push(sr, my_off, my_len);
-        }
-        if (have_top) {
-            const Idx* nx = arena.data() + store[top].obs_off;
-            __builtin_prefetch(nx);
-            __builtin_prefetch(nx + 16);
         }
     }
     return found;
