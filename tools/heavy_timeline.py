@@ -29,7 +29,7 @@ def main(path, lo=None, hi=None):
             conv_stream[st] += e - s
     cs = max(conv_stream.items(), key=lambda kv: kv[1])[0]
     heavy = [(s, e, family(n)) for n, st, s, e in rows if st == cs]
-    starts = [i for i, (s, e, f) in enumerate(heavy) if f == "conv1_relu_pool"]
+    starts = [i for i, (s, e, f) in enumerate(heavy) if f in ("conv1_relu_pool", "conv12_fused")]   # first kernel of a request's conv stack
     lo = 0 if lo is None else lo
     hi = len(starts) - 1 if hi is None else min(hi, len(starts) - 1)
     print("conv-stack stream %d: %d steps in the trace; steps %d..%d" % (cs, len(starts), lo, hi))

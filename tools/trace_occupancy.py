@@ -31,7 +31,7 @@ def union(iv):
 
 def family(name):
     name = re.sub(r"\(.*", "", name)
-    for key in ("conv3x3_ragged", "gru_persistent", "gru_step_fused", "gemm_tiled", "gemm_mfma", "double_conv", "dwpw_fused",
+    for key in ("conv12_fused", "conv3x3_ragged", "gru_persistent", "gru_step_fused", "gemm_tiled", "gemm_mfma", "double_conv", "dwpw_fused",
                 "dwconv3x3", "conv1_relu_pool", "crop_lines", "contour_rect", "trace_count", "ccl_", "log_softmax",
                 "ctc_collapse", "copyBuffer", "fillBuffer", "pool", "resize", "prepare_image"):
         if key in name:
@@ -69,7 +69,7 @@ def main(path, skip=0.45):
         for a, b, n in iv:
             fams[family(n)] += (b - a) / 1e6
         dom = max(fams.items(), key=lambda kv: kv[1])
-        if dom[0] == "conv3x3_ragged" and conv_stream is None:
+        if dom[0] in ("conv3x3_ragged", "conv12_fused") and conv_stream is None:
             conv_stream = st
         print("  stream %3d: %8.1f ms (%5.1f %%)  %6d kernels  %s %.1f ms" % (st, busy, 100 * busy / wall, len(iv), dom[0], dom[1]))
     print("\nper kernel family: summed ms, share of wall with >= 1 such kernel running, launches")
