@@ -189,6 +189,9 @@ void pool_ragged(const float* x, const RaggedView& in, int c, int kh, int kw, bo
                  hipStream_t s);
 void to_seq_packed_ragged(const float* x, const RaggedView& in, int c, const int32_t* d_pos, const int32_t* d_off,
                           float* y, hipStream_t s);
+// AvgPool (in.H, 1) + the sequence packing in one pass (`in`: geometry before the pool, `seq`: after it, height 1)
+void avgpool_to_seq_ragged(const float* x, const RaggedView& in, const RaggedView& seq, int c, const int32_t* d_pos,
+                           const int32_t* d_off, float* y, hipStream_t s);
 // conv1 (Cin = 1) + ReLU + pool 2x2 + conv2 + ReLU + pool 2x2 in one launch; false = not this shape (run the two ops)
 bool conv12_fused_ragged(const float* x, const RaggedView& in0, const RaggedView& mid, const float* w1, const float* b1,
                          int c1, const float* w2, const float* b2, int c2, float* y, const RaggedView& out, hipStream_t s);

@@ -206,6 +206,43 @@ to_seq_packed_ragged_kernel(const float* __restrict__ x, RaggedView in, int c, c
     }
 }
 
+// The column average that ends the conv stack (AvgPool (H, 1) down to height 1) and the sequence packing in one
+// pass: sum of the H rows in ascending order from 0.0f, times 1 / H — pool_ragged_kernel's arithmetic — written
+// straight to the packed row of (line, time step).  `in` is the geometry BEFORE the pool (height H), `seq` after it.
+__global__ void __launch_bounds__(256)
+avgpool_to_seq_ragged_kernel(const float* __restrict__ x, RaggedView in, RaggedView seq, int c,
+                             const int32_t* __restrict__ pos, const int32_t* __restrict__ off, float* __restrict__ y) {
+    const int g = find_group(seq.toff256, seq.G, blockIdx.x);
+    const int tile = blockIdx.x - seq.toff256[g];
+    const int T = seq.W[g], ih = in.H;
+    const int64_t rows = (int64_t)seq.n[g] * T;
+    const float* __restrict__ xg = x + in.poff[g] * c;
+    const int32_t* __restrict__ posg = pos + seq.loff[g];
+    const int cq = c >> 2;
+    const float inv = 1.0f / (float)ih;
+    for (int i = threadIdx.x; i < 256 * cq; i += 256) {
+        const int64_t r = (int64_t)tile * 256 + i / cq;
+        if (r >= rows) break;
+        const int q = i % cq;
+        const int t = (int)(r % T);
+        const int64_t line = r / T;
+        const float* xp = xg + (line * ih * T + t) * c + 4 * q;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int ky = 0; ky < ih; ky++) {
+            const float4 v = *reinterpret_cast<const float4*>(xp + (int64_t)ky * T * c);
+            acc.x = acc.x + v.x; acc.y = acc.y + v.y; acc.z = acc.z + v.z; acc.w = acc.w + v.w;
+        }
+        acc.x = acc.x * inv; acc.y = acc.y * inv; acc.z = acc.z * inv; acc.w = acc.w * inv;
+        *reinterpret_cast<float4*>(y + ((int64_t)off[t] + posg[line]) * c + 4 * q) = acc;
+    }
+}
+
+void avgpool_to_seq_ragged(const float* x, const RaggedView& in, const RaggedView& seq, int c, const int32_t* d_pos,
+                           const int32_t* d_off, float* y, hipStream_t s) {
+    if (seq.ntiles256 <= 0) return;
+    hipLaunchKernelGGL(avgpool_to_seq_ragged_kernel, dim3(seq.ntiles256), dim3(256), 0, s, x, in, seq, c, d_pos, d_off, y);
+}
+
 void to_seq_packed_ragged(const float* x, const RaggedView& in, int c, const int32_t* d_pos, const int32_t* d_off,
                           float* y, hipStream_t s) {
     if (in.ntiles256 <= 0) return;

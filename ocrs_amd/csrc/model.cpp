@@ -874,6 +874,8 @@ float* HipModel::run_prefix_ragged(Workspace& ws, hipStream_t exec, const std::v
             if (!ok) fail(OCRS_ERR_RUN_FAILED, "model run failed: ragged conv %d->%d at height %d not supported", op.cin, op.cout, vin.H);
             curC = op.cout;
             if (fuse) i += 1;
+        } else if (op.type == OP_AVGPOOL && i + 1 == ts && op.kw == 1 && op.kh == vin.H && (curC & 3) == 0) {
+            break;   // the column average down to height 1 that ends the stack: done together with the sequence packing below
         } else {
             const k::RaggedView vout = view(i + 1);
             ybytes = (size_t)vout.pixels * curC * sizeof(float);
@@ -889,8 +891,16 @@ float* HipModel::run_prefix_ragged(Workspace& ws, hipStream_t exec, const std::v
     const k::RaggedView vf = view(ts);
     if (vf.H != 1) fail(OCRS_ERR_RUN_FAILED, "model run failed: TOSEQ expects height 1, got %d", vf.H);
     float* X = ws.alloc_n<float>((size_t)plan.R * curC);
-    timed(KC_OTHER, 0, 8.0 * vf.pixels * curC,
-          [&] { k::to_seq_packed_ragged(cur, vf, curC, groups[0].d_pos, plan.d_off, X, st); });
+    const bool pool_here = ts >= 1 && ops[ts - 1].type == OP_AVGPOOL && ops[ts - 1].kw == 1 && (curC & 3) == 0 &&
+                           ops[ts - 1].kh == view(ts - 1).H;
+    if (pool_here) {
+        const k::RaggedView vp = view(ts - 1);
+        timed(KC_POOL, 0, 4.0 * curC * (vp.pixels + vf.pixels),
+              [&] { k::avgpool_to_seq_ragged(cur, vp, vf, curC, groups[0].d_pos, plan.d_off, X, st); });
+    } else {
+        timed(KC_OTHER, 0, 8.0 * vf.pixels * curC,
+              [&] { k::to_seq_packed_ragged(cur, vf, curC, groups[0].d_pos, plan.d_off, X, st); });
+    }
     if (tok >= 0) timers->end(tok, st);
     if (exec != ws.s()) {  // the request's stream continues once the conv stack has drained
         hipEvent_t done = ws.make_event();
