@@ -15,9 +15,11 @@ N > 1, two shapes (pages are independent units: no collective on the compute pat
     exchange is the final result gather (RCCL all_gather through torch.distributed).  `--spawn-ranks` makes a plain
     launch re-execute itself that way.
   * ONE process driving N GPUs: a plain `python bench.py --gpus N` runs the engine group of the C ABI
-    (ocrs_engine_group_*): page i -> member i mod N, every member on its own host threads / streams, the packed
-    results gathered device to device with librccl's ncclAllGather (`--gather host` = through each member's own pinned
-    staging instead).  `--devices 0,0` puts several members on one GPU (a one-GPU box; the gather then uses the host).
+    (ocrs_engine_group_*): a page is processed on the device it is resident on (blocks of --pages pages per member),
+    every member on its own host threads / streams, per-request results over each member's own PCIe link, and ONE final
+    result gather of the decoded text through librccl's ncclAllGather over xGMI (`--gather host` = the host transport
+    for that too, `--gather rccl` = RCCL for every per-request gather as well).  `--devices 0,0` puts several members
+    on one GPU (a one-GPU box; RCCL refuses such a communicator, the final gather then reports the host and why).
 
 `--stream-pages P` is BASELINE.json configs[4]: P distinct pages (seeds 0..P-1), page i -> rank i mod N,
 processed in requests of `--pages` pages, every page resident in HBM before the timed region.
@@ -228,7 +230,8 @@ def main():
     group = None
     if group_mode:
         devices = [int(x) for x in args.devices.split(",")] if args.devices else list(range(args.gpus))
-        group = EngineGroup(devices, models.synthetic_detection_bytes(), models.synthetic_recognition_bytes(), gather=args.gather)
+        group = EngineGroup(devices, models.synthetic_detection_bytes(), models.synthetic_recognition_bytes(),
+                            gather="rccl" if args.gather == "rccl" else "host")
         engine = group.member(0)[0]     # stage / kernel timers: member 0's
         G = len(devices)
     else:
@@ -238,7 +241,8 @@ def main():
         engine = OcrEngine(detection_model=det, recognition_model=rec)
         G = 1
 
-    # ---- synthetic pages, resident in HBM before the timed region (in group mode: page i on member i mod G's device)
+    # ---- synthetic pages, resident in HBM before the timed region (in group mode: a step's pages in contiguous blocks of
+    # --pages, block j on member j's device; the group processes a page where it lives)
     B, H, W = args.pages, 1024, 1024
     if args.stream_pages:
         my_ids = D.shard_pages(args.stream_pages, rank, world)            # page i -> rank i mod N
@@ -250,7 +254,7 @@ def main():
     for i, pg in enumerate(host_pages):
         p = C.c_void_p()
         if group_mode:
-            _lib.check(L.ocrs_device_malloc_on(C.c_int(devices[i % G]), C.c_size_t(pg.nbytes), C.byref(p)))
+            _lib.check(L.ocrs_device_malloc_on(C.c_int(devices[(i // B) % G]), C.c_size_t(pg.nbytes), C.byref(p)))
         else:
             _lib.check(L.ocrs_device_malloc(C.c_size_t(pg.nbytes), C.byref(p)))
         _lib.check(L.ocrs_device_upload(p, pg.ctypes.data_as(C.c_void_p), C.c_size_t(pg.nbytes)))
@@ -371,6 +375,16 @@ def main():
                 page_lines.append("".join(map(chr, codes[a:b])) if b > a else None)
             local_payload[str(my_ids[si * BG + i] if args.stream_pages else my_ids[i])] = page_lines
     gathered = D.gather_results(local_payload)
+    final_gather = None
+    if group_mode:
+        # ONE process: the FINAL result gather of the stream through the group (RCCL over xGMI when the members are two or
+        # more distinct devices; the per-request gathers above went over each member's own PCIe link)
+        ids = sorted(local_payload, key=int)
+        per_member = [json.dumps({k: local_payload[k] for k in ids if (ids.index(k) // B) % G == m}).encode() for m in range(G)]
+        tg = time.perf_counter()
+        data, offs = group.final_gather(per_member, args.gather)
+        final_gather = dict(group.last_gather(), ms=round(1e3 * (time.perf_counter() - tg), 3),
+                            equals_host_concatenation=(data == b"".join(per_member)))
     elapsed, (n_pages_all, n_lines_all, n_words_all, n_chars_all) = reduce_over_ranks(
         elapsed, (n_pages, n_lines, n_words, n_chars), world, red_dev)
 
@@ -407,8 +421,9 @@ def main():
             "lines_per_page": round(n_lines / max(n_pages, 1), 1),
             "words_per_page": round(n_words / max(n_pages, 1), 1),
             "weights": "seeded synthetic weights on the SURVEY.md §2.4 architectures (real ocrs weights unobtainable offline)",
-            "parallelism": ("page-sharded, ONE process x %d GPUs (engine group of the C ABI, devices %s): page i -> member i mod %d, "
-                            "no data-path collective; result gather: %s" % (G, devices, G, json.dumps(group.last_gather())))
+            "parallelism": ("page-sharded, ONE process x %d GPUs (engine group of the C ABI, devices %s): every page processed where it "
+                            "is resident (blocks of %d pages per member per step), no data-path collective, per-request results over "
+                            "each member's own PCIe link; final result gather: %s" % (G, devices, B, json.dumps(final_gather)))
                            if group_mode else
                            "page-sharded, %d process(es) x 1 GPU, no data-path collective; result gather over %s" % (world, backend),
             "gru": "persistent kernel per layer" if os.environ.get("OCRS_GRU_MODE", "0") == "0" else "one launch per time step",

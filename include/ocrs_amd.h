@@ -119,6 +119,9 @@ OCRS_API ocrs_status ocrs_coalescer_selftest(int n_threads, int requests_per_thr
  *                     its operand there; 0 = two kernels with the 32-channel tensor in HBM between them.  Same bits.
  *   "conv_flat"       recognition 3x3 convs: the 128-pixel patches tile a width group's strip of images side by side
  *                     (1, default: only a group's last patch is ragged) or every image on its own (0); same bits
+ *   "group_min_block" engine group: pages the group places itself go to a device in contiguous blocks of at least this
+ *                     many pages (default 8; a small call then uses fewer devices, successive calls rotate)
+ *   "group_shared_block"  the same between members that share one device (default 16)
  *   "gru_background"  1 = requests too large for one row tile per cluster run the recurrence on the lean multi-tile
  *                     gate-per-wave kernel (a third of the general kernel's registers: conv stacks of other requests keep
  *                     three blocks per CU beside it; slower on its own), default 0
@@ -315,17 +318,31 @@ OCRS_API ocrs_status ocrs_engine_get_text(const ocrs_engine* e, const ocrs_page*
 
 /* ------------------------------------------------------------------------
  * Several GPUs in one process: an engine group.  One engine (and one replica of the weights) per member device;
- * page i of a call is dealt to member i mod G, every member runs its share on its own host
- * thread and streams, results come back in page order.  Pages are independent (OcrEngine is immutable `&self`,
- * ocrs/src/lib.rs:183-256), so there is no collective on the compute path; the only exchange is the gather of the
- * packed results, by one of two transports that deliver the same bytes:
- *   OCRS_GATHER_HOST  every member hands its results over through its own pinned staging / PCIe link
- *   OCRS_GATHER_RCCL  the packed results ({rect f32 x 6} per word, {char, box} per character) are all-gathered
- *                     device to device over xGMI (ncclCommInitAll communicator, one grouped ncclAllGather) and read
- *                     back from the root member
- *   OCRS_GATHER_AUTO  RCCL when the group has more than one member and all devices are distinct, else host.
- * RCCL does not accept the same device twice in one communicator: such a group (useful on a one-GPU box) always uses
- * the host transport; ocrs_group_last_gather reports what a call used and why.
+ * every page of a call is processed by a member of the device the page lives on, every member runs its share on a
+ * worker thread and streams of its own, results come back in page order.  Pages are independent (OcrEngine is
+ * immutable `&self`, ocrs/src/lib.rs:183-256), so there is no collective on the compute path; the only exchange is
+ * the gather of the packed results, by one of two transports that deliver the same bytes:
+ *   OCRS_GATHER_HOST  every member hands its results over through its own pinned staging / PCIe link and the calling
+ *                     thread concatenates them
+ *   OCRS_GATHER_RCCL  the packed results ({rect f32 x 6} per word, {char, box} per character), prefixed by their
+ *                     length, are all-gathered device to device over xGMI (ncclCommInitAll communicator, one grouped
+ *                     ncclAllGather) and read back from the root member
+ *   OCRS_GATHER_AUTO  for ocrs_group_params.gather (the per-request gathers inside ocrs_group_detect_words_batch /
+ *                     ocrs_group_recognize_text_batch): host — inside one process the results are on the host
+ *                     already.  For ocrs_group_final_gather (the end-of-stream gather; north_star: "RCCL over xGMI
+ *                     only for the final result gather"): RCCL when the group has two or more members and a
+ *                     communicator can be had, else host.
+ * librccl is loaded at run time (dlopen: `librccl.so.1`, or what OCRS_RCCL_LIB names) by the first gather that asks for
+ * it; libocrs_amd.so itself does not depend on it.  RCCL not loadable, a communicator refused (RCCL does not accept the
+ * same device twice: a group such as [0, 0] on a one-GPU box) — every such case falls back to the host transport and
+ * ocrs_group_last_gather reports it; none is an error.
+ *
+ * Dealing.  Pages the caller made resident (ocrs_group_prepare_input_device_batch; ocrs_page handles) stay where they
+ * are.  Pages the group places itself (ocrs_group_prepare_input_batch) go to the devices in contiguous blocks of
+ * ceil(n / devices) pages, but at least `group_min_block` (option, default 8): a call of 16 pages on 8 devices uses
+ * two of them, and successive calls start at successive devices — a device handed two pages runs its batch kernels
+ * at a fraction of their efficiency.  Members that share a device split its pages the same way in blocks of at
+ * least `group_shared_block` (16).  ocrs_group_deal is the block rule on its own, starting at member 0.
  * ---------------------------------------------------------------------- */
 typedef struct ocrs_engine_group ocrs_engine_group;
 typedef enum ocrs_gather_mode { OCRS_GATHER_AUTO = 0, OCRS_GATHER_HOST = 1, OCRS_GATHER_RCCL = 2 } ocrs_gather_mode;
@@ -350,20 +367,21 @@ OCRS_API void ocrs_engine_group_free(ocrs_engine_group* g);
 OCRS_API ocrs_status ocrs_engine_group_size(const ocrs_engine_group* g, size_t* n_members);
 /* Member i's engine (borrowed; usable with every ocrs_engine_* call) and device. */
 OCRS_API ocrs_status ocrs_engine_group_member(const ocrs_engine_group* g, size_t i, const ocrs_engine** engine, int* device);
-/* The dealing rule on its own (host only): member_of_page[i] = i mod n_members; pages_per_member may be NULL. */
+/* The dealing rule on its own (host only): block = max(ceil(n_pages / n_members), min(group_min_block, n_pages)),
+ * member_of_page[i] = (i / block) mod n_members; pages_per_member may be NULL. */
 OCRS_API ocrs_status ocrs_group_deal(size_t n_pages, size_t n_members, size_t* member_of_page, size_t* pages_per_member);
 
-/* OcrEngine::prepare_input (lib.rs:183-187) for n equally sized host images: image i is uploaded to and converted on
- * member i mod G.  out[n] receives the pages (each lives on its member's device). */
+/* OcrEngine::prepare_input (lib.rs:183-187) for n equally sized host images, dealt as described above.  out[n]
+ * receives the pages (each lives on its member's device). */
 OCRS_API ocrs_status ocrs_group_prepare_input_batch(const ocrs_engine_group* g, const void* const* pixels, size_t n,
                                                     ocrs_pixel_type type, ocrs_dim_order order, int height, int width,
                                                     int channels, ocrs_page** out);
-/* The same with image i already resident on member i mod G's device (ocrs_device_malloc_on). */
+/* The same with the images already resident on member devices (ocrs_device_malloc_on): each is converted where it is. */
 OCRS_API ocrs_status ocrs_group_prepare_input_device_batch(const ocrs_engine_group* g, const void* const* d_pixels, size_t n,
                                                            ocrs_pixel_type type, ocrs_dim_order order, int height, int width,
                                                            int channels, ocrs_page** out);
-/* OcrEngine::detect_words (lib.rs:193-199) over pages dealt as above (page i must live on member i mod G's device);
- * output as ocrs_engine_detect_words_batch. */
+/* OcrEngine::detect_words (lib.rs:193-199); every page is processed on the device it lives on (which must have a
+ * member); output as ocrs_engine_detect_words_batch. */
 OCRS_API ocrs_status ocrs_group_detect_words_batch(ocrs_engine_group* g, const ocrs_page* const* pages, size_t n_pages,
                                                    float** rects, size_t* offsets);
 /* OcrEngine::recognize_text (lib.rs:237-256); arguments and output as ocrs_engine_recognize_text_batch.
@@ -372,12 +390,19 @@ OCRS_API ocrs_status ocrs_group_recognize_text_batch(ocrs_engine_group* g, const
                                                      const size_t* page_line_offsets, const float* line_rects,
                                                      const size_t* line_offsets, size_t n_lines, ocrs_text_char** chars,
                                                      size_t** char_offsets);
-/* The gather on its own: payloads[m] / bytes[m] = member m's packed bytes (host memory); *out receives their
- * concatenation in member order through the group's transport, offsets[G + 1] the boundaries. */
+/* The per-request gather on its own: payloads[m] / bytes[m] = member m's packed bytes (host memory); *out receives
+ * their concatenation in member order through the group's per-request transport, offsets[G + 1] the boundaries. */
 OCRS_API ocrs_status ocrs_group_gather(ocrs_engine_group* g, const void* const* payloads, const size_t* bytes, void** out,
                                        size_t* offsets);
-/* Transport of the group's most recent gather: 1 host, 2 RCCL (0: none yet), the payload bytes it moved, and — when the
- * group resolved to the host transport — why (static string, "" otherwise).  Any argument may be NULL. */
+/* The final result gather of a stream of requests: the same contract with the transport named per call (AUTO = RCCL
+ * when the group has two or more members and RCCL can be had, else host — never an error for lack of RCCL). */
+OCRS_API ocrs_status ocrs_group_final_gather(ocrs_engine_group* g, ocrs_gather_mode mode, const void* const* payloads,
+                                             const size_t* bytes, void** out, size_t* offsets);
+/* Worker threads the group has created so far (they are kept between calls). */
+OCRS_API ocrs_status ocrs_group_worker_threads(const ocrs_engine_group* g, size_t* n);
+/* Transport of the group's most recent gather: 1 host, 2 RCCL (0: none yet), the payload bytes it moved, and — when it
+ * used the host transport — why (valid until the next call of this function on the group; "" otherwise).  Any
+ * argument may be NULL. */
 OCRS_API ocrs_status ocrs_group_last_gather(const ocrs_engine_group* g, int* transport, size_t* bytes, const char** why_host);
 
 /* ------------------------------------------------------------------------

@@ -589,8 +589,9 @@ def _chars_from_c(chars, coffs, nl):
 
 
 class EngineGroup:
-    """Several GPUs behind one handle in one process (include/ocrs_amd.h "engine group"): page i of a call goes to
-    member i mod G.  `devices` may repeat a device (members then share it; the gather uses the host transport)."""
+    """Several GPUs behind one handle in one process (include/ocrs_amd.h "engine group"): a page is processed by a
+    member of the device it lives on; pages the group places itself go out in contiguous blocks.  `devices` may repeat
+    a device (members then share it; RCCL refuses such a communicator and the gathers use the host transport)."""
 
     GATHER = {"auto": 0, "host": 1, "rccl": 2}
 
@@ -697,6 +698,25 @@ class EngineGroup:
         data = C.string_at(out, offs[g])
         lib().ocrs_buffer_free(out)
         return data, [int(offs[i]) for i in range(g + 1)]
+
+    def final_gather(self, payloads, mode="auto"):
+        """The end-of-stream result gather: like gather(), the transport named per call (auto = RCCL when it can be had)."""
+        g = len(self)
+        assert len(payloads) == g
+        bufs = [C.create_string_buffer(bytes(p), max(len(p), 1)) for p in payloads]
+        ptrs = (C.c_void_p * g)(*[C.addressof(b) for b in bufs])
+        sizes = (C.c_size_t * g)(*[len(p) for p in payloads])
+        out = C.c_void_p()
+        offs = (C.c_size_t * (g + 1))()
+        check(lib().ocrs_group_final_gather(self._h, C.c_int(self.GATHER[mode]), ptrs, sizes, C.byref(out), offs))
+        data = C.string_at(out, offs[g])
+        lib().ocrs_buffer_free(out)
+        return data, [int(offs[i]) for i in range(g + 1)]
+
+    def worker_threads(self):
+        n = C.c_size_t(0)
+        check(lib().ocrs_group_worker_threads(self._h, C.byref(n)))
+        return n.value
 
     def __del__(self):
         try:

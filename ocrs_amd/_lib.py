@@ -65,7 +65,7 @@ DECLARED_SYMBOLS = [
     "ocrs_get_device", "ocrs_model_load_file_on_device", "ocrs_model_load_bytes_on_device", "ocrs_model_device", "ocrs_engine_device",
     "ocrs_engine_group_new", "ocrs_engine_group_free", "ocrs_engine_group_size", "ocrs_engine_group_member", "ocrs_group_deal",
     "ocrs_group_prepare_input_batch", "ocrs_group_prepare_input_device_batch", "ocrs_group_detect_words_batch",
-    "ocrs_group_recognize_text_batch", "ocrs_group_gather", "ocrs_group_last_gather", "ocrs_device_malloc_on", "ocrs_engine_coalesce_stats", "ocrs_coalescer_selftest", "ocrs_engine_kernel_mfma_flops",
+    "ocrs_group_recognize_text_batch", "ocrs_group_gather", "ocrs_group_final_gather", "ocrs_group_worker_threads", "ocrs_group_last_gather", "ocrs_device_malloc_on", "ocrs_engine_coalesce_stats", "ocrs_coalescer_selftest", "ocrs_engine_kernel_mfma_flops",
 ]
 
 _lib = None

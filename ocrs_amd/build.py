@@ -64,9 +64,9 @@ def build(force=False, verbose=False):
         with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
             list(ex.map(run, jobs))
     if jobs or force or not os.path.exists(LIB):
-        # librccl is linked directly: the engine group's result gather calls ncclCommInitAll / ncclAllGather itself
-        run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs +
-            ["-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-lrccl", "-lpthread"])
+        # librccl is NOT linked: the engine group's final result gather binds it at run time (group.cpp, dlopen), so
+        # the library loads on hosts without RCCL and never mixes two RCCL builds in a process that imported torch
+        run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl", "-lpthread"])
     return LIB
 
 

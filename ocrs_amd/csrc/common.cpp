@@ -51,6 +51,12 @@ DeviceContext& ctx() {
 
 DeviceScope::DeviceScope(int device) : prev_(t_ctx) {
     DeviceContext& c = device_context(device < 0 ? default_device() : device);
+    // The binding lasts for the call only: the outermost scope remembers the device the caller's thread was on (torch
+    // or the caller's own HIP code may have selected another GPU) and puts it back on the way out.
+    if (!prev_ && hipGetDevice(&restore_) != hipSuccess) {
+        (void)hipGetLastError();
+        restore_ = -1;
+    }
     // always: other code on this thread (torch, the caller) may have switched the thread's device between our calls
     const hipError_t e = hipSetDevice(c.device);
     if (e != hipSuccess) {
@@ -61,8 +67,10 @@ DeviceScope::DeviceScope(int device) : prev_(t_ctx) {
 }
 
 DeviceScope::~DeviceScope() {
+    const int here = t_ctx ? t_ctx->device : -1;
     t_ctx = prev_;
-    if (prev_) (void)hipSetDevice(prev_->device);
+    const int back = prev_ ? prev_->device : restore_;
+    if (back >= 0 && back != here && hipSetDevice(back) != hipSuccess) (void)hipGetLastError();
 }
 
 const char* const kStageNames[ST_COUNT] = {
@@ -253,6 +261,8 @@ const OptDef kOptDefs[OPT_COUNT] = {
     {"det_heavy", "OCRS_DET_HEAVY", 1},                 // detection kernels on the shared conv-stack stream: 1 = requests of fewer than 8 pages, 2 = all
     {"conv_flat", "OCRS_CONV_FLAT", 1},                 // recognition 3x3 convs: patches tile a width group's whole strip of images (0: every image on its own)
     {"conv12_fuse", "OCRS_CONV12_FUSE", 1},             // first two recognition convs (+ their pools) in one kernel: conv1 into LDS, conv2's MFMA operand from there
+    {"group_min_block", "OCRS_GROUP_MIN_BLOCK", 8},     // engine group: pages the group places itself go to a device in contiguous blocks of at least this many
+    {"group_shared_block", "OCRS_GROUP_SHARED_BLOCK", 16},  // engine group: the same between members that share one device
 };
 std::atomic<long> g_opts[OPT_COUNT];
 std::once_flag g_opts_once;
@@ -313,11 +323,12 @@ std::vector<StageTimers::Pending>& StageTimers::pending() {
     static thread_local std::vector<Pending> p;
     return p;
 }
-std::vector<hipEvent_t>& StageTimers::free_events() {
+std::map<int, std::vector<hipEvent_t>>& StageTimers::thread_events() {
     // events belong to the device they were created on: one free list per (host thread, device)
     static thread_local std::map<int, std::vector<hipEvent_t>> f;
-    return f[ctx().device];
+    return f;
 }
+std::vector<hipEvent_t>& StageTimers::free_events() { return thread_events()[ctx().device]; }
 
 hipEvent_t StageTimers::get_event() {
     auto& fe = free_events();
@@ -372,6 +383,15 @@ void StageTimers::collect() {
     std::lock_guard<std::mutex> g(mu);
     for (int i = 0; i < ST_COUNT; i++) { ms[i] += lms[i]; launches[i] += ln[i]; }
     for (int i = 0; i < KC_COUNT; i++) { kms[i] += lkms[i]; klaunches[i] += lkn[i]; kflops[i] += lkf[i]; kbytes[i] += lkb[i]; kmfma[i] += lkm[i]; }
+}
+
+void StageTimers::release_thread_events() {
+    for (auto& p : pending()) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    pending().clear();
+    for (auto& kv : thread_events()) {
+        for (hipEvent_t e : kv.second) (void)hipEventDestroy(e);
+        kv.second.clear();
+    }
 }
 
 void StageTimers::reset() {

@@ -2,21 +2,33 @@
 //
 // The reference engine is immutable `&self` (ocrs/src/lib.rs:183-256) and pages are independent units
 // (SURVEY.md §8e): an engine group holds one engine per member device (own weight replica, own stream / memory
-// pools — DeviceContext), deals page i to member i mod G, runs the members' shares of a call on their own host
-// threads and merges the results in page order.  There is no collective on the compute path.
+// pools — DeviceContext), routes every page of a call to a member of the device the page lives on, runs the members'
+// shares on the group's worker threads and merges the results in page order.  There is no collective on the compute
+// path.
 //
-// Result gather.  Two transports, selectable per group, delivering the same bytes:
-//   * host: every member hands its packed results over through its own pinned staging (its own PCIe link) and the
-//     calling thread concatenates them.  The fast path inside one process, and the default.
-//   * RCCL: the packed results of every member — {rect f32 x 6} per word, {char u32, box i32 x 4} per character —
-//     go into a device buffer on that member, one grouped ncclAllGather (ncclCommInitAll communicator, one rank per
-//     member, librccl linked directly) moves them over xGMI, and the root member's copy is read back in one D2H.
-//     This is the "RCCL only for the final result gather" leg north_star names.  RCCL refuses a communicator with
-//     the same device twice, so a group with repeated devices (tests on a one-GPU box) falls back to host and says so
-//     (ocrs_group_last_gather).
-#include <rccl/rccl.h>
+// Dealing.  A page is processed where it is resident.  Where the group places pages itself (host pixels), and
+// among members that share a device, pages go out in CONTIGUOUS BLOCKS of at least `group_min_block` pages
+// (`group_shared_block` between members of one device): a member handed two pages of a sixteen-page call runs its
+// conv stacks and recurrences at a fraction of their batch efficiency, so a small call uses fewer members and
+// successive calls start at successive members (round 3 dealt page i to member i mod G: two members on one GPU,
+// 8 pages each, ran 12 % below one 16-page request).
+//
+// Result gather.  Inside one process every member's results reach the host through that member's own pinned staging
+// and PCIe link, and the calling thread concatenates them: that is the transport of every per-request gather unless
+// the group was created with OCRS_GATHER_RCCL.  RCCL is the transport of the FINAL result gather
+// (ocrs_group_final_gather; north_star: "RCCL over xGMI only for the final result gather"): the members' packed
+// bytes, prefixed by their length, go into a device buffer on each member, one grouped ncclAllGather
+// (ncclCommInitAll communicator, one rank per member) moves them over xGMI and the root member's copy is read back.
+// librccl is loaded lazily (dlopen) the first time a gather asks for it — a host-only group never touches it — and
+// every failure on that path (library absent, communicator refused) resolves to the host transport with the reason
+// kept for ocrs_group_last_gather; it is never fatal.
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // types and prototypes only: the library itself is bound at run time (RcclApi)
 
 #include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <functional>
 #include <system_error>
 #include <thread>
 
@@ -27,6 +39,132 @@ using namespace ocrs;
 using namespace ocrs::abi;
 using namespace ocrs::geom;
 
+namespace {
+
+// ------------------------------------------------------------------------------------------------ librccl, lazily
+struct RcclApi {
+    void* handle = nullptr;
+    std::string path, error;
+    bool accepts_duplicate_devices = false;   // only the test double (tests/stubs/rccl_stub.cpp) says so
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    bool ok() const { return handle != nullptr; }
+};
+
+// One binding per library path for the life of the process (OCRS_RCCL_LIB names another library — the tests'
+// double; read when a group first needs RCCL, so a process may use both).
+RcclApi& rccl_api() {
+    static std::mutex mu;
+    static std::map<std::string, std::unique_ptr<RcclApi>> apis;
+    const char* env = getenv("OCRS_RCCL_LIB");
+    const std::string want = env && *env ? env : "";
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = apis.find(want);
+    if (it != apis.end()) return *it->second;
+    auto api = std::make_unique<RcclApi>();
+    std::vector<std::string> candidates;
+    if (!want.empty()) candidates = {want};
+    else candidates = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    for (const auto& c : candidates) {
+        api->handle = dlopen(c.c_str(), RTLD_NOW | RTLD_LOCAL);
+        if (api->handle) { api->path = c; break; }
+        const char* e = dlerror();
+        api->error = std::string("cannot load ") + c + ": " + (e ? e : "?");
+    }
+    if (api->handle) {
+        auto sym = [&](const char* name) {
+            void* p = dlsym(api->handle, name);
+            if (!p && api->error.find("lacks") == std::string::npos) api->error = api->path + " lacks " + name;
+            return p;
+        };
+        api->error.clear();
+        api->CommInitAll = reinterpret_cast<decltype(api->CommInitAll)>(sym("ncclCommInitAll"));
+        api->CommDestroy = reinterpret_cast<decltype(api->CommDestroy)>(sym("ncclCommDestroy"));
+        api->GroupStart = reinterpret_cast<decltype(api->GroupStart)>(sym("ncclGroupStart"));
+        api->GroupEnd = reinterpret_cast<decltype(api->GroupEnd)>(sym("ncclGroupEnd"));
+        api->AllGather = reinterpret_cast<decltype(api->AllGather)>(sym("ncclAllGather"));
+        api->GetErrorString = reinterpret_cast<decltype(api->GetErrorString)>(sym("ncclGetErrorString"));
+        if (!api->error.empty()) {   // not an RCCL: unusable (kept loaded; the entry is per path and immutable)
+            api->handle = nullptr;
+        } else {
+            api->accepts_duplicate_devices = dlsym(api->handle, "ocrs_rccl_stub_accepts_duplicate_devices") != nullptr;
+        }
+    }
+    RcclApi& ref = *api;
+    apis.emplace(want, std::move(api));
+    return ref;
+}
+
+// ------------------------------------------------------------------------------------------------ worker threads
+// The members' shares of a call run on host threads bound to the members' devices.  Threads are kept (a thread
+// per call and member cost a creation on the request path, and the per-thread free lists of timing events died with
+// it); the pool grows with the number of shares in flight and never shrinks below what it reached.
+class WorkerPool {
+  public:
+    ~WorkerPool() {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto& t : threads_) t.join();
+    }
+    // false: no thread could be had — the caller runs the task itself
+    bool submit(std::function<void()> fn) {
+        std::unique_lock<std::mutex> lk(mu_);
+        if (idle_ <= queue_.size()) {   // every idle worker already has a task coming
+            if (threads_.size() >= kMaxThreads) {
+                if (threads_.empty()) return false;
+            } else {
+                try {
+                    threads_.emplace_back([this] { run(); });
+                } catch (const std::system_error&) {
+                    if (threads_.empty()) return false;
+                }
+            }
+        }
+        queue_.push_back(std::move(fn));
+        lk.unlock();
+        cv_.notify_one();
+        return true;
+    }
+    size_t threads() {
+        std::lock_guard<std::mutex> lk(mu_);
+        return threads_.size();
+    }
+
+  private:
+    static constexpr size_t kMaxThreads = 512;
+    void run() {
+        std::unique_lock<std::mutex> lk(mu_);
+        for (;;) {
+            idle_++;
+            cv_.wait(lk, [&] { return stop_ || !queue_.empty(); });
+            idle_--;
+            if (queue_.empty()) break;   // stop_
+            std::function<void()> fn = std::move(queue_.front());
+            queue_.pop_front();
+            lk.unlock();
+            fn();
+            lk.lock();
+        }
+        lk.unlock();
+        StageTimers::release_thread_events();
+    }
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::deque<std::function<void()>> queue_;
+    std::vector<std::thread> threads_;
+    size_t idle_ = 0;
+    bool stop_ = false;
+};
+
+}  // namespace
+
 struct ocrs_engine_group {
     struct Member {
         int device = 0;
@@ -34,34 +172,110 @@ struct ocrs_engine_group {
         std::unique_ptr<ocrs_engine> engine;
     };
     std::vector<Member> members;
-    ocrs_gather_mode gather = OCRS_GATHER_AUTO;
-    bool rccl_ready = false;           // communicators exist (distinct devices, mode != HOST)
+    std::vector<int> devices;                          // distinct devices, in order of first appearance
+    std::vector<std::vector<size_t>> members_of;       // members_of[k]: members on devices[k], ascending
+    ocrs_gather_mode gather = OCRS_GATHER_AUTO;        // transport of the per-request gathers (AUTO = host)
+    bool distinct = true;
+
+    // RCCL state, created by the first gather that asks for it
+    std::mutex init_mu;
+    bool rccl_tried = false, rccl_ready = false;
+    RcclApi* api = nullptr;
     std::vector<ncclComm_t> comms;
-    std::mutex comm_mu;                // collectives on one communicator are issued by one thread at a time
-    std::atomic<int> last_mode{0};     // transport of the most recent gather: 1 host, 2 RCCL
-    std::atomic<size_t> last_bytes{0};
-    std::string why_host;              // why AUTO / RCCL resolved to host ("" if RCCL)
+    std::mutex issue_mu;   // collectives on one communicator are ENQUEUED by one thread at a time (not awaited under it)
+
+    std::mutex info_mu;    // last_* and why_host
+    int last_mode = 0;     // transport of the most recent gather: 1 host, 2 RCCL
+    size_t last_bytes = 0;
+    std::string why_host;  // why the most recent gather that wanted RCCL (or AUTO) used the host ("" if it did not)
+    std::string why_host_out;   // stable copy handed out by ocrs_group_last_gather
+
+    std::atomic<size_t> next_start{0};   // rotation of the block deal
+    WorkerPool workers;
 
     ~ocrs_engine_group() {
-        for (size_t i = 0; i < comms.size(); i++)
-            if (comms[i]) (void)ncclCommDestroy(comms[i]);
+        if (api && api->ok())
+            for (size_t i = 0; i < comms.size(); i++)
+                if (comms[i]) (void)api->CommDestroy(comms[i]);
     }
     size_t size() const { return members.size(); }
 };
 
 namespace {
 
-#define OCRS_NCCL(expr)                                                                                     \
-    do {                                                                                                    \
-        ncclResult_t _r = (expr);                                                                           \
-        if (_r != ncclSuccess)                                                                              \
-            ::ocrs::fail(OCRS_ERR_DEVICE, "RCCL error %s at %s:%d (%s)", ncclGetErrorString(_r), __FILE__, __LINE__, #expr); \
-    } while (0)
+// ------------------------------------------------------------------------------------------------ dealing
+size_t block_size(size_t n_items, size_t n_takers, size_t min_block) {
+    if (n_items == 0 || n_takers == 0) return 1;
+    const size_t even = (n_items + n_takers - 1) / n_takers;
+    return std::max(even, std::min(std::max<size_t>(min_block, 1), n_items));
+}
 
-// Runs fn(m) for every member with work on its own host thread (member 0's share on the calling thread), each bound
-// to its member's device; the first failure (lowest member) is rethrown after all have finished.
+// items[0..n) (in order) -> takers, contiguous blocks, the first block to taker `start`
+void deal_blocks(const std::vector<size_t>& items, const std::vector<size_t>& takers, size_t min_block, size_t start,
+                 std::vector<std::vector<size_t>>* of_taker) {
+    if (items.empty()) return;
+    const size_t b = block_size(items.size(), takers.size(), min_block);
+    for (size_t j = 0; j < items.size(); j++) (*of_taker)[takers[(start + j / b) % takers.size()]].push_back(items[j]);
+}
+
+// Pages that live on devices (device_of_page[i], an index into g->devices): each device's pages to its members.
+std::vector<std::vector<size_t>> deal_resident(ocrs_engine_group* g, const std::vector<size_t>& device_of_page) {
+    std::vector<std::vector<size_t>> of_member(g->size());
+    std::vector<std::vector<size_t>> on_device(g->devices.size());
+    for (size_t i = 0; i < device_of_page.size(); i++) on_device[device_of_page[i]].push_back(i);
+    for (size_t k = 0; k < g->devices.size(); k++) {
+        const auto& mem = g->members_of[k];
+        if (on_device[k].empty()) continue;
+        if (mem.size() == 1) {
+            of_member[mem[0]] = on_device[k];
+        } else {
+            const size_t b = block_size(on_device[k].size(), mem.size(), (size_t)option(OPT_GROUP_SHARED_BLOCK));
+            const size_t used = (on_device[k].size() + b - 1) / b;
+            const size_t start = used < mem.size() ? g->next_start.fetch_add(used) : 0;
+            deal_blocks(on_device[k], mem, (size_t)option(OPT_GROUP_SHARED_BLOCK), start, &of_member);
+        }
+    }
+    return of_member;
+}
+
+// Pages the group places itself: contiguous blocks over the distinct devices, then as above.
+std::vector<std::vector<size_t>> deal_free(ocrs_engine_group* g, size_t n) {
+    const size_t D = g->devices.size();
+    std::vector<size_t> items(n), takers(D);
+    for (size_t i = 0; i < n; i++) items[i] = i;
+    for (size_t k = 0; k < D; k++) takers[k] = k;
+    const size_t b = block_size(n, D, (size_t)option(OPT_GROUP_MIN_BLOCK));
+    const size_t used = (n + b - 1) / b;
+    const size_t start = used < D ? g->next_start.fetch_add(used) : 0;
+    std::vector<std::vector<size_t>> on_device(D);
+    deal_blocks(items, takers, (size_t)option(OPT_GROUP_MIN_BLOCK), start, &on_device);
+    std::vector<size_t> device_of_page(n, 0);
+    for (size_t k = 0; k < D; k++)
+        for (size_t i : on_device[k]) device_of_page[i] = k;
+    return deal_resident(g, device_of_page);
+}
+
+size_t device_slot(const ocrs_engine_group* g, int device) {
+    for (size_t k = 0; k < g->devices.size(); k++)
+        if (g->devices[k] == device) return k;
+    return g->devices.size();
+}
+
+std::vector<std::vector<size_t>> deal_pages(ocrs_engine_group* g, const ocrs_page* const* pages, size_t n) {
+    std::vector<size_t> dev(n);
+    for (size_t i = 0; i < n; i++) {
+        if (!pages[i]) fail(OCRS_ERR_INVALID_ARGUMENT, "null page");
+        dev[i] = device_slot(g, pages[i]->device());
+        if (dev[i] == g->devices.size())
+            fail(OCRS_ERR_INVALID_ARGUMENT, "page %zu lives on device %d, which has no member in this group", i, pages[i]->device());
+    }
+    return deal_resident(g, dev);
+}
+
+// Runs fn(m) for every member with work, each on a worker thread bound to its member's device (the first share on
+// the calling thread); the first failure (lowest member) is rethrown after all have finished.
 template <class Fn>
-void for_each_member(const ocrs_engine_group* g, const std::vector<char>& has_work, Fn&& fn) {
+void for_each_member(ocrs_engine_group* g, const std::vector<std::vector<size_t>>& of_member, Fn&& fn) {
     const size_t G = g->size();
     std::vector<std::exception_ptr> errs(G);
     auto body = [&](size_t m) {
@@ -72,23 +286,42 @@ void for_each_member(const ocrs_engine_group* g, const std::vector<char>& has_wo
             errs[m] = std::current_exception();
         }
     };
-    std::vector<std::thread> th;
+    std::mutex mu;
+    std::condition_variable cv;
+    size_t outstanding = 0;
     size_t mine = G;
     for (size_t m = 0; m < G; m++) {
-        if (!has_work[m]) continue;
+        if (of_member[m].empty()) continue;
         if (mine == G) { mine = m; continue; }
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            outstanding++;
+        }
+        bool queued = false;
         try {
-            th.emplace_back(body, m);
-        } catch (const std::system_error&) {   // no thread to be had: this member's share runs here, after the others were started
+            queued = g->workers.submit([&, m] {
+                body(m);
+                std::lock_guard<std::mutex> lk(mu);   // notify under the lock: `cv` lives on the waiter's stack
+                if (--outstanding == 0) cv.notify_all();
+            });
+        } catch (...) {   // out of memory while queueing: as if no thread could be had
+        }
+        if (!queued) {   // no thread to be had: this member's share runs here, after the others were started
             body(m);
+            std::lock_guard<std::mutex> lk(mu);
+            outstanding--;
         }
     }
     if (mine < G) body(mine);
-    for (auto& t : th) t.join();
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return outstanding == 0; });
+    }
     for (size_t m = 0; m < G; m++)
         if (errs[m]) std::rethrow_exception(errs[m]);
 }
 
+// ------------------------------------------------------------------------------------------------ gather
 // payloads[m] (host bytes) -> one buffer in member order.  offsets: G + 1 entries.
 std::vector<uint8_t> gather_host(const std::vector<std::vector<uint8_t>>& payloads, std::vector<size_t>* offsets) {
     std::vector<uint8_t> out;
@@ -100,15 +333,56 @@ std::vector<uint8_t> gather_host(const std::vector<std::vector<uint8_t>>& payloa
     return out;
 }
 
-// The same through the devices: member m's payload, prefixed by its length, is uploaded to member m's device, one
-// grouped ncclAllGather leaves every member with all G slots, and the root's copy is downloaded.
+// Communicators on first use.  false: RCCL cannot serve this group; *why says so.
+bool ensure_comms(ocrs_engine_group* g, std::string* why) {
+    std::lock_guard<std::mutex> lk(g->init_mu);
+    if (g->rccl_tried) {
+        if (!g->rccl_ready && why) {
+            std::lock_guard<std::mutex> li(g->info_mu);
+            *why = g->why_host;
+        }
+        return g->rccl_ready;
+    }
+    g->rccl_tried = true;
+    std::string reason;
+    RcclApi& api = rccl_api();
+    g->api = &api;
+    if (!api.ok()) {
+        reason = "librccl unavailable (" + api.error + ")";
+    } else if (!g->distinct && !api.accepts_duplicate_devices) {
+        reason = "a device appears more than once in the group: RCCL refuses such a communicator";
+    } else {
+        std::vector<int> devs;
+        for (const auto& mem : g->members) devs.push_back(mem.device);
+        g->comms.assign(devs.size(), nullptr);
+        const ncclResult_t r = api.CommInitAll(g->comms.data(), (int)devs.size(), devs.data());
+        if (r != ncclSuccess) {
+            reason = std::string("ncclCommInitAll failed: ") + api.GetErrorString(r);
+            (void)hipGetLastError();
+            g->comms.clear();
+        } else {
+            g->rccl_ready = true;
+        }
+    }
+    if (!g->rccl_ready) {
+        std::lock_guard<std::mutex> li(g->info_mu);
+        g->why_host = reason;
+        if (why) *why = reason;
+    }
+    return g->rccl_ready;
+}
+
+// Through the devices: member m's payload, prefixed by its length, is uploaded to member m's device on a stream of
+// its own, one grouped ncclAllGather leaves every member with all G slots, and the root's copy is downloaded.
+// Several gathers may be in flight: only the ENQUEUE of a collective is serialised (one communicator, one issue
+// order); uploads, the transfers themselves and the read-back of different calls overlap.
 std::vector<uint8_t> gather_rccl(ocrs_engine_group* g, const std::vector<std::vector<uint8_t>>& payloads,
                                  std::vector<size_t>* offsets) {
     const size_t G = g->size();
+    RcclApi& api = *g->api;
     size_t cap = 0;
     for (const auto& p : payloads) cap = std::max(cap, p.size());
     const size_t slot = ((cap + sizeof(uint64_t) + 15) / 16) * 16;   // [u64 length | bytes | padding]
-    std::lock_guard<std::mutex> lk(g->comm_mu);
     std::vector<std::unique_ptr<Workspace>> ws(G);
     std::vector<uint8_t*> d_send(G), d_recv(G);
     std::vector<uint8_t> stage(slot);
@@ -132,15 +406,20 @@ std::vector<uint8_t> gather_rccl(ocrs_engine_group* g, const std::vector<std::ve
         if (len) memcpy(stage.data() + sizeof len, payloads[m].data(), len);
         ws[m]->upload(d_send[m], stage.data(), slot);
     }
-    OCRS_NCCL(ncclGroupStart());
-    for (size_t m = 0; m < G; m++) {
-        ncclResult_t r = ncclAllGather(d_send[m], d_recv[m], slot, ncclUint8, g->comms[m], ws[m]->s());
-        if (r != ncclSuccess) {
-            (void)ncclGroupEnd();
-            fail(OCRS_ERR_DEVICE, "RCCL error %s in ncclAllGather (member %zu)", ncclGetErrorString(r), m);
+    {
+        std::lock_guard<std::mutex> lk(g->issue_mu);
+        ncclResult_t r = api.GroupStart();
+        if (r != ncclSuccess) fail(OCRS_ERR_DEVICE, "RCCL error %s in ncclGroupStart", api.GetErrorString(r));
+        for (size_t m = 0; m < G; m++) {
+            r = api.AllGather(d_send[m], d_recv[m], slot, ncclUint8, g->comms[m], ws[m]->s());
+            if (r != ncclSuccess) {
+                (void)api.GroupEnd();
+                fail(OCRS_ERR_DEVICE, "RCCL error %s in ncclAllGather (member %zu)", api.GetErrorString(r), m);
+            }
         }
+        r = api.GroupEnd();
+        if (r != ncclSuccess) fail(OCRS_ERR_DEVICE, "RCCL error %s in ncclGroupEnd", api.GetErrorString(r));
     }
-    OCRS_NCCL(ncclGroupEnd());
     std::vector<uint8_t> all(slot * G);
     {
         DeviceScope bind(g->members[0].device);
@@ -165,16 +444,33 @@ std::vector<uint8_t> gather_rccl(ocrs_engine_group* g, const std::vector<std::ve
     return out;
 }
 
-std::vector<uint8_t> gather(ocrs_engine_group* g, const std::vector<std::vector<uint8_t>>& payloads, std::vector<size_t>* offsets) {
+// mode: the transport asked for.  HOST: host.  RCCL: RCCL if it can be had.  AUTO (only the final gather passes it
+// through; per-request gathers map AUTO to HOST before they get here): RCCL when there is something to move between
+// devices (two or more members) and it can be had.
+std::vector<uint8_t> gather(ocrs_engine_group* g, ocrs_gather_mode mode, const std::vector<std::vector<uint8_t>>& payloads,
+                            std::vector<size_t>* offsets) {
     size_t total = 0;
     for (const auto& p : payloads) total += p.size();
-    g->last_bytes.store(total);
-    if (g->rccl_ready) {
-        g->last_mode.store(2);
-        return gather_rccl(g, payloads, offsets);
+    std::string why;
+    bool use_rccl = false;
+    if (mode == OCRS_GATHER_HOST) {
+        why = "host transport requested";
+    } else if (mode == OCRS_GATHER_AUTO && g->size() == 1) {
+        why = "one member: nothing to gather";
+    } else {
+        use_rccl = ensure_comms(g, &why);
     }
-    g->last_mode.store(1);
-    return gather_host(payloads, offsets);
+    {
+        std::lock_guard<std::mutex> li(g->info_mu);
+        g->last_mode = use_rccl ? 2 : 1;
+        g->last_bytes = total;
+        g->why_host = use_rccl ? "" : why;
+    }
+    return use_rccl ? gather_rccl(g, payloads, offsets) : gather_host(payloads, offsets);
+}
+
+std::vector<uint8_t> gather_request(ocrs_engine_group* g, const std::vector<std::vector<uint8_t>>& payloads, std::vector<size_t>* offsets) {
+    return gather(g, g->gather == OCRS_GATHER_RCCL ? OCRS_GATHER_RCCL : OCRS_GATHER_HOST, payloads, offsets);
 }
 
 template <class T>
@@ -183,15 +479,38 @@ void append_bytes(std::vector<uint8_t>& v, const T* p, size_t n) {
     v.insert(v.end(), b, b + n * sizeof(T));
 }
 
-void check_group_pages(const ocrs_engine_group* g, const ocrs_page* const* pages, size_t n) {
-    const size_t G = g->size();
-    for (size_t i = 0; i < n; i++) {
-        if (!pages[i]) fail(OCRS_ERR_INVALID_ARGUMENT, "null page");
-        const int want = g->members[i % G].device;
-        if (pages[i]->device() != want)
-            fail(OCRS_ERR_INVALID_ARGUMENT, "page %zu lives on device %d; the group deals page i to member i mod %zu, here device %d", i,
-                 pages[i]->device(), G, want);
+// Bounds-checked reader of one member's slice of the gathered bytes.
+struct Cursor {
+    const uint8_t* base; size_t at, end, member;
+    uint64_t count() {
+        uint64_t c = 0;
+        need(sizeof c);
+        memcpy(&c, base + at, sizeof c);
+        at += sizeof c;
+        return c;
     }
+    const uint8_t* take(size_t bytes) {
+        need(bytes);
+        const uint8_t* p = base + at;
+        at += bytes;
+        return p;
+    }
+    void need(size_t bytes) const {
+        if (bytes > end - at) fail(OCRS_ERR_DEVICE, "result gather: member %zu's payload is shorter than its contents claim", member);
+    }
+};
+
+std::vector<Cursor> cursors(const std::vector<uint8_t>& all, const std::vector<size_t>& moffs) {
+    std::vector<Cursor> c;
+    for (size_t m = 0; m + 1 < moffs.size(); m++) c.push_back(Cursor{all.data(), moffs[m], moffs[m + 1], m});
+    return c;
+}
+
+std::vector<size_t> member_of_page(const std::vector<std::vector<size_t>>& of_member, size_t n) {
+    std::vector<size_t> mo(n, 0);
+    for (size_t m = 0; m < of_member.size(); m++)
+        for (size_t i : of_member[m]) mo[i] = m;
+    return mo;
 }
 
 }  // namespace
@@ -203,15 +522,22 @@ ocrs_status ocrs_engine_group_new(const ocrs_group_params* params, ocrs_engine_g
         if (!params || !out) fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
         if (!params->devices || params->n_devices == 0 || params->n_devices > 64)
             fail(OCRS_ERR_INVALID_ARGUMENT, "an engine group needs 1..64 member devices");
+        if (params->gather != OCRS_GATHER_AUTO && params->gather != OCRS_GATHER_HOST && params->gather != OCRS_GATHER_RCCL)
+            fail(OCRS_ERR_INVALID_ARGUMENT, "unknown gather mode %d", (int)params->gather);
         auto g = std::make_unique<ocrs_engine_group>();
         g->gather = params->gather;
         g->members.resize(params->n_devices);
-        bool distinct = true;
         for (size_t m = 0; m < params->n_devices; m++) {
             auto& mem = g->members[m];
             mem.device = params->devices[m];
-            for (size_t k = 0; k < m; k++)
-                if (g->members[k].device == mem.device) distinct = false;
+            size_t k = device_slot(g.get(), mem.device);
+            if (k == g->devices.size()) {
+                g->devices.push_back(mem.device);
+                g->members_of.emplace_back();
+            } else {
+                g->distinct = false;
+            }
+            g->members_of[k].push_back(m);
             // one weight replica per member (a few MB), on the member's device
             if (params->detection_model) {
                 mem.detection = std::make_unique<ocrs_model>();
@@ -231,19 +557,6 @@ ocrs_status ocrs_engine_group_new(const ocrs_group_params* params, ocrs_engine_g
             ep.allowed_chars = params->allowed_chars;
             mem.engine = make_engine(ep);
             mem.engine->device = mem.device;   // (an engine without weights has nothing else to pin it to its device)
-        }
-        if (params->gather == OCRS_GATHER_HOST) {
-            g->why_host = "host transport requested";
-        } else if (!distinct) {
-            g->why_host = "a device appears more than once in the group: RCCL refuses such a communicator";
-        } else if (params->gather == OCRS_GATHER_AUTO && params->n_devices == 1) {
-            g->why_host = "one member: nothing to gather";
-        } else {
-            std::vector<int> devs;
-            for (const auto& mem : g->members) devs.push_back(mem.device);
-            g->comms.assign(devs.size(), nullptr);
-            OCRS_NCCL(ncclCommInitAll(g->comms.data(), (int)devs.size(), devs.data()));
-            g->rccl_ready = true;
         }
         *out = g.release();
     });
@@ -266,40 +579,61 @@ ocrs_status ocrs_engine_group_member(const ocrs_engine_group* g, size_t i, const
     });
 }
 
-ocrs_status ocrs_group_deal(size_t n_pages, size_t n_members, size_t* member_of_page, size_t* pages_per_member) {
+ocrs_status ocrs_group_deal(size_t n_pages, size_t n_members, size_t* member_of_page_out, size_t* pages_per_member) {
     return guarded([&] {
-        if (n_members == 0 || (n_pages && !member_of_page)) fail(OCRS_ERR_INVALID_ARGUMENT, "bad argument");
+        if (n_members == 0 || (n_pages && !member_of_page_out)) fail(OCRS_ERR_INVALID_ARGUMENT, "bad argument");
         if (pages_per_member)
             for (size_t m = 0; m < n_members; m++) pages_per_member[m] = 0;
+        const size_t b = block_size(n_pages, n_members, (size_t)option(OPT_GROUP_MIN_BLOCK));
         for (size_t i = 0; i < n_pages; i++) {
-            member_of_page[i] = i % n_members;   // page i -> GPU i mod G
-            if (pages_per_member) pages_per_member[i % n_members]++;
+            const size_t m = (i / b) % n_members;
+            member_of_page_out[i] = m;
+            if (pages_per_member) pages_per_member[m]++;
         }
     });
 }
 
-ocrs_status ocrs_group_last_gather(const ocrs_engine_group* g, int* transport, size_t* bytes, const char** why_host) {
+ocrs_status ocrs_group_last_gather(const ocrs_engine_group* gc, int* transport, size_t* bytes, const char** why_host) {
     return guarded([&] {
-        if (!g) fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
-        if (transport) *transport = g->last_mode.load();
-        if (bytes) *bytes = g->last_bytes.load();
-        if (why_host) *why_host = g->why_host.c_str();
+        if (!gc) fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
+        ocrs_engine_group* g = const_cast<ocrs_engine_group*>(gc);
+        std::lock_guard<std::mutex> li(g->info_mu);
+        if (transport) *transport = g->last_mode;
+        if (bytes) *bytes = g->last_bytes;
+        if (why_host) {
+            g->why_host_out = g->why_host;
+            *why_host = g->why_host_out.c_str();
+        }
     });
 }
 
-static void group_prepare(const ocrs_engine_group* g, const void* const* pixels, size_t n, bool on_device, ocrs_pixel_type type,
+static void group_prepare(ocrs_engine_group* g, const void* const* pixels, size_t n, bool on_device, ocrs_pixel_type type,
                           ocrs_dim_order order, int height, int width, int channels, ocrs_page** out) {
     if (!g || !out || (n > 0 && !pixels)) fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
     for (size_t i = 0; i < n; i++) check_image_args(pixels[i], height, width, channels);
-    const size_t G = g->size();
-    std::vector<char> work(G, 0);
-    for (size_t i = 0; i < n && i < G; i++) work[i] = 1;
+    std::vector<std::vector<size_t>> of_member;
+    if (on_device) {   // a page is converted where its pixels are
+        std::vector<size_t> dev(n);
+        for (size_t i = 0; i < n; i++) {
+            hipPointerAttribute_t attr;
+            if (hipPointerGetAttributes(&attr, pixels[i]) != hipSuccess) {
+                (void)hipGetLastError();
+                fail(OCRS_ERR_INVALID_ARGUMENT, "image %zu: not a device pointer", i);
+            }
+            dev[i] = device_slot(g, attr.device);
+            if (dev[i] == g->devices.size())
+                fail(OCRS_ERR_INVALID_ARGUMENT, "image %zu lives on device %d, which has no member in this group", i, attr.device);
+        }
+        of_member = deal_resident(g, dev);
+    } else {
+        of_member = deal_free(g, n);
+    }
     const size_t bytes = (size_t)height * width * channels * (type == OCRS_U8 ? 1 : 4);
     std::vector<std::unique_ptr<ocrs_page>> made(n);   // freed if any member fails
-    for_each_member(g, work, [&](size_t m) {
+    for_each_member(g, of_member, [&](size_t m) {
         const ocrs_engine* e = g->members[m].engine.get();
         Workspace ws;
-        for (size_t i = m; i < n; i += G) {
+        for (size_t i : of_member[m]) {
             const void* d_px = pixels[i];
             if (!on_device) {
                 void* d = ws.alloc(bytes);
@@ -316,28 +650,26 @@ static void group_prepare(const ocrs_engine_group* g, const void* const* pixels,
 
 ocrs_status ocrs_group_prepare_input_batch(const ocrs_engine_group* g, const void* const* pixels, size_t n, ocrs_pixel_type type,
                                            ocrs_dim_order order, int height, int width, int channels, ocrs_page** out) {
-    return guarded([&] { group_prepare(g, pixels, n, false, type, order, height, width, channels, out); });
+    return guarded([&] { group_prepare(const_cast<ocrs_engine_group*>(g), pixels, n, false, type, order, height, width, channels, out); });
 }
 
 ocrs_status ocrs_group_prepare_input_device_batch(const ocrs_engine_group* g, const void* const* d_pixels, size_t n,
                                                   ocrs_pixel_type type, ocrs_dim_order order, int height, int width, int channels,
                                                   ocrs_page** out) {
-    return guarded([&] { group_prepare(g, d_pixels, n, true, type, order, height, width, channels, out); });
+    return guarded([&] { group_prepare(const_cast<ocrs_engine_group*>(g), d_pixels, n, true, type, order, height, width, channels, out); });
 }
 
 ocrs_status ocrs_group_detect_words_batch(ocrs_engine_group* g, const ocrs_page* const* pages, size_t n_pages, float** rects,
                                           size_t* offsets) {
     return guarded([&] {
         if (!g || !rects || !offsets || (n_pages && !pages)) fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
-        check_group_pages(g, pages, n_pages);
+        const auto of_member = deal_pages(g, pages, n_pages);
         const size_t G = g->size();
-        std::vector<char> work(G, 0);
-        for (size_t i = 0; i < n_pages && i < G; i++) work[i] = 1;
         // member m's payload: for each of its pages (in page order) [u64 word count | count x 6 f32]
         std::vector<std::vector<uint8_t>> payloads(G);
-        for_each_member(g, work, [&](size_t m) {
+        for_each_member(g, of_member, [&](size_t m) {
             std::vector<const ocrs_page*> mine;
-            for (size_t i = m; i < n_pages; i += G) mine.push_back(pages[i]);
+            for (size_t i : of_member[m]) mine.push_back(pages[i]);
             std::vector<std::vector<RotatedRect>> rr;
             g->members[m].engine->detect(mine.data(), mine.size(), &rr, nullptr);
             auto& pl = payloads[m];
@@ -352,19 +684,18 @@ ocrs_status ocrs_group_detect_words_batch(ocrs_engine_group* g, const ocrs_page*
             }
         });
         std::vector<size_t> moffs;
-        const std::vector<uint8_t> all = gather(g, payloads, &moffs);
-        // back to page order: page i is the (i / G)-th page of member i mod G
-        std::vector<size_t> cursor(moffs.begin(), moffs.end() - 1);
+        const std::vector<uint8_t> all = gather_request(g, payloads, &moffs);
+        // back to page order: a member's pages appear in its payload in ascending page order
+        std::vector<Cursor> cur = cursors(all, moffs);
+        const std::vector<size_t> mo = member_of_page(of_member, n_pages);
         std::vector<float> flat;
         offsets[0] = 0;
         for (size_t i = 0; i < n_pages; i++) {
-            size_t& at = cursor[i % G];
-            uint64_t cnt = 0;
-            memcpy(&cnt, all.data() + at, sizeof cnt);
-            at += sizeof cnt;
-            const float* src = reinterpret_cast<const float*>(all.data() + at);
+            Cursor& c = cur[mo[i]];
+            const uint64_t cnt = c.count();
+            if (cnt > (c.end - c.at) / (6 * sizeof(float))) c.need(SIZE_MAX);
+            const float* src = reinterpret_cast<const float*>(c.take(cnt * 6 * sizeof(float)));
             flat.insert(flat.end(), src, src + cnt * 6);
-            at += cnt * 6 * sizeof(float);
             offsets[i + 1] = flat.size() / 6;
         }
         *rects = dup_buffer(flat);
@@ -377,18 +708,22 @@ ocrs_status ocrs_group_recognize_text_batch(ocrs_engine_group* g, const ocrs_pag
     return guarded([&] {
         if (!g || !page_line_offsets || !line_offsets || !chars || !char_offsets || (n_pages && !pages))
             fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
-        if (page_line_offsets[n_pages] != n_lines) fail(OCRS_ERR_INVALID_ARGUMENT, "page_line_offsets do not cover n_lines");
-        check_group_pages(g, pages, n_pages);
+        if (page_line_offsets[0] != 0 || page_line_offsets[n_pages] != n_lines)
+            fail(OCRS_ERR_INVALID_ARGUMENT, "page_line_offsets do not cover n_lines");
+        for (size_t i = 0; i < n_pages; i++)
+            if (page_line_offsets[i] > page_line_offsets[i + 1]) fail(OCRS_ERR_INVALID_ARGUMENT, "page_line_offsets must not decrease");
+        for (size_t l = 0; l < n_lines; l++)
+            if (line_offsets[l] > line_offsets[l + 1]) fail(OCRS_ERR_INVALID_ARGUMENT, "line_offsets must not decrease");
+        if (n_lines && line_offsets[n_lines] > 0 && !line_rects) fail(OCRS_ERR_INVALID_ARGUMENT, "null line_rects");
+        const auto of_member = deal_pages(g, pages, n_pages);
         const size_t G = g->size();
-        std::vector<char> work(G, 0);
-        for (size_t i = 0; i < n_pages && i < G; i++) work[i] = 1;
         // member m's payload: for each of its lines (page order, then line order) [u64 char count | count x ocrs_text_char]
         std::vector<std::vector<uint8_t>> payloads(G);
-        for_each_member(g, work, [&](size_t m) {
+        for_each_member(g, of_member, [&](size_t m) {
             const ocrs_engine* e = g->members[m].engine.get();
             std::vector<const ocrs_page*> mine;
             std::vector<std::vector<std::vector<RotatedRect>>> lpp;
-            for (size_t i = m; i < n_pages; i += G) {
+            for (size_t i : of_member[m]) {
                 mine.push_back(pages[i]);
                 lpp.push_back(unpack_lines(line_rects, line_offsets, page_line_offsets[i], page_line_offsets[i + 1]));
             }
@@ -407,20 +742,20 @@ ocrs_status ocrs_group_recognize_text_batch(ocrs_engine_group* g, const ocrs_pag
             }
         });
         std::vector<size_t> moffs;
-        const std::vector<uint8_t> all = gather(g, payloads, &moffs);
-        std::vector<size_t> cursor(moffs.begin(), moffs.end() - 1);
+        const std::vector<uint8_t> all = gather_request(g, payloads, &moffs);
+        std::vector<Cursor> cur = cursors(all, moffs);
+        const std::vector<size_t> mo = member_of_page(of_member, n_pages);
         std::vector<ocrs_text_char> flat;
         std::vector<size_t> offs{0};
         for (size_t i = 0; i < n_pages; i++) {
-            size_t& at = cursor[i % G];
+            Cursor& c = cur[mo[i]];
             for (size_t l = page_line_offsets[i]; l < page_line_offsets[i + 1]; l++) {
-                uint64_t cnt = 0;
-                memcpy(&cnt, all.data() + at, sizeof cnt);
-                at += sizeof cnt;
+                const uint64_t cnt = c.count();
+                if (cnt > (c.end - c.at) / sizeof(ocrs_text_char)) c.need(SIZE_MAX);
+                const uint8_t* src = c.take(cnt * sizeof(ocrs_text_char));
                 const size_t old = flat.size();
                 flat.resize(old + cnt);
-                if (cnt) memcpy(flat.data() + old, all.data() + at, cnt * sizeof(ocrs_text_char));
-                at += cnt * sizeof(ocrs_text_char);
+                if (cnt) memcpy(flat.data() + old, src, cnt * sizeof(ocrs_text_char));
                 offs.push_back(flat.size());
             }
         }
@@ -429,20 +764,42 @@ ocrs_status ocrs_group_recognize_text_batch(ocrs_engine_group* g, const ocrs_pag
     });
 }
 
+static void gather_entry(ocrs_engine_group* g, ocrs_gather_mode mode, const void* const* payloads, const size_t* bytes, void** out,
+                         size_t* offsets) {
+    if (!g || !payloads || !bytes || !out || !offsets) fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
+    const size_t G = g->size();
+    std::vector<std::vector<uint8_t>> pl(G);
+    for (size_t m = 0; m < G; m++) {
+        if (bytes[m] && !payloads[m]) fail(OCRS_ERR_INVALID_ARGUMENT, "null payload");
+        const uint8_t* p = static_cast<const uint8_t*>(payloads[m]);
+        pl[m].assign(p, p + bytes[m]);
+    }
+    std::vector<size_t> offs;
+    const std::vector<uint8_t> all = gather(g, mode, pl, &offs);
+    for (size_t m = 0; m <= G; m++) offsets[m] = offs[m];
+    *out = dup_buffer(all);
+}
+
 ocrs_status ocrs_group_gather(ocrs_engine_group* g, const void* const* payloads, const size_t* bytes, void** out, size_t* offsets) {
     return guarded([&] {
-        if (!g || !payloads || !bytes || !out || !offsets) fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
-        const size_t G = g->size();
-        std::vector<std::vector<uint8_t>> pl(G);
-        for (size_t m = 0; m < G; m++) {
-            if (bytes[m] && !payloads[m]) fail(OCRS_ERR_INVALID_ARGUMENT, "null payload");
-            const uint8_t* p = static_cast<const uint8_t*>(payloads[m]);
-            pl[m].assign(p, p + bytes[m]);
-        }
-        std::vector<size_t> offs;
-        const std::vector<uint8_t> all = gather(g, pl, &offs);
-        for (size_t m = 0; m <= G; m++) offsets[m] = offs[m];
-        *out = dup_buffer(all);
+        if (!g) fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
+        gather_entry(g, g->gather == OCRS_GATHER_RCCL ? OCRS_GATHER_RCCL : OCRS_GATHER_HOST, payloads, bytes, out, offsets);
+    });
+}
+
+ocrs_status ocrs_group_final_gather(ocrs_engine_group* g, ocrs_gather_mode mode, const void* const* payloads, const size_t* bytes,
+                                    void** out, size_t* offsets) {
+    return guarded([&] {
+        if (mode != OCRS_GATHER_AUTO && mode != OCRS_GATHER_HOST && mode != OCRS_GATHER_RCCL)
+            fail(OCRS_ERR_INVALID_ARGUMENT, "unknown gather mode %d", (int)mode);
+        gather_entry(g, mode, payloads, bytes, out, offsets);
+    });
+}
+
+ocrs_status ocrs_group_worker_threads(const ocrs_engine_group* g, size_t* n) {
+    return guarded([&] {
+        if (!g || !n) fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
+        *n = const_cast<ocrs_engine_group*>(g)->workers.threads();
     });
 }
 

@@ -1,6 +1,6 @@
 """GPU tests of the round-3 work, all through the C ABI and all against the oracle / its golden fixtures:
 
-  * engine group (several members in one process, page i -> member i mod G) incl. the RCCL result gather;
+  * engine group (several members in one process, pages dealt in contiguous blocks) incl. the RCCL result gather;
   * request coalescing: concurrent one-page calls share launches, nobody's bits change;
   * configs[4] stream shape: 32 distinct pages in requests of 16, 6 in flight;
   * masks / lines beyond the old capacity limits (the reference has none: detection.rs:41-62, recognition.rs:29-55);
@@ -63,26 +63,32 @@ def _check_all_golden(out, digests, n=N_PAGES):
 
 # ------------------------------------------------------------------ engine group
 def test_group_of_two_members_on_one_device_gives_golden_bits(bufs, pages16):
-    """devices [0, 0]: two engines (two weight replicas, two host threads per call) on the one GPU of the box; page i
-    goes to member i mod 2.  RCCL refuses such a communicator, so the gather reports the host transport and why."""
+    """devices [0, 0]: two engines (two weight replicas, two host threads per call) on the one GPU of the box; with
+    group_shared_block = 1 the pages of a call are split between them in two contiguous blocks.  The per-request gather
+    is the host transport (AUTO inside one process)."""
     dbuf, rbuf, digests = bufs
-    group = EngineGroup([0, 0], dbuf, rbuf, gather="auto")
-    assert len(group) == 2 and group.member(1)[1] == 0
-    out = _group_pipeline(group, pages16)
-    _check_all_golden(out, digests)
-    lg = group.last_gather()
-    assert lg["transport"] == "host" and "more than once" in lg["why_host"] and lg["bytes"] > 0
-    # three calls in flight on the group (each fans out to both members)
-    with ThreadPoolExecutor(3) as ex:
-        outs = list(ex.map(lambda _: _group_pipeline(group, pages16), range(3)))
-    for o in outs:
-        assert all(np.array_equal(a, b) for a, b in zip(o[0], out[0]))
-        assert np.array_equal(o[4], out[4]) and np.array_equal(o[5], out[5])
-    inputs = group.prepare_input_batch(pages16[:2])
-    assert [i.shape for i in inputs] == [(1, 1024, 1024)] * 2
-    # uneven dealing: 5 pages -> 3 + 2
-    out5 = _group_pipeline(group, pages16[:5])
-    _check_all_golden(out5, digests, n=5)
+    _lib.set_option("group_shared_block", 1)
+    try:
+        group = EngineGroup([0, 0], dbuf, rbuf, gather="auto")
+        assert len(group) == 2 and group.member(1)[1] == 0
+        out = _group_pipeline(group, pages16)
+        _check_all_golden(out, digests)
+        lg = group.last_gather()
+        assert lg["transport"] == "host" and lg["why_host"] == "host transport requested" and lg["bytes"] > 0
+        # three calls in flight on the group (each fans out to both members)
+        with ThreadPoolExecutor(3) as ex:
+            outs = list(ex.map(lambda _: _group_pipeline(group, pages16), range(3)))
+        for o in outs:
+            assert all(np.array_equal(a, b) for a, b in zip(o[0], out[0]))
+            assert np.array_equal(o[4], out[4]) and np.array_equal(o[5], out[5])
+        assert 1 <= group.worker_threads() <= 6      # kept between calls, one per share in flight beyond the callers'
+        inputs = group.prepare_input_batch(pages16[:2])
+        assert [i.shape for i in inputs] == [(1, 1024, 1024)] * 2
+        # uneven dealing: 5 pages -> 3 + 2
+        out5 = _group_pipeline(group, pages16[:5])
+        _check_all_golden(out5, digests, n=5)
+    finally:
+        _lib.set_option("group_shared_block", 16)
 
 
 def test_group_rccl_gather_one_member(bufs, pages16):

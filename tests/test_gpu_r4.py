@@ -1,0 +1,129 @@
+"""GPU tests of the round-4 work, all through the C ABI and against the oracle / its golden fixtures:
+
+  * the engine group's RCCL gather with TWO and EIGHT members on the one GPU of the box, through a test double of
+    librccl (tests/stubs/rccl_stub.cpp, loaded with OCRS_RCCL_LIB): slot layout, length prefixes, per-member streams and
+    syncs, several gathers in flight — code that a one-GPU box could otherwise never execute;
+  * the final result gather (ocrs_group_final_gather) and its fall-backs;
+  * default dealing between members that share a device (whole calls, rotating);
+  * the device binding of an entry point lasts for the call only (needs two GPUs; skipped otherwise).
+"""
+import ctypes as C
+import os
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+import stub_util
+from ocrs_amd import DimOrder, EngineGroup, ImageSource, Model, OcrEngine, _lib
+from test_gpu_r3 import _check_all_golden, _group_pipeline, bufs, pages16  # noqa: F401  (fixtures)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def rccl_stub(monkeypatch):
+    path = stub_util.rccl_stub_path()
+    monkeypatch.setenv("OCRS_RCCL_LIB", path)
+    lib = C.CDLL(path)          # the same mapping group.cpp's dlopen gets: its counters are the ones we read
+    def stats():
+        out = (C.c_uint64 * 5)()
+        lib.ocrs_rccl_stub_stats(out)
+        return dict(zip(("inits", "gathers", "groups", "max_ranks", "bytes"), [int(v) for v in out]))
+    return stats
+
+
+@pytest.mark.parametrize("members", [2, 8])
+def test_group_rccl_gather_with_several_members_through_the_librccl_double(bufs, pages16, rccl_stub, members):
+    """gather = rccl on [0] * G with the double: every per-request gather runs gather_rccl with G ranks — the golden bits
+    of pages 0-15 come back, raw gathers are byte-exact (incl. empty and unequal payloads), three calls in flight."""
+    dbuf, rbuf, digests = bufs
+    before = rccl_stub()
+    _lib.set_option("group_shared_block", 16 // members)
+    try:
+        group = EngineGroup([0] * members, dbuf, rbuf, gather="rccl")
+        out = _group_pipeline(group, pages16)
+        _check_all_golden(out, digests)
+        lg = group.last_gather()
+        assert lg["transport"] == "rccl" and lg["why_host"] == "" and lg["bytes"] > 100000
+        rng = np.random.default_rng(members)
+        for sizes in ([0] * members, [1] + [0] * (members - 1), [17, 100003] + [5] * (members - 2),
+                      list(rng.integers(0, 70000, members))):
+            payloads = [rng.integers(0, 256, int(n), dtype=np.uint8).tobytes() for n in sizes]
+            data, offs = group.gather(payloads)
+            assert data == b"".join(payloads) and offs == [0] + list(np.cumsum([len(p) for p in payloads]))
+            assert group.last_gather()["transport"] == "rccl"
+        with ThreadPoolExecutor(3) as ex:
+            outs = list(ex.map(lambda _: _group_pipeline(group, pages16), range(3)))
+        for o in outs:
+            assert all(np.array_equal(a, b) for a, b in zip(o[0], out[0]))
+            assert np.array_equal(o[4], out[4]) and np.array_equal(o[5], out[5])
+        # uneven shares: 5 pages
+        out5 = _group_pipeline(group, pages16[:5])
+        _check_all_golden(out5, digests, n=5)
+    finally:
+        _lib.set_option("group_shared_block", 16)
+    after = rccl_stub()
+    assert after["inits"] == before["inits"] + 1 and after["max_ranks"] >= members
+    assert after["gathers"] - before["gathers"] >= members * (2 * 5 + 4)     # G all-gathers per gather, 2 gathers per pipeline
+    assert after["groups"] - before["groups"] >= 2 * 5 + 4
+
+
+def test_final_gather_uses_rccl_when_it_can_and_an_rccl_failure_reaches_only_that_call(bufs, pages16, rccl_stub, monkeypatch):
+    """AUTO: per-request gathers on the host, the FINAL gather through RCCL (here the double, 4 members).  A collective that
+    fails is an error of that call (OCRS_ERR_DEVICE), the group keeps working."""
+    dbuf, rbuf, digests = bufs
+    group = EngineGroup([0, 0, 0, 0], dbuf, rbuf, gather="auto")
+    out = _group_pipeline(group, pages16[:4])
+    _check_all_golden(out, digests, n=4)
+    assert group.last_gather()["transport"] == "host"
+    texts = [("member %d: " % m).encode() + bytes(range(m * 10, m * 10 + 7)) * (m + 1) for m in range(4)]
+    data, offs = group.final_gather(texts, "auto")
+    assert data == b"".join(texts) and offs[-1] == len(data)
+    lg = group.last_gather()
+    assert lg["transport"] == "rccl" and lg["why_host"] == ""
+    assert group.final_gather(texts, "host")[0] == data and group.last_gather()["transport"] == "host"
+    n = rccl_stub()["gathers"]
+    monkeypatch.setenv("OCRS_RCCL_STUB_FAIL_GATHER", str(n + 2))     # the second member's call of the next gather
+    with pytest.raises(_lib.OcrsError) as ei:
+        group.final_gather(texts, "rccl")
+    assert "RCCL error" in str(ei.value)
+    monkeypatch.delenv("OCRS_RCCL_STUB_FAIL_GATHER")
+    assert group.final_gather(texts, "rccl")[0] == data and group.last_gather()["transport"] == "rccl"
+    out2 = _group_pipeline(group, pages16[:4])
+    assert np.array_equal(out2[4], out[4])
+
+
+def test_members_sharing_a_device_take_whole_calls_in_turn(bufs, pages16):
+    """Default dealing on [0, 0]: a 16-page call is not split below group_shared_block = 16 pages — one member takes it,
+    the next call goes to the other member (worker threads are kept, none is created per call)."""
+    dbuf, rbuf, digests = bufs
+    group = EngineGroup([0, 0], dbuf, rbuf)
+    e0, e1 = group.member(0)[0], group.member(1)[0]
+    for e in (e0, e1):
+        e.enable_timing(1)
+    outs = [_group_pipeline(group, pages16) for _ in range(2)]
+    _check_all_golden(outs[0], digests)
+    assert np.array_equal(outs[1][4], outs[0][4])
+    t0, t1 = e0.stage_times(), e1.stage_times()
+    # both members worked (prepare / detect / recognize of one call each, give or take the rotation's start)
+    assert sum(n for _, n in t0.values()) > 0 and sum(n for _, n in t1.values()) > 0
+    assert group.worker_threads() <= 2
+
+
+@pytest.mark.skipif(_lib.device_count() < 2 if os.path.exists(_lib.LIB_PATH) else True, reason="needs two GPUs")
+def test_an_entry_point_leaves_the_callers_hip_device_as_it_found_it(bufs, pages16):
+    """DeviceScope must restore the calling thread's device (torch or the caller may use another GPU)."""
+    dbuf, rbuf, _ = bufs
+    hip = C.CDLL("libamdhip64.so")
+    det, rec = Model.load_bytes(dbuf, device=0), Model.load_bytes(rbuf, device=0)
+    eng = OcrEngine(detection_model=det, recognition_model=rec)
+    assert hip.hipSetDevice(1) == 0
+    inp = eng.prepare_input(ImageSource.from_tensor(pages16[0], DimOrder.Hwc))
+    eng.detect_words(inp)
+    d = C.c_int(-1)
+    assert hip.hipGetDevice(C.byref(d)) == 0 and d.value == 1
+    group = EngineGroup([0, 1], dbuf, rbuf)
+    _group_pipeline(group, pages16[:4])
+    assert hip.hipGetDevice(C.byref(d)) == 0 and d.value == 1
+    assert hip.hipSetDevice(0) == 0

@@ -368,19 +368,27 @@ def test_coalescer_runs_every_request_once_and_merges_under_load(lib, threads, m
 
 
 # ---------------------------------------------------------------- engine group: dealing and packing (host side)
-def test_group_deals_pages_round_robin(lib):
-    for n, g in [(0, 1), (7, 3), (16, 8), (5, 8), (10000, 8)]:
+def test_group_deals_pages_in_contiguous_blocks(lib):
+    """block = max(ceil(n / G), min(group_min_block = 8, n)); page i -> member (i / block) mod G: a 16-page call on 8
+    members uses two of them (8 pages each), 10 000 pages on 8 members 1 250 each, in order."""
+    for n, g in [(0, 1), (7, 3), (16, 8), (5, 8), (10000, 8), (16, 2), (24, 2), (9, 2), (64, 8), (65, 8)]:
         mo = (C.c_size_t * max(n, 1))()
         pp = (C.c_size_t * g)()
         assert lib.ocrs_group_deal(C.c_size_t(n), C.c_size_t(g), mo, pp) == 0
-        assert [mo[i] for i in range(n)] == [i % g for i in range(n)]
-        assert [pp[m] for m in range(g)] == [len(range(m, n, g)) for m in range(g)]
+        block = max(-(-n // g), min(8, n)) if n else 1
+        assert [mo[i] for i in range(n)] == [(i // block) % g for i in range(n)]
+        assert [pp[m] for m in range(g)] == [sum(1 for i in range(n) if (i // block) % g == m) for m in range(g)]
+        assert all(mo[i] <= mo[i + 1] for i in range(n - 1))          # contiguous, in order
+        if n >= 8 * g:
+            assert max(pp) - min(pp) <= block and min(pp) > 0            # large calls use every member
+        elif n:
+            assert min(v for v in pp if v) >= min(8, n) or sum(1 for v in pp if v) == 1 or n % block
     assert lib.ocrs_group_deal(C.c_size_t(4), C.c_size_t(0), None, None) == 1
 
 
 def test_group_host_gather_concatenates_member_payloads_in_member_order(lib):
     """A group without models needs no GPU: the host transport of the result gather packs the members' payloads in
-    member order with their boundaries (the RCCL transport must deliver the same bytes: tests/test_gpu_r3.py)."""
+    member order with their boundaries (the RCCL transport must deliver the same bytes: tests/test_gpu_r4.py)."""
     from ocrs_amd import EngineGroup
     g = EngineGroup([0, 0, 0], gather="host")
     assert len(g) == 3 and [g.member(i)[1] for i in range(3)] == [0, 0, 0]
@@ -394,6 +402,43 @@ def test_group_host_gather_concatenates_member_payloads_in_member_order(lib):
     assert g2.gather([b"a", b"bc"])[0] == b"abc" and "more than once" in g2.last_gather()["why_host"]
     with pytest.raises(ocrs_amd.OcrsError):
         EngineGroup([], gather="host")
+
+
+def test_group_auto_gather_is_host_per_request_and_rccl_problems_are_never_fatal(lib, monkeypatch):
+    """AUTO = host for the per-request gathers (inside one process the results are on the host already); the FINAL gather
+    asks for RCCL on a group of two or more members and falls back, with the reason, when librccl cannot be loaded or
+    refuses the communicator.  libocrs_amd.so itself has no RCCL dependency (dlopen on first use)."""
+    import subprocess
+    from ocrs_amd import EngineGroup, _lib
+    deps = subprocess.run(["ldd", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "rccl" not in deps
+    g = EngineGroup([0, 1], gather="auto")
+    assert g.gather([b"xy", b"z"]) == (b"xyz", [0, 2, 3])
+    lg = g.last_gather()
+    assert lg["transport"] == "host" and lg["why_host"] == "host transport requested"
+    # final gather, library missing
+    monkeypatch.setenv("OCRS_RCCL_LIB", "/nonexistent/librccl.so")
+    assert g.final_gather([b"xy", b"z"], "auto") == (b"xyz", [0, 2, 3])
+    lg = g.last_gather()
+    assert lg["transport"] == "host" and "librccl unavailable" in lg["why_host"] and "/nonexistent/librccl.so" in lg["why_host"]
+    assert g.final_gather([b"", b"q"], "rccl") == (b"q", [0, 0, 1])      # asked for explicitly: still not an error
+    assert g.last_gather()["transport"] == "host"
+    # a library that is not an RCCL
+    monkeypatch.setenv("OCRS_RCCL_LIB", "libm.so.6")
+    g3 = EngineGroup([0, 1], gather="rccl")
+    assert g3.gather([b"1", b"2"])[0] == b"12" and "lacks ncclCommInitAll" in g3.last_gather()["why_host"]
+    # the communicator is refused (test double with failure injection; no HIP call happens before the refusal)
+    import stub_util
+    monkeypatch.setenv("OCRS_RCCL_LIB", stub_util.rccl_stub_path())
+    monkeypatch.setenv("OCRS_RCCL_STUB_FAIL_INIT", "1")
+    g4 = EngineGroup([0, 1, 2, 3], gather="auto")
+    assert g4.final_gather([b"a", b"", b"bc", b"d"], "auto") == (b"abcd", [0, 1, 1, 3, 4])
+    assert "ncclCommInitAll failed" in g4.last_gather()["why_host"]
+    # one member: nothing to move between devices
+    g1 = EngineGroup([0], gather="auto")
+    assert g1.final_gather([b"solo"], "auto")[0] == b"solo" and g1.last_gather()["why_host"] == "one member: nothing to gather"
+    with pytest.raises(ocrs_amd.OcrsError):      # an unknown transport is an argument error
+        _lib.check(lib.ocrs_group_final_gather(g1._h, C.c_int(7), None, None, None, None))
 
 
 def test_every_option_of_the_library_is_documented_in_the_header():
