@@ -529,7 +529,9 @@ contour_rect_kernel(const uint8_t* __restrict__ mask, int h, int w, const int32_
         int off32 = 0;
         if (lane == 0) off32 = atomicAdd(&arena_top[page], n);
         off32 = __builtin_amdgcn_readfirstlane(off32);
-        if ((int64_t)off32 + n > arena) {
+        // the bump counter keeps growing after the arena is full and is 32 bits wide: on a very large noisy page it can
+        // wrap, so a negative offset is an overflow too (nothing has been written for this component yet)
+        if (off32 < 0 || (int64_t)off32 + n > arena) {
             if (lane == 0) {
                 overflow[page] = 1;
                 valid[slot] = 0;

@@ -1,7 +1,9 @@
 // Layout analysis: words -> lines in reading order.  Host side by design
 // (O(n^2) on ~600 rects, branchy, sub-millisecond) — mirrors
 // ocrs/src/layout_analysis.rs:19-233 and layout_analysis/empty_rects.rs:47-229.
+#if defined(__SSE2__)
 #include <emmintrin.h>
+#endif
 
 #include <cmath>
 #include <cstdlib>
@@ -192,6 +194,7 @@ std::vector<Rect> max_empty_rects_search(const std::vector<Rect>& obstacles, Rec
             const Idx* src = arena.data() + part.obs_off;
             Idx* dst = arena.data() + arena_n;
             size_t k = 0;
+#if defined(__SSE2__)
             const __m128i bound = _mm_set_epi32(-b.top, -b.left, b.bottom, b.right);
             for (uint32_t q = 0; q < part.obs_len; q++) {   // branch-free filter: store always, advance if it intersects
                 const Idx idx = src[q];
@@ -199,6 +202,15 @@ std::vector<Rect> max_empty_rects_search(const std::vector<Rect>& obstacles, Rec
                 const __m128i lt = _mm_cmplt_epi32(_mm_load_si128(reinterpret_cast<const __m128i*>(oq[idx].v)), bound);
                 k += (size_t)(_mm_movemask_ps(_mm_castsi128_ps(lt)) == 0xF);
             }
+#else
+            const int32_t bound[4] = {b.right, b.bottom, -b.left, -b.top};   // the same four strict comparisons, scalar
+            for (uint32_t q = 0; q < part.obs_len; q++) {
+                const Idx idx = src[q];
+                dst[k] = idx;
+                const int32_t* v = oq[idx].v;
+                k += (size_t)((v[0] < bound[0]) & (v[1] < bound[1]) & (v[2] < bound[2]) & (v[3] < bound[3]));
+            }
+#endif
             my_off = (uint32_t)arena_n;
             my_len = (uint32_t)k;
             arena_n += k;

@@ -214,7 +214,7 @@ class _Builder:
         return o
 
 
-def build_detection(in_hw=(800, 600), depths=(8, 16, 32, 32, 64, 128, 256), seed=1):
+def build_detection(in_hw=(800, 600), depths=(8, 16, 32, 32, 64, 128, 256), seed=1, ink_level=0.0, ink_gain=1.0, ink_sign=1):
     """U-Net of depthwise-separable DoubleConvs (ocrs-models `DetectionModel`,
     recollected): in_conv; Down = MaxPool2 -> DoubleConv; Up = ConvTranspose2x2/s2
     -> pad to skip -> concat [skip, up] -> DoubleConv; 1x1 conv -> Sigmoid.
@@ -223,7 +223,13 @@ def build_detection(in_hw=(800, 600), depths=(8, 16, 32, 32, 64, 128, 256), seed
     "darkness" feature through to the output logit (dark blobs on a light page
     -> probability ~0.98, background ~0.02); every other weight is seeded
     random and contributes a small perturbation.  This gives synthetic pages a
-    realistic component count for the post-processing stages."""
+    realistic component count for the post-processing stages.
+
+    `ink_level` / `ink_gain` (defaults: the file every fixture was made with) move the hand-set feature's operating
+    point: darkness = relu(-2 * ink_sign * (blur(x) - ink_level)), logit = 8 * ink_gain * darkness - 4 (ink_sign = -1:
+    light text on a dark page).  With ink_level ~0.3 the
+    pale, anti-aliased strokes of real text scaled down to the detection input (scanned pages, screenshots) are marked
+    as well, so the masks follow the glyphs — the natural-image fixtures of tests/golden/reference use such a file."""
     rng = np.random.default_rng(seed)
     B = _Builder(rng)
 
@@ -241,8 +247,8 @@ def build_detection(in_hw=(800, 600), depths=(8, 16, 32, 32, 64, 128, 256), seed
                 w_dw1[:, :, 0] = 1.0 / 9.0
                 b_dw1[0] = 0.0
                 w_pw1[0, 0, :, 0] = 0.0
-                w_pw1[0, 0, 0, 0] = -2.0  # darkness = relu(-2 * blur(x))
-                b_pw1[0] = 0.0
+                w_pw1[0, 0, 0, 0] = np.float32(-2.0 * ink_sign)  # darkness = relu(-2 * ink_sign * (blur(x) - ink_level))
+                b_pw1[0] = np.float32(2.0 * ink_sign * ink_level)
                 w_dw2[:, :, 0] = 1.0 / 9.0
             else:
                 w_dw1[:, :, 0] = 0.0
@@ -277,7 +283,7 @@ def build_detection(in_hw=(800, 600), depths=(8, 16, 32, 32, 64, 128, 256), seed
         B.ops.append(Op(OP_PADCAT, skips[i], c, in1=o))
         x = double_conv(c, 2 * cout, cout, carry=(i == 0))
     w_out = B.he((1, 1, depths[0], 1), depths[0], 0.15)
-    w_out[0, 0, 0, 0] = 8.0
+    w_out[0, 0, 0, 0] = np.float32(8.0 * ink_gain)
     x = B.conv(x, depths[0], 1, 1, relu=0, w=w_out, b=np.array([-4.0], np.float32))
     x = B.simple(OP_SIGMOID, x)
     return Graph(KIND_DETECTION, [-1, 1, in_hw[0], in_hw[1]], B.ops, B.n_slots, x)

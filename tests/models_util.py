@@ -30,9 +30,15 @@ def _cached(name, make):
     return buf
 
 
-def detection_model_bytes(in_hw=(800, 600), depths=(8, 16, 32, 32, 64, 128, 256), seed=1):
+def detection_model_bytes(in_hw=(800, 600), depths=(8, 16, 32, 32, 64, 128, 256), seed=1, ink=None):
+    """ink = (ink_level, ink_gain, ink_sign) of modelfile.build_detection; None = the default file."""
     key = "det_%dx%d_%s_s%d_v1.ocrsm" % (in_hw[0], in_hw[1], "-".join(map(str, depths)), seed)
-    return _cached(key, lambda: mf.build_detection(in_hw=in_hw, depths=depths, seed=seed).to_bytes())
+    if ink is None:
+        return _cached(key, lambda: mf.build_detection(in_hw=in_hw, depths=depths, seed=seed).to_bytes())
+    lvl, gain, sign = float(ink[0]), float(ink[1]), int(ink[2])
+    key = key.replace("_v1.ocrsm", "_ink%g_%g_%d_v1.ocrsm" % (lvl, gain, sign))
+    return _cached(key, lambda: mf.build_detection(in_hw=in_hw, depths=depths, seed=seed, ink_level=lvl, ink_gain=gain,
+                                                   ink_sign=sign).to_bytes())
 
 
 def recognition_model_bytes(seed=2, n_classes=97):

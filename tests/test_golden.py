@@ -155,3 +155,39 @@ def test_oracle_reproduces_small_odd_page_golden_end_to_end():
     for i, t in enumerate(text):
         exp = "".join(chr(c) for c in g["chars"][co[i]:co[i + 1], 0])
         assert (str(t) if t is not None else "") == exp
+
+
+# ---------------------------------------------------------------- the reference's own images (round 4)
+REF_IMAGES = ("why-rust", "polar-bears", "rust-book")
+
+
+def _ref_fixture(name):
+    g = np.load(os.path.join(G, "reference", name + ".npz"))
+    dbuf, rbuf = M.detection_model_bytes(ink=tuple(g["ink"])), M.recognition_model_bytes()
+    assert [M.digest(dbuf), M.digest(rbuf)] == list(g["model_digests"]), \
+        "synthetic model files changed: re-run tests/golden/make_golden_reference_images.py"
+    return g, dbuf, rbuf
+
+
+@pytest.mark.parametrize("name", REF_IMAGES)
+def test_oracle_reproduces_the_cheap_stages_of_the_reference_image_goldens(name):
+    """Drift guard without the networks: grey conversion of the stored pixels, mask -> contours -> rects (the stage the
+    natural glyph masks are there for) and the line grouping, re-derived with the oracle."""
+    from oracle import clib
+    from oracle.geometry import RotatedRect
+    from oracle import layout as OL
+    g, _, _ = _ref_fixture(name)
+    px = g["pixels"]
+    grey = OP.prepare_image(OP.ImageSource.from_tensor(px, "hwc"))
+    assert _bits_sum(grey) == int(g["grey_bits_sum"][0])
+    h, w = [int(v) for v in g["mask_shape"]]
+    assert (h, w) == px.shape[:2]
+    mask = np.unpackbits(g["mask"])[: h * w].reshape(h, w).astype(np.uint8)
+    rects = clib.component_rects(mask, 3.0, 100.0)
+    assert np.array_equal(np.asarray(rects, np.float32).reshape(-1, 6), g["word_rects"])
+    n_contours = len(clib.find_contours_external(mask))
+    assert n_contours > 2 * len(rects) or name == "polar-bears"      # many specks below min_area: natural masks
+    words = [RotatedRect.from_array(r) for r in g["word_rects"]]
+    lines = OL.find_text_lines(words)
+    assert np.array_equal(np.cumsum([0] + [len(l) for l in lines]), g["line_offsets"])
+    assert np.array_equal(np.array([x.to_array() for l in lines for x in l], np.float32).reshape(-1, 6), g["line_rects"])

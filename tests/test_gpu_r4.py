@@ -127,3 +127,66 @@ def test_an_entry_point_leaves_the_callers_hip_device_as_it_found_it(bufs, pages
     _group_pipeline(group, pages16[:4])
     assert hip.hipGetDevice(C.byref(d)) == 0 and d.value == 1
     assert hip.hipSetDevice(0) == 0
+
+
+# ------------------------------------------------------------------ the reference's own images as parity fixtures
+REF_IMAGES = ("why-rust", "polar-bears", "rust-book")
+
+
+def _ref_case(name):
+    from test_golden import _ref_fixture
+    g, dbuf, rbuf = _ref_fixture(name)
+    eng = OcrEngine(detection_model=Model.load_bytes(dbuf), recognition_model=Model.load_bytes(rbuf))
+    return g, eng
+
+
+def _bits_sum(a):
+    return int(np.frombuffer(np.ascontiguousarray(a).tobytes(), np.uint32).sum(dtype=np.uint64))
+
+
+@pytest.mark.parametrize("name", REF_IMAGES)
+def test_reference_image_through_the_one_page_api_equals_the_oracle_golden(name):
+    """ocrs-cli/test-data/{why-rust,polar-bears}.png and ocrs/examples/rust-book.jpg, loaded as the CLI loads them
+    (into_rgb8), through prepare_input -> detect_text_pixels / detect_words -> find_text_lines -> recognize: grey page,
+    probability map (checksum of the f32 bits), mask bits, word rects, line grouping, CTC steps, char boxes and text are
+    the oracle's (tests/golden/make_golden_reference_images.py).  polar-bears is 242 rows high: the pad branch of
+    detection.rs:159-160; the masks are glyph-shaped (holes, touching letters, specks)."""
+    g, eng = _ref_case(name)
+    px = np.ascontiguousarray(g["pixels"])
+    inp = eng.prepare_input(ImageSource.from_tensor(px, DimOrder.Hwc))
+    assert _bits_sum(inp.image()) == int(g["grey_bits_sum"][0])
+    prob = eng.detect_text_pixels(inp)
+    assert prob.shape == tuple(g["mask_shape"])
+    assert np.array_equal(np.packbits(prob > np.float32(eng.detection_threshold())), g["mask"])
+    assert _bits_sum(prob) == int(g["prob_bits_sum"][0])
+    words = eng.detect_words(inp)
+    assert np.array_equal(words, g["word_rects"])
+    lines = eng.find_text_lines(inp, words)
+    assert np.array_equal(np.cumsum([0] + [len(l) for l in lines]), g["line_offsets"])
+    assert np.array_equal(np.concatenate(lines), g["line_rects"])
+    toks = eng.recognize_tokens(inp, lines)
+    assert np.array_equal(np.array([t for ts in toks for t in ts], np.int32).reshape(-1, 2), g["tokens"])
+    assert np.array_equal(np.cumsum([0] + [len(t) for t in toks]), g["token_offsets"])
+    assert eng.get_text(inp) == str(g["text"][0])
+
+
+@pytest.mark.parametrize("name", REF_IMAGES)
+def test_reference_image_through_the_batch_api_equals_the_oracle_golden(name):
+    """The same image three times in one batch request (detect_words_batch -> find_text_lines_batch ->
+    recognize_text_batch), two requests in flight: every copy gives the golden word rects, line grouping and char boxes."""
+    from test_gpu_bench_scale import _check_page_against_golden
+    g, eng = _ref_case(name)
+    px = np.ascontiguousarray(g["pixels"])
+
+    def request(_):
+        inputs = [eng.prepare_input(ImageSource.from_tensor(px, DimOrder.Hwc)) for _ in range(3)]
+        words = eng.detect_words_batch(inputs)
+        rects, loffs, poffs = eng.find_text_lines_batch_raw(words)
+        chars, coffs = eng.recognize_text_batch_raw(inputs, rects, loffs, poffs)
+        return words, rects, loffs, poffs, chars, coffs
+
+    with ThreadPoolExecutor(2) as ex:
+        outs = list(ex.map(request, range(2)))
+    for words, rects, loffs, poffs, chars, coffs in outs:
+        for pi in range(3):
+            _check_page_against_golden(g, words[pi], rects, loffs, int(poffs[pi]), int(poffs[pi + 1]), chars, coffs)
