@@ -533,13 +533,16 @@ def pmc_traffic(kernel_class):
     (tools/profile.sh -> tools/pmc_summary.py -> profiles/*_pmc.json: separate FETCH_SIZE / WRITE_SIZE passes,
     FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  None if no summary covers the class."""
     import glob
-    match = {"gemm_conv3x3_mfma": "conv3x3_ragged_kernel",
-             "gemm_gru_hidden_mfma": "gru_persistent_kernel" if os.environ.get("OCRS_GRU_MODE", "0") == "0" else "gru_step_fused_kernel",
-             "gemm_gru_input_mfma": "gemm_tiled_kernelILi128ELb0", "dwconv3x3": "dwconv3x3_kernel"}.get(kernel_class)
+    # every kernel the class launches: the conv class is conv3x3_ragged (four layers) AND the fused conv1+conv2 launch —
+    # its launches_per_step and algorithmic bytes count both, so its traffic must too (r3 matched the first only: 15.8 GB
+    # per launch reported, 13.0 launch-weighted)
+    match = {"gemm_conv3x3_mfma": ("conv3x3_ragged_kernel", "conv12_fused_kernel", "conv3x3_halo_kernel"),
+             "gemm_gru_hidden_mfma": ("gru_persistent_kernel",) if os.environ.get("OCRS_GRU_MODE", "0") == "0" else ("gru_step_fused_kernel",),
+             "gemm_gru_input_mfma": ("gemm_tiled_kernelILi128ELb0",), "dwconv3x3": ("dwconv3x3_kernel",)}.get(kernel_class)
     if not match:
         return None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")), reverse=True):
-        rows = [r for k, r in json.load(open(f)).items() if match in k]
+        rows = [r for k, r in json.load(open(f)).items() if any(m in k for m in match)]
         n = sum(r["launches"] for r in rows)
         if n:
             return {"hbm_bytes_per_launch": round(sum(r["hbm_bytes_per_launch"] * r["launches"] for r in rows) / n),
@@ -817,13 +820,16 @@ def cpu_baseline(pages, engine, gpu_text, np):
     from concurrent.futures import ProcessPoolExecutor
     cores = max(1, (os.cpu_count() or 2) // 2)
     ctx = mp.get_context("spawn")
-    # leg 1: exact, sequential, all physical cores (own process: the OpenMP pool size is fixed when the library loads)
+    # leg 1: exact, sequential (own process: the OpenMP pool size is fixed when the library loads).  Capped at 32 threads:
+    # the checker's per-layer parallel regions peak there (0.26-0.30 pages/s on 32 threads, 0.09 on 128 — r3 ran it on
+    # all 128 and tripled the run time of the default bench for no information)
+    cores_e = min(cores, 32)
     texts_e, n_lines, dt_e, layout_ok = [], 0, 0.0, None
-    with ProcessPoolExecutor(1, mp_context=ctx, initializer=_cpu_worker_init, initargs=(cores,)) as pool:
-        pool.submit(_cpu_worker_run, ("exact", None, cores)).result(timeout=600)
+    with ProcessPoolExecutor(1, mp_context=ctx, initializer=_cpu_worker_init, initargs=(cores_e,)) as pool:
+        pool.submit(_cpu_worker_run, ("exact", None, cores_e)).result(timeout=600)
         t0 = time.perf_counter()
         for pg in pages:
-            _, t, nl = pool.submit(_cpu_worker_run, ("exact", pg, cores)).result(timeout=900)
+            _, t, nl = pool.submit(_cpu_worker_run, ("exact", pg, cores_e)).result(timeout=900)
             texts_e.append(t)
             n_lines += nl
         dt_e = time.perf_counter() - t0
@@ -856,7 +862,7 @@ def cpu_baseline(pages, engine, gpu_text, np):
     lines_equal = sum(sum(1 for x, y in zip(a, b) if x == y) for a, b in zip(texts_e, gpu_text))
     rate_e = len(pages) / dt_e
     best_t = rate_t >= rate_e
-    return {"value": round(max(rate_e, rate_t), 4), "unit": "pages/s", "cores": cores if not best_t else W * T, "kind": "port",
+    return {"value": round(max(rate_e, rate_t), 4), "unit": "pages/s", "cores": cores_e if not best_t else W * T, "kind": "port",
             "host_logical_cpus": os.cpu_count(),
             "lines_per_s": round((lines_t / dt_t) if best_t and dt_t > 0 else n_lines / dt_e, 2),
             "backend": "torch" if best_t else "exact",
@@ -866,9 +872,9 @@ def cpu_baseline(pages, engine, gpu_text, np):
             "layout_checked_against_oracle": layout_ok,
             "sample": "full pipeline on the oracle (C image/contour/crop/CTC; layout shared with the product: its host C++ runs "
                       "inside both timed legs, oracle/layout.py cross-checks it outside the timing). exact: %d of the same "
-                      "synthetic 1024x1024 pages one after the other, networks = C fmaf-chain restatement, %d threads (all "
-                      "physical cores), %.1f s.  torch: %d pages (the same ones, repeated) on %d worker processes x %d "
-                      "threads, networks = PyTorch-CPU fp32, %.1f s" % (len(pages), cores, dt_e, n_pages_t, W, T, dt_t)}
+                      "synthetic 1024x1024 pages one after the other, networks = C fmaf-chain restatement, %d threads (where "
+                      "it peaks), %.1f s.  torch: %d pages (the same ones, repeated) on %d worker processes x %d "
+                      "threads, networks = PyTorch-CPU fp32, %.1f s" % (len(pages), cores_e, dt_e, n_pages_t, W, T, dt_t)}
 
 
 def _cpu_layout_check(page):

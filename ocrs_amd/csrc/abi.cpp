@@ -6,7 +6,9 @@
 
 #include <atomic>
 #include "abi_util.hpp"
+#include "coalesce_selftest.hpp"
 #include "engine.hpp"
+#include "host_pool.hpp"
 #include "kernels.hpp"
 
 using namespace ocrs;
@@ -59,47 +61,7 @@ ocrs_status ocrs_coalescer_selftest(int n_threads, int requests_per_thread, int 
                                     int fail_every, uint64_t out[5]) {
     return guarded([&] {
         if (!out || n_threads < 1 || requests_per_thread < 1 || max_pages < 1) fail(OCRS_ERR_INVALID_ARGUMENT, "bad argument");
-        struct TReq : CoalescedBase { int id = 0, kind = 0; long result = 0; int runs = 0; };
-        std::atomic<uint64_t> max_batch_pages{0}, mixed{0};
-        Coalescer<TReq> q(
-            [&](std::vector<TReq*>& batch) {
-                uint64_t w = 0;
-                for (TReq* r : batch) { w += r->weight; if (r->kind != batch[0]->kind) mixed++; }
-                uint64_t prev = max_batch_pages.load();
-                while (w > prev && !max_batch_pages.compare_exchange_weak(prev, w)) {}
-                std::this_thread::sleep_for(std::chrono::microseconds(300));   // the "GPU work" of a batch
-                for (TReq* r : batch) {
-                    r->runs++;
-                    if (fail_every > 0 && r->id % fail_every == 0) {
-                        try { fail(OCRS_ERR_INVALID_ARGUMENT, "request %d is bad", r->id); } catch (...) { r->error = std::current_exception(); }
-                    } else {
-                        r->result = 3L * r->id + 1;
-                    }
-                }
-            },
-            [](const TReq& a, const TReq& b) { return a.kind == b.kind; });
-        std::atomic<uint64_t> wrong{0}, errors{0};
-        std::vector<std::thread> th;
-        for (int t = 0; t < n_threads; t++)
-            th.emplace_back([&, t] {
-                for (int k = 0; k < requests_per_thread; k++) {
-                    TReq r;
-                    r.id = t * requests_per_thread + k + 1;
-                    r.kind = r.id % 2;
-                    r.weight = 1 + (size_t)(r.id % 3 == 0);
-                    try {
-                        q.submit(r, max_active, (size_t)max_pages, window_us);
-                        if (r.runs != 1 || r.result != 3L * r.id + 1 || (fail_every > 0 && r.id % fail_every == 0)) wrong++;
-                    } catch (const Error& e) {
-                        errors++;
-                        if (r.runs != 1 || !(fail_every > 0 && r.id % fail_every == 0)) wrong++;
-                    }
-                }
-            });
-        for (auto& t : th) t.join();
-        uint64_t batches = 0, reqs = 0;
-        q.stats(&batches, &reqs);
-        out[0] = batches; out[1] = reqs; out[2] = errors.load(); out[3] = wrong.load() + mixed.load(); out[4] = max_batch_pages.load();
+        coalescer_selftest(n_threads, requests_per_thread, max_active, max_pages, window_us, fail_every, out);
     });
 }
 
@@ -450,21 +412,11 @@ ocrs_status ocrs_engine_find_text_lines_batch(const ocrs_engine* e, size_t n_pag
                 errors[p] = ex.what();
             }
         };
-        if (n_pages <= 1) {
-            for (size_t p = 0; p < n_pages; p++) work(p);
-        } else {
-            // a bounded pool pulling pages from a shared counter: option "layout_threads" (0 = one thread per
-            // page up to the host's cores) keeps N ranks x in-flight requests from oversubscribing one host
-            const int opt = option(OPT_LAYOUT_THREADS);
-            const size_t hw = std::max(1u, std::thread::hardware_concurrency());
-            const size_t nth = std::min(n_pages, opt > 0 ? (size_t)opt : hw);
-            std::atomic<size_t> next{0};
-            auto loop = [&] { for (size_t p; (p = next.fetch_add(1)) < n_pages;) work(p); };
-            std::vector<std::thread> th;
-            for (size_t t = 1; t < nth; t++) th.emplace_back(loop);
-            loop();
-            for (auto& t : th) t.join();
-        }
+        // a bounded pool pulling pages from a shared counter: option "layout_threads" (0 = one thread per
+        // page up to the host's cores) keeps N ranks x in-flight requests from oversubscribing one host
+        const int opt = option(OPT_LAYOUT_THREADS);
+        const size_t hw = std::max(1u, std::thread::hardware_concurrency());
+        for_pages(n_pages, opt > 0 ? (size_t)opt : hw, work);
         for (const std::string& er : errors)
             if (!er.empty()) fail(OCRS_ERR_RUN_FAILED, "%s", er.c_str());
         std::vector<float> flat;

@@ -26,13 +26,9 @@
 #include <rccl/rccl.h>   // types and prototypes only: the library itself is bound at run time (RcclApi)
 
 #include <atomic>
-#include <condition_variable>
-#include <deque>
-#include <functional>
-#include <system_error>
-#include <thread>
 
 #include "abi_util.hpp"
+#include "host_pool.hpp"
 #include "kernels.hpp"
 
 using namespace ocrs;
@@ -99,70 +95,6 @@ RcclApi& rccl_api() {
     return ref;
 }
 
-// ------------------------------------------------------------------------------------------------ worker threads
-// The members' shares of a call run on host threads bound to the members' devices.  Threads are kept (a thread
-// per call and member cost a creation on the request path, and the per-thread free lists of timing events died with
-// it); the pool grows with the number of shares in flight and never shrinks below what it reached.
-class WorkerPool {
-  public:
-    ~WorkerPool() {
-        {
-            std::lock_guard<std::mutex> lk(mu_);
-            stop_ = true;
-        }
-        cv_.notify_all();
-        for (auto& t : threads_) t.join();
-    }
-    // false: no thread could be had — the caller runs the task itself
-    bool submit(std::function<void()> fn) {
-        std::unique_lock<std::mutex> lk(mu_);
-        if (idle_ <= queue_.size()) {   // every idle worker already has a task coming
-            if (threads_.size() >= kMaxThreads) {
-                if (threads_.empty()) return false;
-            } else {
-                try {
-                    threads_.emplace_back([this] { run(); });
-                } catch (const std::system_error&) {
-                    if (threads_.empty()) return false;
-                }
-            }
-        }
-        queue_.push_back(std::move(fn));
-        lk.unlock();
-        cv_.notify_one();
-        return true;
-    }
-    size_t threads() {
-        std::lock_guard<std::mutex> lk(mu_);
-        return threads_.size();
-    }
-
-  private:
-    static constexpr size_t kMaxThreads = 512;
-    void run() {
-        std::unique_lock<std::mutex> lk(mu_);
-        for (;;) {
-            idle_++;
-            cv_.wait(lk, [&] { return stop_ || !queue_.empty(); });
-            idle_--;
-            if (queue_.empty()) break;   // stop_
-            std::function<void()> fn = std::move(queue_.front());
-            queue_.pop_front();
-            lk.unlock();
-            fn();
-            lk.lock();
-        }
-        lk.unlock();
-        StageTimers::release_thread_events();
-    }
-    std::mutex mu_;
-    std::condition_variable cv_;
-    std::deque<std::function<void()>> queue_;
-    std::vector<std::thread> threads_;
-    size_t idle_ = 0;
-    bool stop_ = false;
-};
-
 }  // namespace
 
 struct ocrs_engine_group {
@@ -191,7 +123,7 @@ struct ocrs_engine_group {
     std::string why_host_out;   // stable copy handed out by ocrs_group_last_gather
 
     std::atomic<size_t> next_start{0};   // rotation of the block deal
-    WorkerPool workers;
+    WorkerPool workers{[] { StageTimers::release_thread_events(); }};   // the members' shares of a call run here
 
     ~ocrs_engine_group() {
         if (api && api->ok())
@@ -276,49 +208,13 @@ std::vector<std::vector<size_t>> deal_pages(ocrs_engine_group* g, const ocrs_pag
 // the calling thread); the first failure (lowest member) is rethrown after all have finished.
 template <class Fn>
 void for_each_member(ocrs_engine_group* g, const std::vector<std::vector<size_t>>& of_member, Fn&& fn) {
-    const size_t G = g->size();
-    std::vector<std::exception_ptr> errs(G);
-    auto body = [&](size_t m) {
-        try {
-            DeviceScope bind(g->members[m].device);
-            fn(m);
-        } catch (...) {
-            errs[m] = std::current_exception();
-        }
-    };
-    std::mutex mu;
-    std::condition_variable cv;
-    size_t outstanding = 0;
-    size_t mine = G;
-    for (size_t m = 0; m < G; m++) {
-        if (of_member[m].empty()) continue;
-        if (mine == G) { mine = m; continue; }
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            outstanding++;
-        }
-        bool queued = false;
-        try {
-            queued = g->workers.submit([&, m] {
-                body(m);
-                std::lock_guard<std::mutex> lk(mu);   // notify under the lock: `cv` lives on the waiter's stack
-                if (--outstanding == 0) cv.notify_all();
-            });
-        } catch (...) {   // out of memory while queueing: as if no thread could be had
-        }
-        if (!queued) {   // no thread to be had: this member's share runs here, after the others were started
-            body(m);
-            std::lock_guard<std::mutex> lk(mu);
-            outstanding--;
-        }
-    }
-    if (mine < G) body(mine);
-    {
-        std::unique_lock<std::mutex> lk(mu);
-        cv.wait(lk, [&] { return outstanding == 0; });
-    }
-    for (size_t m = 0; m < G; m++)
-        if (errs[m]) std::rethrow_exception(errs[m]);
+    std::vector<char> has_work(g->size(), 0);
+    for (size_t m = 0; m < g->size(); m++) has_work[m] = !of_member[m].empty();
+    std::vector<std::exception_ptr> errs;
+    run_shares(g->workers, has_work, errs, [&](size_t m) {
+        DeviceScope bind(g->members[m].device);
+        fn(m);
+    });
 }
 
 // ------------------------------------------------------------------------------------------------ gather

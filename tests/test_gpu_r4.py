@@ -190,3 +190,13 @@ def test_reference_image_through_the_batch_api_equals_the_oracle_golden(name):
     for words, rects, loffs, poffs, chars, coffs in outs:
         for pi in range(3):
             _check_page_against_golden(g, words[pi], rects, loffs, int(poffs[pi]), int(poffs[pi + 1]), chars, coffs)
+
+
+def test_mixed_load_soak_20_seconds():
+    """tools/soak.py as a test: one-page pipelines (coalesced), 16-page batch pipelines and engine-group calls at once
+    for 20 s, every result compared with the sequential reference; any error or differing byte fails."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak.py"), "20"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "errors: none" in r.stdout, (r.stdout + r.stderr)[-3000:]
