@@ -596,30 +596,42 @@ def extra_legs(engine, dptrs, host_pages, H, W, synth, np, DimOrder, sync_all, a
     # recognize_text on one page at a time through the one-page entry points; inside the engine concurrent small
     # requests share launches (option "coalesce"; the bits of every call are those of the call alone).
     def one_page(i):
-        t = time.perf_counter()
+        t0_ = time.perf_counter()
         inp = engine.prepare_input_device(dptrs[i % len(dptrs)].value, np.uint8, DimOrder.Hwc, H, W, 3)
+        t1_ = time.perf_counter()
         w1 = engine.detect_words_batch([inp])
+        t2_ = time.perf_counter()
         r1, lo1, po1 = engine.find_text_lines_batch_raw(w1)
+        t3_ = time.perf_counter()
         ch1, _ = engine.recognize_text_batch_raw([inp], r1, lo1, po1)
-        return time.perf_counter() - t, len(ch1)
-    threads, n_req = 12, 360
-    with ThreadPoolExecutor(threads) as pool:
-        list(pool.map(one_page, range(3 * threads)))
-        sync_all()
-        c0 = engine.coalesce_stats()
-        t0 = time.perf_counter()
-        lat = list(pool.map(one_page, range(n_req)))
-        sync_all()
-        dt = time.perf_counter() - t0
-        c1 = engine.coalesce_stats()
-    lat_ms = np.array([x[0] for x in lat]) * 1e3
-    out["single_page_api"] = {
-        "pages_per_s": round(n_req / dt, 1), "threads_in_flight": threads, "requests": n_req,
-        "latency_ms": {"p50": round(float(np.percentile(lat_ms, 50)), 2), "p99": round(float(np.percentile(lat_ms, 99)), 2)},
-        "merged_batches": {k: [c1[k][0] - c0[k][0], c1[k][1] - c0[k][1]] for k in c1},
-        "how": "one page per call from 12 host threads (the reference's call pattern); merged_batches = [batches run, "
-               "calls they carried] per stage inside the engine",
-    }
+        t4_ = time.perf_counter()
+        return t4_ - t0_, len(ch1), (t1_ - t0_, t2_ - t1_, t3_ - t2_, t4_ - t3_)
+
+    def one_page_run(threads, n_req):
+        with ThreadPoolExecutor(threads) as pool:
+            list(pool.map(one_page, range(2 * threads)))
+            sync_all()
+            c0 = engine.coalesce_stats()
+            t0 = time.perf_counter()
+            lat = list(pool.map(one_page, range(n_req)))
+            sync_all()
+            dt = time.perf_counter() - t0
+            c1 = engine.coalesce_stats()
+        lat_ms = np.array([x[0] for x in lat]) * 1e3
+        st = np.array([x[2] for x in lat]).mean(axis=0) * 1e3
+        return {"pages_per_s": round(n_req / dt, 1), "threads_in_flight": threads, "requests": n_req,
+                "latency_ms": {"p50": round(float(np.percentile(lat_ms, 50)), 2), "p99": round(float(np.percentile(lat_ms, 99)), 2)},
+                "mean_stage_ms": {"prepare": round(float(st[0]), 2), "detect": round(float(st[1]), 2), "layout": round(float(st[2]), 2),
+                                  "recognize": round(float(st[3]), 2)},
+                "merged_batches": {k: [c1[k][0] - c0[k][0], c1[k][1] - c0[k][1]] for k in c1}}
+
+    t_alone = [one_page(0)[0] for _ in range(6)]
+    out["single_page_api"] = dict(one_page_run(12, 360),
+        one_page_alone_ms=round(1e3 * float(np.median(t_alone[1:])), 2),
+        how="one page per call from 12 host threads (the reference's call pattern); merged_batches = [batches run, "
+            "calls they carried] per stage inside the engine; `concurrency_curve`: the same with 24 / 48 / 96 threads (96 pages "
+            "offered = the batch bench's 6 requests x 16 pages)")
+    out["single_page_api"]["concurrency_curve"] = {str(t): one_page_run(t, n) for t, n in ((24, 480), (48, 576), (96, 768))}
     # roofline of the detection CNN stack (the stack north_star names; depthwise-separable => HBM-bound):
     # algorithmic bytes of its layers (from the loaded graph) over the summed duration of its kernels
     if not args.no_kernel_timing:

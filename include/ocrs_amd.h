@@ -78,9 +78,11 @@ OCRS_API ocrs_status ocrs_ctc_beam_search(const float* logp, int t, int c, uint3
 
 /* Test hook (host only, no GPU work): how the persistent GRU kernel would deal the 16-line row tiles of a request
  * to its waves.  lengths_desc = sequence lengths of the lines, descending (tile k = lines 16k .. 16k+15).
- * *n_clusters = clusters per direction; tiles[512]: for wave slot s = cluster * 4 + wave, tiles[4s .. 4s+3] are the
- * tile indices it serves (longest first), -1 = none.  OCRS_ERR_CAPACITY if the shape has no persistent plan. */
-OCRS_API ocrs_status ocrs_gru_tile_plan(const int32_t* lengths_desc, size_t n_lines, int hidden, int32_t* n_clusters,
+ * *n_clusters = clusters per direction, *waves = waves per workgroup of the kernel the plan is for (option "gru_waves").
+ * waves = 4 (general kernel): 4 wave slots per cluster, tiles[4s .. 4s+3] for slot s = cluster * 4 + wave.
+ * waves = 16 (teams kernel): 4 team slots per cluster, tiles[8s .. 8s+7] for slot s = cluster * 4 + team.
+ * Tile indices longest first, -1 = none.  OCRS_ERR_CAPACITY if the shape has no persistent plan. */
+OCRS_API ocrs_status ocrs_gru_tile_plan(const int32_t* lengths_desc, size_t n_lines, int hidden, int32_t* n_clusters, int32_t* waves,
                                         int16_t* tiles);
 
 /* Test hook (host only, no GPU work) for the request coalescer behind the one-page entry points (option "coalesce"):
@@ -122,6 +124,9 @@ OCRS_API ocrs_status ocrs_coalescer_selftest(int n_threads, int requests_per_thr
  *   "group_min_block" engine group: pages the group places itself go to a device in contiguous blocks of at least this
  *                     many pages (default 8; a small call then uses fewer devices, successive calls rotate)
  *   "group_shared_block"  the same between members that share one device (default 16)
+ *   "gru_waves"       recurrence kernel of requests with more row tiles than clusters: 4 (default) = the general kernel (one
+ *                     wave per SIMD, three interleaved MFMA chains per wave); 16 = four gate-per-wave teams of four waves
+ *                     per workgroup, state through LDS (round-4 experiment, same bits, 12 % slower per layer)
  *   "gru_background"  1 = requests too large for one row tile per cluster run the recurrence on the lean multi-tile
  *                     gate-per-wave kernel (a third of the general kernel's registers: conv stacks of other requests keep
  *                     three blocks per CU beside it; slower on its own), default 0

@@ -42,15 +42,16 @@ ocrs_status ocrs_get_device(int* device) {
     });
 }
 
-ocrs_status ocrs_gru_tile_plan(const int32_t* lengths_desc, size_t n_lines, int hidden, int32_t* n_clusters, int16_t* tiles) {
+ocrs_status ocrs_gru_tile_plan(const int32_t* lengths_desc, size_t n_lines, int hidden, int32_t* n_clusters, int32_t* waves,
+                               int16_t* tiles) {
     return guarded([&] {
-        if (!lengths_desc || !n_clusters || !tiles || n_lines == 0 || n_lines > (size_t)1 << 20)
+        if (!lengths_desc || !n_clusters || !waves || !tiles || n_lines == 0 || n_lines > (size_t)1 << 20)
             fail(OCRS_ERR_INVALID_ARGUMENT, "bad argument");
         for (size_t i = 0; i < n_lines; i++)
             if (lengths_desc[i] < 1 || (i > 0 && lengths_desc[i] > lengths_desc[i - 1]))
                 fail(OCRS_ERR_INVALID_ARGUMENT, "lengths must be positive and descending");
         int ncl = 0;
-        if (!k::gru_tile_plan(lengths_desc, (int)n_lines, hidden, &ncl, tiles))
+        if (!k::gru_tile_plan(lengths_desc, (int)n_lines, hidden, &ncl, waves, tiles))
             fail(OCRS_ERR_CAPACITY, "no persistent-kernel plan for this shape (the engine then runs the recurrence as one fused launch per time step)");
         *n_clusters = ncl;
     });

@@ -137,7 +137,7 @@ bool gru_step_fused(const float* gx, const float* wh, const float* bh, const flo
 // flag); call it on a stream ordered before gru_persistent.
 size_t gru_persistent_sync_words(int M);
 bool gru_persistent_supported(int M, int Tmax, int64_t R, int H);
-bool gru_tile_plan(const int32_t* h_Tm, int M, int H, int* ncl, int16_t* tiles /* [512] */);  // host only: the deal of row tiles to waves
+bool gru_tile_plan(const int32_t* h_Tm, int M, int H, int* ncl, int* waves, int16_t* tiles /* [512] */);  // host only: the deal of row tiles to waves
 hipError_t gru_persistent_prepare(float* y, int64_t R, int H, hipStream_t s);
 // h_Tm: the same lengths as d_Tm on the host (descending) — the deal of row tiles to waves is computed from them.
 bool gru_persistent(const float* gx, const float* wh, const float* bh, float* y, const int32_t* d_Tm, const int32_t* d_off,

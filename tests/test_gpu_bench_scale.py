@@ -224,25 +224,27 @@ def test_oversized_recognition_request_is_split_into_sub_requests(engine):
         assert got == ref, budget
 
 
-def test_more_than_2048_lines_second_wave_of_gru_clusters(engine):
-    """2 560 lines = 160 row tiles: more than the 32 wave slots x 4 tiles of a 256-workgroup grid, so the persistent
-    GRU kernel is launched with 512 workgroups — the second half becomes resident as workgroups of the first exit
-    (clusters never depend on each other).  Chars and boxes must equal the per-step kernel's, and the first 2 048
-    lines (same crops, lines are independent) the golden request's."""
+@pytest.mark.parametrize("waves,extra", [(4, 512), (16, 2560)])
+def test_more_lines_than_one_grid_holds_second_wave_of_gru_clusters(engine, waves, extra):
+    """More row tiles than the slots of a 256-workgroup grid hold (2 560 lines for the general kernel, 4 608 for the
+    teams kernel): the persistent GRU kernel is launched with 512 workgroups — the second half becomes
+    resident as workgroups of the first exit (clusters never depend on each other).  Chars and boxes must equal the
+    per-step kernel's, and the first 2 048 lines (same crops, lines are independent) the golden request's."""
     g = np.load(os.path.join(GOLD, "bench_crops_2048.npz"))
     inp, rects, n = _crops_request(engine)
-    extra = 512
-    idx = np.concatenate([np.arange(n), np.arange(extra)])          # the first 512 crops again, as lines 2048..2559
+    idx = np.concatenate([np.arange(n), np.arange(extra) % n])          # the first crops again, as lines 2048..
     rects2 = rects[idx]
     m = n + extra
     loffs = np.arange(m + 1, dtype=np.uintp)
     res = {}
     try:
+        _lib.set_option("gru_waves", waves)
         for mode in (0, 1):
             _lib.set_option("gru_mode", mode)
             res[mode] = engine.recognize_text_batch_raw([inp], rects2, loffs, np.array([0, m], dtype=np.uintp))
     finally:
         _lib.set_option("gru_mode", 0)
+        _lib.set_option("gru_waves", 4)
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
     chars, coffs = res[0]
     coffs = np.asarray(coffs, np.int64)
@@ -250,7 +252,8 @@ def test_more_than_2048_lines_second_wave_of_gru_clusters(engine):
     k = int(coffs[n])
     got = np.stack([chars["ch"].astype(np.int64), chars["top"], chars["left"], chars["bottom"], chars["right"]], axis=1)
     assert np.array_equal(got[:k], g["chars"].astype(np.int64))
-    assert np.array_equal(got[k:], got[: int(coffs[extra])])   # the repeated crops decode to the same text and boxes
+    rep = min(extra, n)
+    assert np.array_equal(got[k: k + int(coffs[rep])], got[: int(coffs[rep])])   # the repeated crops decode to the same text and boxes
 
 
 def test_gru_modes_give_identical_bits(engine):
@@ -276,13 +279,16 @@ def test_gru_modes_give_identical_bits(engine):
         # 7 = gate-per-wave kernel packed two workgroups per CU (gru_gates_pack 2): applies to requests of 9-16 row tiles
         # 8 = the background (lean, multi-tile gate-per-wave) kernel for requests beyond one tile per cluster; 9 = the same
         #     with forced write-through hand-offs
-        for mode in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9):
+        # 10, 11 = round 4's teams kernel (gru_waves 16: four gate-per-wave teams per workgroup, state through LDS) for every
+        # request beyond the gate-per-wave kernel's size / everywhere, the latter with scattered clusters
+        for mode in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11):
+            _lib.set_option("gru_waves", 16 if mode in (10, 11) else 4)
             _lib.set_option("gru_gates_pack", 2 if mode == 7 else 1)
             _lib.set_option("gru_background", 1 if mode in (8, 9) else 0)
             _lib.set_option("gru_mode", 1 if mode == 1 else 0)
             _lib.set_option("gru_local", 0 if mode in (2, 5, 9) else 1)
-            _lib.set_option("gru_scatter", 1 if mode in (3, 6) else 0)
-            _lib.set_option("gru_gates", 0 if mode in (2, 3, 4) else 1)
+            _lib.set_option("gru_scatter", 1 if mode in (3, 6, 11) else 0)
+            _lib.set_option("gru_gates", 0 if mode in (2, 3, 4, 11) else 1)
             a = engine.recognize_text(inp, req) + engine.recognize_text(inp, req2)
             b = engine.recognize_text_batch_raw([cinp], crects, cl, np.array([0, n], dtype=np.uintp))
             res[mode] = ([(str(t), [c.rect for c in t.chars()]) if t else None for t in a], b)
@@ -293,7 +299,8 @@ def test_gru_modes_give_identical_bits(engine):
         _lib.set_option("gru_gates", 1)
         _lib.set_option("gru_gates_pack", 1)
         _lib.set_option("gru_background", 0)
-    for mode in (1, 2, 3, 4, 5, 6, 7, 8, 9):
+        _lib.set_option("gru_waves", 4)
+    for mode in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11):
         assert res[0][0] == res[mode][0], mode
         assert np.array_equal(res[0][1][0], res[mode][1][0]) and np.array_equal(res[0][1][1], res[mode][1][1]), mode
     assert sum(1 for t in res[0][0] if t) > 80

@@ -296,34 +296,49 @@ def test_beam_search_host_equals_oracle(lib):
         assert abs(OP.beam_lse(a, b) - (max(a, b) + math.log1p(math.exp(-abs(a - b))))) < 1e-14
 
 
-def _gru_plan(lib, lengths, hidden=256):
+def _gru_plan(lib, lengths, hidden=256, waves=4):
+    assert lib.ocrs_set_option(b"gru_waves", C.c_long(waves)) == 0
+    try:
+        return _gru_plan_now(lib, lengths, hidden)
+    finally:
+        lib.ocrs_set_option(b"gru_waves", C.c_long(4))
+
+
+def _gru_plan_now(lib, lengths, hidden):
     a = np.ascontiguousarray(np.asarray(lengths, np.int32))
-    ncl = C.c_int32(0)
+    ncl, waves = C.c_int32(0), C.c_int32(0)
     tiles = np.full(512, -2, np.int16)
     st = lib.ocrs_gru_tile_plan(a.ctypes.data_as(C.POINTER(C.c_int32)), C.c_size_t(len(a)), C.c_int(hidden), C.byref(ncl),
-                                tiles.ctypes.data_as(C.POINTER(C.c_int16)))
-    return st, ncl.value, tiles
+                                C.byref(waves), tiles.ctypes.data_as(C.POINTER(C.c_int16)))
+    return st, ncl.value, tiles, waves.value
 
 
-def _wave_cost(lens, c=4.7, L=6.6):
+def _wave_cost(lens, c, L):
     """the cost model of gru_assign_tiles (kernels_gru.hip): a round with n live tiles costs max(n c, L)"""
     ls = sorted(lens, reverse=True) + [0]
     return sum((ls[i] - ls[i + 1]) * max((i + 1) * c, L) for i in range(len(ls) - 1))
 
 
-@pytest.mark.parametrize("n_lines", [1, 16, 17, 77, 1232, 2048, 2049, 4096])
-def test_gru_tile_plan_covers_every_tile_once_and_balances(lib, n_lines):
-    """Host side of the persistent GRU kernel (kernels_gru.hip::gru_assign_tiles): every 16-line tile of the
-    length-sorted batch goes to exactly one wave slot, at most 4 per slot, longest first; the slowest wave of the
-    deal is no slower (cost model of the kernel) than under the contiguous deal it replaced."""
+@pytest.mark.parametrize("waves", [4, 16])
+@pytest.mark.parametrize("n_lines", [1, 16, 17, 77, 1232, 2048, 2049, 4096, 8192])
+def test_gru_tile_plan_covers_every_tile_once_and_balances(lib, n_lines, waves):
+    """Host side of the persistent GRU kernels (kernels_gru.hip::gru_assign_tiles): every 16-line tile of the
+    length-sorted batch goes to exactly one slot (general kernel: 4 waves per cluster, at most 4 tiles each; teams
+    kernel: 4 teams per cluster, at most 8 tiles each), longest first; the slowest slot of the deal is no slower (cost
+    model of the kernel) than under the contiguous deal it replaced."""
     rng = np.random.default_rng(n_lines)
     lengths = np.sort(rng.integers(25, 601, n_lines))[::-1]
-    st, ncl, tiles = _gru_plan(lib, lengths)
-    assert st == 0
+    st, ncl, tiles, W = _gru_plan(lib, lengths, waves=waves)
+    if waves == 4 and n_lines > 4096:
+        assert st == 9                                         # OCRS_ERR_CAPACITY: the general kernel holds 4 096 lines
+        return
+    assert st == 0 and W == waves
+    S, per = 4, (8 if waves == 16 else 4)                      # slots per cluster, tiles per slot
+    c, L = (3.0, 4.6) if waves == 16 else (4.7, 6.6)
     ntiles = (n_lines + 15) // 16
-    assert 1 <= ncl <= (8 if ntiles <= 128 else 16)
-    used = tiles[: 4 * 4 * ncl].reshape(-1, 4)
-    assert np.all(tiles[4 * 4 * ncl:] == -1)                   # the whole 512-entry buffer is initialised
+    assert 1 <= ncl <= (8 if ntiles <= 32 * per else 16)
+    used = tiles[: per * S * ncl].reshape(-1, per)
+    assert np.all(tiles[per * S * ncl:] == -1)                 # the whole 512-entry buffer is initialised
     flat = used[used >= 0]
     assert sorted(flat.tolist()) == list(range(ntiles))
     tl = [int(lengths[16 * k]) for k in range(ntiles)]
@@ -332,15 +347,16 @@ def test_gru_tile_plan_covers_every_tile_once_and_balances(lib, n_lines):
         idx = [int(t) for t in row if t >= 0]
         assert all(t == -1 for t in row[len(idx):])           # filled from the front
         assert idx == sorted(idx)                              # longest (lowest index) first
-        costs.append(_wave_cost([tl[t] for t in idx]))
-    rt = -(-ntiles // (4 * ncl))
-    contiguous = [_wave_cost([tl[k] for k in range((s // 4) * 4 * rt + s % 4, min(ntiles, (s // 4 + 1) * 4 * rt), 4)])
-                  for s in range(4 * ncl)]
+        costs.append(_wave_cost([tl[t] for t in idx], c, L))
+    rt = -(-ntiles // (S * ncl))
+    contiguous = [_wave_cost([tl[k] for k in range((s // S) * S * rt + s % S, min(ntiles, (s // S + 1) * S * rt), S)], c, L)
+                  for s in range(S * ncl)]
     assert max(costs) <= max(contiguous) + 1e-6
 
 
 def test_gru_tile_plan_rejects_what_the_kernel_cannot_hold(lib):
-    assert _gru_plan(lib, np.full(4097, 50, np.int32))[0] == 9      # OCRS_ERR_CAPACITY: > 4096 lines at H = 256
+    assert _gru_plan(lib, np.full(4097, 50, np.int32))[0] == 9      # OCRS_ERR_CAPACITY: > 4096 lines at H = 256 (general kernel)
+    assert _gru_plan(lib, np.full(8193, 50, np.int32), waves=16)[0] == 9   # > 8192 lines (teams kernel)
     assert _gru_plan(lib, np.full(64, 50, np.int32), hidden=96)[0] == 9  # unsupported hidden size
     assert _gru_plan(lib, [10, 20])[0] == 1                  # OCRS_ERR_INVALID_ARGUMENT: not descending
 

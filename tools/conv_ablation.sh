@@ -9,5 +9,5 @@ for v in ${ABL_SET:-0 1 2 4 6 7 0}; do
   hipcc $FLAGS -DOCRS_ABL=$v -c ocrs_amd/csrc/kernels_rec.hip -o ocrs_amd/_build/kernels_rec.o || exit 1
   hipcc --offload-arch=gfx950 -shared -fPIC -o ocrs_amd/libocrs_amd.so ocrs_amd/_build/*.o -lpthread || exit 1
   echo "== ablation mask $v"
-  timeout 200 python bench.py --pages 8 --steps 6 --warmup 2 --inflight 1 --no-cpu-baseline --no-extras --profile-hint --no-pipeline 2>&1 >/dev/null | grep -E "gemm_conv3x3"
+  timeout 200 python bench.py --pages ${ABL_PAGES:-16} --steps 6 --warmup 2 --inflight 1 --no-cpu-baseline --no-extras --profile-hint --no-pipeline 2>&1 >/dev/null | grep -E "gemm_conv3x3"
 done
