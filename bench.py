@@ -757,6 +757,32 @@ def extra_legs(engine, dptrs, host_pages, H, W, synth, np, DimOrder, sync_all, a
         out["host_decode"] = {"png_ms_per_page": round(1e3 * dec["PNG"], 2), "jpeg_ms_per_page": round(1e3 * dec["JPEG"], 2),
                               "png_bytes": len(enc["PNG"]), "jpeg_bytes": len(enc["JPEG"]),
                               "how": "PIL decode of one synthetic 1024x1024 RGB page to a u8 HWC array, one host core"}
+        # The JPEG hand-off (row f4): the host only entropy-decodes, the GPU does IDCT / upsampling / colour / grey conversion
+        # (pixels equal PIL's, tests/test_jpeg.py).  4:2:0 quality 90, what scanners write; one host core.
+        b = io.BytesIO()
+        Image.fromarray(host_pages[0]).save(b, "JPEG", quality=90, subsampling=2)
+        jdata = b.getvalue()
+        t0 = time.perf_counter()
+        for _ in range(6):
+            np.asarray(Image.open(io.BytesIO(jdata)).convert("RGB"))
+        pil_ms = 1e3 * (time.perf_counter() - t0) / 6
+        _lib.jpeg_info(jdata)
+        t0 = time.perf_counter()
+        for _ in range(6):
+            _lib.jpeg_info(jdata)
+        host_ms = 1e3 * (time.perf_counter() - t0) / 6
+        inp_j, coef_bytes = engine.prepare_input_jpeg(jdata)
+        t0 = time.perf_counter()
+        for _ in range(6):
+            inp_j, coef_bytes = engine.prepare_input_jpeg(jdata)
+        e2e_ms = 1e3 * (time.perf_counter() - t0) / 6
+        ref_j = engine.prepare_input(ImageSource.from_tensor(np.ascontiguousarray(np.asarray(Image.open(io.BytesIO(jdata)).convert("RGB"))), DimOrder.Hwc))
+        out["jpeg_handoff"] = {
+            "file_bytes": len(jdata), "bytes_to_gpu": coef_bytes, "rgb_bytes": int(host_pages[0].nbytes),
+            "host_entropy_decode_ms": round(host_ms, 2), "prepare_input_jpeg_ms": round(e2e_ms, 2), "pil_full_decode_ms": round(pil_ms, 2),
+            "grey_page_equals_pil_path": bool(np.array_equal(inp_j.image(), ref_j.image())),
+            "how": "one 1024x1024 synthetic page, JPEG 4:2:0 q90: host Huffman decode (one core) + GPU dequant / islow IDCT / fancy "
+                   "upsampling / YCbCr->RGB / grey conversion vs PIL decoding the same file on the host"}
     except Exception as e:  # PIL missing: the leg is informational
         out["host_decode"] = {"error": str(e)}
     # what this box sustains, next to the nominal peaks the roofline divides by

@@ -322,6 +322,32 @@ OCRS_API ocrs_status ocrs_engine_prepare_recognition_input(const ocrs_engine* e,
 OCRS_API ocrs_status ocrs_engine_get_text(const ocrs_engine* e, const ocrs_page* page, char** text);
 
 /* ------------------------------------------------------------------------
+ * JPEG hand-off.  The reference decodes image files on the host with the `image` crate before
+ * prepare_input (ocrs-cli/src/main.rs:312-333: image::open(path).into_rgb8()).  Here the host does only what is
+ * inherently serial — marker parsing and Huffman entropy decoding, baseline / extended sequential and progressive —
+ * and the GPU does dequantisation, the 8x8 inverse DCT, chroma upsampling and YCbCr -> RGB with libjpeg's integer
+ * arithmetic (jidctint.c islow, jdsample.c fancy upsampling, jdcolor.c), so the pixels equal libjpeg-turbo's / PIL's
+ * bit for bit; what crosses PCIe is the sparse coefficient stream (*coef_bytes, ~0.5-1 byte per pixel) instead of
+ * 3 bytes per pixel.  Unsupported flavours (arithmetic coding, lossless, 12-bit, CMYK, 4:4:0 or exotic sampling) return
+ * OCRS_ERR_IMAGE_SOURCE: decode those on the host as the reference does and call ocrs_engine_prepare_input.
+ *   ocrs_engine_prepare_input_jpeg  OcrEngine::prepare_input(ImageSource::from_bytes(into_rgb8(decode(file)))) in one call
+ *   ocrs_jpeg_decode_rgb            the decoded RGB8 HWC pixels on the host (tests, debugging); *rgb: ocrs_buffer_free
+ *   ocrs_jpeg_info                  host only: dimensions, component count, progressive?, non-zero coefficients
+ * coef_bytes and the out-parameters of ocrs_jpeg_info may be NULL.
+ * ---------------------------------------------------------------------- */
+OCRS_API ocrs_status ocrs_engine_prepare_input_jpeg(const ocrs_engine* e, const void* jpeg, size_t len, ocrs_page** out,
+                                                    size_t* coef_bytes);
+OCRS_API ocrs_status ocrs_jpeg_decode_rgb(int device, const void* jpeg, size_t len, uint8_t** rgb, int* height, int* width,
+                                          size_t* coef_bytes);
+OCRS_API ocrs_status ocrs_jpeg_info(const void* jpeg, size_t len, int* height, int* width, int* components, int* progressive,
+                                    size_t* nonzero);
+/* Test hook (host only): what the host half hands to the GPU, dense.  geom = {width, height, components, hmax, vmax,
+ * progressive, ycc} + per component {h, v, tq, width, height, blocks_w, blocks_h}; quant = 4 tables x 64, natural order;
+ * *coef = n_blocks x 64 quantised coefficients in natural order, blocks in component order, row-major (ocrs_buffer_free). */
+OCRS_API ocrs_status ocrs_jpeg_coefficients(const void* jpeg, size_t len, int32_t geom[28], uint16_t quant[256], int16_t** coef,
+                                            size_t* n_blocks);
+
+/* ------------------------------------------------------------------------
  * Several GPUs in one process: an engine group.  One engine (and one replica of the weights) per member device;
  * every page of a call is processed by a member of the device the page lives on, every member runs its share on a
  * worker thread and streams of its own, results come back in page order.  Pages are independent (OcrEngine is

@@ -354,6 +354,16 @@ class OcrEngine:
                                                      h, w, c, C.byref(h_out)))
         return OcrInput(h_out)
 
+    def prepare_input_jpeg(self, data):
+        """prepare_input fed with a JPEG file's bytes (ocrs-cli/src/main.rs:312-333 decodes on the host first): Huffman
+        decoding on the host, IDCT / upsampling / colour conversion / grey conversion on the GPU.  -> (OcrInput, bytes that
+        crossed PCIe).  Raises OcrsError (IMAGE_SOURCE) for flavours the hand-off does not cover."""
+        h_out = C.c_void_p()
+        cb = C.c_size_t(0)
+        buf = C.create_string_buffer(bytes(data), len(data))
+        check(lib().ocrs_engine_prepare_input_jpeg(self._h, buf, C.c_size_t(len(data)), C.byref(h_out), C.byref(cb)))
+        return OcrInput(h_out), cb.value
+
     # ---- lib.rs:193-199
     def detect_words(self, inp):
         rects = C.POINTER(C.c_float)()

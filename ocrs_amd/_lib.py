@@ -65,7 +65,7 @@ DECLARED_SYMBOLS = [
     "ocrs_get_device", "ocrs_model_load_file_on_device", "ocrs_model_load_bytes_on_device", "ocrs_model_device", "ocrs_engine_device",
     "ocrs_engine_group_new", "ocrs_engine_group_free", "ocrs_engine_group_size", "ocrs_engine_group_member", "ocrs_group_deal",
     "ocrs_group_prepare_input_batch", "ocrs_group_prepare_input_device_batch", "ocrs_group_detect_words_batch",
-    "ocrs_group_recognize_text_batch", "ocrs_group_gather", "ocrs_group_final_gather", "ocrs_group_worker_threads", "ocrs_group_last_gather", "ocrs_device_malloc_on", "ocrs_engine_coalesce_stats", "ocrs_coalescer_selftest", "ocrs_engine_kernel_mfma_flops",
+    "ocrs_group_recognize_text_batch", "ocrs_group_gather", "ocrs_group_final_gather", "ocrs_group_worker_threads", "ocrs_group_last_gather", "ocrs_device_malloc_on", "ocrs_engine_coalesce_stats", "ocrs_coalescer_selftest", "ocrs_engine_kernel_mfma_flops", "ocrs_engine_prepare_input_jpeg", "ocrs_jpeg_decode_rgb", "ocrs_jpeg_info", "ocrs_jpeg_coefficients",
 ]
 
 _lib = None
@@ -135,3 +135,36 @@ def require_gpu():
     if n < 1:
         raise OcrsError(7, "no HIP device visible: the ocrs_amd engine has no CPU fallback")
     return n
+
+
+def jpeg_coefficients(data):
+    """ocrs_jpeg_coefficients (host only): (geom int32[28], quant uint16[256], coef int16[n_blocks, 64])."""
+    import numpy as np
+    geom = (C.c_int32 * 28)()
+    quant = (C.c_uint16 * 256)()
+    coef = C.POINTER(C.c_int16)()
+    nb = C.c_size_t(0)
+    buf = C.create_string_buffer(bytes(data), len(data))
+    check(lib().ocrs_jpeg_coefficients(buf, C.c_size_t(len(data)), geom, quant, C.byref(coef), C.byref(nb)))
+    a = np.ctypeslib.as_array(coef, shape=(max(nb.value, 1) * 64,))[: nb.value * 64].reshape(-1, 64).copy()
+    lib().ocrs_buffer_free(coef)
+    return np.array(geom[:], np.int32), np.array(quant[:], np.uint16), a
+
+
+def jpeg_info(data):
+    h, w, n, prog, nz = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0), C.c_size_t(0)
+    buf = C.create_string_buffer(bytes(data), len(data))
+    check(lib().ocrs_jpeg_info(buf, C.c_size_t(len(data)), C.byref(h), C.byref(w), C.byref(n), C.byref(prog), C.byref(nz)))
+    return {"height": h.value, "width": w.value, "components": n.value, "progressive": bool(prog.value), "nonzero": nz.value}
+
+
+def jpeg_decode_rgb(data, device=-1):
+    """ocrs_jpeg_decode_rgb: host entropy decode + GPU IDCT / upsampling / colour -> (RGB8 [H, W, 3], bytes that crossed PCIe)."""
+    import numpy as np
+    rgb = C.POINTER(C.c_uint8)()
+    h, w, cb = C.c_int(0), C.c_int(0), C.c_size_t(0)
+    buf = C.create_string_buffer(bytes(data), len(data))
+    check(lib().ocrs_jpeg_decode_rgb(C.c_int(device), buf, C.c_size_t(len(data)), C.byref(rgb), C.byref(h), C.byref(w), C.byref(cb)))
+    a = np.ctypeslib.as_array(rgb, shape=(h.value * w.value * 3,)).reshape(h.value, w.value, 3).copy()
+    lib().ocrs_buffer_free(rgb)
+    return a, cb.value

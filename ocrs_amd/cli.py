@@ -51,13 +51,31 @@ def main(argv=None):
     args = ap.parse_args(argv)
 
     from . import DecodeMethod, DimOrder, ImageSource, Model, OcrEngine, models, output
+    from ._lib import OcrsError
     det = Model.load_file(args.detect_model) if args.detect_model else Model.load_bytes(models.synthetic_detection_bytes())
     rec = Model.load_file(args.rec_model) if args.rec_model else Model.load_bytes(models.synthetic_recognition_bytes())
     engine = OcrEngine(detection_model=det, recognition_model=rec, debug=args.debug, alphabet=args.alphabet,
                        allowed_chars=args.allowed_chars,
                        decode_method=DecodeMethod.BeamSearch(100) if args.beam else DecodeMethod.Greedy)
-    img = load_image(args.image)
-    inp = engine.prepare_input(ImageSource.from_tensor(img, DimOrder.Hwc))
+    # JPEG files: Huffman decoding here, everything per-sample on the GPU (include/ocrs_amd.h "JPEG hand-off"); flavours
+    # the hand-off does not cover, and every other format, are decoded on the host as the reference does (main.rs:312-323)
+    inp, shape_hw = None, None
+    with open(args.image, "rb") as f:
+        head = f.read(2)
+        if head == b"\xff\xd8" and not os.environ.get("OCRS_CLI_HOST_DECODE"):
+            data = head + f.read()
+            try:
+                inp, coef_bytes = engine.prepare_input_jpeg(data)
+                shape_hw = inp.shape[-2:]
+                if args.debug:
+                    print("JPEG hand-off: %d bytes of coefficients to the GPU for %dx%d pixels" % (coef_bytes, shape_hw[1], shape_hw[0]))
+            except OcrsError as e:
+                if e.status != 6:   # OCRS_ERR_IMAGE_SOURCE = a flavour to decode on the host
+                    raise
+    if inp is None:
+        img = load_image(args.image)
+        shape_hw = img.shape[:2]
+        inp = engine.prepare_input(ImageSource.from_tensor(img, DimOrder.Hwc))
     if args.text_map or args.text_mask:
         tm = engine.detect_text_pixels(inp)
         if args.text_map:
@@ -72,7 +90,7 @@ def main(argv=None):
             write_image("lines/line-%d.png" % i, engine.prepare_recognition_input(inp, line) + np.float32(0.5))
     texts = engine.recognize_text(inp, lines)
     if args.json:
-        content = output.format_json_output(args.image, img.shape[:2], texts)
+        content = output.format_json_output(args.image, tuple(shape_hw), texts)
     else:
         content = output.format_text_output(texts)
     if args.output:
@@ -81,7 +99,7 @@ def main(argv=None):
     else:
         print(content)
     if args.debug:
-        print("Found %d words, %d lines in image of size %dx%d" % (len(words), len(lines), img.shape[1], img.shape[0]))
+        print("Found %d words, %d lines in image of size %dx%d" % (len(words), len(lines), shape_hw[1], shape_hw[0]))
     return 0
 
 

@@ -9,6 +9,7 @@
 #include "coalesce_selftest.hpp"
 #include "engine.hpp"
 #include "host_pool.hpp"
+#include "jpeg.hpp"
 #include "kernels.hpp"
 
 using namespace ocrs;
@@ -311,6 +312,91 @@ ocrs_status ocrs_engine_prepare_input_device(const ocrs_engine* e, const void* d
         ws.sync();
         if (e->tm()) e->tm()->collect();
         *out = p;
+    });
+}
+
+namespace {
+// Host entropy decode -> sparse coefficients to the device -> IDCT / upsampling / colour on the GPU: RGB u8 HWC in `ws`.
+// *coef_bytes = what crossed PCIe instead of width * height * 3 bytes of pixels.
+uint8_t* jpeg_to_device_rgb(Workspace& ws, const void* jpeg, size_t len, int* height, int* width, size_t* coef_bytes) {
+    const ocrs::jpeg::Coefficients c = ocrs::jpeg::decode_coefficients(static_cast<const uint8_t*>(jpeg), len);
+    const size_t nb = c.nblocks();
+    uint64_t* d_mask = ws.alloc_n<uint64_t>(nb);
+    uint32_t* d_off = ws.alloc_n<uint32_t>(nb + 1);
+    int16_t* d_val = ws.alloc_n<int16_t>(c.values.size() + 1);
+    uint16_t* d_q = ws.alloc_n<uint16_t>(4 * 64);
+    ws.upload(d_mask, c.mask.data(), nb * sizeof(uint64_t));
+    ws.upload(d_off, c.offset.data(), (nb + 1) * sizeof(uint32_t));
+    ws.upload(d_val, c.values.data(), c.values.size() * sizeof(int16_t));
+    ws.upload(d_q, c.quant, sizeof c.quant);
+    uint8_t* d_samples = ws.alloc_n<uint8_t>(k::jpeg_sample_bytes(c));
+    uint8_t* d_rgb = ws.alloc_n<uint8_t>((size_t)c.width * c.height * 3);
+    k::jpeg_decode(c, d_mask, d_off, d_val, d_q, d_samples, d_rgb, ws.s());
+    OCRS_HIP(hipGetLastError());
+    *height = c.height;
+    *width = c.width;
+    if (coef_bytes) *coef_bytes = nb * 12 + 4 + c.values.size() * 2 + sizeof c.quant;
+    return d_rgb;
+}
+}  // namespace
+
+ocrs_status ocrs_engine_prepare_input_jpeg(const ocrs_engine* e, const void* jpeg, size_t len, ocrs_page** out, size_t* coef_bytes) {
+    return guarded_on(e ? e->device : -1, [&] {
+        if (!e || !jpeg || !out) fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
+        Workspace ws;
+        int h = 0, w = 0;
+        const uint8_t* d_rgb = jpeg_to_device_rgb(ws, jpeg, len, &h, &w, coef_bytes);
+        ocrs_page* p = make_page(d_rgb, OCRS_U8, OCRS_HWC, h, w, 3, ws.s(), e->tm());
+        ws.sync();
+        if (e->tm()) e->tm()->collect();
+        *out = p;
+    });
+}
+
+ocrs_status ocrs_jpeg_decode_rgb(int device, const void* jpeg, size_t len, uint8_t** rgb, int* height, int* width, size_t* coef_bytes) {
+    return guarded_on(device, [&] {
+        if (!jpeg || !rgb || !height || !width) fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
+        Workspace ws;
+        const uint8_t* d_rgb = jpeg_to_device_rgb(ws, jpeg, len, height, width, coef_bytes);
+        std::vector<uint8_t> host((size_t)*height * *width * 3);
+        ws.download(host.data(), d_rgb, host.size());
+        ws.sync();
+        *rgb = dup_buffer(host);
+    });
+}
+
+ocrs_status ocrs_jpeg_info(const void* jpeg, size_t len, int* height, int* width, int* components, int* progressive, size_t* nonzero) {
+    return guarded([&] {
+        if (!jpeg) fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
+        const ocrs::jpeg::Coefficients c = ocrs::jpeg::decode_coefficients(static_cast<const uint8_t*>(jpeg), len);
+        if (height) *height = c.height;
+        if (width) *width = c.width;
+        if (components) *components = c.ncomp;
+        if (progressive) *progressive = c.progressive ? 1 : 0;
+        if (nonzero) *nonzero = c.values.size();
+    });
+}
+
+ocrs_status ocrs_jpeg_coefficients(const void* jpeg, size_t len, int32_t geom[28], uint16_t quant[256], int16_t** coef, size_t* n_blocks) {
+    return guarded([&] {
+        if (!jpeg || !geom || !quant || !coef || !n_blocks) fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
+        const ocrs::jpeg::Coefficients c = ocrs::jpeg::decode_coefficients(static_cast<const uint8_t*>(jpeg), len);
+        const int32_t head[7] = {c.width, c.height, c.ncomp, c.hmax, c.vmax, c.progressive ? 1 : 0, c.ycc ? 1 : 0};
+        memcpy(geom, head, sizeof head);
+        for (int i = 0; i < 3; i++) {
+            const auto& k = c.comp[i];
+            const int32_t row[7] = {k.h, k.v, k.tq, k.width, k.height, k.blocks_w, k.blocks_h};
+            memcpy(geom + 7 + 7 * i, row, sizeof row);
+        }
+        memcpy(quant, c.quant, sizeof c.quant);
+        std::vector<int16_t> dense(c.nblocks() * 64, 0);
+        for (size_t b = 0; b < c.nblocks(); b++) {
+            uint32_t at = c.offset[b];
+            for (int p = 0; p < 64; p++)
+                if ((c.mask[b] >> p) & 1) dense[b * 64 + p] = c.values[at++];
+        }
+        *coef = dup_buffer(dense);
+        *n_blocks = c.nblocks();
     });
 }
 

@@ -6,6 +6,7 @@
 #include <cstdint>
 
 namespace ocrs {
+namespace jpeg { struct Coefficients; }
 namespace k {
 
 // ---- kernels_image.hip ----------------------------------------------------
@@ -216,6 +217,11 @@ void crop_lines(const float* const* d_pages, const int32_t* d_page_hw /*[pages][
 
 // kernels_peaks.hip
 void measure_peaks(double* mfma_tflops, double* copy_gbps);
+
+// kernels_jpeg.hip — the GPU half of the JPEG hand-off (jpeg.hpp)
+size_t jpeg_sample_bytes(const jpeg::Coefficients& c);
+void jpeg_decode(const jpeg::Coefficients& c, const uint64_t* d_mask, const uint32_t* d_offset, const int16_t* d_values,
+                 const uint16_t* d_quant, uint8_t* d_samples, uint8_t* d_rgb, hipStream_t s);
 
 }  // namespace k
 }  // namespace ocrs

@@ -85,8 +85,12 @@ def main(names):
         results = recognize_with_steps(ora, inp, lines)
         toks, toff, chars, coff = pack(results)
         text = "\n".join(str(tl) for _, tl in results if tl is not None)
+        # the JPEG's own bytes travel too (the GPU box has no /root/reference): the JPEG hand-off of row f4 decodes THEM
+        file_bytes = np.frombuffer(open(os.path.join(REF, IMAGES[name]), "rb").read(), np.uint8) if IMAGES[name].endswith(".jpg") \
+            else np.zeros(0, np.uint8)
         np.savez_compressed(
             os.path.join(out_dir, name + ".npz"), model_digests=digests, ink=np.array(INK[name], np.float64), source=np.array([IMAGES[name]]), pixels=px,
+            file_bytes=file_bytes,
             grey_bits_sum=np.array([bits_sum(inp)], np.uint64), prob_bits_sum=np.array([bits_sum(prob)], np.uint64),
             mask=np.packbits(mask), mask_shape=np.array(mask.shape, np.int64),
             word_rects=np.array([w.to_array() for w in words], np.float32).reshape(-1, 6),

@@ -10,6 +10,8 @@
 //                                          every page also twice at once; prints an FNV-1a hash of all lines
 //   host_harness beam                      ctc_beam_search (ctc_beam.cpp) against its textbook formulation on random matrices
 //   host_harness text_items                text_item_rotated_rect (text_items.cpp) on random character boxes
+//   host_harness jpeg <streams.bin>        the JPEG marker parser and Huffman decoders (jpeg_host.cpp) on valid, truncated and
+//                                          corrupted streams: every one must come back as coefficients or as an ocrs::Error
 #include <cinttypes>
 #include <cstdio>
 #include <cstdlib>
@@ -21,6 +23,7 @@
 #include "../../ocrs_amd/csrc/engine.hpp"
 #include "../../ocrs_amd/csrc/geometry.hpp"
 #include "../../ocrs_amd/csrc/host_pool.hpp"
+#include "../../ocrs_amd/csrc/jpeg.hpp"
 
 using namespace ocrs;
 using ocrs::geom::RotatedRect;
@@ -196,6 +199,33 @@ static int run_text_items() {
     return check(made > 1500, "most random character runs have a rotated rect");
 }
 
+static int run_jpeg(const char* path) {
+    FILE* f = fopen(path, "rb");
+    if (!f) { perror(path); return 1; }
+    uint32_t n = 0;
+    if (fread(&n, 4, 1, f) != 1) return 1;
+    int decoded = 0, refused = 0;
+    uint64_t h = 14695981039346656037ull;
+    for (uint32_t i = 0; i < n; i++) {
+        uint32_t len = 0;
+        if (fread(&len, 4, 1, f) != 1) return 1;
+        std::vector<uint8_t> buf(len);   // exact size: an over-read is an ASan report
+        if (len && fread(buf.data(), 1, len, f) != len) return 1;
+        try {
+            const jpeg::Coefficients c = jpeg::decode_coefficients(buf.data(), buf.size());
+            decoded++;
+            h = fnv(h, c.values.data(), c.values.size() * sizeof(int16_t));
+            h = fnv(h, c.mask.data(), c.mask.size() * sizeof(uint64_t));
+            if (c.offset.size() != c.mask.size() + 1 || c.offset.back() != c.values.size()) return check(false, "sparse layout inconsistent");
+        } catch (const Error&) {
+            refused++;
+        }
+    }
+    fclose(f);
+    printf("jpeg: %d decoded, %d refused, hash %016" PRIx64 "\n", decoded, refused, h);
+    return check(decoded > 0, "at least the intact streams decode");
+}
+
 int main(int argc, char** argv) {
     const std::string mode = argc > 1 ? argv[1] : "";
     int bad = 0;
@@ -204,7 +234,8 @@ int main(int argc, char** argv) {
     else if (mode == "layout" && argc > 3) bad = run_layout(argv[2], atoi(argv[3]));
     else if (mode == "beam") bad = run_beam();
     else if (mode == "text_items") bad = run_text_items();
-    else { fprintf(stderr, "usage: host_harness coalescer|shares|layout <pages.bin> <threads>|beam|text_items\n"); return 2; }
+    else if (mode == "jpeg" && argc > 2) bad = run_jpeg(argv[2]);
+    else { fprintf(stderr, "usage: host_harness coalescer|shares|layout <pages.bin> <threads>|beam|text_items|jpeg <streams.bin>\n"); return 2; }
     printf("%s: %s\n", mode.c_str(), bad ? "FAILED" : "ok");
     return bad ? 1 : 0;
 }

@@ -18,8 +18,8 @@ ROOT = os.path.dirname(HERE)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 CSRC = os.path.join(ROOT, "ocrs_amd", "csrc")
 OUT = os.path.join(HERE, "sanitize", "_build")
-SOURCES = [os.path.join(HERE, "sanitize", "host_harness.cpp")] + [os.path.join(CSRC, f) for f in ("layout.cpp", "ctc_beam.cpp", "text_items.cpp")]
-HEADERS = [os.path.join(CSRC, f) for f in ("coalesce.hpp", "coalesce_selftest.hpp", "host_pool.hpp", "geometry.hpp", "engine.hpp", "beam_math.hpp")]
+SOURCES = [os.path.join(HERE, "sanitize", "host_harness.cpp")] + [os.path.join(CSRC, f) for f in ("layout.cpp", "ctc_beam.cpp", "text_items.cpp", "jpeg_host.cpp")]
+HEADERS = [os.path.join(CSRC, f) for f in ("coalesce.hpp", "coalesce_selftest.hpp", "host_pool.hpp", "geometry.hpp", "engine.hpp", "beam_math.hpp", "jpeg.hpp")]
 REPORT_MARKS = ("WARNING: ThreadSanitizer", "ERROR: AddressSanitizer", "ERROR: LeakSanitizer", "runtime error:")
 
 
@@ -106,6 +106,41 @@ def test_layout_analysis_on_the_batch_pool_is_clean_and_gives_the_librarys_lines
     for ptr in (lr, lo, po):
         L.ocrs_buffer_free(ptr)
     assert got == "%016x" % h
+
+
+@pytest.mark.parametrize("kind", ["address,undefined"])
+def test_jpeg_parser_and_huffman_decoders_survive_corrupt_streams_under_asan(kind, tmp_path):
+    """jpeg_host.cpp parses bytes from files: intact streams of every flavour, every prefix length class, bit flips in headers,
+    tables and entropy-coded data — each must return coefficients or an error, with no out-of-bounds access, overflow or
+    leak; the intact ones hash like the library's own decode."""
+    import io
+    from PIL import Image
+    from ocrs_amd import synth
+    rng = np.random.default_rng(11)
+    px = synth.synthetic_page(2, 96, 128, lines=6, columns=1)
+    intact = []
+    for ss, prog, rst in ((0, False, 0), (2, False, 3), (1, True, 0), (2, True, 4)):
+        b = io.BytesIO()
+        Image.fromarray(px).save(b, "JPEG", quality=70, subsampling=ss, progressive=prog, **({"restart_marker_blocks": rst} if rst else {}))
+        intact.append(b.getvalue())
+    streams = list(intact)
+    for data in intact:
+        for cut in sorted(set(int(v) for v in rng.integers(0, len(data), 40))):
+            streams.append(data[:cut])
+        for _ in range(120):
+            a = bytearray(data)
+            for _ in range(int(rng.integers(1, 6))):
+                a[int(rng.integers(2, len(a)))] ^= 1 << int(rng.integers(0, 8))
+            streams.append(bytes(a))
+    path = tmp_path / "streams.bin"
+    with open(path, "wb") as f:
+        f.write(np.uint32(len(streams)).tobytes())
+        for sdata in streams:
+            f.write(np.uint32(len(sdata)).tobytes())
+            f.write(sdata)
+    out = run(kind, "jpeg", path)
+    line = [l for l in out.splitlines() if l.startswith("jpeg:")][0]
+    assert int(line.split()[1]) >= len(intact)
 
 
 def _fuzz_range(lo_hi):
