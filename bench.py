@@ -63,8 +63,10 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pages", type=int, default=2, help="pages in the bounded CPU-baseline sample")
     ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--inflight", type=int, default=6,
-                    help="full steps kept in flight on separate host threads / HIP streams (default 6; 1 = the "
+    ap.add_argument("--inflight", type=int, default=5,
+                    help="full steps kept in flight on separate host threads / HIP streams (default 5 = the knee of the "
+                         "throughput / latency / memory curve, tools/inflight_sweep.sh: 6 and 7 add 0.3 % and 1 % pages/s for "
+                         "+50 / +110 ms of request latency and +6 GB each; 1 = the "
                          "2-stage pipeline or, with --no-pipeline, strictly sequential steps)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="run the stages of each step strictly one after another (default: 2-stage software "
@@ -353,6 +355,11 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
     host_cpu_s = time.process_time() - cpu0  # all host threads of this rank (layout analysis dominates)
+    try:   # device memory in use by this process's pools after the timed region (cached blocks included)
+        free_b, total_b = torch.cuda.mem_get_info(dev_index)
+        dev_mem_gb = round((total_b - free_b) / 2**30, 1)
+    except Exception:
+        dev_mem_gb = None
     stages = engine.stage_times(reset=False)
     kstats = engine.kernel_stats(reset=True)
     engine.enable_timing(0)
@@ -439,6 +446,7 @@ def main():
                                 "p99": round(1e3 * float(np.percentile(step_latency, 99)), 2),
                                 "pages_per_request": BG, "requests_in_flight": max(1, args.inflight)} if step_latency else None),
         "host_cpu_cores_busy_per_gpu": round(host_cpu_s / elapsed, 2),
+        "device_memory_in_use_gb": dev_mem_gb,
         "host_cores_budget_per_rank": per_rank_cores,
         "chars_last_step": len(last[2][0]),
         "gathered_pages": sum(len(g) for g in gathered if g),

@@ -100,6 +100,9 @@ struct DeviceContext {
     hipStream_t heavy_stream();
     hipStream_t recurrent_stream();
     int cu_count();
+    // intermediate activations of the conv stacks that run on heavy_stream(): shared by all requests (stream order is
+    // the exclusion), guarded by heavy_phase; see HipModel::run_prefix_ragged
+    std::vector<struct DevBuf> heavy_arena;
     // recycled per-call streams (StreamLease)
     std::mutex stream_mu;
     std::vector<std::pair<hipStream_t, hipEvent_t>> streams;

@@ -816,11 +816,29 @@ float* HipModel::run_prefix_ragged(Workspace& ws, hipStream_t exec, const std::v
     int curC = 1;
     float* prev_buf = nullptr;  // buffer holding `cur` (nullptr: the caller's input)
     std::vector<std::pair<float*, size_t>> spare;  // released buffers, reused by later layers
+    // On the device's shared conv-stack stream the intermediate activations come from the DEVICE's arena instead of the
+    // request's workspace: they are touched only by kernels of that one stream, which run in the order they were enqueued
+    // (under heavy_phase, held here since before_launch), so every request's stack can use the same few buffers — with
+    // six 16-page requests in flight that is ~5 GB once instead of ~5 GB per request.  Buffers are never handed back while
+    // the process runs (an earlier request's kernels may still be using them); the arena grows to the largest request seen.
+    const bool shared_arena = exec != ws.s();
+    std::vector<char> arena_taken;
     auto get = [&](size_t floats) -> float* {
         const size_t bytes = floats * sizeof(float);
         for (size_t i = 0; i < spare.size(); i++)
             if (spare[i].second >= bytes) { float* p = spare[i].first; spare.erase(spare.begin() + i); return p; }
-        return static_cast<float*>(ws.alloc(bytes));
+        if (!shared_arena) return static_cast<float*>(ws.alloc(bytes));
+        auto& arena = ctx().heavy_arena;
+        arena_taken.resize(arena.size(), 0);
+        size_t best = arena.size();
+        for (size_t i = 0; i < arena.size(); i++)
+            if (!arena_taken[i] && arena[i].bytes >= bytes && (best == arena.size() || arena[i].bytes < arena[best].bytes)) best = i;
+        if (best == arena.size()) {
+            arena.emplace_back(bytes + bytes / 8);   // a little head-room: requests of a stream differ by a few lines
+            arena_taken.push_back(0);
+        }
+        arena_taken[best] = 1;
+        return arena[best].as<float>();
     };
     size_t prev_bytes = 0;
     for (int i = 0; i < ts; i++) {
@@ -1002,13 +1020,19 @@ int HipModel::run_recognition_packed(Workspace& ws, const std::vector<PackedGrou
     int curC = C0;
     int classes = 0;
     int gru_layer = 0;
+    float* gx_buf = nullptr;
+    size_t gx_cap = 0;
     for (size_t i = ts + 1; i < ops.size(); i++) {
         const GraphOp& op = ops[i];
         if (op.type == OP_GRU) {
             const int H = op.hidden, I = op.cin;
             if (I != curC) fail(OCRS_ERR_RUN_FAILED, "model run failed: GRU input size %d != %d", I, curC);
             int tok = timers ? timers->begin(ST_REC_GRU, st, 0) : -1;
-            float* gx = ws.alloc_n<float>((size_t)2 * R * 3 * H);
+            // the input projections of a layer are dead once its recurrence has run, and the next layer's projection is
+            // ordered after that recurrence (it reads its output): one buffer serves every layer (2.3 GB per layer at 16 pages)
+            const size_t gx_floats = (size_t)2 * R * 3 * H;
+            if (gx_floats > gx_cap) { gx_buf = ws.alloc_n<float>(gx_floats); gx_cap = gx_floats; }
+            float* gx = gx_buf;
             float* y = ws.alloc_n<float>((size_t)R * 2 * H);
             const bool fused = (H == 256 || H == 128 || H == 64);
             const bool persistent = fused && gru_mode() == GRU_PERSISTENT && k::gru_persistent_supported(M, plan.Tmax, R, H);
