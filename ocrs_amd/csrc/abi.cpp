@@ -392,8 +392,11 @@ ocrs_status ocrs_jpeg_coefficients(const void* jpeg, size_t len, int32_t geom[28
         std::vector<int16_t> dense(c.nblocks() * 64, 0);
         for (size_t b = 0; b < c.nblocks(); b++) {
             uint32_t at = c.offset[b];
-            for (int p = 0; p < 64; p++)
-                if ((c.mask[b] >> p) & 1) dense[b * 64 + p] = c.values[at++];
+            for (int p = 0; p < 64; p++) {
+                const int z = ocrs::jpeg::Coefficients::kZigzagOfNatural[p];
+                if ((c.mask[b] >> z) & 1) dense[b * 64 + p] = c.values[c.offset[b] + __builtin_popcountll(c.mask[b] & ((uint64_t(1) << z) - 1))];
+            }
+            (void)at;
         }
         *coef = dup_buffer(dense);
         *n_blocks = c.nblocks();

@@ -37,9 +37,11 @@ struct Coefficients {
     Component comp[3];
     uint16_t quant[4][64] = {};         // natural (row-major) order
     // sparse coefficients, blocks in component order, row-major inside a component:
-    std::vector<uint64_t> mask;         // bit p set <=> coefficient at natural position p (row * 8 + col) is non-zero
-    std::vector<uint32_t> offset;       // [nblocks + 1] index of the block's first value
-    std::vector<int16_t> values;        // the non-zero coefficients of a block in ascending natural position
+    std::vector<uint64_t> mask;         // bit z set <=> the coefficient with ZIG-ZAG index z is non-zero
+    std::vector<uint32_t> offset;       // [nblocks + 1] index of the block's first value (blocks may sit in `values` in any
+                                        // order — the order they were decoded in; [nblocks] = values.size())
+    std::vector<int16_t> values;        // the non-zero coefficients of a block in ascending zig-zag index
+    static const uint8_t kZigzagOfNatural[64];   // natural position (row * 8 + col) -> zig-zag index
     size_t nblocks() const { return mask.size(); }
 };
 

@@ -17,6 +17,14 @@ const uint8_t kNatural[64 + 16] = {   // zig-zag index -> natural (row * 8 + col
     35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63,
     63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63};
 
+}  // namespace
+
+const uint8_t Coefficients::kZigzagOfNatural[64] = {
+    0,  1,  5,  6,  14, 15, 27, 28, 2,  4,  7,  13, 16, 26, 29, 42, 3,  8,  12, 17, 25, 30, 41, 43, 9,  11, 18, 24, 31, 40, 44, 53,
+    10, 19, 23, 32, 39, 45, 52, 54, 20, 22, 33, 38, 46, 51, 55, 60, 21, 34, 37, 47, 50, 56, 59, 61, 35, 36, 48, 49, 57, 58, 62, 63};
+
+namespace {
+
 [[noreturn]] void bad(const char* what) { fail(OCRS_ERR_IMAGE_SOURCE, "JPEG: %s", what); }
 
 struct Huff {
@@ -24,7 +32,11 @@ struct Huff {
     uint8_t bits[17] = {};
     uint8_t vals[256] = {};
     int32_t mincode[17] = {}, maxcode[18] = {}, valptr[17] = {};
-    uint8_t look_n[256] = {}, look_v[256] = {};   // codes of up to 8 bits by their left-aligned 8-bit prefix
+    static constexpr int kLook = 9;
+    uint8_t look_n[1 << kLook] = {}, look_v[1 << kLook] = {};   // codes of up to 9 bits by their left-aligned 9-bit prefix
+    // AC fast path: when code + magnitude bits fit the 9-bit window and the value fits 8 bits, the whole coefficient comes
+    // from one table look-up: (value << 8) | (run << 4) | total bits; 0 = take the general path
+    int16_t fast_ac[1 << kLook] = {};
     void build() {
         int code = 0, k = 0;
         memset(look_n, 0, sizeof look_n);
@@ -32,11 +44,11 @@ struct Huff {
             valptr[l] = k;
             mincode[l] = code;
             if (bits[l]) {
-                if (l <= 8) {
+                if (l <= kLook) {
                     for (int i = 0; i < bits[l]; i++) {
-                        const int first = (code + i) << (8 - l);
-                        for (int f = 0; f < (1 << (8 - l)); f++) {
-                            if (first + f > 255) bad("bad Huffman table");
+                        const int first = (code + i) << (kLook - l);
+                        for (int f = 0; f < (1 << (kLook - l)); f++) {
+                            if (first + f >= (1 << kLook)) bad("bad Huffman table");
                             look_n[first + f] = (uint8_t)l;
                             look_v[first + f] = vals[k + i];
                         }
@@ -52,6 +64,16 @@ struct Huff {
             code <<= 1;
         }
         maxcode[17] = 0x7fffffff;
+        for (int i = 0; i < (1 << kLook); i++) {
+            fast_ac[i] = 0;
+            const int len = look_n[i];
+            if (!len) continue;
+            const int rs = look_v[i], run = rs >> 4, mag = rs & 15;
+            if (mag == 0 || len + mag > kLook) continue;
+            int v = ((i << len) & ((1 << kLook) - 1)) >> (kLook - mag);
+            if (v < (1 << (mag - 1))) v += (int)((~0u) << mag) + 1;   // EXTEND
+            if (v >= -128 && v <= 127) fast_ac[i] = (int16_t)(v * 256 + run * 16 + (len + mag));
+        }
         present = true;
     }
 };
@@ -90,10 +112,10 @@ struct Bits {
     void skip(int k) { n -= k; }
     uint32_t get(int k) { if (k == 0) return 0; const uint32_t v = peek(k); skip(k); return v; }
     int decode(const Huff& h) {
-        const uint32_t p8 = peek(8);
-        if (h.look_n[p8]) { skip(h.look_n[p8]); return h.look_v[p8]; }
-        int l = 9;
-        int32_t code = (int32_t)peek(9);
+        const uint32_t p9 = peek(Huff::kLook);
+        if (h.look_n[p9]) { skip(h.look_n[p9]); return h.look_v[p9]; }
+        int l = Huff::kLook + 1;
+        int32_t code = (int32_t)peek(l);
         while (l <= 16 && code > h.maxcode[l]) { l++; if (l <= 16) code = (int32_t)peek(l); }
         if (l > 16) { skip(16); return 0; }   // corrupt data: the garbage-in rule of every decoder, no error
         skip(l);
@@ -120,7 +142,8 @@ struct Decoder {
     bool saw_sof = false, adobe = false, jfif = false;
     int adobe_transform = -1;
 
-    int16_t* block(const Component& k, int by, int bx) { return coef.data() + (k.first_block + (size_t)by * k.blocks_w + bx) * 64; }
+    size_t block_index(const Component& k, int by, int bx) const { return k.first_block + (size_t)by * k.blocks_w + bx; }
+    int16_t* block(const Component& k, int by, int bx) { return coef.data() + block_index(k, by, bx) * 64; }
 
     void parse_sof(const uint8_t* s, size_t len, int marker) {
         if (saw_sof) bad("more than one frame");
@@ -160,7 +183,13 @@ struct Decoder {
             first += (size_t)k.blocks_w * k.blocks_h;
         }
         if (first > ((size_t)1 << 26)) bad("image too large");
-        coef.assign(first * 64, 0);
+        // progressive scans refine coefficients in place: dense accumulation, made sparse at the end.  Sequential streams
+        // decode every block exactly once: the sparse form is written directly (no 2 bytes-per-sample buffer to clear and scan)
+        if (c.progressive) coef.assign(first * 64, 0);
+        c.mask.assign(first, 0);
+        c.offset.assign(first + 1, 0);
+        c.values.clear();
+        c.values.reserve(first * 12);
         saw_sof = true;
     }
 
@@ -252,9 +281,12 @@ struct Decoder {
                     const int bh = inter ? k.h : 1, bv = inter ? k.v : 1;
                     for (int v = 0; v < bv; v++)
                         for (int h = 0; h < bh; h++) {
+                            if (!c.progressive) {
+                                sequential_block(br, block_index(k, my * bv + v, mx * bh + h), dc[td[i]], ac[ta[i]], pred[i]);
+                                continue;
+                            }
                             int16_t* b = block(k, my * bv + v, mx * bh + h);
-                            if (!c.progressive) sequential_block(br, b, dc[td[i]], ac[ta[i]], pred[i]);
-                            else if (Ss == 0) { if (Ah == 0) dc_first(br, b, dc[td[i]], pred[i], Al); else dc_refine(br, b, Al); }
+                            if (Ss == 0) { if (Ah == 0) dc_first(br, b, dc[td[i]], pred[i], Al); else dc_refine(br, b, Al); }
                             else if (Ah == 0) ac_first(br, b, ac[ta[i]], Ss, Se, Al, eobrun);
                             else ac_refine(br, b, ac[ta[i]], Ss, Se, Al, eobrun);
                         }
@@ -269,23 +301,38 @@ struct Decoder {
         return p;
     }
 
-    static void sequential_block(Bits& br, int16_t* b, const Huff& hd, const Huff& ha, int& pred) {
+    // One block of a sequential scan, straight into the sparse form: mask bit z = zig-zag index z is non-zero, values in
+    // ascending zig-zag index = the order they are decoded in.  (A block named by two scans of a corrupt stream keeps the last.)
+    void sequential_block(Bits& br, size_t blk, const Huff& hd, const Huff& ha, int& pred) {
         int s = br.decode(hd);
         if (s) { if (s > 15) s = 15; const int r = (int)br.get(s); s = extend(r, s); }
         pred += s;
-        b[0] = (int16_t)pred;
+        uint64_t m = 0;
+        c.offset[blk] = (uint32_t)c.values.size();
+        if ((int16_t)pred != 0) { m |= 1; c.values.push_back((int16_t)pred); }
         for (int k = 1; k < 64; k++) {
+            const int fa = ha.fast_ac[br.peek(Huff::kLook)];
+            if (fa) {
+                k += (fa >> 4) & 15;
+                br.skip(fa & 15);
+                if (k > 63) break;   // corrupt run
+                m |= uint64_t(1) << k;
+                c.values.push_back((int16_t)(fa >> 8));
+                continue;
+            }
             const int rs = br.decode(ha);
             const int r = rs >> 4, sz = rs & 15;
             if (sz) {
                 k += r;
                 const int v = extend((int)br.get(sz), sz);
-                b[kNatural[k]] = (int16_t)v;
+                if (k > 63) break;
+                if ((int16_t)v != 0) { m |= uint64_t(1) << k; c.values.push_back((int16_t)v); }
             } else {
                 if (r != 15) break;
                 k += 15;
             }
         }
+        c.mask[blk] = m;
     }
     static void dc_first(Bits& br, int16_t* b, const Huff& hd, int& pred, int Al) {
         int s = br.decode(hd);
@@ -351,18 +398,18 @@ struct Decoder {
         }
     }
 
-    void sparsify() {
-        const size_t nb = coef.size() / 64;
-        c.mask.resize(nb);
-        c.offset.resize(nb + 1);
+    void sparsify() {   // progressive: dense -> sparse, values in ascending zig-zag index
+        const size_t nb = c.mask.size();
+        if (!c.progressive) { c.offset[nb] = (uint32_t)c.values.size(); return; }
         c.values.clear();
-        c.values.reserve(nb * 8);
         for (size_t i = 0; i < nb; i++) {
             const int16_t* b = coef.data() + i * 64;
             uint64_t m = 0;
             c.offset[i] = (uint32_t)c.values.size();
-            for (int p = 0; p < 64; p++)
-                if (b[p]) { m |= uint64_t(1) << p; c.values.push_back(b[p]); }
+            for (int z = 0; z < 64; z++) {
+                const int16_t v = b[kNatural[z]];
+                if (v) { m |= uint64_t(1) << z; c.values.push_back(v); }
+            }
             c.mask[i] = m;
         }
         c.offset[nb] = (uint32_t)c.values.size();

@@ -56,6 +56,12 @@ __device__ __forceinline__ uint8_t range_limit_idct(int64_t x) {
     return (uint8_t)(i < 128 ? i + 128 : i < 512 ? 255 : i < 896 ? 0 : i - 896);
 }
 
+// natural position (row * 8 + col) -> zig-zag index (the sparse coefficient stream is ordered by zig-zag index: the order
+// the entropy decoder produces the values in)
+__constant__ uint8_t kZigOfNat[64] = {
+    0,  1,  5,  6,  14, 15, 27, 28, 2,  4,  7,  13, 16, 26, 29, 42, 3,  8,  12, 17, 25, 30, 41, 43, 9,  11, 18, 24, 31, 40, 44, 53,
+    10, 19, 23, 32, 39, 45, 52, 54, 20, 22, 33, 38, 46, 51, 55, 60, 21, 34, 37, 47, 50, 56, 59, 61, 35, 36, 48, 49, 57, 58, 62, 63};
+
 struct JpegComp {
     int blocks_w, blocks_h;       // block grid
     int width, height;            // samples that matter
@@ -93,8 +99,9 @@ jpeg_idct_kernel(JpegArgs a, const uint64_t* __restrict__ mask, const uint32_t* 
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             const int p = r * 8 + c;
+            const int z = kZigOfNat[p];
             int v = 0;
-            if ((m >> p) & 1) v = values[off + __popcll(m & ((uint64_t(1) << p) - 1))];
+            if ((m >> z) & 1) v = values[off + __popcll(m & ((uint64_t(1) << z) - 1))];
             in[r] = (int64_t)v * (int64_t)q[p];   // DEQUANTIZE
         }
         idct8(in, out, kConstBits - kPass1Bits);
