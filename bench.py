@@ -531,6 +531,10 @@ def main():
                     lines.append("".join(map(chr, chars["ch"][a:b])))
             gpu_text.append(lines)
         result["cpu_baseline"] = cpu_baseline(host_pages[: args.cpu_pages], engine, gpu_text, np)
+    try:   # RCCL prints its version banner through C stdio, which flushes at exit when stdout is a pipe: push it out first so
+        C.CDLL(None).fflush(None)   # that the JSON line is the LAST line of the output
+    except Exception:
+        pass
     print(json.dumps(result), flush=True)
     if world > 1:
         dist.destroy_process_group()
