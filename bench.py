@@ -79,7 +79,9 @@ def parse(argv=None):
                          "process per GPU) instead of driving the N GPUs from this process through the engine group")
     ap.add_argument("--devices", type=str, default="",
                     help="engine-group mode: comma-separated member devices (default 0..N-1; a device may repeat)")
-    ap.add_argument("--gather", choices=("auto", "host", "rccl"), default="auto", help="engine-group mode: result transport")
+    ap.add_argument("--gather", choices=("auto", "host", "rccl", "rccl-final"), default="auto",
+                    help="engine-group mode: transport of the FINAL result gather (auto = RCCL for >= 2 distinct devices); 'rccl' also "
+                         "sends every per-request gather through RCCL (opt-in), 'rccl-final' forces RCCL for the final gather only")
     ap.add_argument("--dist-selftest", action="store_true",
                     help="exercise only the multi-rank plumbing (spawn, rendezvous, page sharding, result gather, "
                          "reductions) with fake per-page results and no GPU: the CPU test of the N > 1 path")
@@ -389,7 +391,7 @@ def main():
         ids = sorted(local_payload, key=int)
         per_member = [json.dumps({k: local_payload[k] for k in ids if (ids.index(k) // B) % G == m}).encode() for m in range(G)]
         tg = time.perf_counter()
-        data, offs = group.final_gather(per_member, args.gather)
+        data, offs = group.final_gather(per_member, "rccl" if args.gather == "rccl-final" else args.gather)
         final_gather = dict(group.last_gather(), ms=round(1e3 * (time.perf_counter() - tg), 3),
                             equals_host_concatenation=(data == b"".join(per_member)))
     elapsed, (n_pages_all, n_lines_all, n_words_all, n_chars_all) = reduce_over_ranks(

@@ -77,7 +77,7 @@ group)
   say "== engine group in ONE process: 2 members on this one GPU (devices 0,0; host gather), 8 pages per member per step"
   timeout 600 python bench.py --gpus 2 --devices 0,0 --steps 12 --warmup 6 --pages 8 --settle-s 0 > $OUT/bench_group00.json 2> $OUT/bench_group00.err; say "rc=$?"; jsum $OUT/bench_group00.json "group [0,0]"; tail -2 $OUT/bench_group00.err | cut -c1-300 | tee -a $S
   say "== engine group of one member with the RCCL gather (ncclCommInitAll on one device)"
-  timeout 600 python bench.py --devices 0 --gather rccl --steps 12 --warmup 6 --settle-s 0 > $OUT/bench_group0_rccl.json 2> $OUT/bench_group0_rccl.err; say "rc=$?"; jsum $OUT/bench_group0_rccl.json "group [0] rccl"; tail -2 $OUT/bench_group0_rccl.err | cut -c1-300 | tee -a $S
+  timeout 600 python bench.py --devices 0 --gather ${GROUP_GATHER:-rccl-final} --steps 12 --warmup 6 --settle-s 0 > $OUT/bench_group0_rccl.json 2> $OUT/bench_group0_rccl.err; say "rc=$?"; jsum $OUT/bench_group0_rccl.json "group [0] rccl"; tail -2 $OUT/bench_group0_rccl.err | cut -c1-300 | tee -a $S
   python - $OUT/bench_group0_rccl.json <<'PY' | tee -a $S
 import json, sys
 try:
