@@ -101,8 +101,9 @@ OCRS_API ocrs_status ocrs_coalescer_selftest(int n_threads, int requests_per_thr
  *   "det_mfma"        1 = DoubleConv blocks of the detection U-Net (8 to 32 channels) run as fused launches with their
  *                     pointwise convolutions and ConvTranspose on MFMA (default), 0 = thread-per-pixel VALU kernels
  *   "det_heavy"       the detection stage's kernels run on the device's shared conv-stack stream (queued between other
- *                     requests' conv stacks, at full speed) instead of on the call's own stream (beside them, every one of its
- *                     ~50 launches waiting for CU slots): 1 = for requests of fewer than 8 pages (default), 2 = always, 0 = never
+ *                     requests' conv stacks, at full speed) instead of on the call's own stream (beside them): 1 = for requests
+ *                     of fewer than 8 pages (round 3's default), 2 = always, 0 = never (default since round 4: with the conv
+ *                     stacks' shared arena the FIFO wait costs one-page calls from 12 threads 7 % — 180 vs 194 pages/s)
  *   "gx_heavy"        1 = the GRU input projections of large requests run on that stream too (every MFMA-bound class then
  *                     runs at its alone speed, the throughput is the same or slightly lower), default 0
  *   "layout_threads"  host threads ocrs_engine_find_text_lines_batch may use (0 = automatic)

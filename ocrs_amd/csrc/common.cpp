@@ -258,7 +258,7 @@ const OptDef kOptDefs[OPT_COUNT] = {
     {"det_mfma", "OCRS_DET_MFMA", 1},                   // fused detection blocks: pointwise convs + ConvTranspose on MFMA, all block shapes incl. the 32-channel levels (1); VALU kernels (0)
     {"gru_background", "OCRS_GRU_BACKGROUND", 0},       // requests beyond the gate-per-wave kernel's size: 1 = lean multi-tile gate-per-wave kernel (small footprint, slower alone)
     {"gx_heavy", "OCRS_GX_HEAVY", 0},                   // GRU input projections of large requests on the shared conv-stack stream (serialised with the conv stacks)
-    {"det_heavy", "OCRS_DET_HEAVY", 1},                 // detection kernels on the shared conv-stack stream: 1 = requests of fewer than 8 pages, 2 = all
+    {"det_heavy", "OCRS_DET_HEAVY", 0},                 // detection kernels on the shared conv-stack stream: 0 = never (default since r4: 194 vs 180 pages/s for one-page calls from 12 threads, ABAB), 1 = requests of fewer than 8 pages (r3 default), 2 = all
     {"conv_flat", "OCRS_CONV_FLAT", 1},                 // recognition 3x3 convs: patches tile a width group's whole strip of images (0: every image on its own)
     {"conv12_fuse", "OCRS_CONV12_FUSE", 1},             // first two recognition convs (+ their pools) in one kernel: conv1 into LDS, conv2's MFMA operand from there
     {"group_min_block", "OCRS_GROUP_MIN_BLOCK", 8},     // engine group: pages the group places itself go to a device in contiguous blocks of at least this many
