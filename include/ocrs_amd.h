@@ -125,6 +125,10 @@ OCRS_API ocrs_status ocrs_coalescer_selftest(int n_threads, int requests_per_thr
  *   "group_min_block" engine group: pages the group places itself go to a device in contiguous blocks of at least this
  *                     many pages (default 8; a small call then uses fewer devices, successive calls rotate)
  *   "group_shared_block"  the same between members that share one device (default 16)
+ *   "det_tail"        1 = the deep levels of the detection U-Net (every operator with at most 2 048 output pixels per page:
+ *                     pools, depthwise / pointwise convs, ConvTransposes, concatenations) run as ONE persistent launch whose
+ *                     workgroups step through the operators together (44 -> 23 dispatches per request; round-4 experiment,
+ *                     slower than the per-operator kernels as built); 0 (default) = one launch per operator.  Same bits.
  *   "gru_waves"       recurrence kernel of requests with more row tiles than clusters: 4 (default) = the general kernel (one
  *                     wave per SIMD, three interleaved MFMA chains per wave); 16 = four gate-per-wave teams of four waves
  *                     per workgroup, state through LDS (round-4 experiment, same bits, 12 % slower per layer)

@@ -364,6 +364,35 @@ float* HipModel::run_device(Workspace& ws, const float* d_in, int n, int h, int 
 
     std::vector<char> covered(ops.size(), 0);   // ops already done by a fused DoubleConv launch
     const int det_fuse = option(OPT_DET_FUSE);
+    const int det_tail = option(OPT_DET_TAIL);
+    // operators the one-launch tail (kernels_tail.hip) takes: pool 2x2, depthwise 3x3 (also over a concatenation read in
+    // place), pointwise 1x1, ConvTranspose 2x2/s2, channel counts in fours, at most kTailMaxPx output pixels per page, and not
+    // part of a fused DoubleConv block
+    constexpr int64_t kTailMaxPx = 2048;
+    std::vector<char> in_block(ops.size(), 0);
+    if (det_fuse)
+        for (const DcBlock& b : dc_blocks)
+            for (int q = b.first; q >= 0 && q <= b.last && q < (int)ops.size(); q++) in_block[q] = 1;
+    auto tail_ok = [&](size_t j) -> bool {
+        if (j >= n_run || covered[j] || in_block[j]) return false;
+        const GraphOp& q = ops[j];
+        if (q.fused_into_prev || q.fuse_next_pw || q.done_by_prev) return false;
+        const TensorShape qi = shp[q.in0], qo = shp[q.out];
+        if (qi.seq || qo.seq || (int64_t)qo.h * qo.w > kTailMaxPx || (int64_t)qi.h * qi.w > 4 * kTailMaxPx + 4096) return false;
+        switch (q.type) {
+            case OP_MAXPOOL: return q.kh == 2 && q.kw == 2 && (qi.c % 4) == 0 && qo.h == qi.h / 2 && qo.w == qi.w / 2;
+            case OP_DWCONV3:
+                if (q.reads_cat && j > 0 && cat_fused(j - 1)) {
+                    const TensorShape sk = shp[ops[j - 1].in0], up = shp[ops[j - 1].in1];
+                    return (sk.c % 4) == 0 && (up.c % 4) == 0 && up.h <= sk.h && up.w <= sk.w;
+                }
+                return (qi.c % 4) == 0;
+            case OP_PADCAT: return cat_fused(j);
+            case OP_CONV: return q.kh == 1 && q.kw == 1 && (q.cin % 4) == 0 && (q.cout % 4) == 0;
+            case OP_CONVT2: return (q.cin % 4) == 0 && (q.cout % 4) == 0 && q.aux0 && q.aux1;
+            default: return false;
+        }
+    };
     for (size_t i = 0; i < n_run; i++) {
         const GraphOp& op = ops[i];
         const TensorShape a = shp[op.in0];
@@ -374,6 +403,7 @@ float* HipModel::run_device(Workspace& ws, const float* d_in, int n, int h, int 
         else if (op.type == OP_LINEAR || op.type == OP_LOGSOFTMAX) enter_stage(seen_seq ? ST_REC_HEAD : ST_REC_CONV);
         else enter_stage(seen_seq ? ST_REC_GRU : ST_REC_CONV);
         if (op.type == OP_TOSEQ) seen_seq = true;
+        if (covered[i] == 2) continue;   // part of a one-launch tail run: its buffers were handled there
         if (covered[i]) {
             for (int sl = 1; sl < (int)n_slots; sl++)   // any slot whose last reader this op was (incl. a skipped PADCAT's inputs)
                 if (last_use[sl] == (int)i && ptr[sl] && cap[sl]) {
@@ -383,6 +413,76 @@ float* HipModel::run_device(Workspace& ws, const float* d_in, int n, int h, int 
                 }
             if (print_timing) OCRS_HIP(hipEventRecord(ev[i + 1], st));
             continue;
+        }
+        // ---- the deep levels of a detection U-Net as ONE launch (kernels_tail.hip): a maximal run of small operators
+        if (kind == 0 && det_tail && !print_timing) {
+            size_t j_end = i;
+            while (tail_ok(j_end)) j_end++;
+            while (j_end > i && ops[j_end - 1].type == OP_PADCAT) j_end--;   // a concatenation needs its consumer in the run
+            size_t n_real = 0;
+            for (size_t j = i; j < j_end; j++) n_real += ops[j].type != OP_PADCAT;
+            if (n_real >= 6 && n_real <= (size_t)k::kTailMaxPhases) {
+                k::TailArgs ta{};
+                int np = 0;
+                double fl = 0, by = 0;
+                std::vector<std::pair<size_t, float*>> release_later;   // nothing freed inside the run is handed out again inside it:
+                                                                        // pages advance through the phases independently
+                const int pages = shp[ops[i].in0].n;
+                for (size_t j = i; j < j_end; j++) {
+                    const GraphOp& q = ops[j];
+                    const TensorShape qi = shp[q.in0], qo = shp[q.out];
+                    if (q.type != OP_PADCAT) {
+                        auto r = get((size_t)qo.count());
+                        ptr[q.out] = r.first;
+                        cap[q.out] = r.second;
+                        k::TailPhase& ph = ta.ph[np++];
+                        ph.dst = r.first;
+                        ph.src = ptr[q.in0];
+                        ph.relu = q.relu;
+                        switch (q.type) {
+                            case OP_MAXPOOL:
+                                ph.type = k::TAIL_POOL; ph.h = qo.h; ph.w = qo.w; ph.cout = qo.c; ph.cin = qo.c; ph.h2 = qi.h; ph.w2 = qi.w; ph.relu = 0;
+                                by += 4.0 * (qi.count() + qo.count());
+                                break;
+                            case OP_DWCONV3:
+                                ph.type = k::TAIL_DW; ph.h = qo.h; ph.w = qo.w; ph.cout = qo.c; ph.cin = qo.c; ph.wt = q.w[0]; ph.bias = q.w[1];
+                                if (q.reads_cat && j > 0 && cat_fused(j - 1)) {
+                                    const GraphOp& cat = ops[j - 1];
+                                    const TensorShape sk = shp[cat.in0], up = shp[cat.in1];
+                                    ph.src = ptr[cat.in0]; ph.cin = sk.c;
+                                    ph.src2 = ptr[cat.in1]; ph.h2 = up.h; ph.w2 = up.w; ph.c2 = up.c;
+                                }
+                                fl += 18.0 * qo.count(); by += 8.0 * qo.count();
+                                break;
+                            case OP_CONV:
+                                ph.type = k::TAIL_PW; ph.h = qi.h; ph.w = qi.w; ph.cin = q.cin; ph.cout = q.cout; ph.wt = q.w[0]; ph.bias = q.w[1];
+                                fl += 2.0 * (double)qi.n * qi.h * qi.w * q.cin * q.cout; by += 4.0 * (qi.count() + qo.count()) + wbytes(q, 0);
+                                break;
+                            case OP_CONVT2:
+                                ph.type = k::TAIL_CONVT; ph.h = qi.h; ph.w = qi.w; ph.cin = q.cin; ph.cout = q.cout; ph.wt = q.aux0; ph.bias = q.aux1; ph.relu = 0;
+                                fl += 2.0 * (double)qi.n * qi.h * qi.w * q.cin * q.cout * 4; by += 4.0 * (qi.count() + qo.count()) + wbytes(q, 0);
+                                break;
+                            default: break;
+                        }
+                        if (!ph.src || !ph.dst) fail(OCRS_ERR_RUN_FAILED, "model run failed: internal (tail run reads an unset slot)");
+                    }
+                    std::vector<int> dying = {q.in0, q.in1};
+                    if (q.type == OP_DWCONV3 && q.reads_cat && j > 0 && cat_fused(j - 1)) { dying.push_back(ops[j - 1].in0); dying.push_back(ops[j - 1].in1); }
+                    for (int sl : dying)
+                        if (sl > 0 && last_use[sl] == (int)j && ptr[sl] && cap[sl]) {
+                            release_later.emplace_back(cap[sl], ptr[sl]);
+                            ptr[sl] = nullptr;
+                            cap[sl] = 0;
+                        }
+                    if (j > i) covered[j] = 2;   // (2: bookkeeping already done here)
+                }
+                uint32_t* d_bar = ws.alloc_n<uint32_t>((size_t)pages);
+                OCRS_HIP(hipMemsetAsync(d_bar, 0, (size_t)pages * sizeof(uint32_t), st));
+                timed(KC_DET_BLOCK, fl, by, [&] { k::det_tail(ta, np, pages, d_bar, st); }, 0.0);
+                for (auto& r : release_later) free_local.emplace(r.first, r.second);
+                i = j_end - 1;
+                continue;
+            }
         }
         if (det_fuse && op.dc_block >= 0) {
             const DcBlock& b = dc_blocks[op.dc_block];

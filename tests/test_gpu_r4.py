@@ -200,3 +200,37 @@ def test_mixed_load_soak_20_seconds():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak.py"), "20"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "errors: none" in r.stdout, (r.stdout + r.stderr)[-3000:]
+
+
+# ------------------------------------------------------------------ the detection U-Net's deep levels in one launch
+@pytest.mark.parametrize("in_hw,depths", [((800, 600), (8, 16, 32, 32, 64, 128, 256)), ((320, 256), (8, 16, 32, 64, 128)),
+                                          ((160, 128), (8, 16, 32, 32))])
+def test_one_launch_detection_tail_equals_the_per_operator_kernels_and_the_oracle(in_hw, depths):
+    """option det_tail = 1: pools, depthwise / pointwise convs, ConvTransposes and in-place concatenations of the levels below
+    2 048 pixels per page run as ONE persistent launch (kernels_tail.hip; an experiment, off by default).  Same
+    probability-map bits as one launch per operator, for 1, 3 and 9 pages per request (9 = two page groups), and equal
+    to the oracle's exact chain."""
+    import models_util as M
+    from oracle import pipeline as OP
+    from oracle.nn import OracleGraph, OracleModel
+    from ocrs_amd import synth
+    dbuf = M.detection_model_bytes(in_hw, depths)
+    eng = OcrEngine(detection_model=Model.load_bytes(dbuf))
+    pages = [synth.synthetic_page(40 + s, 317, 409, lines=10, columns=1) for s in range(9)]
+    inputs = [eng.prepare_input(ImageSource.from_tensor(p, DimOrder.Hwc)) for p in pages]
+    res = {}
+    try:
+        for tail in (1, 0):
+            _lib.set_option("det_tail", tail)
+            res[tail] = ([eng.detect_text_pixels(i) for i in inputs[:3]],
+                         eng.detect_words_batch(inputs[:1]), eng.detect_words_batch(inputs[:3]), eng.detect_words_batch(inputs))
+    finally:
+        _lib.set_option("det_tail", 0)
+    for a, b in zip(res[1][0], res[0][0]):
+        assert np.array_equal(a, b)
+    for k in (1, 2, 3):
+        assert all(np.array_equal(a, b) for a, b in zip(res[1][k], res[0][k]))
+    assert all(np.array_equal(a, b) for a, b in zip(res[1][3][:3], res[1][2]))   # a page's result does not depend on its batch
+    ora = OP.OcrEngine(detection_model=OracleModel(OracleGraph(dbuf), "exact"))
+    oin = ora.prepare_input(OP.ImageSource.from_tensor(pages[0], "hwc"))
+    assert np.array_equal(res[1][0][0], ora.detect_text_pixels(oin))
