@@ -263,8 +263,8 @@ const OptDef kOptDefs[OPT_COUNT] = {
     {"conv12_fuse", "OCRS_CONV12_FUSE", 1},             // first two recognition convs (+ their pools) in one kernel: conv1 into LDS, conv2's MFMA operand from there
     {"group_min_block", "OCRS_GROUP_MIN_BLOCK", 8},     // engine group: pages the group places itself go to a device in contiguous blocks of at least this many
     {"group_shared_block", "OCRS_GROUP_SHARED_BLOCK", 16},  // engine group: the same between members that share one device
-    {"det_tail", "OCRS_DET_TAIL", 0},                   // detection U-Net: every operator of the deep levels (<= 2048 pixels per page) in ONE persistent launch (1; r4 experiment: 44 -> 23 dispatches but 1.03 vs 0.24 ms) or one launch per operator (0, default)
     {"gru_waves", "OCRS_GRU_WAVES", 4},                 // recurrence of requests beyond one row tile per cluster: 4 = the general kernel (one wave per SIMD; default), 16 = four gate-per-wave teams per workgroup (r4 experiment: 12 % slower)
+    {"det_tail", "OCRS_DET_TAIL", 0},                   // detection U-Net: every operator of the deep levels (<= 2048 pixels per page) in ONE persistent launch (1; r4 experiment: 44 -> 23 dispatches but 1.03 vs 0.24 ms) or one launch per operator (0, default)
 };
 std::atomic<long> g_opts[OPT_COUNT];
 std::once_flag g_opts_once;

@@ -467,3 +467,9 @@ def test_every_option_of_the_library_is_documented_in_the_header():
     hdr = open(os.path.join(root, "include", "ocrs_amd.h")).read()
     missing = [n for n in names if '"%s"' % n not in hdr]
     assert not missing, missing
+    # the table is indexed by `enum Option`: entry i must be the option enumerator i names (a det_tail / gru_waves swap once
+    # made one option read the other's value)
+    chp = open(os.path.join(root, "ocrs_amd", "csrc", "common.hpp")).read()
+    enum = re.search(r"enum Option \{(.*?)OPT_COUNT", chp, re.S).group(1)
+    ids = [x.split("=")[0].strip() for x in enum.replace("\n", " ").split(",") if x.strip()]
+    assert ["OPT_" + n.upper() for n in names] == ids
