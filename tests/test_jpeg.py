@@ -146,3 +146,163 @@ def test_prepare_input_jpeg_gives_the_page_of_prepare_input_on_the_decoded_pixel
     assert eng.get_text(inp) == str(g["text"][0])
     with pytest.raises(ocrs_amd.OcrsError):
         eng.prepare_input_jpeg(b"\x89PNG not a jpeg")
+
+
+# ------------------------------------------------------------------------------------------------ flavours PIL cannot write
+def _parse_dht(data):
+    """{(class, id): (bits[16], vals)} of a JPEG stream's DHT segments."""
+    out, i = {}, 2
+    while i < len(data):
+        if data[i] != 0xFF:
+            i += 1
+            continue
+        m = data[i + 1]
+        if m in (0xD8, 0x01) or 0xD0 <= m <= 0xD7:
+            i += 2
+            continue
+        L = (data[i + 2] << 8) | data[i + 3]
+        if m == 0xC4:
+            s, e = i + 4, i + 2 + L
+            while s < e:
+                tc, th = data[s] >> 4, data[s] & 15
+                bits = list(data[s + 1:s + 17])
+                n = sum(bits)
+                out[(tc, th)] = (bits, list(data[s + 17:s + 17 + n]))
+                s += 17 + n
+        if m == 0xDA:
+            break
+        i += 2 + L
+    return out
+
+
+def _codes(bits, vals):
+    code, k, table = 0, 0, {}
+    for l in range(1, 17):
+        for _ in range(bits[l - 1]):
+            table[vals[k]] = (code, l)
+            code += 1
+            k += 1
+        code <<= 1
+    return table
+
+
+class _BitWriter:
+    def __init__(self):
+        self.out, self.acc, self.n = bytearray(), 0, 0
+
+    def put(self, value, length):
+        self.acc = (self.acc << length) | (value & ((1 << length) - 1))
+        self.n += length
+        while self.n >= 8:
+            b = (self.acc >> (self.n - 8)) & 0xFF
+            self.out.append(b)
+            if b == 0xFF:
+                self.out.append(0)
+            self.n -= 8
+
+    def flush(self):
+        if self.n:
+            self.put((1 << (8 - self.n)) - 1, 8 - self.n)
+
+
+ZIGZAG = [0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28, 35, 42, 49,
+          56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63]
+
+
+def _reencode_non_interleaved(geom, quant, coef, dht, restart=0, dqt16=True):
+    """A baseline JPEG with ONE SCAN PER COMPONENT (each walks its own block grid), optional restart intervals and 16-bit
+    quantisation tables, from decoded coefficients — stream flavours no PIL option produces."""
+    width, height, ncomp, hmax, vmax = [int(v) for v in geom[:5]]
+    comps = [[int(v) for v in geom[7 + 7 * i:14 + 7 * i]] for i in range(ncomp)]   # h, v, tq, cw, ch, bw, bh
+    out = bytearray(b"\xff\xd8")
+    out += b"\xff\xe0\x00\x10JFIF\x00\x01\x01\x00\x00\x01\x00\x01\x00\x00"
+    for tq in sorted(set(c[2] for c in comps)):
+        q = [int(quant[tq * 64 + ZIGZAG[z]]) for z in range(64)]
+        if dqt16:
+            out += b"\xff\xdb" + (2 + 1 + 128).to_bytes(2, "big") + bytes([0x10 | tq]) + b"".join(v.to_bytes(2, "big") for v in q)
+        else:
+            out += b"\xff\xdb" + (2 + 1 + 64).to_bytes(2, "big") + bytes([tq]) + bytes(q)
+    out += b"\xff\xc0" + (8 + 3 * ncomp).to_bytes(2, "big") + b"\x08" + height.to_bytes(2, "big") + width.to_bytes(2, "big") + bytes([ncomp])
+    for i, c in enumerate(comps):
+        out += bytes([i + 1, (c[0] << 4) | c[1], c[2]])
+    for (tc, th), (bits, vals) in sorted(dht.items()):
+        out += b"\xff\xc4" + (2 + 17 + len(vals)).to_bytes(2, "big") + bytes([(tc << 4) | th]) + bytes(bits) + bytes(vals)
+    if restart:
+        out += b"\xff\xdd\x00\x04" + restart.to_bytes(2, "big")
+    first = 0
+    for i, c in enumerate(comps):
+        _h, _v, _tq, cw, ch, bw, bh = c
+        blocks = coef[first:first + bw * bh].reshape(bh, bw, 64)
+        first += bw * bh
+        t = 0 if i == 0 else min(1, max(k[1] for k in dht))
+        dc, ac = _codes(*dht[(0, t)]), _codes(*dht[(1, t)])
+        out += b"\xff\xda\x00\x08\x01" + bytes([i + 1, (t << 4) | t]) + b"\x00\x3f\x00"
+        w, pred, n_mcu, rst = _BitWriter(), 0, 0, 0
+        for by in range((ch + 7) // 8):
+            for bx in range((cw + 7) // 8):
+                if restart and n_mcu and n_mcu % restart == 0:
+                    w.flush()
+                    w.out += bytes([0xFF, 0xD0 + (rst & 7)])
+                    rst += 1
+                    pred = 0
+                b = blocks[by, bx]
+                d = int(b[0]) - pred
+                pred = int(b[0])
+                s = abs(d).bit_length()
+                w.put(*dc[s])
+                if s:
+                    w.put(d if d > 0 else d + (1 << s) - 1, s)
+                run = 0
+                last = max([z for z in range(1, 64) if b[ZIGZAG[z]]] or [0])
+                for z in range(1, last + 1):
+                    v = int(b[ZIGZAG[z]])
+                    if v == 0:
+                        run += 1
+                        continue
+                    while run > 15:
+                        w.put(*ac[0xF0])
+                        run -= 16
+                    s = abs(v).bit_length()
+                    w.put(*ac[(run << 4) | s])
+                    w.put(v if v > 0 else v + (1 << s) - 1, s)
+                    run = 0
+                if last < 63:
+                    w.put(*ac[0x00])
+                n_mcu += 1
+        w.flush()
+        out += w.out
+    out += b"\xff\xd9"
+    return bytes(out)
+
+
+REENC = [(2, 0, True), (1, 7, False), (0, 3, True), (2, 11, True)]
+
+
+def _check_reencoded(ss, restart, dqt16, gpu):
+    px = synth.synthetic_page(9, 203, 157, lines=6, columns=1)
+    src = _encode(px, quality=85, subsampling=ss)
+    geom, quant, coef = _lib.jpeg_coefficients(src)
+    data = _reencode_non_interleaved(geom, quant, coef, _parse_dht(src), restart=restart, dqt16=dqt16)
+    ref = _pil(data)
+    assert np.array_equal(ref, _pil(src))            # the re-encoding is lossless: libjpeg sees the same image
+    if gpu:
+        rgb, _ = _lib.jpeg_decode_rgb(data)
+        assert np.array_equal(rgb, ref)
+    else:
+        g2, q2, c2 = _lib.jpeg_coefficients(data)
+        assert np.array_equal(OJ.decode_from_coefficients(g2, q2, c2), ref)
+
+
+@pytest.mark.parametrize("ss,restart,dqt16", REENC)
+def test_single_component_scans_restart_intervals_and_16_bit_tables(ss, restart, dqt16):
+    """Baseline streams with one scan per component (each walking only the blocks that cover ITS plane, not the padded MCU
+    grid), restart intervals inside such scans and 16-bit DQT segments: re-encoded here from decoded coefficients, decoded by
+    libjpeg (PIL) and by the host decoder + oracle: the same pixels."""
+    _check_reencoded(ss, restart, dqt16, gpu=False)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ss,restart,dqt16", REENC)
+def test_gpu_decode_of_single_component_scans_restart_intervals_and_16_bit_tables(ss, restart, dqt16):
+    _lib.require_gpu()
+    _check_reencoded(ss, restart, dqt16, gpu=True)
