@@ -129,6 +129,11 @@ OCRS_API ocrs_status ocrs_coalescer_selftest(int n_threads, int requests_per_thr
  *                     pools, depthwise / pointwise convs, ConvTransposes, concatenations) run as ONE persistent launch whose
  *                     workgroups step through the operators together (44 -> 23 dispatches per request; round-4 experiment,
  *                     slower than the per-operator kernels as built); 0 (default) = one launch per operator.  Same bits.
+ *   "det_stream"      1 (default) = the DoubleConv blocks of the detection U-Net's full-resolution levels run as
+ *                     row-streaming kernels (a wave walks down a 64-column strip, a lane keeps its pixel's channels in
+ *                     registers, horizontal taps through DPP lane shifts: no LDS, no barriers), rows per wave chosen from
+ *                     the request's size; 8 / 14 / 32 = the same with that many rows per wave; 0 = the LDS-tiled blocks
+ *                     (rounds 2-3).  Same bits.
  *   "gru_waves"       recurrence kernel of requests with more row tiles than clusters: 4 (default) = the general kernel (one
  *                     wave per SIMD, three interleaved MFMA chains per wave); 16 = four gate-per-wave teams of four waves
  *                     per workgroup, state through LDS (round-4 experiment, same bits, 12 % slower per layer)

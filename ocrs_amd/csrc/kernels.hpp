@@ -1,6 +1,7 @@
 // Launch wrappers for every HIP kernel in libocrs_amd (gfx950).  All take the
 // stream to launch on; none synchronises.  Activations are NHWC fp32.
 #pragma once
+#include <vector>
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -94,6 +95,12 @@ struct DoubleConvArgs {
     int n, h, w, h1, w1;
     int relu_d1, relu_p1, relu_d2, relu_p2, sigmoid;
     int tiles_x, tiles_y;         // filled by the launcher
+    const float* tape = nullptr;  // streaming kernels (kernels_det_stream.hip): the block's weight tape(s) on the device
+    int tape_len = 0;             // floats per tape
+};
+// host pointers to a block's weights, for building its tape
+struct StreamWeights {
+    const float *wt, *bt, *wd1, *bd1, *wp1, *bp1, *wd2, *bd2, *wp2, *bp2, *wf, *bf;
 };
 // true if a fused kernel exists for the shape (cs skip channels, cx ConvT input channels or 0, ...) at this
 // fuse level (option "det_fuse": 1 = the shapes where fusion wins, 2 = every shape that has a kernel);
@@ -101,6 +108,12 @@ struct DoubleConvArgs {
 // (option "det_mfma").
 bool double_conv_fused(const DoubleConvArgs& a, int cs, int cx, int cmid, int cout, bool pool, bool final_conv, int fuse_level,
                        bool launch, hipStream_t s, bool* on_mfma = nullptr);
+// ---- kernels_det_stream.hip (r4): the same blocks as row-streaming register kernels for the full-resolution levels;
+// true if the shape has one (launches it when `launch` is set).  Same bits as the tiled blocks and the per-op kernels.
+// With `hw` / `tape_out` the block's weight tape is built (the weights in the order a row step consumes them; the caller
+// uploads it and passes it in DoubleConvArgs::tape); *tape_len = floats per tape.
+bool double_conv_stream(const DoubleConvArgs& a, int cs, int cx, int cmid, int cout, bool pool, bool final_conv, bool launch, hipStream_t s,
+                        const StreamWeights* hw = nullptr, std::vector<float>* tape_out = nullptr, int* tape_len = nullptr);
 void maxpool(const float* x, int n, int h, int w, int c, int kh, int kw, float* y, hipStream_t s);
 void avgpool(const float* x, int n, int h, int w, int c, int kh, int kw, float* y, hipStream_t s);
 void padcat(const float* skip, int n, int sh, int sw, int cs, const float* x, int h, int w, int cx, float* y,

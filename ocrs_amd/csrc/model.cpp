@@ -241,6 +241,19 @@ std::unique_ptr<HipModel> HipModel::load(const void* data, size_t len, int devic
             }
             k::DoubleConvArgs none{};
             if (!k::double_conv_fused(none, b.cs, b.cx, b.cmid, b.cout, b.pool >= 0, b.fin >= 0, 2, false, nullptr)) continue;
+            {   // a row-streaming kernel for the shape: its weights laid out as the tape a row step reads (kernels_det_stream.hip)
+                auto host = [&](int op, int j) -> const float* { return op >= 0 ? slab.data() + fops[op].w[j].off : nullptr; };
+                k::StreamWeights hw{host(b.convt, 0), host(b.convt, 1), host(b.dw1, 0), host(b.dw1, 1), host(b.pw1, 0), host(b.pw1, 1),
+                                    host(b.dw2, 0), host(b.dw2, 1), host(b.pw2, 0), host(b.pw2, 1), host(b.fin, 0), host(b.fin, 1)};
+                std::vector<float> tape;
+                int tape_len = 0;
+                if (k::double_conv_stream(none, b.cs, b.cx, b.cmid, b.cout, b.pool >= 0, b.fin >= 0, false, nullptr, &hw, &tape, &tape_len)) {
+                    m->tapes.emplace_back(tape.size() * sizeof(float));
+                    OCRS_HIP(hipMemcpy(m->tapes.back().p, tape.data(), tape.size() * sizeof(float), hipMemcpyHostToDevice));
+                    b.tape = m->tapes.back().as<float>();
+                    b.tape_len = tape_len;
+                }
+            }
             ops[i].dc_block = (int)m->dc_blocks.size();
             m->dc_blocks.push_back(b);
             i = b.last;   // blocks do not overlap
@@ -510,6 +523,7 @@ float* HipModel::run_device(Workspace& ws, const float* d_in, int n, int h, int 
                 da.wd1 = d1.w[0]; da.bd1 = d1.w[1]; da.wp1 = p1.w[0]; da.bp1 = p1.w[1];
                 da.wd2 = d2.w[0]; da.bd2 = d2.w[1]; da.wp2 = p2.w[0]; da.bp2 = p2.w[1];
                 da.relu_d1 = d1.relu; da.relu_p1 = p1.relu; da.relu_d2 = d2.relu; da.relu_p2 = p2.relu;
+                da.tape = b.tape; da.tape_len = b.tape_len;
                 const double px = (double)sk.n * sk.h * sk.w;
                 double out_floats = 0;
                 if (ok) {

@@ -40,6 +40,8 @@ struct DcBlock {
     int first = -1, last = -1;
     int convt = -1, cat = -1, dw1 = -1, pw1 = -1, dw2 = -1, pw2 = -1, pool = -1, fin = -1, sig = -1;
     int cs = 0, cx = 0, cmid = 0, cout = 0;
+    const float* tape = nullptr;  // row-streaming kernel (kernels_det_stream.hip): the block's weight tape on the device
+    int tape_len = 0;
 };
 
 struct TensorShape {  // NHWC activations, or [T,N,C] sequences (n=T, h=N, w=1, c=C)
@@ -71,6 +73,7 @@ struct HipModel : ModelBase {
     std::vector<DcBlock> dc_blocks;
     uint32_t n_slots = 0, out_slot = 0;
     DevBuf weights;      // one slab: file blob + derived tensors
+    std::vector<DevBuf> tapes;   // weight tapes of the row-streaming DoubleConv blocks (DcBlock::tape)
     bool is_callback() const override { return false; }
 
     // device < 0: the process default (ocrs_set_device)

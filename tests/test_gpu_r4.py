@@ -234,3 +234,28 @@ def test_one_launch_detection_tail_equals_the_per_operator_kernels_and_the_oracl
     ora = OP.OcrEngine(detection_model=OracleModel(OracleGraph(dbuf), "exact"))
     oin = ora.prepare_input(OP.ImageSource.from_tensor(pages[0], "hwc"))
     assert np.array_equal(res[1][0][0], ora.detect_text_pixels(oin))
+
+
+# ------------------------------------------------------------------ row-streaming DoubleConv blocks (kernels_det_stream.hip)
+@pytest.mark.parametrize("in_hw,n,depths", [((96, 64), 3, (8, 16, 32, 32)), ((131, 157), 2, (8, 16, 32, 32)), ((61, 59), 1, (8, 16)),
+                                            ((240, 121), 5, (8, 16, 32))])
+def test_streaming_detection_blocks_equal_the_tiled_blocks_and_the_oracle(in_hw, n, depths):
+    """option det_stream: the full-resolution DoubleConv blocks as row-streaming register kernels (a wave per 64-column
+    strip, DPP lane shifts for the horizontal taps, the weights as a tape through the SGPRs).  Same bits as the LDS-tiled
+    blocks (det_stream 0) and as the oracle's exact chain, for every segment height (8 / 14 / 32 rows per wave; 1 = chosen
+    from the request size), on sizes whose last strip / last segment are partial, odd sizes (the decoder's ConvTranspose
+    output is one row / column short of the skip tensor: zero-padded `up` channels) and an image narrower than a strip."""
+    import models_util as M
+    from oracle.nn import OracleGraph
+    buf = M.detection_model_bytes(in_hw, depths)
+    rng = np.random.default_rng(5)
+    x = (rng.random((n, 1) + in_hw, dtype=np.float32) - 0.5).astype(np.float32)
+    m = Model.load_bytes(buf)
+    exp = OracleGraph(buf).run_exact(x)
+    try:
+        for mode in (0, 8, 14, 32, 1):
+            _lib.set_option("det_stream", mode)
+            got = m.run(x)
+            assert got.shape == exp.shape and np.array_equal(got, exp), mode
+    finally:
+        _lib.set_option("det_stream", 1)
