@@ -522,15 +522,17 @@ std::vector<float> build_tape(const StreamWeights& w) {
 // weight tape is built from the host weights in `hw` (the caller uploads it and passes it in DoubleConvArgs::tape).
 //
 // Segment height S: a wave's run time is proportional to S + 4 rows, the redundant work to (S + 4) / S, and the launch
-// wants at least a wave per SIMD (1 024 on the MI355X) to run in one round: 32 rows where the request is large enough
-// (8 pages of 800 x 600: 2 000 waves; measured per 8 pages at S = 8 / 14 / 20 / 26 / 32 / 44: decoder block 129 / 128 /
-// 133 / 127 / 116 / 142 us, encoder block 44 / 44 / 48 / 53 / 48 / 60 us), 14 or 8 rows for a few pages or one
-// (one page at S = 8: 1 000 waves of 12 rows instead of 250 of 36).  The tape does not depend on S.
+// wants at least a wave per SIMD (1 024 on the MI355X) and at most one round of resident waves: measured per 8 pages of
+// 800 x 600 at S = 8 / 14 / 20 / 26 / 32 / 44: decoder block (147 VGPRs, 3 waves per SIMD) 129 / 128 / 133 / 127 / 116 /
+// 142 us, encoder block 44 / 44 / 48 / 53 / 48 / 60 us.  So: decoder 32 rows where that still gives 1 024 waves (8 pages:
+// 2 000), else 14, else 8 (one page at S = 8: 1 000 waves of 12 rows instead of 250 of 36); encoder 14, else 8.  The tape
+// does not depend on S.
 bool double_conv_stream(const DoubleConvArgs& a, int cs, int cx, int cmid, int cout, bool pool, bool final_conv, bool launch, hipStream_t s,
                         const StreamWeights* hw, std::vector<float>* tape_out, int* tape_len) {
     auto waves = [&](int S) { return (int64_t)a.n * ((a.w + kValid - 1) / kValid) * ((a.h + S - 1) / S); };
     const int opt = option(OPT_DET_STREAM);   // 1: by the rule above; 8 / 14 / 32: that segment height (tests, A/B)
-    const int S = (opt == 8 || opt == 14 || opt == 32) ? opt : waves(32) >= 1024 ? 32 : waves(14) >= 1024 ? 14 : 8;
+    // (the encoder block is light — 66 VGPRs, seven waves per SIMD — and runs 4 640 waves of 18 rows in one round: 14 rows)
+    const int S = (opt == 8 || opt == 14 || opt == 32) ? opt : (cx > 0 && waves(32) >= 1024) ? 32 : waves(14) >= 1024 ? 14 : 8;
 #define OCRS_ST(CS, CX, CM, CO, P, F)                                                             \
     if (cs == CS && cx == CX && cmid == CM && cout == CO && pool == P && final_conv == F) {        \
         typedef StCfg<CS, CX, CM, CO, P, F, 32> Cfg;                                               \
