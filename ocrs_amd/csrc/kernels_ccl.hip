@@ -501,10 +501,10 @@ __device__ __forceinline__ void hull_rect(const uint32_t* simp, uint32_t* sorted
 }
 
 constexpr int kSmallPoly = 64;   // simplified polygons up to this size keep their sort / hull scratch in LDS
-constexpr int kWalkBuf = 1024;   // border points buffered in LDS by the contour kernel: LDS per 64-thread block stays near 10 KB, i.e. ~15 components in flight per CU — the stage is bound by one wave's instruction latencies, so concurrency matters more than where the data sits
+constexpr int kWalkBuf = 1024;   // border points buffered in LDS by the contour kernel: LDS per 64-thread block stays near 10 KB, i.e. ~15 components in flight per CU — the stage is bound by one wave's instruction latencies, so concurrency matters more than where the data sits.  (r4: the kernel took 196 VGPRs, which allowed only 8 per CU whatever the LDS said; __launch_bounds__(64, 4) caps it at 128 — 64 registers of the rectangle geometry spill to scratch — and the 15 are real: 151 -> 138 us per 8 pages)
 
 // One wavefront (= one 64-thread block) per component.
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64, 4)
 contour_rect_kernel(const uint8_t* __restrict__ mask, int h, int w, const int32_t* __restrict__ n_roots,
                     const int32_t* __restrict__ roots, int32_t* __restrict__ arena_top, int32_t* __restrict__ overflow,
                     uint32_t* __restrict__ pts_all, uint32_t* __restrict__ tmp_all, uint8_t* __restrict__ keep_all,
