@@ -259,3 +259,25 @@ def test_streaming_detection_blocks_equal_the_tiled_blocks_and_the_oracle(in_hw,
             assert got.shape == exp.shape and np.array_equal(got, exp), mode
     finally:
         _lib.set_option("det_stream", 1)
+
+
+def test_streaming_detection_blocks_on_random_sizes():
+    """The same comparison on eight random model-input sizes (61-330 pixels a side, 1-4 pages): strips, segments and the
+    ConvTranspose's zero-padded last row / column fall differently every time."""
+    import models_util as M
+    from oracle.nn import OracleGraph
+    rng = np.random.default_rng(2024)
+    try:
+        for _ in range(8):
+            in_hw = (int(rng.integers(61, 331)), int(rng.integers(61, 331)))
+            n = int(rng.integers(1, 5))
+            buf = M.detection_model_bytes(in_hw, (8, 16, 32))
+            x = (rng.random((n, 1) + in_hw, dtype=np.float32) - 0.5).astype(np.float32)
+            m = Model.load_bytes(buf)
+            exp = OracleGraph(buf).run_exact(x)
+            for mode in (1, 8, 32):
+                _lib.set_option("det_stream", mode)
+                assert np.array_equal(m.run(x), exp), (in_hw, n, mode)
+    finally:
+        _lib.set_option("det_stream", 1)
+
