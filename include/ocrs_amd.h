@@ -134,6 +134,9 @@ OCRS_API ocrs_status ocrs_coalescer_selftest(int n_threads, int requests_per_thr
  *                     registers, horizontal taps through DPP lane shifts: no LDS, no barriers), rows per wave chosen from
  *                     the request's size; 8 / 14 / 32 = the same with that many rows per wave; 0 = the LDS-tiled blocks
  *                     (rounds 2-3).  Same bits.
+ *   "ccl_quad"        1 (default) = the component-labelling and root-compaction kernels of detect_words handle four mask
+ *                     pixels per thread (word loads, neighbours from the neighbouring lanes) when the page width is a
+ *                     multiple of 4; 0 = one pixel per thread.  Same components, same order.
  *   "gru_waves"       recurrence kernel of requests with more row tiles than clusters: 4 (default) = the general kernel (one
  *                     wave per SIMD, three interleaved MFMA chains per wave); 16 = four gate-per-wave teams of four waves
  *                     per workgroup, state through LDS (round-4 experiment, same bits, 12 % slower per layer)

@@ -266,6 +266,7 @@ const OptDef kOptDefs[OPT_COUNT] = {
     {"gru_waves", "OCRS_GRU_WAVES", 4},                 // recurrence of requests beyond one row tile per cluster: 4 = the general kernel (one wave per SIMD; default), 16 = four gate-per-wave teams per workgroup (r4 experiment: 12 % slower)
     {"det_tail", "OCRS_DET_TAIL", 0},                   // detection U-Net: every operator of the deep levels (<= 2048 pixels per page) in ONE persistent launch (1; r4 experiment: 44 -> 23 dispatches but 1.03 vs 0.24 ms) or one launch per operator (0, default)
     {"det_stream", "OCRS_DET_STREAM", 1},               // detection U-Net, DoubleConv blocks of the full-resolution levels: row-streaming register kernels (1, default; kernels_det_stream.hip) or the LDS-tiled blocks of kernels_det.hip (0)
+    {"ccl_quad", "OCRS_CCL_QUAD", 1},                   // component labelling / root compaction kernels: four pixels per thread on word-aligned masks (1, default) or one (0)
 };
 std::atomic<long> g_opts[OPT_COUNT];
 std::once_flag g_opts_once;

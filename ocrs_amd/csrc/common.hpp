@@ -144,7 +144,7 @@ inline hipStream_t recurrent_stream() { return ctx().recurrent_stream(); }
 // Process-wide tuning options (ocrs_set_option; initial value from the environment variable OCRS_<NAME>).
 // Integer-valued, looked up by name; unknown names are rejected by the ABI.
 enum Option { OPT_GRU_MODE = 0, OPT_DET_FUSE, OPT_LAYOUT_THREADS, OPT_BEAM_GPU, OPT_GRU_LOCAL, OPT_GRU_SCATTER, OPT_REC_MAX_PIXELS, OPT_GEMM_NFAST, OPT_GRU_GATES,
-              OPT_COALESCE, OPT_COALESCE_PAGES, OPT_COALESCE_WINDOW_US, OPT_GRU_GATES_PACK, OPT_CONV_OCCUPANCY, OPT_DET_MFMA, OPT_GRU_BACKGROUND, OPT_GX_HEAVY, OPT_DET_HEAVY, OPT_CONV_FLAT, OPT_CONV12_FUSE, OPT_GROUP_MIN_BLOCK, OPT_GROUP_SHARED_BLOCK, OPT_GRU_WAVES, OPT_DET_TAIL, OPT_DET_STREAM, OPT_COUNT };
+              OPT_COALESCE, OPT_COALESCE_PAGES, OPT_COALESCE_WINDOW_US, OPT_GRU_GATES_PACK, OPT_CONV_OCCUPANCY, OPT_DET_MFMA, OPT_GRU_BACKGROUND, OPT_GX_HEAVY, OPT_DET_HEAVY, OPT_CONV_FLAT, OPT_CONV12_FUSE, OPT_GROUP_MIN_BLOCK, OPT_GROUP_SHARED_BLOCK, OPT_GRU_WAVES, OPT_DET_TAIL, OPT_DET_STREAM, OPT_CCL_QUAD, OPT_COUNT };
 enum { GRU_PERSISTENT = 0, GRU_STEP = 1 };
 int option(Option o);
 long option_long(Option o);

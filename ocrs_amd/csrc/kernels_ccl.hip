@@ -21,6 +21,7 @@
 //     arena, write walk + simplify + rectangle.
 // Everything here is integer/byte work or latency-bound geometry on a 1 MiB
 // mask that lives in L2: there is no MFMA-shaped computation in this stage.
+#include "common.hpp"
 #include "kernels.hpp"
 
 namespace ocrs {
@@ -197,7 +198,214 @@ write_roots_kernel(const uint8_t* __restrict__ mask, const int32_t* __restrict__
     }
 }
 
+// ---------------------------------------------------------------------------
+// r4: the same four passes with FOUR pixels per thread (w % 4 == 0: the masks resize_threshold writes).  The byte
+// kernels above issue 4-6 one-byte loads per 64 pixels and are bound by load instructions, not by bytes (8 pages:
+// 17 + 101 + 19 + 16 us for 8 MiB of mask and 32 MiB of labels); here a thread loads its row's mask word and the word
+// above, takes the neighbouring pixels from the neighbouring lanes' registers (DPP wave shifts; the two lanes at a
+// wave's ends fetch the missing bytes themselves) and stores its four labels as one 16-byte word.  A wave's run
+// segment is 256 pixels instead of 64.  The unions made are a different set with the same transitive closure, and a
+// tree's root is the minimum index of its nodes whatever the order of the unions, so roots, their order and every
+// later stage are unchanged (test_component_rects_*: both kernel sets against the oracle).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t lane_prev_u32(uint32_t v) {   // lane - 1's value (0 at lane 0)
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xF, 0xF, true);
+}
+__device__ __forceinline__ uint32_t lane_next_u32(uint32_t v) {   // lane + 1's value (0 at lane 63)
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xF, 0xF, true);
+}
+
+__global__ void __launch_bounds__(256)
+ccl_init4_kernel(const uint8_t* __restrict__ mask, int32_t* __restrict__ labels, int h, int w) {
+    const int n = blockIdx.z, y = blockIdx.y;
+    const int x0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    const int lane = threadIdx.x & 63;
+    const bool inb = x0 < w;                                   // w % 4 == 0: a thread is inside or outside as a whole
+    const int64_t row = ((int64_t)n * h + y) * w;
+    const uint32_t cur = inb ? *reinterpret_cast<const uint32_t*>(mask + row + x0) : 0x02020202u;
+    const uint32_t prev = lane_prev_u32(cur);
+    const int v0 = cur & 0xFF, v1 = (cur >> 8) & 0xFF, v2 = (cur >> 16) & 0xFF, v3 = cur >> 24;
+    const bool b0 = lane == 0 || v0 != (int)(prev >> 24), b1 = v1 != v0, b2 = v2 != v1, b3 = v3 != v2;
+    const int top = b3 ? 3 : b2 ? 2 : b1 ? 1 : b0 ? 0 : -1;    // the lane's last boundary
+    const unsigned long long any = __ballot(top >= 0);
+    const unsigned long long below = any & ((1ull << lane) - 1ull);
+    const int src = below ? 63 - __clzll(below) : 0;           // the nearest lower lane that holds a boundary
+    const int src_top = __shfl(top, src);
+    if (!inb) return;
+    const int seg = (int)(row - (int64_t)n * h * w) + x0 - 4 * lane;   // page-local index of the wave's first pixel
+    const int carried = seg + 4 * src + src_top;               // run start inherited from the lanes below (lane 0 has b0)
+    int4 out;
+    const int s0 = b0 ? seg + 4 * lane : carried;
+    const int s1 = b1 ? seg + 4 * lane + 1 : s0;
+    const int s2 = b2 ? seg + 4 * lane + 2 : s1;
+    const int s3 = b3 ? seg + 4 * lane + 3 : s2;
+    out.x = s0; out.y = s1; out.z = s2; out.w = s3;
+    *reinterpret_cast<int4*>(labels + row + x0) = out;
+}
+
+__global__ void __launch_bounds__(256)
+ccl_merge4_kernel(const uint8_t* __restrict__ mask, int32_t* __restrict__ labels, int h, int w) {
+    const int n = blockIdx.z, y = blockIdx.y;
+    const int x0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    const int lane = threadIdx.x & 63;
+    const bool inb = x0 < w;
+    const uint8_t* m = mask + (int64_t)n * h * w;
+    int32_t* L = labels + (int64_t)n * h * w;
+    const int p0 = y * w + x0;
+    const bool hasN = y > 0;
+    // 0xFF = "no such pixel": differs from both classes, like the -1 of the byte kernel
+    const uint32_t cur = inb ? *reinterpret_cast<const uint32_t*>(m + p0) : 0xFFFFFFFFu;
+    const uint32_t up = (inb && hasN) ? *reinterpret_cast<const uint32_t*>(m + p0 - w) : 0xFFFFFFFFu;
+    uint32_t cur_w = lane_prev_u32(cur) >> 24, up_w = lane_prev_u32(up) >> 24;     // pixel x0 - 1
+    uint32_t cur_e = lane_next_u32(cur) & 0xFF, up_e = lane_next_u32(up) & 0xFF;   // pixel x0 + 4
+    if (lane == 0) {
+        cur_w = (inb && x0 > 0) ? m[p0 - 1] : 0xFF;
+        up_w = (inb && x0 > 0 && hasN) ? m[p0 - w - 1] : 0xFF;
+    }
+    if (lane == 63) {
+        cur_e = (inb && x0 + 4 < w) ? m[p0 + 4] : 0xFF;
+        up_e = (inb && x0 + 4 < w && hasN) ? m[p0 - w + 4] : 0xFF;
+    }
+    if (!inb) return;
+    const uint32_t c[6] = {cur_w, cur & 0xFF, (cur >> 8) & 0xFF, (cur >> 16) & 0xFF, cur >> 24, cur_e};   // x0 - 1 .. x0 + 4
+    const uint32_t u[6] = {up_w, up & 0xFF, (up >> 8) & 0xFF, (up >> 16) & 0xFF, up >> 24, up_e};
+    // The unions this thread has to make, as a bit set: bit 5 j + t = pixel j with its neighbour of kind t
+    // (0: W, 1: N, 2: NW, 3: NE, 4: the frame node).  They are then made one per loop iteration: a wave pays one union
+    // latency (a few dependent L2 round trips) per iteration, and the number of iterations is the largest number of unions
+    // any of its lanes has (1-3 inside text) — as straight-line code every one of the 20 union sites that ANY lane needs
+    // costs the wave that latency.
+    uint32_t todo = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int x = x0 + j;
+        const uint32_t v = c[j + 1], vW = c[j], vN = u[j + 1], vNW = u[j], vNE = u[j + 2], vE = c[j + 2];
+        const bool run_start = (lane == 0 && j == 0) || vW != v;
+        uint32_t t = 0;
+        if (run_start && vW == v) t |= 1u;
+        if (v) {
+            // 8-connectivity.  p~N unless already implied through W and NW.
+            if (vN == 1) {
+                if (!(vW == 1 && vNW == 1)) t |= 2u;
+            } else {
+                if (vNW == 1 && vW != 1) t |= 4u;
+                if (vNE == 1 && vE != 1) t |= 8u;     // (vNE is 0xFF without a row above or a column to the right)
+            }
+        } else {
+            // 4-connectivity + virtual frame node.
+            if (vN == 0 && !(vW == 0 && vNW == 0)) t |= 2u;
+            const bool on_frame = (y == 0 || y == h - 1) ? run_start : false;
+            if (on_frame || x == 0 || x == w - 1) t |= 16u;
+        }
+        todo |= t << (5 * j);
+    }
+    while (todo) {
+        const int k = __ffs(todo) - 1;
+        todo &= todo - 1;
+        const int j = k / 5, t = k - 5 * j;
+        const int p = p0 + j;
+        const int q = t == 0 ? p - 1 : t == 1 ? p - w : t == 2 ? p - w - 1 : t == 3 ? p - w + 1 : -1;
+        uf_union(L, p, q);
+    }
+}
+
+// is_external_root for four pixels: bit j of the result
+__device__ __forceinline__ uint32_t external_roots4(const uint8_t* m, const int32_t* L, int p0, int x0) {
+    const uint32_t mv = *reinterpret_cast<const uint32_t*>(m + p0);
+    if (mv == 0) return 0;
+    const int4 lv = *reinterpret_cast<const int4*>(L + p0);
+    uint32_t r = 0;
+    if ((mv & 0xFF) && lv.x == p0 && (x0 == 0 || uf_find(L, p0 - 1) < 0)) r |= 1;
+    if (((mv >> 8) & 0xFF) && lv.y == p0 + 1 && uf_find(L, p0) < 0) r |= 2;
+    if (((mv >> 16) & 0xFF) && lv.z == p0 + 2 && uf_find(L, p0 + 1) < 0) r |= 4;
+    if ((mv >> 24) && lv.w == p0 + 3 && uf_find(L, p0 + 2) < 0) r |= 8;
+    return r;
+}
+
+// One block per (row, page): counts the row's external roots, four pixels per thread.
+__global__ void __launch_bounds__(256)
+count_roots4_kernel(const uint8_t* __restrict__ mask, const int32_t* __restrict__ labels, int h, int w,
+                    int32_t* __restrict__ row_counts) {
+    const int y = blockIdx.x, n = blockIdx.y;
+    const uint8_t* m = mask + (int64_t)n * h * w;
+    const int32_t* L = labels + (int64_t)n * h * w;
+    int cnt = 0;
+    for (int x0 = threadIdx.x * 4; x0 < w; x0 += 1024) cnt += __popc(external_roots4(m, L, y * w + x0, x0));
+    __shared__ int red[256];
+    red[threadIdx.x] = cnt;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) row_counts[n * h + y] = red[0];
+}
+
+__global__ void __launch_bounds__(256)
+write_roots4_kernel(const uint8_t* __restrict__ mask, const int32_t* __restrict__ labels, int h, int w,
+                    const int32_t* __restrict__ row_counts, int32_t* __restrict__ roots, int32_t* __restrict__ n_roots,
+                    int32_t* __restrict__ overflow, int max_comp) {
+    const int y = blockIdx.x, n = blockIdx.y;
+    const uint8_t* m = mask + (int64_t)n * h * w;
+    const int32_t* L = labels + (int64_t)n * h * w;
+    __shared__ int wave_cnt[4];
+    __shared__ int red[256];
+    __shared__ int base;
+    int above = 0;
+    for (int i = threadIdx.x; i < y; i += blockDim.x) above += row_counts[n * h + i];
+    red[threadIdx.x] = above;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        base = red[0];
+        if (y == h - 1) {
+            const int total = red[0] + row_counts[n * h + y];
+            n_roots[n] = total;
+            if (total > max_comp) overflow[n] = 1;
+        }
+    }
+    __syncthreads();
+    if (row_counts[n * h + y] == 0) return;   // (uniform) most rows of a page start no component
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int xb = 0; xb < w; xb += 1024) {
+        const int x0 = xb + threadIdx.x * 4;
+        const uint32_t r = x0 < w ? external_roots4(m, L, y * w + x0, x0) : 0;
+        const int mine = __popc(r);
+        // exclusive prefix of `mine` over the wave's lanes (roots are numbered in x order)
+        int pre = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int t = __shfl_up(pre, d);
+            if (lane >= d) pre += t;
+        }
+        if (lane == 63) wave_cnt[wv] = pre;
+        __syncthreads();
+        int off = base + pre - mine;
+        for (int i = 0; i < wv; i++) off += wave_cnt[i];
+        for (int j = 0; j < 4; j++)
+            if (r & (1u << j)) {
+                if (off < max_comp) roots[(int64_t)n * max_comp + off] = y * w + x0 + j;
+                off++;
+            }
+        __syncthreads();
+        if (threadIdx.x == 0) base += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+        __syncthreads();
+    }
+}
+
 void ccl_label(const uint8_t* d_mask, int n, int h, int w, const CclBuffers& b, int max_comp, hipStream_t s) {
+    // option "ccl_quad" (default 1): four pixels per thread where the rows are word-aligned
+    if (option(OPT_CCL_QUAD) && (w & 3) == 0 && (((uintptr_t)d_mask) & 3) == 0 && (((uintptr_t)b.labels) & 15) == 0) {
+        dim3 grid4((w + 1023) / 1024, h, n);
+        hipLaunchKernelGGL(ccl_init4_kernel, grid4, dim3(256), 0, s, d_mask, b.labels, h, w);
+        hipLaunchKernelGGL(ccl_merge4_kernel, grid4, dim3(256), 0, s, d_mask, b.labels, h, w);
+        hipLaunchKernelGGL(count_roots4_kernel, dim3(h, n), dim3(256), 0, s, d_mask, b.labels, h, w, b.row_counts);
+        hipLaunchKernelGGL(write_roots4_kernel, dim3(h, n), dim3(256), 0, s, d_mask, b.labels, h, w, b.row_counts, b.roots,
+                           b.n_roots, b.overflow, max_comp);
+        return;
+    }
     dim3 grid((w + 255) / 256, h, n);
     hipLaunchKernelGGL(ccl_init_kernel, grid, dim3(256), 0, s, d_mask, b.labels, h, w);
     hipLaunchKernelGGL(ccl_merge_kernel, grid, dim3(256), 0, s, d_mask, b.labels, h, w);

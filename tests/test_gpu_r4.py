@@ -281,3 +281,42 @@ def test_streaming_detection_blocks_on_random_sizes():
     finally:
         _lib.set_option("det_stream", 1)
 
+
+# ------------------------------------------------------------------ component labelling, four pixels per thread
+@pytest.mark.parametrize("h,w", [(100, 1032), (100, 2052), (100, 260), (33, 64), (50, 8)])
+def test_quad_pixel_component_kernels_equal_the_byte_kernels_and_the_oracle(h, w):
+    """option ccl_quad: labelling and root compaction with four mask pixels per thread (a wave's run segment is 256 pixels,
+    a block's 1 024).  Widths that end inside a wave / cross the 256- and 1 024-pixel boundaries / are narrower than one
+    thread group; masks whose runs and diagonal contacts straddle those boundaries.  Same rects in the same order as the
+    one-pixel-per-thread kernels and the oracle."""
+    from test_gpu_parity import _adversarial_masks, _mask_engine_pair, rects_of
+    box, gpu, ora = _mask_engine_pair(h, w)
+    page = np.zeros((1, h, w), np.float32)
+    inp = gpu.prepare_input(ImageSource.from_tensor(page, DimOrder.Chw))
+    rng = np.random.default_rng(w)
+    masks = list(_adversarial_masks(h, w)) if h >= 100 and w >= 200 else [("empty", np.zeros((h, w), np.uint8)), ("full", np.ones((h, w), np.uint8))]
+    m = np.zeros((h, w), np.uint8)
+    for y in range(2, h - 2, 4):                       # long runs ending / starting exactly at the segment boundaries
+        for b in (64, 256, 1024, 2048):
+            if b + 3 < w:
+                m[y, max(b - 40, 0):b] = 1             # ends at b - 1
+                m[y + 1, b:min(b + 37, w)] = 1         # starts at b: diagonal contact across the boundary
+    masks.append(("boundary runs", m))
+    m = (rng.random((h, w)) < 0.5).astype(np.uint8)
+    m[:, 250:262] = (rng.random((h, 12)) < 0.8) if w > 262 else m[:, 250:262]
+    masks.append(("noise50", m))
+    m = np.ones((h, w), np.uint8)
+    m[h // 2, :] = 0                                   # one background line across every boundary, touching the frame
+    m[3:h - 3:5, 1:w - 1] = 0                          # and lines that do not
+    masks.append(("background lines", m))
+    try:
+        for name, mask in masks:
+            box["prob"] = mask.astype(np.float32)
+            exp = rects_of(ora.detect_words(page))
+            for quad in (1, 0):
+                _lib.set_option("ccl_quad", quad)
+                got = gpu.detect_words(inp)
+                assert got.shape == exp.shape and np.array_equal(got, exp), (name, quad)
+    finally:
+        _lib.set_option("ccl_quad", 1)
+
