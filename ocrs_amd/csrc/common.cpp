@@ -267,6 +267,7 @@ const OptDef kOptDefs[OPT_COUNT] = {
     {"det_tail", "OCRS_DET_TAIL", 0},                   // detection U-Net: every operator of the deep levels (<= 2048 pixels per page) in ONE persistent launch (1; r4 experiment: 44 -> 23 dispatches but 1.03 vs 0.24 ms) or one launch per operator (0, default)
     {"det_stream", "OCRS_DET_STREAM", 1},               // detection U-Net, DoubleConv blocks of the full-resolution levels: row-streaming register kernels (1, default; kernels_det_stream.hip) or the LDS-tiled blocks of kernels_det.hip (0)
     {"ccl_quad", "OCRS_CCL_QUAD", 1},                   // component labelling / root compaction kernels: four pixels per thread on word-aligned masks (1, default) or one (0)
+    {"det_rows", "OCRS_DET_ROWS", 1},                   // detection U-Net, DoubleConv blocks of the 16-64-channel levels: row-streaming workgroup kernels (1, default; kernels_det_rows.hip; 8 / 14 / 32 = that many rows per workgroup) or the LDS-tiled blocks of kernels_det.hip (0)
 };
 std::atomic<long> g_opts[OPT_COUNT];
 std::once_flag g_opts_once;

@@ -1,6 +1,7 @@
 // Shared host-side plumbing for libocrs_amd: error reporting, HIP checks,
 // a caching device allocator and per-call streams.
 #pragma once
+#include <atomic>
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
@@ -144,9 +145,21 @@ inline hipStream_t recurrent_stream() { return ctx().recurrent_stream(); }
 // Process-wide tuning options (ocrs_set_option; initial value from the environment variable OCRS_<NAME>).
 // Integer-valued, looked up by name; unknown names are rejected by the ABI.
 enum Option { OPT_GRU_MODE = 0, OPT_DET_FUSE, OPT_LAYOUT_THREADS, OPT_BEAM_GPU, OPT_GRU_LOCAL, OPT_GRU_SCATTER, OPT_REC_MAX_PIXELS, OPT_GEMM_NFAST, OPT_GRU_GATES,
-              OPT_COALESCE, OPT_COALESCE_PAGES, OPT_COALESCE_WINDOW_US, OPT_GRU_GATES_PACK, OPT_CONV_OCCUPANCY, OPT_DET_MFMA, OPT_GRU_BACKGROUND, OPT_GX_HEAVY, OPT_DET_HEAVY, OPT_CONV_FLAT, OPT_CONV12_FUSE, OPT_GROUP_MIN_BLOCK, OPT_GROUP_SHARED_BLOCK, OPT_GRU_WAVES, OPT_DET_TAIL, OPT_DET_STREAM, OPT_CCL_QUAD, OPT_COUNT };
+              OPT_COALESCE, OPT_COALESCE_PAGES, OPT_COALESCE_WINDOW_US, OPT_GRU_GATES_PACK, OPT_CONV_OCCUPANCY, OPT_DET_MFMA, OPT_GRU_BACKGROUND, OPT_GX_HEAVY, OPT_DET_HEAVY, OPT_CONV_FLAT, OPT_CONV12_FUSE, OPT_GROUP_MIN_BLOCK, OPT_GROUP_SHARED_BLOCK, OPT_GRU_WAVES, OPT_DET_TAIL, OPT_DET_STREAM, OPT_CCL_QUAD, OPT_DET_ROWS, OPT_COUNT };
 enum { GRU_PERSISTENT = 0, GRU_STEP = 1 };
 int option(Option o);
+
+// Kernels that need more than 64 KB of dynamic LDS have to opt in with hipFuncSetAttribute — per DEVICE (the function
+// object belongs to the device that is current): once per (kernel, device), remembered in `done` (bit = device ordinal
+// mod 64).  A process that drives several GPUs (engine group) launches the same kernel on each of them.
+inline void allow_dynamic_lds(const void* kernel, std::atomic<uint64_t>& done) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const uint64_t bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_relaxed) & bit) return;
+    (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    done.fetch_or(bit, std::memory_order_relaxed);
+}
 long option_long(Option o);
 bool set_option(const char* name, long value);  // false: unknown name
 inline int gru_mode() { return option(OPT_GRU_MODE); }

@@ -114,6 +114,11 @@ bool double_conv_fused(const DoubleConvArgs& a, int cs, int cx, int cmid, int co
 // uploads it and passes it in DoubleConvArgs::tape); *tape_len = floats per tape.
 bool double_conv_stream(const DoubleConvArgs& a, int cs, int cx, int cmid, int cout, bool pool, bool final_conv, bool launch, hipStream_t s,
                         const StreamWeights* hw = nullptr, std::vector<float>* tape_out = nullptr, int* tape_len = nullptr);
+// ---- kernels_det_rows.hip (r4): the blocks of the 16-64-channel levels as row-streaming workgroup kernels; same contract
+// (the tape holds the four waves' depthwise weights).  At launch time false also when the geometry does not fit (then the
+// tiled block runs).
+bool double_conv_rows(const DoubleConvArgs& a, int cs, int cx, int cmid, int cout, bool pool, bool final_conv, bool launch, hipStream_t s,
+                      const StreamWeights* hw = nullptr, std::vector<float>* tape_out = nullptr, int* tape_len = nullptr);
 void maxpool(const float* x, int n, int h, int w, int c, int kh, int kw, float* y, hipStream_t s);
 void avgpool(const float* x, int n, int h, int w, int c, int kh, int kw, float* y, hipStream_t s);
 void padcat(const float* skip, int n, int sh, int sw, int cs, const float* x, int h, int w, int cx, float* y,

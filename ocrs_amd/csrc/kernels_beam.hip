@@ -15,6 +15,7 @@
 //   * new prefixes get nodes (parent, label) / (parent, time) in per-line arenas in HBM; the answer is read back
 //     by walking the best beam's chain.
 #include "beam_math.hpp"
+#include "common.hpp"
 #include "kernels.hpp"
 
 namespace ocrs {
@@ -371,12 +372,8 @@ bool ctc_beam_packed(const float* logp, const int32_t* d_Tm, const int32_t* d_of
     a.out_labels = out_labels; a.out_pos = out_pos; a.out_count = out_count;
     a.M = M; a.C = C; a.W = width; a.Tmax = Tmax; a.cap = (int)ctc_beam_arena_entries(Tmax, width);
     const size_t lds = beam_lds_bytes(width, C);
-    static size_t raised = 0;
-    if (lds > 64 * 1024 && lds > raised) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ctc_beam_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  160 * 1024);
-        raised = 160 * 1024;
-    }
+    static std::atomic<uint64_t> lds_ok{0};
+    if (lds > 64 * 1024) allow_dynamic_lds(reinterpret_cast<const void*>(&ctc_beam_kernel), lds_ok);
     hipLaunchKernelGGL(ctc_beam_kernel, dim3(M), dim3(BEAM_NT), lds, s, a);
     return true;
 }

@@ -295,13 +295,8 @@ void launch_dc(const DoubleConvArgs& a0, hipStream_t s) {
     a.tiles_x = (a.w + Cfg::TW - 1) / Cfg::TW;
     const int tiles = a.n * a.tiles_y * a.tiles_x;
     const int grid = ((tiles + 7) / 8) * 8;
-    static bool attr_set = [] {
-        if (Cfg::LDS_BYTES > 64 * 1024)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&double_conv_kernel<Cfg>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
-        return true;
-    }();
-    (void)attr_set;
+    static std::atomic<uint64_t> lds_ok{0};
+    if (Cfg::LDS_BYTES > 64 * 1024) allow_dynamic_lds(reinterpret_cast<const void*>(&double_conv_kernel<Cfg>), lds_ok);
     hipLaunchKernelGGL((double_conv_kernel<Cfg>), dim3(grid), dim3(256), Cfg::LDS_BYTES, s, a);
 }
 
@@ -709,13 +704,8 @@ void launch_mc(const DoubleConvArgs& a0, hipStream_t s) {
     a.tiles_x = (a.w + Cfg::TW - 1) / Cfg::TW;
     const int tiles = a.n * a.tiles_y * a.tiles_x;
     const int grid = ((tiles + 7) / 8) * 8;
-    static bool attr_set = [] {
-        if (Cfg::LDS_BYTES > 64 * 1024)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&double_conv_mfma_kernel<Cfg>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS_BYTES);
-        return true;
-    }();
-    (void)attr_set;
+    static std::atomic<uint64_t> lds_ok{0};
+    if (Cfg::LDS_BYTES > 64 * 1024) allow_dynamic_lds(reinterpret_cast<const void*>(&double_conv_mfma_kernel<Cfg>), lds_ok);
     hipLaunchKernelGGL((double_conv_mfma_kernel<Cfg>), dim3(grid), dim3(Cfg::NT), Cfg::LDS_BYTES, s, a);
 }
 
@@ -733,6 +723,11 @@ bool double_conv_fused(const DoubleConvArgs& a, int cs, int cx, int cmid, int co
     // option "det_stream" (default 1): the row-streaming kernels of kernels_det_stream.hip where the shape has one
     if (option(OPT_DET_STREAM) >= 1 && fuse_level >= 1 && (!launch || a.tape) && double_conv_stream(a, cs, cx, cmid, cout, pool, final_conv, launch, s)) {
         if (on_mfma) *on_mfma = false;
+        return true;
+    }
+    // option "det_rows" (default 1): the row-streaming workgroup kernels of kernels_det_rows.hip where the shape has one
+    if (option(OPT_DET_ROWS) >= 1 && fuse_level >= 1 && (!launch || a.tape) && double_conv_rows(a, cs, cx, cmid, cout, pool, final_conv, launch, s)) {
+        if (on_mfma) *on_mfma = true;
         return true;
     }
 #define OCRS_DC(CS, CX, CM, CO, TH, TW, P, F)                                                   \

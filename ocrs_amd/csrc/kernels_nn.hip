@@ -1040,12 +1040,8 @@ bool log_softmax_argmax(const float* logits, int64_t rows, int c, const uint8_t*
     // instead of a generic launch failure
     if (lds > 160 * 1024) return false;
     if (lds > 64 * 1024) {
-        static size_t raised = 0;
-        if (lds > raised) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&log_softmax_argmax_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            raised = 160 * 1024;
-        }
+        static std::atomic<uint64_t> lds_ok{0};
+        allow_dynamic_lds(reinterpret_cast<const void*>(&log_softmax_argmax_kernel), lds_ok);
     }
     int grid = (int)((rows + LSM_ROWS - 1) / LSM_ROWS);
     hipLaunchKernelGGL(log_softmax_argmax_kernel, dim3(grid), dim3(LSM_ROWS), lds, s, logits, rows, c, d_excluded, logp,

@@ -247,7 +247,8 @@ std::unique_ptr<HipModel> HipModel::load(const void* data, size_t len, int devic
                                     host(b.dw2, 0), host(b.dw2, 1), host(b.pw2, 0), host(b.pw2, 1), host(b.fin, 0), host(b.fin, 1)};
                 std::vector<float> tape;
                 int tape_len = 0;
-                if (k::double_conv_stream(none, b.cs, b.cx, b.cmid, b.cout, b.pool >= 0, b.fin >= 0, false, nullptr, &hw, &tape, &tape_len)) {
+                if (k::double_conv_stream(none, b.cs, b.cx, b.cmid, b.cout, b.pool >= 0, b.fin >= 0, false, nullptr, &hw, &tape, &tape_len) ||
+                    k::double_conv_rows(none, b.cs, b.cx, b.cmid, b.cout, b.pool >= 0, b.fin >= 0, false, nullptr, &hw, &tape, &tape_len)) {
                     m->tapes.emplace_back(tape.size() * sizeof(float));
                     OCRS_HIP(hipMemcpy(m->tapes.back().p, tape.data(), tape.size() * sizeof(float), hipMemcpyHostToDevice));
                     b.tape = m->tapes.back().as<float>();

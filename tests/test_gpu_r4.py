@@ -238,7 +238,7 @@ def test_one_launch_detection_tail_equals_the_per_operator_kernels_and_the_oracl
 
 # ------------------------------------------------------------------ row-streaming DoubleConv blocks (kernels_det_stream.hip)
 @pytest.mark.parametrize("in_hw,n,depths", [((96, 64), 3, (8, 16, 32, 32)), ((131, 157), 2, (8, 16, 32, 32)), ((61, 59), 1, (8, 16)),
-                                            ((240, 121), 5, (8, 16, 32))])
+                                            ((240, 121), 5, (8, 16, 32)), ((176, 272), 2, (8, 16, 32, 32, 64)), ((402, 250), 1, (8, 16, 32, 32, 64))])
 def test_streaming_detection_blocks_equal_the_tiled_blocks_and_the_oracle(in_hw, n, depths):
     """option det_stream: the full-resolution DoubleConv blocks as row-streaming register kernels (a wave per 64-column
     strip, DPP lane shifts for the horizontal taps, the weights as a tape through the SGPRs).  Same bits as the LDS-tiled
@@ -253,12 +253,14 @@ def test_streaming_detection_blocks_equal_the_tiled_blocks_and_the_oracle(in_hw,
     m = Model.load_bytes(buf)
     exp = OracleGraph(buf).run_exact(x)
     try:
-        for mode in (0, 8, 14, 32, 1):
+        for mode in (0, 8, 14, 32, 1):     # the wave kernels of the 8-channel level and the workgroup kernels of the 16-64-channel levels
             _lib.set_option("det_stream", mode)
+            _lib.set_option("det_rows", mode)
             got = m.run(x)
             assert got.shape == exp.shape and np.array_equal(got, exp), mode
     finally:
         _lib.set_option("det_stream", 1)
+        _lib.set_option("det_rows", 1)
 
 
 def test_streaming_detection_blocks_on_random_sizes():
@@ -271,15 +273,17 @@ def test_streaming_detection_blocks_on_random_sizes():
         for _ in range(8):
             in_hw = (int(rng.integers(61, 331)), int(rng.integers(61, 331)))
             n = int(rng.integers(1, 5))
-            buf = M.detection_model_bytes(in_hw, (8, 16, 32))
+            buf = M.detection_model_bytes(in_hw, (8, 16, 32, 32) if min(in_hw) >= 100 else (8, 16, 32))
             x = (rng.random((n, 1) + in_hw, dtype=np.float32) - 0.5).astype(np.float32)
             m = Model.load_bytes(buf)
             exp = OracleGraph(buf).run_exact(x)
             for mode in (1, 8, 32):
                 _lib.set_option("det_stream", mode)
+                _lib.set_option("det_rows", mode)
                 assert np.array_equal(m.run(x), exp), (in_hw, n, mode)
     finally:
         _lib.set_option("det_stream", 1)
+        _lib.set_option("det_rows", 1)
 
 
 # ------------------------------------------------------------------ component labelling, four pixels per thread
