@@ -137,8 +137,10 @@ OCRS_API ocrs_status ocrs_coalescer_selftest(int n_threads, int requests_per_thr
  *   "det_rows"        1 (default) = the DoubleConv blocks of the detection U-Net's 16-64-channel levels run as row-streaming
  *                     workgroup kernels (four waves walk down a 64-column strip: depthwise convs in registers with the
  *                     channels split over the waves, pointwise convs and ConvTransposes on the matrix cores with the
- *                     pixels split over the waves, rows — not halo tiles — through LDS); 8 / 14 / 20 / 32 = the same with that
- *                     many rows per workgroup; 0 = the LDS-tiled blocks (rounds 2-3).  Same bits.
+ *                     pixels split over the waves, rows — not halo tiles — through LDS) for requests of up to 8 pages
+ *                     (larger batches keep the tiled blocks, which co-schedule better beside other requests' kernels);
+ *                     8 / 14 / 20 / 32 = those kernels for every request, with that many rows per workgroup; 0 = the
+ *                     LDS-tiled blocks (rounds 2-3) always.  Same bits.
  *   "ccl_quad"        1 (default) = the component-labelling and root-compaction kernels of detect_words handle four mask
  *                     pixels per thread (word loads, neighbours from the neighbouring lanes) when the page width is a
  *                     multiple of 4; 0 = one pixel per thread.  Same components, same order.
