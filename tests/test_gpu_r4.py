@@ -324,3 +324,30 @@ def test_quad_pixel_component_kernels_equal_the_byte_kernels_and_the_oracle(h, w
     finally:
         _lib.set_option("ccl_quad", 1)
 
+
+def test_quad_pixel_component_kernels_on_page_sized_masks():
+    """The same comparison on 1024 x 1024 masks: a thresholded synthetic text page (word blobs), the page with 2 % salt noise
+    on top (thousands of one-pixel components between the words) and a dense random texture cropped to text lines."""
+    from ocrs_amd import synth
+    from test_gpu_parity import _mask_engine_pair, rects_of
+    h = w = 1024
+    box, gpu, ora = _mask_engine_pair(h, w)
+    page = np.zeros((1, h, w), np.float32)
+    inp = gpu.prepare_input(ImageSource.from_tensor(page, DimOrder.Chw))
+    rng = np.random.default_rng(77)
+    grey = synth.synthetic_page(5, h, w, lines=70).astype(np.float32).mean(axis=2)
+    text = (grey < 128).astype(np.uint8)
+    salt = text | (rng.random((h, w)) < 0.02).astype(np.uint8)
+    texture = ((rng.random((h, w)) < 0.55) & (text > 0)).astype(np.uint8)
+    try:
+        for name, mask in (("text", text), ("text + salt", salt), ("texture", texture)):
+            box["prob"] = mask.astype(np.float32)
+            exp = rects_of(ora.detect_words(page))
+            assert len(exp) > 100, name
+            for quad in (1, 0):
+                _lib.set_option("ccl_quad", quad)
+                got = gpu.detect_words(inp)
+                assert got.shape == exp.shape and np.array_equal(got, exp), (name, quad)
+    finally:
+        _lib.set_option("ccl_quad", 1)
+
