@@ -42,7 +42,7 @@ PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md "HBM3E peak BW" (spec)
 PEAK_FP32_VALU_TFLOPS = 157.3  # MI355X_MICROARCH.md "Peak FP32 (vector)": 256 CUs x 128 lanes x 2 (FMA) x 2.4 GHz
 # kernel classes of the detection CNN (HBM-bound: depthwise-separable U-Net)
-DETECTION_CLASSES = ("det_fused_block", "dwconv3x3", "gemm_pointwise_mfma", "gemm_convt_mfma", "pool", "padcat",
+DETECTION_CLASSES = ("det_fused_block", "det_stream_wave_block", "det_stream_rows_block", "dwconv3x3", "gemm_pointwise_mfma", "gemm_convt_mfma", "pool", "padcat",
                      "conv1x1_sigmoid", "conv_direct")
 MFMA_CLASSES = ("gemm_conv3x3_mfma", "gemm_gru_input_mfma", "gemm_gru_hidden_mfma", "gemm_linear_mfma")
 

@@ -81,7 +81,7 @@ const char* const kKernelClassNames[KC_COUNT] = {
     "gemm_conv3x3_mfma", "gemm_pointwise_mfma", "gemm_convt_mfma", "gemm_gru_input_mfma", "gemm_gru_hidden_mfma",
     "gemm_linear_mfma",  "dwconv3x3",           "conv_direct",     "pool",                "padcat",
     "conv1x1_sigmoid",   "gru_gates",           "logsoftmax_argmax", "other",
-    "det_fused_block"};
+    "det_fused_block",   "det_stream_wave_block", "det_stream_rows_block"};
 
 // ---------------------------------------------------------------- DevicePool
 static size_t round_size(size_t n) {

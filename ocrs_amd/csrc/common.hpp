@@ -251,7 +251,7 @@ extern const char* const kStageNames[ST_COUNT];
 enum KernelClass {
     KC_GEMM_CONV3X3 = 0, KC_GEMM_POINTWISE, KC_GEMM_CONVT, KC_GEMM_GRU_INPUT, KC_GEMM_GRU_HIDDEN, KC_GEMM_LINEAR,
     KC_DWCONV3X3, KC_CONV_DIRECT, KC_POOL, KC_PADCAT, KC_CONV1X1_SIGMOID, KC_GRU_GATES, KC_LOGSOFTMAX_ARGMAX,
-    KC_OTHER, KC_DET_BLOCK, KC_COUNT
+    KC_OTHER, KC_DET_BLOCK, KC_DET_STREAM_WAVE, KC_DET_STREAM_ROWS, KC_COUNT
 };
 extern const char* const kKernelClassNames[KC_COUNT];
 

@@ -106,8 +106,10 @@ struct StreamWeights {
 // fuse level (option "det_fuse": 1 = the shapes where fusion wins, 2 = every shape that has a kernel);
 // launches it when `launch` is set.  *on_mfma: the block's pointwise convs / ConvTranspose run on the matrix cores
 // (option "det_mfma").
+// *path: which kernel family takes the shape with the current options and this request (a.n, a.h, a.w): 0 = LDS-tiled
+// block, 1 = row-streaming wave kernel, 2 = row-streaming workgroup kernel.
 bool double_conv_fused(const DoubleConvArgs& a, int cs, int cx, int cmid, int cout, bool pool, bool final_conv, int fuse_level,
-                       bool launch, hipStream_t s, bool* on_mfma = nullptr);
+                       bool launch, hipStream_t s, bool* on_mfma = nullptr, int* path = nullptr);
 // ---- kernels_det_stream.hip (r4): the same blocks as row-streaming register kernels for the full-resolution levels;
 // true if the shape has one (launches it when `launch` is set).  Same bits as the tiled blocks and the per-op kernels.
 // With `hw` / `tape_out` the block's weight tape is built (the weights in the order a row step consumes them; the caller
@@ -119,6 +121,8 @@ bool double_conv_stream(const DoubleConvArgs& a, int cs, int cx, int cmid, int c
 // tiled block runs).
 bool double_conv_rows(const DoubleConvArgs& a, int cs, int cx, int cmid, int cout, bool pool, bool final_conv, bool launch, hipStream_t s,
                       const StreamWeights* hw = nullptr, std::vector<float>* tape_out = nullptr, int* tape_len = nullptr);
+// the launch-time conditions of double_conv_rows (request size under option value 1, geometry): true if it will run
+bool double_conv_rows_takes(const DoubleConvArgs& a, int cx);
 void maxpool(const float* x, int n, int h, int w, int c, int kh, int kw, float* y, hipStream_t s);
 void avgpool(const float* x, int n, int h, int w, int c, int kh, int kw, float* y, hipStream_t s);
 void padcat(const float* skip, int n, int sh, int sw, int cs, const float* x, int h, int w, int cx, float* y,

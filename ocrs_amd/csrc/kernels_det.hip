@@ -713,7 +713,8 @@ void launch_mc(const DoubleConvArgs& a0, hipStream_t s) {
 
 // Shapes with a fused kernel: (skip channels, ConvT input channels or 0, mid, out, pool, final).
 bool double_conv_fused(const DoubleConvArgs& a, int cs, int cx, int cmid, int cout, bool pool, bool final_conv, int fuse_level,
-                       bool launch, hipStream_t s, bool* on_mfma) {
+                       bool launch, hipStream_t s, bool* on_mfma, int* path) {
+    if (path) *path = 0;
     // option "det_mfma": 1 (default) = the pointwise convs and ConvTransposes of every block shape listed below run on
     // the matrix cores (double_conv_mfma_kernel, 512 threads per tile) — including the 32-channel levels, which as
     // thread-per-pixel blocks lost to the per-op kernels and as MFMA blocks win (detection-only +4 %); 0 = the round-2
@@ -723,11 +724,13 @@ bool double_conv_fused(const DoubleConvArgs& a, int cs, int cx, int cmid, int co
     // option "det_stream" (default 1): the row-streaming kernels of kernels_det_stream.hip where the shape has one
     if (option(OPT_DET_STREAM) >= 1 && fuse_level >= 1 && (!launch || a.tape) && double_conv_stream(a, cs, cx, cmid, cout, pool, final_conv, launch, s)) {
         if (on_mfma) *on_mfma = false;
+        if (path) *path = 1;
         return true;
     }
     // option "det_rows" (default 1): the row-streaming workgroup kernels of kernels_det_rows.hip where the shape has one
     if (option(OPT_DET_ROWS) >= 1 && fuse_level >= 1 && (!launch || a.tape) && double_conv_rows(a, cs, cx, cmid, cout, pool, final_conv, launch, s)) {
         if (on_mfma) *on_mfma = true;
+        if (path) *path = 2;
         return true;
     }
 #define OCRS_DC(CS, CX, CM, CO, TH, TW, P, F)                                                   \

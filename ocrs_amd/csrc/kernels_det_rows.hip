@@ -408,6 +408,14 @@ std::vector<float> build_rows_tape(const StreamWeights& w) {
 
 }  // namespace
 
+bool double_conv_rows_takes(const DoubleConvArgs& a, int cx) {
+    const int opt = option(OPT_DET_ROWS);
+    if (opt < 1) return false;
+    if (opt == 1 && a.n > 8) return false;
+    if (cx > 0 && (((a.w - 2 * a.w1) / 2) & 1)) return false;
+    return true;
+}
+
 // Shapes with a workgroup row-streaming kernel (option "det_rows"); same contract as double_conv_stream.
 // Rows per workgroup: a workgroup's run time is (S + 4) x the latency of one row step (tape stages, four barriers, LDS
 // round trips, dependent MFMA chains: ~2 us), and what hides it is other workgroups on the same CU — so the launch wants

@@ -553,8 +553,14 @@ float* HipModel::run_device(Workspace& ws, const float* d_in, int n, int h, int 
                     const double fl_dense = 2.0 * px * ((double)cin * b.cmid + (double)b.cmid * b.cout) +
                                             2.0 * px * (b.convt >= 0 ? (double)b.cx * b.cs : 0.0);
                     bool on_mfma = false;
-                    k::double_conv_fused(k::DoubleConvArgs{}, b.cs, b.cx, b.cmid, b.cout, b.pool >= 0, b.fin >= 0, det_fuse, false, nullptr, &on_mfma);
-                    timed(KC_DET_BLOCK, fl, 4.0 * (px * b.cs + px1 * b.cx + out_floats), [&] {
+                    int path = 0;   // which kernel family will take it (the workgroup kernels decline large requests at launch time)
+                    {
+                        k::DoubleConvArgs probe = da;
+                        probe.tape = nullptr;   // a query: nothing is launched
+                        k::double_conv_fused(probe, b.cs, b.cx, b.cmid, b.cout, b.pool >= 0, b.fin >= 0, det_fuse, false, nullptr, &on_mfma, &path);
+                        if (path == 2 && !k::double_conv_rows_takes(da, b.cx)) { path = 0; }
+                    }
+                    timed(path == 1 ? KC_DET_STREAM_WAVE : path == 2 ? KC_DET_STREAM_ROWS : KC_DET_BLOCK, fl, 4.0 * (px * b.cs + px1 * b.cx + out_floats), [&] {
                         k::double_conv_fused(da, b.cs, b.cx, b.cmid, b.cout, b.pool >= 0, b.fin >= 0, det_fuse, true, st);
                     }, on_mfma ? fl_dense : 0.0);
                     for (int q = b.first + 1; q <= b.last; q++) covered[q] = 1;
