@@ -95,8 +95,10 @@ struct DoubleConvArgs {
     int n, h, w, h1, w1;
     int relu_d1, relu_p1, relu_d2, relu_p2, sigmoid;
     int tiles_x, tiles_y;         // filled by the launcher
-    const float* tape = nullptr;  // streaming kernels (kernels_det_stream.hip): the block's weight tape(s) on the device
+    const float* tape = nullptr;  // wave streaming kernels (kernels_det_stream.hip): the block's weight tape(s) on the device
     int tape_len = 0;             // floats per tape
+    const float* rtape = nullptr; // workgroup streaming kernels (kernels_det_rows.hip): the four waves' tapes
+    int rtape_len = 0;
 };
 // host pointers to a block's weights, for building its tape
 struct StreamWeights {

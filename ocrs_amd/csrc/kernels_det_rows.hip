@@ -134,7 +134,7 @@ __device__ __forceinline__ void rows_step(const DoubleConvArgs& a, const RGeo<Cf
     const int tid = threadIdx.x;
     const int i = g.Y0 - 2 + t;                        // the arriving input row
     Tape<Cfg::NST, Cfg::STG> tape;
-    tape.base = (cfp)(uintptr_t)(a.tape + (size_t)g.wave * Cfg::LEN);
+    tape.base = (cfp)(uintptr_t)(a.rtape + (size_t)g.wave * Cfg::LEN);
     tape.template issue<0>();
 
     // ---- the wave's slice of the input row: skip channels from HBM (fetched a step ahead), or ConvTranspose channels
@@ -448,7 +448,7 @@ bool double_conv_rows(const DoubleConvArgs& a, int cs, int cx, int cmid, int cou
         if (tape_out) *tape_out = build_rows_tape<Cfg>(*hw);                                       \
         if (tape_len) *tape_len = 4 * Cfg::LEN;                                                    \
         if (launch) {                                                                              \
-            if (!a.tape || a.tape_len != 4 * Cfg::LEN) fail(OCRS_ERR_RUN_FAILED, "row-streaming DoubleConv block without its weight tape"); \
+            if (!a.rtape || a.rtape_len != 4 * Cfg::LEN) fail(OCRS_ERR_RUN_FAILED, "row-streaming DoubleConv block without its weight tape"); \
             const int S = pick(OCC);                                                               \
             if (S == 32) launch_rows<Cfg>(a, s);                                                   \
             else if (S == 20) launch_rows<RwCfg<CS, CX, CM, CO, P, 20>>(a, s);                      \
@@ -459,7 +459,9 @@ bool double_conv_rows(const DoubleConvArgs& a, int cs, int cx, int cmid, int cou
     }
     // (shape, workgroups resident per CU: 58 / 109 / 199 / 205 VGPRs, 13 / 37 / 66 / 87 KB of LDS)
     OCRS_RW(8, 0, 16, 16, true, 8)
-    // (the 32-channel encoder blocks were measured too: 38 / 28 us against 35 / 22 for the tiled blocks — they stay tiled)
+    // (the 32-channel encoder blocks were measured too: 38 / 28 us against 35 / 22 for the tiled blocks — they stay tiled;
+    // so was the 8-channel decoder block at full resolution: 140 us against 117 for the wave kernel of kernels_det_stream.hip —
+    // with 2-4 channels per wave a row step is all fixed cost: barriers, tape, masks, LDS round trips)
     OCRS_RW(16, 32, 16, 16, false, 4)
     OCRS_RW(32, 32, 32, 32, false, 2)
     OCRS_RW(32, 64, 32, 32, false, 1)

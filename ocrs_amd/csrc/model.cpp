@@ -247,12 +247,17 @@ std::unique_ptr<HipModel> HipModel::load(const void* data, size_t len, int devic
                                     host(b.dw2, 0), host(b.dw2, 1), host(b.pw2, 0), host(b.pw2, 1), host(b.fin, 0), host(b.fin, 1)};
                 std::vector<float> tape;
                 int tape_len = 0;
-                if (k::double_conv_stream(none, b.cs, b.cx, b.cmid, b.cout, b.pool >= 0, b.fin >= 0, false, nullptr, &hw, &tape, &tape_len) ||
-                    k::double_conv_rows(none, b.cs, b.cx, b.cmid, b.cout, b.pool >= 0, b.fin >= 0, false, nullptr, &hw, &tape, &tape_len)) {
+                if (k::double_conv_stream(none, b.cs, b.cx, b.cmid, b.cout, b.pool >= 0, b.fin >= 0, false, nullptr, &hw, &tape, &tape_len)) {
                     m->tapes.emplace_back(tape.size() * sizeof(float));
                     OCRS_HIP(hipMemcpy(m->tapes.back().p, tape.data(), tape.size() * sizeof(float), hipMemcpyHostToDevice));
                     b.tape = m->tapes.back().as<float>();
                     b.tape_len = tape_len;
+                }
+                if (k::double_conv_rows(none, b.cs, b.cx, b.cmid, b.cout, b.pool >= 0, b.fin >= 0, false, nullptr, &hw, &tape, &tape_len)) {
+                    m->tapes.emplace_back(tape.size() * sizeof(float));
+                    OCRS_HIP(hipMemcpy(m->tapes.back().p, tape.data(), tape.size() * sizeof(float), hipMemcpyHostToDevice));
+                    b.rtape = m->tapes.back().as<float>();
+                    b.rtape_len = tape_len;
                 }
             }
             ops[i].dc_block = (int)m->dc_blocks.size();
@@ -524,7 +529,7 @@ float* HipModel::run_device(Workspace& ws, const float* d_in, int n, int h, int 
                 da.wd1 = d1.w[0]; da.bd1 = d1.w[1]; da.wp1 = p1.w[0]; da.bp1 = p1.w[1];
                 da.wd2 = d2.w[0]; da.bd2 = d2.w[1]; da.wp2 = p2.w[0]; da.bp2 = p2.w[1];
                 da.relu_d1 = d1.relu; da.relu_p1 = p1.relu; da.relu_d2 = d2.relu; da.relu_p2 = p2.relu;
-                da.tape = b.tape; da.tape_len = b.tape_len;
+                da.tape = b.tape; da.tape_len = b.tape_len; da.rtape = b.rtape; da.rtape_len = b.rtape_len;
                 const double px = (double)sk.n * sk.h * sk.w;
                 double out_floats = 0;
                 if (ok) {
@@ -553,13 +558,8 @@ float* HipModel::run_device(Workspace& ws, const float* d_in, int n, int h, int 
                     const double fl_dense = 2.0 * px * ((double)cin * b.cmid + (double)b.cmid * b.cout) +
                                             2.0 * px * (b.convt >= 0 ? (double)b.cx * b.cs : 0.0);
                     bool on_mfma = false;
-                    int path = 0;   // which kernel family will take it (the workgroup kernels decline large requests at launch time)
-                    {
-                        k::DoubleConvArgs probe = da;
-                        probe.tape = nullptr;   // a query: nothing is launched
-                        k::double_conv_fused(probe, b.cs, b.cx, b.cmid, b.cout, b.pool >= 0, b.fin >= 0, det_fuse, false, nullptr, &on_mfma, &path);
-                        if (path == 2 && !k::double_conv_rows_takes(da, b.cx)) { path = 0; }
-                    }
+                    int path = 0;   // which kernel family will take it (a query: nothing is launched)
+                    k::double_conv_fused(da, b.cs, b.cx, b.cmid, b.cout, b.pool >= 0, b.fin >= 0, det_fuse, false, nullptr, &on_mfma, &path);
                     timed(path == 1 ? KC_DET_STREAM_WAVE : path == 2 ? KC_DET_STREAM_ROWS : KC_DET_BLOCK, fl, 4.0 * (px * b.cs + px1 * b.cx + out_floats), [&] {
                         k::double_conv_fused(da, b.cs, b.cx, b.cmid, b.cout, b.pool >= 0, b.fin >= 0, det_fuse, true, st);
                     }, on_mfma ? fl_dense : 0.0);

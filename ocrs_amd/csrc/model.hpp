@@ -40,8 +40,10 @@ struct DcBlock {
     int first = -1, last = -1;
     int convt = -1, cat = -1, dw1 = -1, pw1 = -1, dw2 = -1, pw2 = -1, pool = -1, fin = -1, sig = -1;
     int cs = 0, cx = 0, cmid = 0, cout = 0;
-    const float* tape = nullptr;  // row-streaming kernel (kernels_det_stream.hip): the block's weight tape on the device
+    const float* tape = nullptr;  // row-streaming wave kernel (kernels_det_stream.hip): the block's weight tape on the device
     int tape_len = 0;
+    const float* rtape = nullptr; // row-streaming workgroup kernel (kernels_det_rows.hip): its four per-wave tapes
+    int rtape_len = 0;
 };
 
 struct TensorShape {  // NHWC activations, or [T,N,C] sequences (n=T, h=N, w=1, c=C)

@@ -253,9 +253,11 @@ def test_streaming_detection_blocks_equal_the_tiled_blocks_and_the_oracle(in_hw,
     m = Model.load_bytes(buf)
     exp = OracleGraph(buf).run_exact(x)
     try:
-        for mode in (0, 8, 14, 32, 1):     # the wave kernels of the 8-channel level and the workgroup kernels of the 16-64-channel levels
-            _lib.set_option("det_stream", mode)
-            _lib.set_option("det_rows", mode)
+        # (wave kernels of the 8-channel level, workgroup kernels of the 8-64-channel levels): the decoder block at full
+        # resolution has both, the workgroup kernel goes first when it is on
+        for mode in ((0, 0), (8, 8), (14, 14), (32, 32), (1, 1), (8, 0), (32, 0), (1, 0), (0, 20), (0, 1)):
+            _lib.set_option("det_stream", mode[0])
+            _lib.set_option("det_rows", mode[1])
             got = m.run(x)
             assert got.shape == exp.shape and np.array_equal(got, exp), mode
     finally:
@@ -277,9 +279,9 @@ def test_streaming_detection_blocks_on_random_sizes():
             x = (rng.random((n, 1) + in_hw, dtype=np.float32) - 0.5).astype(np.float32)
             m = Model.load_bytes(buf)
             exp = OracleGraph(buf).run_exact(x)
-            for mode in (1, 8, 32):
-                _lib.set_option("det_stream", mode)
-                _lib.set_option("det_rows", mode)
+            for mode in ((1, 1), (8, 8), (32, 32), (14, 0), (0, 14)):
+                _lib.set_option("det_stream", mode[0])
+                _lib.set_option("det_rows", mode[1])
                 assert np.array_equal(m.run(x), exp), (in_hw, n, mode)
     finally:
         _lib.set_option("det_stream", 1)
