@@ -408,11 +408,16 @@ std::vector<float> build_rows_tape(const StreamWeights& w) {
 
 }  // namespace
 
+// The launch-time conditions.  Under option value 1 requests of more than 8 pages keep the other kernels: such requests are
+// the 16-page batches of the full pipeline, whose detection kernels run beside other requests' recognition conv stacks — and
+// there short-lived workgroups (~10 us each for the tiled blocks) co-schedule better than these (a workgroup lives 30-70 us
+// and keeps its CU slot): default bench 271.5 / 271.6 / 272.2 / 270.6 pages/s without these against 267.2 / 270.0 / 269.7 with
+// them (ABAB, one box), while a detection request on its own is 8-10 % faster with these.
 bool double_conv_rows_takes(const DoubleConvArgs& a, int cx) {
     const int opt = option(OPT_DET_ROWS);
     if (opt < 1) return false;
     if (opt == 1 && a.n > 8) return false;
-    if (cx > 0 && (((a.w - 2 * a.w1) / 2) & 1)) return false;
+    if (cx > 0 && (((a.w - 2 * a.w1) / 2) & 1)) return false;   // the strip's first column must map to the first half of a low-resolution pixel
     return true;
 }
 
@@ -431,16 +436,7 @@ bool double_conv_rows(const DoubleConvArgs& a, int cs, int cx, int cmid, int cou
         const int64_t cap = (int64_t)occ * 256;
         return groups(8) <= cap ? 8 : groups(14) <= cap ? 14 : groups(20) <= cap ? 20 : 32;
     };
-    // Requests of more than 8 pages keep the LDS-tiled blocks (option value 1): such requests are the 16-page batches of
-    // the full pipeline, whose detection kernels run beside other requests' recognition conv stacks — and there the
-    // tiled blocks' short-lived workgroups (~10 us each) co-schedule better than these (a workgroup lives 30-70 us and keeps
-    // its CU slot): default bench 271.5 / 271.6 / 272.2 / 270.6 pages/s with the tiled blocks against 267.2 / 270.0 / 269.7
-    // with these (ABAB, one box), while a detection request on its own is 8-10 % faster with these.
-    if (launch && opt == 1 && a.n > 8) return false;
-    if (launch && cx > 0) {
-        const int pxo = (a.w - 2 * a.w1) / 2;
-        if (pxo & 1) return false;            // the strip's first column must map to the first half of a low-resolution pixel
-    }
+    if (launch && !double_conv_rows_takes(a, cx)) return false;
     if (launch && ((int64_t)a.h * a.w * cs * 4 >= kOobOffset || (int64_t)a.h1 * a.w1 * cx * 4 >= kOobOffset)) return false;
 #define OCRS_RW(CS, CX, CM, CO, P, OCC)                                                           \
     if (cs == CS && cx == CX && cmid == CM && cout == CO && pool == P) {                            \
