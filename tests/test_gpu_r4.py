@@ -353,3 +353,28 @@ def test_quad_pixel_component_kernels_on_page_sized_masks():
     finally:
         _lib.set_option("ccl_quad", 1)
 
+
+def test_streaming_detection_kernels_at_bench_scale_give_the_golden_word_rects(bufs, pages16):
+    """The 16 bench pages (800 x 600 detection input, full seven-level U-Net) through detect_words_batch with the row-streaming
+    kernels forced on for every request size and each rows-per-wave / rows-per-workgroup choice, with them off, and in the
+    default configuration (16 pages: wave kernels + tiled blocks; 8 pages: wave + workgroup kernels): always the word rects of
+    the golden fixtures the oracle made."""
+    from test_gpu_bench_scale import _golden_page
+    dbuf, rbuf, digests = bufs
+    eng = OcrEngine(detection_model=Model.load_bytes(dbuf))
+    inputs = [eng.prepare_input(ImageSource.from_tensor(p, DimOrder.Hwc)) for p in pages16]
+    golden = [_golden_page(pi, digests) for pi in range(len(pages16))]
+    assert sum(g is not None for g in golden) >= 2
+    try:
+        for mode in ((1, 1), (8, 8), (32, 32), (14, 20), (0, 0), (1, 0), (0, 1)):
+            _lib.set_option("det_stream", mode[0])
+            _lib.set_option("det_rows", mode[1])
+            for lo, hi in ((0, 16), (0, 8), (8, 11)):
+                words = eng.detect_words_batch(inputs[lo:hi])
+                for pi in range(lo, hi):
+                    if golden[pi] is not None:
+                        assert np.array_equal(words[pi - lo], golden[pi]["word_rects"]), (mode, lo, hi, pi)
+    finally:
+        _lib.set_option("det_stream", 1)
+        _lib.set_option("det_rows", 1)
+
