@@ -433,7 +433,7 @@ bool double_conv_rows(const DoubleConvArgs& a, int cs, int cx, int cmid, int cou
     const int opt = option(OPT_DET_ROWS);     // 1: by the rule above; 8 / 14 / 20 / 32: that segment height (tests, A/B)
     auto pick = [&](int occ) {
         if (opt == 8 || opt == 14 || opt == 20 || opt == 32) return opt;
-        const int64_t cap = (int64_t)occ * 256;
+        const int64_t cap = (int64_t)occ * (launch ? ctx().cu_count() : 256);
         return groups(8) <= cap ? 8 : groups(14) <= cap ? 14 : groups(20) <= cap ? 20 : 32;
     };
     if (launch && !double_conv_rows_takes(a, cx)) return false;

@@ -410,7 +410,8 @@ bool double_conv_stream(const DoubleConvArgs& a, int cs, int cx, int cmid, int c
     auto waves = [&](int S) { return (int64_t)a.n * ((a.w + kValid - 1) / kValid) * ((a.h + S - 1) / S); };
     const int opt = option(OPT_DET_STREAM);   // 1: by the rule above; 8 / 14 / 32: that segment height (tests, A/B)
     // (the encoder block is light — 66 VGPRs, seven waves per SIMD — and runs 4 640 waves of 18 rows in one round: 14 rows)
-    const int S = (opt == 8 || opt == 14 || opt == 32) ? opt : (cx > 0 && waves(32) >= 1024) ? 32 : waves(14) >= 1024 ? 14 : 8;
+    const int64_t simds = launch ? 4 * (int64_t)ctx().cu_count() : 1024;   // (1 024 on the MI355X)
+    const int S = (opt == 8 || opt == 14 || opt == 32) ? opt : (cx > 0 && waves(32) >= simds) ? 32 : waves(14) >= simds ? 14 : 8;
 #define OCRS_ST(CS, CX, CM, CO, P, F)                                                             \
     if (cs == CS && cx == CX && cmid == CM && cout == CO && pool == P && final_conv == F) {        \
         typedef StCfg<CS, CX, CM, CO, P, F, 32> Cfg;                                               \
