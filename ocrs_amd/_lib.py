@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libocrs_amd.so")
+# OCRS_AMD_LIB: an ablation build of the same library (ocrs_amd.build --variant), for A/B timing only
+LIB_PATH = os.environ.get("OCRS_AMD_LIB") or os.path.join(_HERE, "libocrs_amd.so")
 
 OCRS_OK = 0
 STATUS_NAMES = {

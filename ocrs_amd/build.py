@@ -38,6 +38,27 @@ def _newest_header():
     return t
 
 
+def build_variant(tag, defines, sources, verbose=False):
+    """An ablation build: `sources` recompiled with -D<defines>, linked with the stock objects of everything else into
+    libocrs_amd.<tag>.so (loaded instead of the product when OCRS_AMD_LIB names it; tools/ab_*.sh)."""
+    build()
+    vdir = os.path.join(OBJ, tag)
+    os.makedirs(vdir, exist_ok=True)
+    objs = []
+    for src in SOURCES:
+        op = os.path.join(OBJ, src.rsplit(".", 1)[0] + ".o")
+        if src in sources:
+            op = os.path.join(vdir, src.rsplit(".", 1)[0] + ".o")
+            cmd = [_hipcc()] + FLAGS + ["-D" + d for d in defines] + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", os.path.join(CSRC, src), "-o", op]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.run(cmd, check=True)
+        objs.append(op)
+    out = os.path.join(HERE, "libocrs_amd.%s.so" % tag)
+    subprocess.run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs + ["-ldl", "-lpthread"], check=True)
+    return out
+
+
 def build(force=False, verbose=False):
     os.makedirs(OBJ, exist_ok=True)
     hdr_t = _newest_header()
@@ -71,4 +92,8 @@ def build(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    if "--variant" in sys.argv:   # python -m ocrs_amd.build --variant <tag> <file.hip>[,<file>] <DEFINE>[,<DEFINE>]
+        i = sys.argv.index("--variant")
+        print(build_variant(sys.argv[i + 1], sys.argv[i + 3].split(","), sys.argv[i + 2].split(","), verbose=True))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

@@ -249,11 +249,54 @@ __device__ __forceinline__ float expf_sl(float x0) {
     const float v = __int_as_float(__float_as_int(q) + (((int)kf) << 23));
     return x0 != x0 ? x0 : v;
 }
+#ifndef OCRS_GATE_MATH
+#define OCRS_GATE_MATH 0   // timing ablations (tools/ab_gate_math.sh; results are WRONG on purpose for 1..3)
+#endif
+#if OCRS_GATE_MATH == 0
 __device__ __forceinline__ float sigmoidf_sl(float x) { return 1.0f / (1.0f + expf_sl(-x)); }
 __device__ __forceinline__ float tanhf_sl(float x) {
     const float t = expf_sl(2.0f * x);
     return (t - 1.0f) / (t + 1.0f);
 }
+#elif OCRS_GATE_MATH == 1   // hardware v_exp_f32 / v_rcp_f32
+__device__ __forceinline__ float sigmoidf_sl(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896341f)); }
+__device__ __forceinline__ float tanhf_sl(float x) {
+    const float t = __builtin_amdgcn_exp2f(x * 2.88539008177792682f);
+    return (t - 1.0f) * __builtin_amdgcn_rcpf(t + 1.0f);
+}
+#elif OCRS_GATE_MATH == 2   // candidate re-spec: degree-6 exp, division-free reciprocal (magic seed + two cubic steps)
+__device__ __forceinline__ float expf_v2(float x0) {
+    const float x = __builtin_amdgcn_fmed3f(x0, -87.0f, 88.0f);
+    const float kf = rintf(x * 1.44269504088896341f);
+    float r = fmaf(kf, -0.693145751953125f, x);
+    r = fmaf(kf, -1.42860682030941723212e-6f, r);
+    float q = 1.38888888888888894e-3f;
+    q = fmaf(q, r, 8.33333333333333322e-3f);
+    q = fmaf(q, r, 4.16666666666666644e-2f);
+    q = fmaf(q, r, 1.66666666666666657e-1f);
+    q = fmaf(q, r, 0.5f);
+    q = fmaf(q, r, 1.0f);
+    q = fmaf(q, r, 1.0f);
+    return __int_as_float(__float_as_int(q) + (((int)kf) << 23));
+}
+__device__ __forceinline__ float rcp_v2(float d) {
+    float r = __int_as_float(0x7EF311C7 - __float_as_int(d));
+    float e = fmaf(-d, r, 1.0f);
+    float t = fmaf(e, e, e);
+    r = fmaf(r, t, r);
+    e = fmaf(-d, r, 1.0f);
+    t = fmaf(e, e, e);
+    return fmaf(r, t, r);
+}
+__device__ __forceinline__ float sigmoidf_sl(float x) { return rcp_v2(1.0f + expf_v2(-x)); }
+__device__ __forceinline__ float tanhf_sl(float x) {
+    const float t = expf_v2(2.0f * x);
+    return (t - 1.0f) * rcp_v2(t + 1.0f);
+}
+#else                       // 3: no transcendental at all (the floor of the item's other work)
+__device__ __forceinline__ float sigmoidf_sl(float x) { return x; }
+__device__ __forceinline__ float tanhf_sl(float x) { return x; }
+#endif
 
 // gates + new state of the lane's 4 units; `store` = this lane's row is live at this step
 template <int H>
