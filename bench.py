@@ -123,9 +123,12 @@ def cap_host_threads(world_local):
     os.environ.setdefault("GOMP_SPINCOUNT", "0")
     os.environ.setdefault("OMP_NUM_THREADS", str(min(per_rank, 32)))
     os.environ.setdefault("MKL_NUM_THREADS", os.environ["OMP_NUM_THREADS"])
-    # find_text_lines_batch: one host thread per page of a request, at most this many per call
-    os.environ.setdefault("OCRS_LAYOUT_THREADS", str(max(2, min(16, per_rank // 2))))
     return per_rank
+
+
+def layout_threads_for(per_rank):
+    """find_text_lines_batch: one host thread per page of a request, at most this many per call (ocrs_engine_params.layout_threads)"""
+    return max(2, min(16, per_rank // 2))
 
 
 def dist_setup(args):
@@ -185,7 +188,7 @@ def selftest_main(args):
         print(json.dumps({"metric": "dist-selftest", "n_gpus": world, "backend": backend, "pages": n_pages, "lines": n_lines,
                           "gathered_pages": len(merged), "complete": sorted(int(k) for k in merged) == list(range(total)),
                           "elapsed_is_max": elapsed >= 1e-3 * world, "omp_threads": os.environ["OMP_NUM_THREADS"],
-                          "layout_threads": os.environ["OCRS_LAYOUT_THREADS"]}), flush=True)
+                          "layout_threads": layout_threads_for(int(os.environ["OMP_NUM_THREADS"]))}), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
@@ -235,14 +238,14 @@ def main():
     if group_mode:
         devices = [int(x) for x in args.devices.split(",")] if args.devices else list(range(args.gpus))
         group = EngineGroup(devices, models.synthetic_detection_bytes(), models.synthetic_recognition_bytes(),
-                            gather="rccl" if args.gather == "rccl" else "host")
+                            gather="rccl" if args.gather == "rccl" else "host", layout_threads=layout_threads_for(per_rank_cores))
         engine = group.member(0)[0]     # stage / kernel timers: member 0's
         G = len(devices)
     else:
         devices = [dev_index]
         det = Model.load_bytes(models.synthetic_detection_bytes())
         rec = Model.load_bytes(models.synthetic_recognition_bytes())
-        engine = OcrEngine(detection_model=det, recognition_model=rec)
+        engine = OcrEngine(detection_model=det, recognition_model=rec, layout_threads=layout_threads_for(per_rank_cores))
         G = 1
 
     # ---- synthetic pages, resident in HBM before the timed region (in group mode: a step's pages in contiguous blocks of
@@ -425,8 +428,8 @@ def main():
                         ", ~%d lines/page; prepare_input -> detect_words (U-Net @800x600 + threshold + components->rects) "
                         "-> find_text_lines (host) -> recognize_text (crops, CRNN, greedy CTC)" % args.lines,
             "pages_per_step_per_gpu": B,
-            "coalesce": ("concurrent small requests share launches (option coalesce = %s): %s" % (
-                os.environ.get("OCRS_COALESCE", "2"), json.dumps(engine.coalesce_stats()))),
+            "coalesce": ("concurrent small requests share launches (ocrs_engine_params.coalesce -> %d): %s" % (
+                engine.get_option("coalesce"), json.dumps(engine.coalesce_stats()))),
             "lines_per_page": round(n_lines / max(n_pages, 1), 1),
             "words_per_page": round(n_words / max(n_pages, 1), 1),
             "weights": "seeded synthetic weights on the SURVEY.md §2.4 architectures (real ocrs weights unobtainable offline)",
@@ -435,7 +438,7 @@ def main():
                             "each member's own PCIe link; final result gather: %s" % (G, devices, B, json.dumps(final_gather)))
                            if group_mode else
                            "page-sharded, %d process(es) x 1 GPU, no data-path collective; result gather over %s" % (world, backend),
-            "gru": "persistent kernel per layer" if os.environ.get("OCRS_GRU_MODE", "0") == "0" else "one launch per time step",
+            "gru": "persistent kernel per layer" if engine.get_option("gru_mode") == 0 else "one launch per time step",
             "step_overlap": ("%d whole steps in flight (one host thread + HIP stream each); the conv stacks of all "
                              "requests run FIFO on one shared stream, the GRU recurrences on another, the host layout "
                              "overlaps both; every step still does all of its work" % args.inflight) if args.inflight > 1 else

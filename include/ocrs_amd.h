@@ -78,14 +78,12 @@ OCRS_API ocrs_status ocrs_ctc_beam_search(const float* logp, int t, int c, uint3
 
 /* Test hook (host only, no GPU work): how the persistent GRU kernel would deal the 16-line row tiles of a request
  * to its waves.  lengths_desc = sequence lengths of the lines, descending (tile k = lines 16k .. 16k+15).
- * *n_clusters = clusters per direction, *waves = waves per workgroup of the kernel the plan is for (option "gru_waves").
- * waves = 4 (general kernel): 4 wave slots per cluster, tiles[4s .. 4s+3] for slot s = cluster * 4 + wave.
- * waves = 16 (teams kernel): 4 team slots per cluster, tiles[8s .. 8s+7] for slot s = cluster * 4 + team.
- * Tile indices longest first, -1 = none.  OCRS_ERR_CAPACITY if the shape has no persistent plan. */
+ * *n_clusters = clusters per direction, *waves = 4 = wave slots per cluster; tiles[4s .. 4s+3] for slot
+ * s = cluster * 4 + wave.  Tile indices longest first, -1 = none.  OCRS_ERR_CAPACITY if the shape has no persistent plan. */
 OCRS_API ocrs_status ocrs_gru_tile_plan(const int32_t* lengths_desc, size_t n_lines, int hidden, int32_t* n_clusters, int32_t* waves,
                                         int16_t* tiles);
 
-/* Test hook (host only, no GPU work) for the request coalescer behind the one-page entry points (option "coalesce"):
+/* Test hook (host only, no GPU work) for the request coalescer behind the one-page entry points (ocrs_engine_params.coalesce):
  * n_threads callers submit requests_per_thread requests each (of two incompatible kinds, weights 1..2 pages); request
  * ids divisible by fail_every (> 0) fail.  out = {batches run, requests carried, errors delivered to their callers,
  * requests that were run twice / not at all / got a wrong result or shared a batch with the other kind, largest batch
@@ -93,74 +91,54 @@ OCRS_API ocrs_status ocrs_gru_tile_plan(const int32_t* lengths_desc, size_t n_li
 OCRS_API ocrs_status ocrs_coalescer_selftest(int n_threads, int requests_per_thread, int max_active, int max_pages,
                                              long window_us, int fail_every, uint64_t out[5]);
 
-/* Process-wide integer tuning options (no reference counterpart: RTen's equivalents are compile-time).
- * Each also reads its initial value from the environment variable OCRS_<NAME IN CAPITALS>.
+/* Integer tuning options (no reference counterpart: RTen's equivalents are compile-time).  They select between kernels
+ * that compute the SAME bits — results never depend on an option; the tests run the alternatives against each other.
+ *
+ * Scope.  The process holds the defaults: initial value from the environment variable OCRS_<NAME IN CAPITALS>, read once
+ * when the library first needs an option; ocrs_set_option changes a default.  An engine COPIES the defaults when it is
+ * created (ocrs_engine_new / ocrs_engine_group_new) and from then on owns its copy: ocrs_engine_set_option changes one
+ * engine only, two engines in one process can differ, and changing a default never affects an engine that exists.
+ * ocrs_model_run on a bare model uses the defaults.  Set an engine's options before it is in use by other threads.
+ *
  *   "gru_mode"        0 = one persistent kernel per GRU layer (default), 1 = one launch per time step
- *   "det_fuse"        1 = fused LDS-tiled DoubleConv blocks of the detection U-Net where they win (default),
- *                     2 = for every block shape that has a fused kernel, 0 = per-op kernels only
- *   "det_mfma"        1 = DoubleConv blocks of the detection U-Net (8 to 32 channels) run as fused launches with their
- *                     pointwise convolutions and ConvTranspose on MFMA (default), 0 = thread-per-pixel VALU kernels
- *   "det_heavy"       the detection stage's kernels run on the device's shared conv-stack stream (queued between other
- *                     requests' conv stacks, at full speed) instead of on the call's own stream (beside them): 1 = for requests
- *                     of fewer than 8 pages (round 3's default), 2 = always, 0 = never (default since round 4: with the conv
- *                     stacks' shared arena the FIFO wait costs one-page calls from 12 threads 7 % — 180 vs 194 pages/s)
- *   "gx_heavy"        1 = the GRU input projections of large requests run on that stream too (every MFMA-bound class then
- *                     runs at its alone speed, the throughput is the same or slightly lower), default 0
- *   "layout_threads"  host threads ocrs_engine_find_text_lines_batch may use (0 = automatic)
- *   "beam_gpu"        1 = DecodeMethod::BeamSearch runs on the GPU (default), 0 = on the host (threaded over lines)
- *   "gru_local"       persistent GRU kernel: 1 = a cluster of workgroups that finds itself on one XCD hands its state
- *                     over through that XCD's L2 (default), 0 = always through write-through stores
- *   "rec_max_pixels"  input pixels (padded line batch) one recognition sub-request may hold; larger requests are run
- *                     as consecutive sub-requests (default 0 = 2e9, sized for the activation memory of one GPU)
  *   "gru_gates"       1 = requests small enough that every 16-line row tile gets its own cluster of workgroups run the
  *                     gate-per-wave recurrence kernel (default), 0 = always the general persistent kernel
- *   "gru_gates_pack"  2 = the gate-per-wave kernel also takes requests of up to twice the row tiles by running two workgroups
- *                     per CU (default 1: one workgroup per CU)
- *   "conv_occupancy"  recognition 3x3 conv blocks per CU: 4 (default) or 3
- *   "conv12_fuse"     the first two recognition convs and their 2x2 pools (1 -> 32 -> 64 channels) run as one kernel
- *                     (1, default): conv1 is computed into an LDS tile per patch and conv2's matrix-core loop reads
- *                     its operand there; 0 = two kernels with the 32-channel tensor in HBM between them.  Same bits.
- *   "conv_flat"       recognition 3x3 convs: the 128-pixel patches tile a width group's strip of images side by side
- *                     (1, default: only a group's last patch is ragged) or every image on its own (0); same bits
- *   "group_min_block" engine group: pages the group places itself go to a device in contiguous blocks of at least this
- *                     many pages (default 8; a small call then uses fewer devices, successive calls rotate)
- *   "group_shared_block"  the same between members that share one device (default 16)
- *   "det_tail"        1 = the deep levels of the detection U-Net (every operator with at most 2 048 output pixels per page:
- *                     pools, depthwise / pointwise convs, ConvTransposes, concatenations) run as ONE persistent launch whose
- *                     workgroups step through the operators together (44 -> 23 dispatches per request; round-4 experiment,
- *                     slower than the per-operator kernels as built); 0 (default) = one launch per operator.  Same bits.
- *   "det_stream"      1 (default) = the DoubleConv blocks of the detection U-Net's full-resolution levels run as
- *                     row-streaming kernels (a wave walks down a 64-column strip, a lane keeps its pixel's channels in
- *                     registers, horizontal taps through DPP lane shifts: no LDS, no barriers), rows per wave chosen from
- *                     the request's size; 8 / 14 / 32 = the same with that many rows per wave; 0 = the LDS-tiled blocks
- *                     (rounds 2-3).  Same bits.
- *   "det_rows"        1 (default) = the DoubleConv blocks of the detection U-Net's 16-64-channel levels run as row-streaming
- *                     workgroup kernels (four waves walk down a 64-column strip: depthwise convs in registers with the
- *                     channels split over the waves, pointwise convs and ConvTransposes on the matrix cores with the
- *                     pixels split over the waves, rows — not halo tiles — through LDS) for requests of up to 8 pages
- *                     (larger batches keep the tiled blocks, which co-schedule better beside other requests' kernels);
- *                     8 / 14 / 20 / 32 = those kernels for every request, with that many rows per workgroup; 0 = the
- *                     LDS-tiled blocks (rounds 2-3) always.  Same bits.
+ *   "gru_local"       persistent GRU kernels: 1 = a cluster of workgroups that finds itself on one XCD hands its state
+ *                     over through that XCD's L2 (default), 0 = always through write-through stores
+ *   "det_fuse"        1 = fused DoubleConv blocks of the detection U-Net where they win (default), 2 = for every block
+ *                     shape that has a fused kernel, 0 = per-operator kernels only
+ *   "det_mfma"        1 = the LDS-tiled DoubleConv blocks run their pointwise convolutions and ConvTranspose on the matrix
+ *                     cores (default), 0 = thread-per-pixel VALU kernels
+ *   "det_stream"      1 (default) = the DoubleConv blocks of the U-Net's full-resolution level run as row-streaming wave
+ *                     kernels (a wave walks down a 64-column strip, a lane keeps its pixel's channels in registers,
+ *                     horizontal taps through DPP lane shifts), rows per wave chosen from the request's size; 8 / 14 / 32 =
+ *                     the same with that many rows per wave; 0 = the LDS-tiled blocks
+ *   "det_rows"        1 (default) = the DoubleConv blocks of the 16-64-channel levels run as row-streaming workgroup
+ *                     kernels for requests of up to 8 pages; 8 / 14 / 20 / 32 = those kernels for every request, with that
+ *                     many rows per workgroup; 0 = the LDS-tiled blocks always
  *   "ccl_quad"        1 (default) = the component-labelling and root-compaction kernels of detect_words handle four mask
- *                     pixels per thread (word loads, neighbours from the neighbouring lanes) when the page width is a
- *                     multiple of 4; 0 = one pixel per thread.  Same components, same order.
- *   "gru_waves"       recurrence kernel of requests with more row tiles than clusters: 4 (default) = the general kernel (one
- *                     wave per SIMD, three interleaved MFMA chains per wave); 16 = four gate-per-wave teams of four waves
- *                     per workgroup, state through LDS (round-4 experiment, same bits, 12 % slower per layer)
- *   "gru_background"  1 = requests too large for one row tile per cluster run the recurrence on the lean multi-tile
- *                     gate-per-wave kernel (a third of the general kernel's registers: conv stacks of other requests keep
- *                     three blocks per CU beside it; slower on its own), default 0
- *   "gemm_nfast"      1 = dense GEMMs run the column tiles of a row tile side by side on one XCD (default), 0 = column
- *                     tile on the grid's y axis
- *   "gru_scatter"     test knob: 1 = spread every cluster over all XCDs (exercises the write-through path), default 0
- *   "coalesce"        the reference API is one page per call with concurrency from host threads (ocrs-cli/src/main.rs:420-446,
- *                     recognition.rs:465-485); small detect / recognize requests that wait at the same time are merged into one
- *                     ragged request per stage (lines are independent: nobody's bits change).  Value = merged batches in flight
- *                     per engine and stage (default 2), 0 = every call runs on its own
- *   "coalesce_pages"  pages per merged batch (default 16); requests of half that size or more are never merged
- *   "coalesce_window_us"  while other batches are in flight, how long the next one lets its queue fill (default 300)
- * Results never depend on an option; OCRS_ERR_INVALID_ARGUMENT for an unknown name. */
+ *                     pixels per thread when the page width is a multiple of 4; 0 = one pixel per thread
+ *   "conv12_fuse"     1 (default) = the first two recognition convs and their 2x2 pools run as one kernel (conv1 into an
+ *                     LDS tile per patch, conv2's matrix-core loop reads its operand there); 0 = two kernels
+ *   "conv_flat"       recognition 3x3 convs: the 128-pixel patches tile a width group's strip of images side by side
+ *                     (1, default: only a group's last patch is ragged) or every image on its own (0)
+ *   "beam_gpu"        1 = DecodeMethod::BeamSearch runs on the GPU (default), 0 = on the host (threaded over lines)
+ *
+ * OCRS_ERR_INVALID_ARGUMENT for an unknown name.  (Rounds 2-4 carried 28 process-wide options, many of them switches for
+ * experiments that had lost their A/B; round 5 removed those kernels and moved what is configuration — numerics, request
+ * coalescing, host threads, the sub-request size, the group's dealing blocks — into ocrs_engine_params / ocrs_group_params.) */
 OCRS_API ocrs_status ocrs_set_option(const char* name, long value);
+/* Name of option `index` (0 .. count - 1); *name = NULL past the last one. */
+OCRS_API ocrs_status ocrs_option_name(int index, const char** name);
+
+/* Memory the library holds on a device: out = {device bytes in use, device bytes cached (free, reusable), cap on the
+ * cached device bytes, peak of bytes in use, hipMalloc calls, blocks returned to the driver, and the same six numbers for
+ * the pinned host staging pool of that device's context}.  device < 0: the default device. */
+OCRS_API ocrs_status ocrs_device_pool_stats(int device, uint64_t out[12]);
+/* Caps on the CACHED bytes (0 = leave as is).  Defaults: a quarter of the device's memory (environment variable
+ * OCRS_POOL_CAP_GB, read once per device, overrides) and 1 GiB of pinned host memory.  Blocks above a cap are returned
+ * to the driver by a background thread, never on a request's thread (hipFree waits for the device). */
+OCRS_API ocrs_status ocrs_device_pool_configure(int device, uint64_t device_cached_cap_bytes, uint64_t pinned_cached_cap_bytes);
 
 /* ------------------------------------------------------------------------
  * L2 seam: `trait Model` (ocrs/src/model.rs:6-17) and its rten impl
@@ -217,6 +195,8 @@ OCRS_API void ocrs_model_free(ocrs_model* m);
 typedef struct ocrs_engine ocrs_engine;
 typedef struct ocrs_page ocrs_page; /* OcrInput */
 
+typedef enum ocrs_numerics { OCRS_NUMERICS_EXACT = 0, OCRS_NUMERICS_RELAXED = 1 } ocrs_numerics;
+
 typedef enum ocrs_decode_method { /* DecodeMethod, recognition.rs:198-205 */
     OCRS_DECODE_GREEDY = 0,
     OCRS_DECODE_BEAM_SEARCH = 1
@@ -232,6 +212,20 @@ typedef struct ocrs_engine_params {
     uint32_t beam_width;
     const char* alphabet;      /* UTF-8 */
     const char* allowed_chars; /* UTF-8 */
+    /* --- no reference counterpart (RTen is fp32 on the CPU, one page per call) --- */
+    ocrs_numerics numerics;    /* OCRS_NUMERICS_EXACT (0, default): every kernel follows the numeric spec, results are
+                                * bit-identical to the CPU oracle.  OCRS_NUMERICS_RELAXED: hardware transcendentals, operands
+                                * split into bf16 terms on the 16x faster bf16 matrix cores, free accumulation order — boxes
+                                * and tokens are expected, not guaranteed, to match (DESIGN.md "what exactness costs") */
+    int coalesce;              /* one-page calls that wait at the same time are merged into one ragged request per stage
+                                * (lines are independent: nobody's bits change).  Merged batches in flight per stage:
+                                * 0 = default (2), negative = every call runs on its own */
+    int coalesce_pages;        /* pages per merged batch (0 = default 16); requests of half that size or more are never merged */
+    int coalesce_window_us;    /* while other batches are in flight, how long the next one lets its queue fill
+                                * (0 = default 300, negative = no wait) */
+    int layout_threads;        /* host threads ocrs_engine_find_text_lines_batch may use (0 = one per page up to the host's cores) */
+    int64_t rec_max_pixels;    /* input pixels (padded line batch) one recognition sub-request may hold; larger requests run
+                                * as consecutive sub-requests (0 = 2e9, sized for the activation memory of one GPU) */
 } ocrs_engine_params;
 
 /* OcrEngine::new (lib.rs:132-180).  The engine lives on its models' device (both models must be on the same one;
@@ -240,6 +234,11 @@ typedef struct ocrs_engine_params {
 OCRS_API ocrs_status ocrs_engine_new(const ocrs_engine_params* params, ocrs_engine** out);
 OCRS_API void ocrs_engine_free(ocrs_engine* e);
 OCRS_API ocrs_status ocrs_engine_device(const ocrs_engine* e, int* device);
+/* This engine's copy of a tuning option (see ocrs_set_option for the list and the scoping rule).  Also accepted, by
+ * field name: "coalesce", "coalesce_pages", "coalesce_window_us", "layout_threads", "rec_max_pixels" (the values as
+ * stored: coalesce 0 = off); "numerics" can be read but is fixed when the engine is created. */
+OCRS_API ocrs_status ocrs_engine_set_option(ocrs_engine* e, const char* name, long value);
+OCRS_API ocrs_status ocrs_engine_get_option(const ocrs_engine* e, const char* name, long* value);
 
 typedef enum ocrs_dim_order { OCRS_HWC = 0, OCRS_CHW = 1 } ocrs_dim_order; /* DimOrder, preprocess.rs:50-57 */
 typedef enum ocrs_pixel_type { OCRS_U8 = 0, OCRS_F32 = 1 } ocrs_pixel_type; /* ImagePixels, preprocess.rs:9-14 */
@@ -411,6 +410,12 @@ typedef struct ocrs_group_params { /* OcrEngineParams (lib.rs:38-71) + the membe
     const char* alphabet;
     const char* allowed_chars;
     ocrs_gather_mode gather;
+    ocrs_numerics numerics;        /* as in ocrs_engine_params, for every member */
+    int coalesce, coalesce_pages, coalesce_window_us, layout_threads;
+    int64_t rec_max_pixels;
+    int min_block;                 /* pages the group places itself go to a device in contiguous blocks of at least this
+                                    * many (0 = default 8; a small call then uses fewer devices, successive calls rotate) */
+    int shared_block;              /* the same between members that share one device (0 = default 16) */
 } ocrs_group_params;
 
 OCRS_API ocrs_status ocrs_engine_group_new(const ocrs_group_params* params, ocrs_engine_group** out);
@@ -418,9 +423,9 @@ OCRS_API void ocrs_engine_group_free(ocrs_engine_group* g);
 OCRS_API ocrs_status ocrs_engine_group_size(const ocrs_engine_group* g, size_t* n_members);
 /* Member i's engine (borrowed; usable with every ocrs_engine_* call) and device. */
 OCRS_API ocrs_status ocrs_engine_group_member(const ocrs_engine_group* g, size_t i, const ocrs_engine** engine, int* device);
-/* The dealing rule on its own (host only): block = max(ceil(n_pages / n_members), min(group_min_block, n_pages)),
- * member_of_page[i] = (i / block) mod n_members; pages_per_member may be NULL. */
-OCRS_API ocrs_status ocrs_group_deal(size_t n_pages, size_t n_members, size_t* member_of_page, size_t* pages_per_member);
+/* The dealing rule on its own (host only): block = max(ceil(n_pages / n_members), min(min_block, n_pages)) with
+ * min_block = 0 meaning the default 8, member_of_page[i] = (i / block) mod n_members; pages_per_member may be NULL. */
+OCRS_API ocrs_status ocrs_group_deal(size_t n_pages, size_t n_members, size_t min_block, size_t* member_of_page, size_t* pages_per_member);
 
 /* OcrEngine::prepare_input (lib.rs:183-187) for n equally sized host images, dealt as described above.  out[n]
  * receives the pages (each lives on its member's device). */
@@ -489,7 +494,7 @@ OCRS_API ocrs_status ocrs_engine_stage_times(ocrs_engine* e, double* ms, uint64_
  * figures of DESIGN.md §6 summed over the launches. */
 /* Restrict per-launch kernel timing to the classes whose bit is set (default: all). */
 OCRS_API ocrs_status ocrs_engine_set_kernel_timing_mask(ocrs_engine* e, uint32_t mask);
-/* Request coalescing (option "coalesce"): {merged batches run, caller requests they carried} per stage since the engine
+/* Request coalescing (ocrs_engine_params.coalesce): {merged batches run, caller requests they carried} per stage since the engine
  * was created.  requests > batches means calls of different host threads shared launches. */
 OCRS_API ocrs_status ocrs_engine_coalesce_stats(const ocrs_engine* e, uint64_t detect[2], uint64_t recognize[2]);
 OCRS_API int ocrs_kernel_class_count(void);

@@ -171,9 +171,22 @@ class Model:
             pass
 
 
+NUMERICS = {"exact": 0, "relaxed": 1}   # ocrs_numerics
+
+
 class OcrEngineParams:  # lib.rs:38-71
     def __init__(self, detection_model=None, recognition_model=None, debug=False, decode_method=DecodeMethod.Greedy,
-                 alphabet=None, allowed_chars=None):
+                 alphabet=None, allowed_chars=None, numerics="exact", coalesce=0, coalesce_pages=0, coalesce_window_us=0,
+                 layout_threads=0, rec_max_pixels=0, options=None):
+        # numerics / coalesce*: ocrs_engine_params fields without a reference counterpart (0 = default);
+        # options: {name: value} applied to the new engine with ocrs_engine_set_option
+        self.numerics = numerics
+        self.coalesce = coalesce
+        self.coalesce_pages = coalesce_pages
+        self.coalesce_window_us = coalesce_window_us
+        self.layout_threads = layout_threads
+        self.rec_max_pixels = rec_max_pixels
+        self.options = dict(options or {})
         self.detection_model = detection_model
         self.recognition_model = recognition_model
         self.debug = debug
@@ -301,8 +314,25 @@ class OcrEngine:
         p.beam_width = params.decode_method[1]
         p.alphabet = params.alphabet.encode("utf-8") if params.alphabet is not None else None
         p.allowed_chars = params.allowed_chars.encode("utf-8") if params.allowed_chars is not None else None
+        p.numerics = NUMERICS[params.numerics]
+        p.coalesce = int(params.coalesce)
+        p.coalesce_pages = int(params.coalesce_pages)
+        p.coalesce_window_us = int(params.coalesce_window_us)
+        p.layout_threads = int(params.layout_threads)
+        p.rec_max_pixels = int(params.rec_max_pixels)
         self._h = C.c_void_p()
         check(lib().ocrs_engine_new(C.byref(p), C.byref(self._h)))
+        for k, v in params.options.items():
+            self.set_option(k, v)
+
+    def set_option(self, name, value):
+        """ocrs_engine_set_option: this engine's copy of a tuning option (results never depend on one)."""
+        check(lib().ocrs_engine_set_option(self._h, name.encode(), C.c_long(int(value))))
+
+    def get_option(self, name):
+        v = C.c_long(0)
+        check(lib().ocrs_engine_get_option(self._h, name.encode(), C.byref(v)))
+        return v.value
 
     @classmethod
     def _borrowed(cls, handle, keep):
@@ -606,8 +636,13 @@ class EngineGroup:
     GATHER = {"auto": 0, "host": 1, "rccl": 2}
 
     def __init__(self, devices, detection_bytes=None, recognition_bytes=None, debug=False, decode_method=DecodeMethod.Greedy,
-                 alphabet=None, allowed_chars=None, gather="auto"):
+                 alphabet=None, allowed_chars=None, gather="auto", numerics="exact", coalesce=0, coalesce_pages=0,
+                 coalesce_window_us=0, layout_threads=0, rec_max_pixels=0, min_block=0, shared_block=0):
         p = _lib.GroupParams()
+        p.numerics = NUMERICS[numerics]
+        p.coalesce, p.coalesce_pages, p.coalesce_window_us = int(coalesce), int(coalesce_pages), int(coalesce_window_us)
+        p.layout_threads, p.rec_max_pixels = int(layout_threads), int(rec_max_pixels)
+        p.min_block, p.shared_block = int(min_block), int(shared_block)
         self._det = bytes(detection_bytes) if detection_bytes is not None else None
         self._rec = bytes(recognition_bytes) if recognition_bytes is not None else None
         p.detection_model = C.cast(C.c_char_p(self._det), C.c_void_p) if self._det else None
@@ -637,6 +672,11 @@ class EngineGroup:
         e, d = C.c_void_p(), C.c_int(-1)
         check(lib().ocrs_engine_group_member(self._h, C.c_size_t(i), C.byref(e), C.byref(d)))
         return OcrEngine._borrowed(e, self), d.value
+
+    def set_option(self, name, value):
+        """ocrs_engine_set_option on every member."""
+        for i in range(len(self)):
+            self.member(i)[0].set_option(name, value)
 
     def last_gather(self):
         t, b, why = C.c_int(0), C.c_size_t(0), C.c_char_p()

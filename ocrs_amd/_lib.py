@@ -23,14 +23,17 @@ RUN_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_in
 class EngineParams(C.Structure):
     _fields_ = [("detection_model", C.c_void_p), ("recognition_model", C.c_void_p), ("debug", C.c_int),
                 ("decode_method", C.c_int), ("beam_width", C.c_uint32), ("alphabet", C.c_char_p),
-                ("allowed_chars", C.c_char_p)]
+                ("allowed_chars", C.c_char_p), ("numerics", C.c_int), ("coalesce", C.c_int), ("coalesce_pages", C.c_int),
+                ("coalesce_window_us", C.c_int), ("layout_threads", C.c_int), ("rec_max_pixels", C.c_int64)]
 
 
 class GroupParams(C.Structure):
     _fields_ = [("detection_model", C.c_void_p), ("detection_model_len", C.c_size_t), ("recognition_model", C.c_void_p),
                 ("recognition_model_len", C.c_size_t), ("devices", C.POINTER(C.c_int)), ("n_devices", C.c_size_t),
                 ("debug", C.c_int), ("decode_method", C.c_int), ("beam_width", C.c_uint32), ("alphabet", C.c_char_p),
-                ("allowed_chars", C.c_char_p), ("gather", C.c_int)]
+                ("allowed_chars", C.c_char_p), ("gather", C.c_int), ("numerics", C.c_int), ("coalesce", C.c_int),
+                ("coalesce_pages", C.c_int), ("coalesce_window_us", C.c_int), ("layout_threads", C.c_int), ("rec_max_pixels", C.c_int64),
+                ("min_block", C.c_int), ("shared_block", C.c_int)]
 
 
 class RunOptions(C.Structure):
@@ -67,6 +70,7 @@ DECLARED_SYMBOLS = [
     "ocrs_engine_group_new", "ocrs_engine_group_free", "ocrs_engine_group_size", "ocrs_engine_group_member", "ocrs_group_deal",
     "ocrs_group_prepare_input_batch", "ocrs_group_prepare_input_device_batch", "ocrs_group_detect_words_batch",
     "ocrs_group_recognize_text_batch", "ocrs_group_gather", "ocrs_group_final_gather", "ocrs_group_worker_threads", "ocrs_group_last_gather", "ocrs_device_malloc_on", "ocrs_engine_coalesce_stats", "ocrs_coalescer_selftest", "ocrs_engine_kernel_mfma_flops", "ocrs_engine_prepare_input_jpeg", "ocrs_jpeg_decode_rgb", "ocrs_jpeg_info", "ocrs_jpeg_coefficients",
+    "ocrs_engine_set_option", "ocrs_engine_get_option", "ocrs_option_name", "ocrs_device_pool_stats", "ocrs_device_pool_configure",
 ]
 
 _lib = None
@@ -113,8 +117,35 @@ def measure_peaks():
 
 
 def set_option(name, value):
-    """ocrs_set_option: process-wide tuning knob (results never depend on it)."""
+    """ocrs_set_option: the process DEFAULT of a tuning option — what engines created afterwards start with, and what a
+    bare Model.run uses.  An existing engine keeps its own copy: OcrEngine.set_option."""
     check(lib().ocrs_set_option(name.encode(), C.c_long(int(value))))
+
+
+def option_names():
+    out, i = [], 0
+    while True:
+        n = C.c_char_p()
+        check(lib().ocrs_option_name(i, C.byref(n)))
+        if not n.value:
+            return out
+        out.append(n.value.decode())
+        i += 1
+
+
+POOL_FIELDS = ("device_live", "device_cached", "device_cap", "device_peak_live", "device_driver_allocs", "device_driver_frees",
+               "pinned_live", "pinned_cached", "pinned_cap", "pinned_peak_live", "pinned_driver_allocs", "pinned_driver_frees")
+
+
+def pool_stats(device=-1):
+    """ocrs_device_pool_stats as a dict (bytes / counts)."""
+    v = (C.c_uint64 * 12)()
+    check(lib().ocrs_device_pool_stats(int(device), v))
+    return dict(zip(POOL_FIELDS, (int(x) for x in v)))
+
+
+def pool_configure(device=-1, device_cached_cap=0, pinned_cached_cap=0):
+    check(lib().ocrs_device_pool_configure(int(device), C.c_uint64(int(device_cached_cap)), C.c_uint64(int(pinned_cached_cap))))
 
 
 def ctc_beam_search(logp, width, impl=0):

@@ -117,6 +117,46 @@ ocrs_status ocrs_set_option(const char* name, long value) {
     });
 }
 
+ocrs_status ocrs_engine_set_option(ocrs_engine* e, const char* name, long value) {
+    return guarded([&] {
+        if (!e) fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
+        if (!set_option(e->tuning, name, value)) fail(OCRS_ERR_INVALID_ARGUMENT, "unknown option '%s'", name ? name : "(null)");
+    });
+}
+
+ocrs_status ocrs_engine_get_option(const ocrs_engine* e, const char* name, long* value) {
+    return guarded([&] {
+        if (!e || !value) fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
+        if (!get_option(e->tuning, name, value)) fail(OCRS_ERR_INVALID_ARGUMENT, "unknown option '%s'", name ? name : "(null)");
+    });
+}
+
+ocrs_status ocrs_option_name(int index, const char** name) {
+    return guarded([&] {
+        if (!name) fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
+        *name = option_name(index);   // NULL past the last option
+    });
+}
+
+ocrs_status ocrs_device_pool_stats(int device, uint64_t out[12]) {
+    return guarded([&] {
+        if (!out) fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
+        DeviceContext& c = device_context(device < 0 ? default_device() : device);
+        const PoolStats d = c.pool.stats(), h = c.host_pool.stats();
+        const uint64_t v[12] = {d.live, d.cached, d.cap, d.peak_live, d.driver_allocs, d.driver_frees,
+                                h.live, h.cached, h.cap, h.peak_live, h.driver_allocs, h.driver_frees};
+        for (int i = 0; i < 12; i++) out[i] = v[i];
+    });
+}
+
+ocrs_status ocrs_device_pool_configure(int device, uint64_t device_cached_cap_bytes, uint64_t pinned_cached_cap_bytes) {
+    return guarded([&] {
+        DeviceContext& c = device_context(device < 0 ? default_device() : device);
+        if (device_cached_cap_bytes) c.pool.set_cap(device_cached_cap_bytes);
+        if (pinned_cached_cap_bytes) c.host_pool.set_cap(pinned_cached_cap_bytes);
+    });
+}
+
 // ------------------------------------------------------------------ models
 ocrs_status ocrs_model_load_bytes_on_device(const void* data, size_t len, int device, ocrs_model** out) {
     return guarded([&] {
@@ -266,7 +306,7 @@ ocrs_status ocrs_image_source_check_bytes(size_t len, uint32_t width, uint32_t h
 
 ocrs_status ocrs_engine_prepare_input(const ocrs_engine* e, const void* pixels, ocrs_pixel_type type,
                                       ocrs_dim_order order, int height, int width, int channels, ocrs_page** out) {
-    return guarded_on(e ? e->device : -1, [&] {
+    return guarded_engine(e, [&] {
         if (!e || !out) fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
         check_image_args(pixels, height, width, channels);
         Workspace ws;
@@ -282,7 +322,7 @@ ocrs_status ocrs_engine_prepare_input(const ocrs_engine* e, const void* pixels, 
 
 ocrs_status ocrs_engine_prepare_input_batch(const ocrs_engine* e, const void* const* pixels, size_t n, ocrs_pixel_type type,
                                             ocrs_dim_order order, int height, int width, int channels, ocrs_page** out) {
-    return guarded_on(e ? e->device : -1, [&] {
+    return guarded_engine(e, [&] {
         if (!e || !out || (n > 0 && !pixels)) fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
         for (size_t i = 0; i < n; i++) check_image_args(pixels[i], height, width, channels);
         Workspace ws;
@@ -304,7 +344,7 @@ ocrs_status ocrs_engine_prepare_input_batch(const ocrs_engine* e, const void* co
 ocrs_status ocrs_engine_prepare_input_device(const ocrs_engine* e, const void* d_pixels, ocrs_pixel_type type,
                                              ocrs_dim_order order, int height, int width, int channels,
                                              ocrs_page** out) {
-    return guarded_on(e ? e->device : -1, [&] {
+    return guarded_engine(e, [&] {
         if (!e || !out) fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
         check_image_args(d_pixels, height, width, channels);
         Workspace ws;
@@ -341,7 +381,7 @@ uint8_t* jpeg_to_device_rgb(Workspace& ws, const void* jpeg, size_t len, int* he
 }  // namespace
 
 ocrs_status ocrs_engine_prepare_input_jpeg(const ocrs_engine* e, const void* jpeg, size_t len, ocrs_page** out, size_t* coef_bytes) {
-    return guarded_on(e ? e->device : -1, [&] {
+    return guarded_engine(e, [&] {
         if (!e || !jpeg || !out) fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
         Workspace ws;
         int h = 0, w = 0;
@@ -422,7 +462,7 @@ ocrs_status ocrs_page_image(const ocrs_page* p, float* out_hw) {
 
 ocrs_status ocrs_engine_detect_words_batch(const ocrs_engine* e, const ocrs_page* const* pages, size_t n_pages,
                                            float** rects, size_t* offsets) {
-    return guarded_on(e ? e->device : -1, [&] {
+    return guarded_engine(e, [&] {
         if (!e || !pages || !rects || !offsets) fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
         check_pages_on(e, pages, n_pages);
         std::vector<std::vector<RotatedRect>> rr;
@@ -449,7 +489,7 @@ ocrs_status ocrs_engine_detect_words(const ocrs_engine* e, const ocrs_page* page
 }
 
 ocrs_status ocrs_engine_detect_text_pixels(const ocrs_engine* e, const ocrs_page* page, float* out_hw) {
-    return guarded_on(e ? e->device : -1, [&] {
+    return guarded_engine(e, [&] {
         if (!e || !page || !out_hw) fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
         check_pages_on(e, &page, 1);
         e->detect(&page, 1, nullptr, out_hw);
@@ -486,8 +526,8 @@ ocrs_status ocrs_engine_find_text_lines(const ocrs_engine* e, const ocrs_page* p
 ocrs_status ocrs_engine_find_text_lines_batch(const ocrs_engine* e, size_t n_pages, const float* word_rects,
                                               const size_t* word_offsets, float** line_rects, size_t** line_offsets,
                                               size_t** page_line_offsets) {
-    (void)e;
     return guarded([&] {
+        TuningScope tune(e ? &e->tuning : nullptr);   // option "layout_threads" of this engine
         if (!word_offsets || !line_rects || !line_offsets || !page_line_offsets)
             fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
         std::vector<std::vector<std::vector<RotatedRect>>> per_page(n_pages);
@@ -532,7 +572,7 @@ ocrs_status ocrs_engine_recognize_text_batch(const ocrs_engine* e, const ocrs_pa
                                              const size_t* page_line_offsets, const float* line_rects,
                                              const size_t* line_offsets, size_t n_lines, ocrs_text_char** chars,
                                              size_t** char_offsets) {
-    return guarded_on(e ? e->device : -1, [&] {
+    return guarded_engine(e, [&] {
         if (!e || !pages || !page_line_offsets || !line_offsets || !chars || !char_offsets)
             fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
         check_pages_on(e, pages, n_pages);
@@ -566,7 +606,7 @@ ocrs_status ocrs_engine_recognize_text(const ocrs_engine* e, const ocrs_page* pa
 ocrs_status ocrs_engine_recognize_tokens(const ocrs_engine* e, const ocrs_page* page, const float* line_rects,
                                          const size_t* line_offsets, size_t n_lines, uint32_t** labels,
                                          uint32_t** positions, size_t** token_offsets) {
-    return guarded_on(e ? e->device : -1, [&] {
+    return guarded_engine(e, [&] {
         if (!e || !page || !line_offsets || !labels || !positions || !token_offsets)
             fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
         check_pages_on(e, &page, 1);
@@ -607,7 +647,7 @@ ocrs_status ocrs_rotated_rect_corners(const float rect6[6], float out8[8]) {
 
 ocrs_status ocrs_engine_prepare_recognition_input(const ocrs_engine* e, const ocrs_page* page, const float* line,
                                                   size_t n_words, float** out, int* height, int* width) {
-    return guarded_on(e ? e->device : -1, [&] {
+    return guarded_engine(e, [&] {
         if (!e || !page || !line || !out || !height || !width) fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
         check_pages_on(e, &page, 1);
         if (!e->recognition) fail(OCRS_ERR_MODEL_NOT_LOADED, "Recognition model not loaded");
@@ -647,7 +687,7 @@ ocrs_status ocrs_engine_prepare_recognition_input(const ocrs_engine* e, const oc
 }
 
 ocrs_status ocrs_engine_get_text(const ocrs_engine* e, const ocrs_page* page, char** text) {
-    return guarded_on(e ? e->device : -1, [&] {  // lib.rs:290-300
+    return guarded_engine(e, [&] {  // lib.rs:290-300
         if (!e || !page || !text) fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
         check_pages_on(e, &page, 1);
         std::vector<std::vector<RotatedRect>> rr;
@@ -708,14 +748,14 @@ ocrs_status ocrs_device_measure_peaks(double* mfma_f32_tflops, double* hbm_copy_
 }
 
 ocrs_status ocrs_engine_enable_timing(ocrs_engine* e, int enable) {
-    return guarded_on(e ? e->device : -1, [&] {
+    return guarded_engine(e, [&] {
         if (!e) fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
         e->timers.enabled = enable != 0;
         e->timers.kernels_enabled = enable >= 2;
     });
 }
 ocrs_status ocrs_engine_set_kernel_timing_mask(ocrs_engine* e, uint32_t mask) {
-    return guarded_on(e ? e->device : -1, [&] {
+    return guarded_engine(e, [&] {
         if (!e) fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
         e->timers.kernel_mask = mask;
     });
@@ -732,7 +772,7 @@ int ocrs_kernel_class_count(void) { return KC_COUNT; }
 const char* ocrs_kernel_class_name(int cls) { return cls >= 0 && cls < KC_COUNT ? kKernelClassNames[cls] : ""; }
 ocrs_status ocrs_engine_kernel_stats(ocrs_engine* e, double* ms, uint64_t* launches, double* flops, double* bytes,
                                      int reset) {
-    return guarded_on(e ? e->device : -1, [&] {
+    return guarded_engine(e, [&] {
         if (!e) fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
         e->timers.collect();
         for (int i = 0; i < KC_COUNT; i++) {
@@ -745,7 +785,7 @@ ocrs_status ocrs_engine_kernel_stats(ocrs_engine* e, double* ms, uint64_t* launc
     });
 }
 ocrs_status ocrs_engine_kernel_mfma_flops(ocrs_engine* e, double* mfma_flops) {
-    return guarded_on(e ? e->device : -1, [&] {
+    return guarded_engine(e, [&] {
         if (!e || !mfma_flops) fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
         e->timers.collect();
         for (int i = 0; i < KC_COUNT; i++) mfma_flops[i] = e->timers.kmfma[i];
@@ -754,7 +794,7 @@ ocrs_status ocrs_engine_kernel_mfma_flops(ocrs_engine* e, double* mfma_flops) {
 int ocrs_stage_count(void) { return ST_COUNT; }
 const char* ocrs_stage_name(int stage) { return stage >= 0 && stage < ST_COUNT ? kStageNames[stage] : ""; }
 ocrs_status ocrs_engine_stage_times(ocrs_engine* e, double* ms, uint64_t* launches, int reset) {
-    return guarded_on(e ? e->device : -1, [&] {
+    return guarded_engine(e, [&] {
         if (!e) fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
         e->timers.collect();
         for (int i = 0; i < ST_COUNT; i++) {

@@ -89,6 +89,16 @@ std::unique_ptr<ocrs_engine> make_engine(const ocrs_engine_params& params) {
         fail(OCRS_ERR_INVALID_ARGUMENT, "detection model is on device %d, recognition model on device %d", dd, rd);
     e->device = dd >= 0 ? dd : rd >= 0 ? rd : default_device();
     e->debug = params.debug != 0;
+    e->tuning = default_tuning();
+    if (params.numerics != OCRS_NUMERICS_EXACT && params.numerics != OCRS_NUMERICS_RELAXED)
+        fail(OCRS_ERR_INVALID_ARGUMENT, "unknown numerics mode %d", (int)params.numerics);
+    e->tuning.v[OPT_NUMERICS] = params.numerics == OCRS_NUMERICS_RELAXED ? 1 : 0;
+    // coalescing fields: 0 = default, negative = off / zero
+    if (params.coalesce) e->tuning.v[OPT_COALESCE] = params.coalesce < 0 ? 0 : params.coalesce;
+    if (params.coalesce_pages) e->tuning.v[OPT_COALESCE_PAGES] = params.coalesce_pages < 0 ? 1 : params.coalesce_pages;
+    if (params.coalesce_window_us) e->tuning.v[OPT_COALESCE_WINDOW_US] = params.coalesce_window_us < 0 ? 0 : params.coalesce_window_us;
+    if (params.layout_threads > 0) e->tuning.v[OPT_LAYOUT_THREADS] = params.layout_threads;
+    if (params.rec_max_pixels > 0) e->tuning.v[OPT_REC_MAX_PIXELS] = (long)params.rec_max_pixels;
     e->decode_method = params.decode_method;
     e->beam_width = params.beam_width ? params.beam_width : 100;
     e->alphabet = decode_utf8(params.alphabet ? params.alphabet : kDefaultAlphabet);

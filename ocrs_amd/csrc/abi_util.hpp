@@ -40,6 +40,16 @@ ocrs_status guarded_on(int device, F&& f) {
     });
 }
 
+// Entry points of an engine: bound to the engine's device, with the engine's own options installed for the call.
+template <class F>
+ocrs_status guarded_engine(const ocrs_engine* e, F&& f) {
+    return guarded([&] {
+        DeviceScope bind(e ? e->device : -1);
+        TuningScope tune(e ? &e->tuning : nullptr);
+        f();
+    });
+}
+
 template <class T>
 T* dup_buffer(const std::vector<T>& v) {
     T* p = static_cast<T*>(malloc(std::max<size_t>(v.size(), 1) * sizeof(T)));

@@ -4,7 +4,11 @@
 #include <cstdlib>
 #include <cstring>
 
+#include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <system_error>
 
 namespace ocrs {
 
@@ -93,15 +97,97 @@ static size_t round_size(size_t n) {
     return ((n + step - 1) / step) * step;
 }
 
-// Cached (free) bytes above this are returned to the driver on release, largest blocks first: scratch sizes follow
-// the pages, so an unbounded cache would only be trimmed by the first failing hipMalloc.  OCRS_POOL_CAP_GB overrides.
-static size_t pool_cap_bytes() {
-    static const size_t cap = [] {
+// ---- the trimmer: one detached thread per process that returns memory to the driver.  hipFree / hipHostFree wait for
+// the device to go idle, which under load takes as long as the queued work: a request's thread never pays that.
+namespace {
+struct Trimmer {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<std::pair<int, void*>> q;   // (device or -1 for pinned host memory, pointer)
+    bool started = false;
+    void run() {
+        for (;;) {
+            std::pair<int, void*> it;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return !q.empty(); });
+                it = q.front();
+                q.pop_front();
+            }
+            if (it.first >= 0) {
+                if (hipSetDevice(it.first) == hipSuccess) (void)hipFree(it.second);
+            } else {
+                (void)hipHostFree(it.second);
+            }
+            (void)hipGetLastError();
+        }
+    }
+    void give(int device, void* p) {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!started) {
+            started = true;
+            try {
+                std::thread([this] { run(); }).detach();
+            } catch (const std::system_error&) {
+                started = false;
+            }
+        }
+        if (!started) {   // no thread to be had: free here after all
+            if (device >= 0) (void)hipFree(p); else (void)hipHostFree(p);
+            return;
+        }
+        q.emplace_back(device, p);
+        cv.notify_one();
+    }
+};
+Trimmer& trimmer() {
+    static Trimmer* t = new Trimmer;   // leaked on purpose: its thread may outlive static destruction
+    return *t;
+}
+}  // namespace
+
+uint64_t DevicePool::cap_locked() {
+    if (!cap_) {
+        // default: a quarter of the device's memory (72 GB on an MI355X: the 16-page bench request peaks at ~20 GB of
+        // scratch, five requests in flight cache ~50 GB); OCRS_POOL_CAP_GB, read once per pool, overrides
         const char* e = getenv("OCRS_POOL_CAP_GB");
-        const double gb = e && *e ? atof(e) : 96.0;
-        return (size_t)(gb * (double)(size_t(1) << 30));
-    }();
-    return cap;
+        if (e && *e) {
+            cap_ = (uint64_t)(atof(e) * (double)(uint64_t(1) << 30));
+        } else {
+            size_t fr = 0, tot = 0;
+            int cur = -1;
+            const bool rebind = hipGetDevice(&cur) == hipSuccess && cur != device_;
+            if (rebind) (void)hipSetDevice(device_);
+            if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); tot = size_t(64) << 30; }
+            if (rebind) (void)hipSetDevice(cur);
+            cap_ = tot / 4;
+        }
+        if (!cap_) cap_ = 1;
+    }
+    return cap_;
+}
+
+void DevicePool::set_cap(uint64_t bytes) {
+    std::vector<void*> drop;
+    {
+        std::lock_guard<std::mutex> g(mu_);
+        cap_ = bytes ? bytes : 1;
+        while (cached_ > cap_ && !free_.empty()) {
+            auto big = std::prev(free_.end());
+            drop.push_back(big->second);
+            cached_ -= big->first;
+            frees_++;
+            free_.erase(big);
+        }
+    }
+    for (void* p : drop) trimmer().give(device_, p);
+}
+
+PoolStats DevicePool::stats() {
+    std::lock_guard<std::mutex> g(mu_);
+    PoolStats st;
+    st.live = live_bytes_; st.cached = cached_; st.cap = cap_locked(); st.peak_live = peak_live_; st.driver_allocs = allocs_; st.driver_frees = frees_;
+    return st;
 }
 
 void* DevicePool::alloc(size_t bytes) {
@@ -110,55 +196,59 @@ void* DevicePool::alloc(size_t bytes) {
     {
         // smallest cached block that fits, if it wastes at most a quarter of the request
         std::lock_guard<std::mutex> g(mu_);
-        static const bool exact = getenv("OCRS_POOL_EXACT") != nullptr;
-        auto it = exact ? free_.find(sz) : free_.lower_bound(sz);
+        auto it = free_.lower_bound(sz);
         if (it != free_.end() && it->first <= sz + sz / 4) {
             void* p = it->second;
             const size_t got = it->first;
             free_.erase(it);
             cached_ -= got;
             live_[p] = got;
+            live_bytes_ += got;
+            peak_live_ = std::max(peak_live_, live_bytes_);
             return p;
         }
     }
     void* p = nullptr;
-    static const bool trace = getenv("OCRS_POOL_TRACE") != nullptr;
-    const auto t0 = std::chrono::steady_clock::now();
     hipError_t e = hipMalloc(&p, sz);
     if (e != hipSuccess) {
         (void)hipGetLastError();  // the retry below decides; do not leave a stale out-of-memory for later checks
         trim();
         OCRS_HIP(hipMalloc(&p, sz));
     }
-    if (trace) {
-        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        const double now = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
-        fprintf(stderr, "[pool] t=%.3f hipMalloc %.1f MB took %.2f ms\n", now, sz / 1e6, ms);
-    }
     std::lock_guard<std::mutex> g(mu_);
     live_[p] = sz;
+    live_bytes_ += sz;
+    peak_live_ = std::max(peak_live_, live_bytes_);
+    allocs_++;
     return p;
 }
 
 void DevicePool::release(void* p) {
     if (!p) return;
-    std::lock_guard<std::mutex> g(mu_);
-    auto it = live_.find(p);
-    if (it == live_.end()) return;
-    free_.emplace(it->second, p);
-    cached_ += it->second;
-    live_.erase(it);
-    while (cached_ > pool_cap_bytes() && !free_.empty()) {  // rare: hipFree synchronises the device
-        auto big = std::prev(free_.end());
-        (void)hipFree(big->second);
-        cached_ -= big->first;
-        free_.erase(big);
+    std::vector<void*> drop;
+    {
+        std::lock_guard<std::mutex> g(mu_);
+        auto it = live_.find(p);
+        if (it == live_.end()) return;
+        free_.emplace(it->second, p);
+        cached_ += it->second;
+        live_bytes_ -= it->second;
+        live_.erase(it);
+        const uint64_t cap = cap_locked();
+        while (cached_ > cap && !free_.empty()) {   // largest first; returned to the driver by the trimmer thread
+            auto big = std::prev(free_.end());
+            drop.push_back(big->second);
+            cached_ -= big->first;
+            frees_++;
+            free_.erase(big);
+        }
     }
+    for (void* q : drop) trimmer().give(device_, q);
 }
 
 void DevicePool::trim() {
     std::lock_guard<std::mutex> g(mu_);
-    for (auto& kv : free_) (void)hipFree(kv.second);
+    for (auto& kv : free_) { (void)hipFree(kv.second); frees_++; }
     free_.clear();
     cached_ = 0;
 }
@@ -172,11 +262,15 @@ void* HostPool::alloc(size_t bytes) {
     const size_t sz = round_size(bytes);
     {
         std::lock_guard<std::mutex> g(mu_);
-        auto it = free_.find(sz);
-        if (it != free_.end()) {
+        auto it = free_.lower_bound(sz);
+        if (it != free_.end() && it->first <= sz + sz / 4) {
             void* p = it->second;
+            const size_t got = it->first;
             free_.erase(it);
-            live_[p] = sz;
+            cached_ -= got;
+            live_[p] = got;
+            live_bytes_ += got;
+            peak_live_ = std::max(peak_live_, live_bytes_);
             return p;
         }
     }
@@ -184,16 +278,44 @@ void* HostPool::alloc(size_t bytes) {
     OCRS_HIP(hipHostMalloc(&p, sz, hipHostMallocPortable));
     std::lock_guard<std::mutex> g(mu_);
     live_[p] = sz;
+    live_bytes_ += sz;
+    peak_live_ = std::max(peak_live_, live_bytes_);
+    allocs_++;
     return p;
 }
 
 void HostPool::release(void* p) {
     if (!p) return;
+    std::vector<void*> drop;
+    {
+        std::lock_guard<std::mutex> g(mu_);
+        auto it = live_.find(p);
+        if (it == live_.end()) return;
+        free_.emplace(it->second, p);
+        cached_ += it->second;
+        live_bytes_ -= it->second;
+        live_.erase(it);
+        while (cached_ > cap_ && !free_.empty()) {
+            auto big = std::prev(free_.end());
+            drop.push_back(big->second);
+            cached_ -= big->first;
+            frees_++;
+            free_.erase(big);
+        }
+    }
+    for (void* q : drop) trimmer().give(-1, q);
+}
+
+void HostPool::set_cap(uint64_t bytes) {
     std::lock_guard<std::mutex> g(mu_);
-    auto it = live_.find(p);
-    if (it == live_.end()) return;
-    free_.emplace(it->second, p);
-    live_.erase(it);
+    cap_ = bytes;
+}
+
+PoolStats HostPool::stats() {
+    std::lock_guard<std::mutex> g(mu_);
+    PoolStats st;
+    st.live = live_bytes_; st.cached = cached_; st.cap = cap_; st.peak_live = peak_live_; st.driver_allocs = allocs_; st.driver_frees = frees_;
+    return st;
 }
 
 hipStream_t DeviceContext::heavy_stream() {
@@ -205,13 +327,12 @@ hipStream_t DeviceContext::heavy_stream() {
         // the recurrence in one persistent launch per layer that reason is gone.  The GPU is work-conserving — every
         // combination of stream priorities measured the same 256-259 pages/s — but here the dominant kernels are
         // stretched least by what runs beside them: 9.9-10.4 ms per launch against 11.2-11.4.)
-        // Round 3, OCRS_HEAVY_LOW=1 again: +0.8 % on the 16-page bench (eight of eight ABAB pairs) — and 2-8 pages/s instead
-        // of 180 for one-page calls from 12 threads (detect latencies of seconds): with the queue at the lowest priority its
-        // kernels starve as long as any other request has something queued.  The switch stays an experiment.
+        // Round 3 tried the lowest priority again: +0.8 % on the 16-page bench — and 2-8 pages/s instead of 180 for one-page
+        // calls from 12 threads (detect latencies of seconds): its kernels starve as long as any other request has something queued.
         DeviceScope bind(device);
         int least = 0, greatest = 0;
         OCRS_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        OCRS_HIP(hipStreamCreateWithPriority(&heavy_, hipStreamNonBlocking, getenv("OCRS_HEAVY_LOW") ? least : greatest));
+        OCRS_HIP(hipStreamCreateWithPriority(&heavy_, hipStreamNonBlocking, greatest));
     }
     return heavy_;
 }
@@ -242,61 +363,81 @@ namespace {
 struct OptDef { const char* name; const char* env; long def; };
 const OptDef kOptDefs[OPT_COUNT] = {
     {"gru_mode", "OCRS_GRU_MODE", GRU_PERSISTENT},      // 0 persistent recurrence kernel, 1 one launch per time step
-    {"det_fuse", "OCRS_DET_FUSE", 1},                   // fused DoubleConv blocks: 1 where they win, 2 every shape, 0 none
-    {"layout_threads", "OCRS_LAYOUT_THREADS", 0},       // host threads of find_text_lines_batch (0 = automatic)
-    {"beam_gpu", "OCRS_BEAM_GPU", 1},                   // 1 CTC beam search on the GPU, 0 on the host
-    {"gru_local", "OCRS_GRU_LOCAL", 1},                 // persistent GRU: 1 same-XCD clusters hand off through L2, 0 always write-through
-    {"gru_scatter", "OCRS_GRU_SCATTER", 0},             // persistent GRU test knob: 1 spreads every cluster over the XCDs
-    {"rec_max_pixels", "OCRS_REC_MAX_PIXELS", 0},       // input pixels per recognition sub-request (0 = 2e9, the memory budget)
-    {"gemm_nfast", "OCRS_GEMM_NFAST", 1},               // dense GEMMs: column tiles of a row tile side by side on one XCD
     {"gru_gates", "OCRS_GRU_GATES", 1},                 // persistent GRU: gate-per-wave kernel when every row tile gets its own cluster
-    {"coalesce", "OCRS_COALESCE", 2},                   // merged batches of small requests in flight per engine and stage (0 = no merging)
-    {"coalesce_pages", "OCRS_COALESCE_PAGES", 16},      // pages per merged batch; requests of half that size or more run on their own
-    {"coalesce_window_us", "OCRS_COALESCE_WINDOW_US", 300},  // how long a would-be leader lets the queue fill while other batches run
-    {"gru_gates_pack", "OCRS_GRU_GATES_PACK", 1},       // gate-per-wave GRU kernel: 2 = two workgroups per CU for requests of twice the row tiles
-    {"conv_occupancy", "OCRS_CONV_OCCUPANCY", 4},       // recognition conv blocks per CU: 4 (fastest alone), 3 leaves room for other requests' small kernels
-    {"det_mfma", "OCRS_DET_MFMA", 1},                   // fused detection blocks: pointwise convs + ConvTranspose on MFMA, all block shapes incl. the 32-channel levels (1); VALU kernels (0)
-    {"gru_background", "OCRS_GRU_BACKGROUND", 0},       // requests beyond the gate-per-wave kernel's size: 1 = lean multi-tile gate-per-wave kernel (small footprint, slower alone)
-    {"gx_heavy", "OCRS_GX_HEAVY", 0},                   // GRU input projections of large requests on the shared conv-stack stream (serialised with the conv stacks)
-    {"det_heavy", "OCRS_DET_HEAVY", 0},                 // detection kernels on the shared conv-stack stream: 0 = never (default since r4: 194 vs 180 pages/s for one-page calls from 12 threads, ABAB), 1 = requests of fewer than 8 pages (r3 default), 2 = all
+    {"gru_local", "OCRS_GRU_LOCAL", 1},                 // persistent GRU: 1 same-XCD clusters hand off through L2, 0 always write-through
+    {"det_fuse", "OCRS_DET_FUSE", 1},                   // fused DoubleConv blocks: 1 where they win, 2 every shape, 0 none
+    {"det_mfma", "OCRS_DET_MFMA", 1},                   // fused detection blocks: pointwise convs + ConvTranspose on MFMA (1); VALU kernels (0)
+    {"det_stream", "OCRS_DET_STREAM", 1},               // DoubleConv blocks of the full-resolution levels: row-streaming wave kernels (1; 8 / 14 / 32 rows per wave) or LDS-tiled (0)
+    {"det_rows", "OCRS_DET_ROWS", 1},                   // DoubleConv blocks of the 16-64-channel levels: row-streaming workgroup kernels (1; 8 / 14 / 20 / 32 rows) or LDS-tiled (0)
+    {"ccl_quad", "OCRS_CCL_QUAD", 1},                   // component labelling / root compaction: four pixels per thread on word-aligned masks (1) or one (0)
+    {"conv12_fuse", "OCRS_CONV12_FUSE", 1},             // first two recognition convs (+ their pools) in one kernel
     {"conv_flat", "OCRS_CONV_FLAT", 1},                 // recognition 3x3 convs: patches tile a width group's whole strip of images (0: every image on its own)
-    {"conv12_fuse", "OCRS_CONV12_FUSE", 1},             // first two recognition convs (+ their pools) in one kernel: conv1 into LDS, conv2's MFMA operand from there
-    {"group_min_block", "OCRS_GROUP_MIN_BLOCK", 8},     // engine group: pages the group places itself go to a device in contiguous blocks of at least this many
-    {"group_shared_block", "OCRS_GROUP_SHARED_BLOCK", 16},  // engine group: the same between members that share one device
-    {"gru_waves", "OCRS_GRU_WAVES", 4},                 // recurrence of requests beyond one row tile per cluster: 4 = the general kernel (one wave per SIMD; default), 16 = four gate-per-wave teams per workgroup (r4 experiment: 12 % slower)
-    {"det_tail", "OCRS_DET_TAIL", 0},                   // detection U-Net: every operator of the deep levels (<= 2048 pixels per page) in ONE persistent launch (1; r4 experiment: 44 -> 23 dispatches but 1.03 vs 0.24 ms) or one launch per operator (0, default)
-    {"det_stream", "OCRS_DET_STREAM", 1},               // detection U-Net, DoubleConv blocks of the full-resolution levels: row-streaming register kernels (1, default; kernels_det_stream.hip) or the LDS-tiled blocks of kernels_det.hip (0)
-    {"ccl_quad", "OCRS_CCL_QUAD", 1},                   // component labelling / root compaction kernels: four pixels per thread on word-aligned masks (1, default) or one (0)
-    {"det_rows", "OCRS_DET_ROWS", 1},                   // detection U-Net, DoubleConv blocks of the 16-64-channel levels: row-streaming workgroup kernels (1, default; kernels_det_rows.hip; 8 / 14 / 32 = that many rows per workgroup) or the LDS-tiled blocks of kernels_det.hip (0)
+    {"beam_gpu", "OCRS_BEAM_GPU", 1},                   // 1 CTC beam search on the GPU, 0 on the host
+    // not options: ocrs_engine_params fields (no name, no environment variable)
+    // (ocrs_engine_set_option accepts these names too, except numerics: an engine's numerics are fixed when it is created)
+    {"numerics", nullptr, 0},                           // exact
+    {"coalesce", nullptr, 2},                           // merged batches of small requests in flight per engine and stage (0 = no merging)
+    {"coalesce_pages", nullptr, 16},                    // pages per merged batch
+    {"coalesce_window_us", nullptr, 300},
+    {"layout_threads", nullptr, 0},                     // host threads of find_text_lines_batch (0 = automatic)
+    {"rec_max_pixels", nullptr, 0},                     // input pixels per recognition sub-request (0 = 2e9, the memory budget)
 };
 std::atomic<long> g_opts[OPT_COUNT];
 std::once_flag g_opts_once;
-void init_options() {
+void init_options() {   // the only getenv of the option system: once per process
     for (int i = 0; i < OPT_COUNT; i++) {
-        const char* e = getenv(kOptDefs[i].env);
+        const char* e = kOptDefs[i].env ? getenv(kOptDefs[i].env) : nullptr;
         g_opts[i].store(e && *e ? strtol(e, nullptr, 10) : kOptDefs[i].def);
     }
 }
+int find_option(const char* name, int count = OPT_PUBLIC_COUNT) {
+    for (int i = 0; i < count; i++)
+        if (name && i != OPT_NUMERICS && strcmp(name, kOptDefs[i].name) == 0) return i;
+    return -1;
+}
+thread_local const Tuning* t_tuning = nullptr;
 }  // namespace
 
-int option(Option o) {
-    std::call_once(g_opts_once, init_options);
-    return (int)g_opts[o].load(std::memory_order_relaxed);
-}
+TuningScope::TuningScope(const Tuning* t) : prev_(t_tuning) { t_tuning = t; }
+TuningScope::~TuningScope() { t_tuning = prev_; }
+const Tuning* current_tuning() { return t_tuning; }
 
 long option_long(Option o) {
+    if (t_tuning) return t_tuning->v[o];
     std::call_once(g_opts_once, init_options);
     return g_opts[o].load(std::memory_order_relaxed);
 }
+int option(Option o) { return (int)option_long(o); }
+
+Tuning default_tuning() {
+    std::call_once(g_opts_once, init_options);
+    Tuning t;
+    for (int i = 0; i < OPT_COUNT; i++) t.v[i] = g_opts[i].load(std::memory_order_relaxed);
+    return t;
+}
+
+const char* option_name(int i) { return i >= 0 && i < OPT_PUBLIC_COUNT ? kOptDefs[i].name : nullptr; }
 
 bool set_option(const char* name, long value) {
     std::call_once(g_opts_once, init_options);
-    for (int i = 0; i < OPT_COUNT; i++)
-        if (name && strcmp(name, kOptDefs[i].name) == 0) {
-            g_opts[i].store(value);
-            return true;
-        }
-    return false;
+    const int i = find_option(name);
+    if (i < 0) return false;
+    g_opts[i].store(value);
+    return true;
+}
+
+bool set_option(Tuning& t, const char* name, long value) {
+    const int i = find_option(name, OPT_COUNT);   // an engine's copy: also the configuration fields, by their field names
+    if (i < 0) return false;
+    t.v[i] = value;
+    return true;
+}
+
+bool get_option(const Tuning& t, const char* name, long* value) {
+    const int i = name && strcmp(name, "numerics") == 0 ? (int)OPT_NUMERICS : find_option(name, OPT_COUNT);
+    if (i < 0) return false;
+    *value = t.v[i];
+    return true;
 }
 
 // ---------------------------------------------------------------- streams

@@ -57,36 +57,47 @@ void set_last_error(const std::string& msg);
 
 // Size-bucketed caching allocator: hipMalloc is far too slow to sit on the
 // per-page path, and stages need scratch whose size depends on the page.
+// Cached (free) bytes are bounded: above the cap (default: a quarter of the device's memory; OCRS_POOL_CAP_GB read once
+// at first use, ocrs_device_pool_configure) the largest cached blocks are handed to the process's trimmer thread, which
+// returns them to the driver — hipFree waits for the device, so it never runs on a request's thread.
+struct PoolStats { uint64_t live = 0, cached = 0, cap = 0, peak_live = 0, driver_allocs = 0, driver_frees = 0; };
 class DevicePool {
   public:
     explicit DevicePool(int device) : device_(device) {}
     ~DevicePool();
     void* alloc(size_t bytes);     // the calling thread must be bound to this pool's device
     void release(void* p);         // any thread
-    void trim();
+    void trim();                   // returns every cached block to the driver, on the calling thread
+    void set_cap(uint64_t bytes);
+    PoolStats stats();
     int device() const { return device_; }
 
   private:
+    uint64_t cap_locked();
     const int device_;
     std::mutex mu_;
     std::multimap<size_t, void*> free_;
     std::map<void*, size_t> live_;
-    size_t cached_ = 0;  // bytes in free_
+    uint64_t cached_ = 0, live_bytes_ = 0, peak_live_ = 0, cap_ = 0, allocs_ = 0, frees_ = 0;
 };
 
-// Pinned host staging (hipHostMalloc), cached by size.  Device-to-host results go through it: a
-// hipMemcpyAsync into PAGEABLE memory does not return until the stream has reached and finished the
-// copy, and the calling thread spins for all of that time — tens of milliseconds per request when
+// Pinned host staging (hipHostMalloc), cached in the same size buckets with the same reuse rule (smallest cached block
+// that wastes at most a quarter) and a cap on the cached bytes (default 1 GiB per device context).  Device-to-host
+// results go through it: a hipMemcpyAsync into PAGEABLE memory does not return until the stream has reached and
+// finished the copy, and the calling thread spins for all of that time — tens of milliseconds per request when
 // the copy is queued behind the request's own kernels.
 class HostPool {
   public:
     void* alloc(size_t bytes);
     void release(void* p);
+    void set_cap(uint64_t bytes);
+    PoolStats stats();
 
   private:
     std::mutex mu_;
     std::multimap<size_t, void*> free_;
     std::map<void*, size_t> live_;
+    uint64_t cached_ = 0, live_bytes_ = 0, peak_live_ = 0, cap_ = uint64_t(1) << 30, allocs_ = 0, frees_ = 0;
 };
 
 struct DeviceContext {
@@ -142,10 +153,35 @@ inline HostPool& host_pool() { return ctx().host_pool; }
 inline hipStream_t heavy_stream() { return ctx().heavy_stream(); }
 inline hipStream_t recurrent_stream() { return ctx().recurrent_stream(); }
 
-// Process-wide tuning options (ocrs_set_option; initial value from the environment variable OCRS_<NAME>).
-// Integer-valued, looked up by name; unknown names are rejected by the ABI.
-enum Option { OPT_GRU_MODE = 0, OPT_DET_FUSE, OPT_LAYOUT_THREADS, OPT_BEAM_GPU, OPT_GRU_LOCAL, OPT_GRU_SCATTER, OPT_REC_MAX_PIXELS, OPT_GEMM_NFAST, OPT_GRU_GATES,
-              OPT_COALESCE, OPT_COALESCE_PAGES, OPT_COALESCE_WINDOW_US, OPT_GRU_GATES_PACK, OPT_CONV_OCCUPANCY, OPT_DET_MFMA, OPT_GRU_BACKGROUND, OPT_GX_HEAVY, OPT_DET_HEAVY, OPT_CONV_FLAT, OPT_CONV12_FUSE, OPT_GROUP_MIN_BLOCK, OPT_GROUP_SHARED_BLOCK, OPT_GRU_WAVES, OPT_DET_TAIL, OPT_DET_STREAM, OPT_CCL_QUAD, OPT_DET_ROWS, OPT_COUNT };
+// Tuning options (include/ocrs_amd.h, ocrs_set_option / ocrs_engine_set_option): integer-valued, looked up by name.
+// The process holds the DEFAULTS (initial value from the environment variable OCRS_<NAME>, read once at first use;
+// ocrs_set_option changes them); an engine copies the defaults when it is created and keeps its own copy (Tuning),
+// which ocrs_engine_set_option changes — two engines in one process can differ, and changing a default never
+// affects an engine that already exists.  Every engine entry point installs its engine's copy for the calling
+// thread (TuningScope); code outside an engine call (ocrs_model_run on a bare model) sees the process defaults.
+// The entries after OPT_PUBLIC_COUNT are not options: they are fields of ocrs_engine_params that travel the same way.
+enum Option { OPT_GRU_MODE = 0, OPT_GRU_GATES, OPT_GRU_LOCAL, OPT_DET_FUSE, OPT_DET_MFMA, OPT_DET_STREAM, OPT_DET_ROWS, OPT_CCL_QUAD,
+              OPT_CONV12_FUSE, OPT_CONV_FLAT, OPT_BEAM_GPU, OPT_PUBLIC_COUNT,
+              OPT_NUMERICS = OPT_PUBLIC_COUNT,   // ocrs_engine_params.numerics: 0 exact (the numeric spec), 1 relaxed
+              OPT_COALESCE, OPT_COALESCE_PAGES, OPT_COALESCE_WINDOW_US,   // ocrs_engine_params.coalesce*
+              OPT_LAYOUT_THREADS, OPT_REC_MAX_PIXELS,                     // ocrs_engine_params.layout_threads / rec_max_pixels
+              OPT_COUNT };
+struct Tuning { long v[OPT_COUNT]; };
+Tuning default_tuning();                                   // the process defaults as they are now
+bool set_option(const char* name, long value);             // process default; false: unknown name
+bool set_option(Tuning& t, const char* name, long value);  // one engine's copy
+bool get_option(const Tuning& t, const char* name, long* value);
+const char* option_name(int i);                            // i < OPT_PUBLIC_COUNT
+class TuningScope {   // installs `t` for the calling thread for the lifetime of the object; nests
+  public:
+    explicit TuningScope(const Tuning* t);
+    ~TuningScope();
+    TuningScope(const TuningScope&) = delete;
+    TuningScope& operator=(const TuningScope&) = delete;
+  private:
+    const Tuning* prev_;
+};
+const Tuning* current_tuning();   // what the calling thread has installed (nullptr: none) — handed to worker threads
 enum { GRU_PERSISTENT = 0, GRU_STEP = 1 };
 int option(Option o);
 
@@ -161,7 +197,6 @@ inline void allow_dynamic_lds(const void* kernel, std::atomic<uint64_t>& done) {
     done.fetch_or(bit, std::memory_order_relaxed);
 }
 long option_long(Option o);
-bool set_option(const char* name, long value);  // false: unknown name
 inline int gru_mode() { return option(OPT_GRU_MODE); }
 
 // RAII device buffer from the pool of the device the allocating thread is bound to; remembers its pool, so it may

@@ -36,27 +36,8 @@ void ocrs_engine::detect_now(const ocrs_page* const* pages, size_t n, std::vecto
     Workspace ws;
     hipStream_t st = ws.s();
     StageTimers* T = tm();
-    // Option "det_heavy": a small request's kernels go through the device's conv-stack stream instead of its own.
-    // Beside other requests' conv stacks the ~50 short dependent launches of this stage each wait for CU slots between
-    // 0.5 ms-long conv blocks (detect_words 0.8 ms alone, 14 ms with a dozen one-page requests in flight); queued
-    // BETWEEN the conv stacks they run at full speed and wait once, for at most one (short: small requests) conv stack.
-    const int det_heavy = option(OPT_DET_HEAVY);
-    const bool on_heavy = !detection->is_callback() && rects_out && !host_map && !debug &&
-                          (det_heavy >= 2 || (det_heavy == 1 && n < 8));
-    hipStream_t ex = on_heavy ? heavy_stream() : st;       // where the kernels run; copies stay on st
-    std::unique_lock<std::mutex> heavy(ctx().heavy_phase, std::defer_lock);
-    auto leave_heavy = [&](bool ok) {   // st continues after everything queued on the shared stream
-        if (!on_heavy || !heavy.owns_lock()) return;
-        hipEvent_t e = nullptr;
-        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess) {
-            ws.events.push_back(e);
-            if (hipEventRecord(e, ex) != hipSuccess || hipStreamWaitEvent(st, e, 0) != hipSuccess) (void)hipStreamSynchronize(ex);
-        } else {
-            (void)hipStreamSynchronize(ex);
-        }
-        heavy.unlock();
-        (void)ok;
-    };
+    hipStream_t ex = st;   // (round 3 could route a small request's kernels through the device's conv-stack stream — option det_heavy,
+                           // off since round 4: 180 vs 194 pages/s for one-page calls from 12 threads — removed in round 5)
 
     // page pointer table
     std::vector<const float*> hp(n);
@@ -65,11 +46,6 @@ void ocrs_engine::detect_now(const ocrs_page* const* pages, size_t n, std::vecto
     ws.upload(d_ptrs, hp.data(), n * sizeof(float*));
 
     float* d_in = ws.alloc_n<float>((size_t)N * in_h * in_w);
-    if (on_heavy) {
-        ws.stream.sync();     // inputs on the device before anything enters the shared stream (nothing there may wait)
-        heavy.lock();
-    }
-    try {
     {
         StageScope sc(T, ST_RESIZE_IN, ex);
         k::resize_pages_to_model(d_ptrs, N, h, w, vh, vw, d_in, in_h, in_w, ex);
@@ -99,7 +75,7 @@ void ocrs_engine::detect_now(const ocrs_page* const* pages, size_t n, std::vecto
     } else {
         const auto* hm = static_cast<const HipModel*>(detection);
         TensorShape os;
-        d_prob = hm->run_device(ws, d_in, N, in_h, in_w, &os, T, nullptr, nullptr, true, debug, -1, on_heavy ? ex : nullptr);
+        d_prob = hm->run_device(ws, d_in, N, in_h, in_w, &os, T, nullptr, nullptr, true, debug, -1, nullptr);
         if (os.n != N || os.h != in_h || os.w != in_w || os.c != 1)
             fail(OCRS_ERR_WRONG_OUTPUT, "model output had unexpected type or shape: detection output [%d,%d,%d,%d]", os.n,
                  os.c, os.h, os.w);
@@ -116,7 +92,6 @@ void ocrs_engine::detect_now(const ocrs_page* const* pages, size_t n, std::vecto
     if (host_map)
         ws.download(host_map, d_map, (size_t)N * h * w * sizeof(float));
     if (!rects_out) {
-        leave_heavy(true);
         ws.sync();
         if (T) T->collect();
         return;
@@ -159,7 +134,6 @@ void ocrs_engine::detect_now(const ocrs_page* const* pages, size_t n, std::vecto
     };
     const k::CclBuffers b = alloc_ccl(N, max_comp, arena, ex);
     run_ccl(d_mask, N, b, max_comp, arena, ex);
-    leave_heavy(true);
     // One round trip in the common case: the counts travel together with the first kSpec candidate rects of every
     // page (a page of text has a few hundred to ~1 500 components); only a page with more needs a second one.
     constexpr int kSpec = 2048;
@@ -220,10 +194,6 @@ void ocrs_engine::detect_now(const ocrs_page* const* pages, size_t n, std::vecto
         auto& out = (*rects_out)[i];
         for (int c = 0; c < counts[i]; c++)
             if (hv[i][c]) out.push_back(RotatedRect::from_array(&hr[i][(size_t)c * 6]));
-    }
-    } catch (...) {
-        leave_heavy(false);   // scratch of this call may still be in use on the shared stream: st waits for it before ~Workspace drains st
-        throw;
     }
     if (T) T->collect();
 }

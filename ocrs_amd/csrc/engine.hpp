@@ -72,6 +72,9 @@ struct ocrs_engine {
     float min_area = 100.0f;
     float text_threshold = 0.2f;
     mutable ocrs::StageTimers timers;
+    // the engine's copy of the tuning options (common.hpp): the process defaults at creation + ocrs_engine_params +
+    // ocrs_engine_set_option; installed for the calling thread by every entry point (abi_util.hpp guarded_engine)
+    ocrs::Tuning tuning{};
 
     ocrs::StageTimers* tm() const { return timers.enabled ? &timers : nullptr; }
 

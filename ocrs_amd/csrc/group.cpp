@@ -120,9 +120,11 @@ struct ocrs_engine_group {
     int last_mode = 0;     // transport of the most recent gather: 1 host, 2 RCCL
     size_t last_bytes = 0;
     std::string why_host;  // why the most recent gather that wanted RCCL (or AUTO) used the host ("" if it did not)
+    std::string rccl_fail_reason;   // why the communicators could not be created (init_mu); outlives later gathers
     std::string why_host_out;   // stable copy handed out by ocrs_group_last_gather
 
     std::atomic<size_t> next_start{0};   // rotation of the block deal
+    size_t min_block = 8, shared_block = 16;   // ocrs_group_params.min_block / shared_block
     WorkerPool workers{[] { StageTimers::release_thread_events(); }};   // the members' shares of a call run here
 
     ~ocrs_engine_group() {
@@ -161,10 +163,10 @@ std::vector<std::vector<size_t>> deal_resident(ocrs_engine_group* g, const std::
         if (mem.size() == 1) {
             of_member[mem[0]] = on_device[k];
         } else {
-            const size_t b = block_size(on_device[k].size(), mem.size(), (size_t)option(OPT_GROUP_SHARED_BLOCK));
+            const size_t b = block_size(on_device[k].size(), mem.size(), g->shared_block);
             const size_t used = (on_device[k].size() + b - 1) / b;
             const size_t start = used < mem.size() ? g->next_start.fetch_add(used) : 0;
-            deal_blocks(on_device[k], mem, (size_t)option(OPT_GROUP_SHARED_BLOCK), start, &of_member);
+            deal_blocks(on_device[k], mem, g->shared_block, start, &of_member);
         }
     }
     return of_member;
@@ -176,11 +178,11 @@ std::vector<std::vector<size_t>> deal_free(ocrs_engine_group* g, size_t n) {
     std::vector<size_t> items(n), takers(D);
     for (size_t i = 0; i < n; i++) items[i] = i;
     for (size_t k = 0; k < D; k++) takers[k] = k;
-    const size_t b = block_size(n, D, (size_t)option(OPT_GROUP_MIN_BLOCK));
+    const size_t b = block_size(n, D, g->min_block);
     const size_t used = (n + b - 1) / b;
     const size_t start = used < D ? g->next_start.fetch_add(used) : 0;
     std::vector<std::vector<size_t>> on_device(D);
-    deal_blocks(items, takers, (size_t)option(OPT_GROUP_MIN_BLOCK), start, &on_device);
+    deal_blocks(items, takers, g->min_block, start, &on_device);
     std::vector<size_t> device_of_page(n, 0);
     for (size_t k = 0; k < D; k++)
         for (size_t i : on_device[k]) device_of_page[i] = k;
@@ -213,6 +215,7 @@ void for_each_member(ocrs_engine_group* g, const std::vector<std::vector<size_t>
     std::vector<std::exception_ptr> errs;
     run_shares(g->workers, has_work, errs, [&](size_t m) {
         DeviceScope bind(g->members[m].device);
+        TuningScope tune(&g->members[m].engine->tuning);   // the member engine's own options, on whichever thread runs its share
         fn(m);
     });
 }
@@ -233,10 +236,7 @@ std::vector<uint8_t> gather_host(const std::vector<std::vector<uint8_t>>& payloa
 bool ensure_comms(ocrs_engine_group* g, std::string* why) {
     std::lock_guard<std::mutex> lk(g->init_mu);
     if (g->rccl_tried) {
-        if (!g->rccl_ready && why) {
-            std::lock_guard<std::mutex> li(g->info_mu);
-            *why = g->why_host;
-        }
+        if (!g->rccl_ready && why) *why = g->rccl_fail_reason;   // (not why_host: every later gather overwrites that)
         return g->rccl_ready;
     }
     g->rccl_tried = true;
@@ -261,6 +261,7 @@ bool ensure_comms(ocrs_engine_group* g, std::string* why) {
         }
     }
     if (!g->rccl_ready) {
+        g->rccl_fail_reason = reason;
         std::lock_guard<std::mutex> li(g->info_mu);
         g->why_host = reason;
         if (why) *why = reason;
@@ -422,6 +423,8 @@ ocrs_status ocrs_engine_group_new(const ocrs_group_params* params, ocrs_engine_g
             fail(OCRS_ERR_INVALID_ARGUMENT, "unknown gather mode %d", (int)params->gather);
         auto g = std::make_unique<ocrs_engine_group>();
         g->gather = params->gather;
+        if (params->min_block > 0) g->min_block = (size_t)params->min_block;
+        if (params->shared_block > 0) g->shared_block = (size_t)params->shared_block;
         g->members.resize(params->n_devices);
         for (size_t m = 0; m < params->n_devices; m++) {
             auto& mem = g->members[m];
@@ -451,6 +454,12 @@ ocrs_status ocrs_engine_group_new(const ocrs_group_params* params, ocrs_engine_g
             ep.beam_width = params->beam_width;
             ep.alphabet = params->alphabet;
             ep.allowed_chars = params->allowed_chars;
+            ep.numerics = params->numerics;
+            ep.coalesce = params->coalesce;
+            ep.coalesce_pages = params->coalesce_pages;
+            ep.coalesce_window_us = params->coalesce_window_us;
+            ep.layout_threads = params->layout_threads;
+            ep.rec_max_pixels = params->rec_max_pixels;
             mem.engine = make_engine(ep);
             mem.engine->device = mem.device;   // (an engine without weights has nothing else to pin it to its device)
         }
@@ -475,12 +484,12 @@ ocrs_status ocrs_engine_group_member(const ocrs_engine_group* g, size_t i, const
     });
 }
 
-ocrs_status ocrs_group_deal(size_t n_pages, size_t n_members, size_t* member_of_page_out, size_t* pages_per_member) {
+ocrs_status ocrs_group_deal(size_t n_pages, size_t n_members, size_t min_block, size_t* member_of_page_out, size_t* pages_per_member) {
     return guarded([&] {
         if (n_members == 0 || (n_pages && !member_of_page_out)) fail(OCRS_ERR_INVALID_ARGUMENT, "bad argument");
         if (pages_per_member)
             for (size_t m = 0; m < n_members; m++) pages_per_member[m] = 0;
-        const size_t b = block_size(n_pages, n_members, (size_t)option(OPT_GROUP_MIN_BLOCK));
+        const size_t b = block_size(n_pages, n_members, min_block ? min_block : 8);
         for (size_t i = 0; i < n_pages; i++) {
             const size_t m = (i / b) % n_members;
             member_of_page_out[i] = m;

@@ -140,6 +140,8 @@ struct Decoder {
     int restart_interval = 0;
     std::vector<int16_t> coef;   // dense [nblocks][64], natural order
     bool saw_sof = false, adobe = false, jfif = false;
+    int n_scans = 0;                 // scans decoded so far (bounded: every scan re-walks every block it names)
+    bool seq_done[3] = {false, false, false};   // sequential streams: components a scan has already decoded
     int adobe_transform = -1;
 
     size_t block_index(const Component& k, int by, int bx) const { return k.first_block + (size_t)by * k.blocks_w + bx; }
@@ -155,6 +157,10 @@ struct Decoder {
         c.progressive = marker == 0xC2;
         if (c.width <= 0 || c.height <= 0) bad("empty image");
         if (c.ncomp != 1 && c.ncomp != 3) bad("only 1- and 3-component images are supported");
+        // Budget BEFORE any allocation: a 200-byte file may claim 65535 x 65535.  512 MiB of decoded samples is the default
+        // allocation limit of the `image` crate the reference decodes with (ocrs-cli/src/main.rs:312-323).
+        if ((uint64_t)c.width * (uint64_t)c.height * (uint64_t)c.ncomp > (uint64_t(512) << 20))
+            bad("image too large (more than 512 MiB of decoded samples)");
         if (len < 6 + 3 * (size_t)c.ncomp) bad("short SOF");
         for (int i = 0; i < c.ncomp; i++) {
             Component& k = c.comp[i];
@@ -189,7 +195,7 @@ struct Decoder {
         c.mask.assign(first, 0);
         c.offset.assign(first + 1, 0);
         c.values.clear();
-        c.values.reserve(first * 12);
+        c.values.reserve(std::min<size_t>(first * 12, (size_t)1 << 24));   // (grows with what the stream really holds)
         saw_sof = true;
     }
 
@@ -230,6 +236,7 @@ struct Decoder {
     const uint8_t* scan(const uint8_t* s, size_t len, const uint8_t* data, const uint8_t* end) {
         if (!saw_sof) bad("SOS before SOF");
         if (len < 1) bad("short SOS");
+        if (++n_scans > 500) bad("too many scans");   // (libjpeg-turbo's scan limit for untrusted input; real progressive files have ~10)
         const int ns = s[0];
         if (ns < 1 || ns > c.ncomp || len < 1 + 2 * (size_t)ns + 3) bad("bad SOS");
         int ci[3], td[3], ta[3];
@@ -253,6 +260,10 @@ struct Decoder {
             if (Ah != 0 && Ah != Al + 1) bad("bad successive approximation");
         } else {
             Ss = 0; Se = 63; Ah = 0; Al = 0;
+            for (int i = 0; i < ns; i++) {   // a sequential scan decodes its blocks once and for all: a second one would append to `values`
+                if (seq_done[ci[i]]) bad("a component is coded by two scans");
+                seq_done[ci[i]] = true;
+            }
         }
         for (int i = 0; i < ns; i++) {
             if ((Ss == 0 && Ah == 0) && !dc[td[i]].present) bad("missing DC Huffman table");
@@ -306,7 +317,7 @@ struct Decoder {
     void sequential_block(Bits& br, size_t blk, const Huff& hd, const Huff& ha, int& pred) {
         int s = br.decode(hd);
         if (s) { if (s > 15) s = 15; const int r = (int)br.get(s); s = extend(r, s); }
-        pred += s;
+        pred = (int16_t)(pred + s);   // (wraps like the 16-bit coefficient it becomes: no signed overflow on corrupt streams)
         uint64_t m = 0;
         c.offset[blk] = (uint32_t)c.values.size();
         if ((int16_t)pred != 0) { m |= 1; c.values.push_back((int16_t)pred); }
@@ -337,8 +348,8 @@ struct Decoder {
     static void dc_first(Bits& br, int16_t* b, const Huff& hd, int& pred, int Al) {
         int s = br.decode(hd);
         if (s) { if (s > 15) s = 15; const int r = (int)br.get(s); s = extend(r, s); }
-        pred += s;
-        b[0] = (int16_t)(pred * (1 << Al));
+        pred = (int16_t)(pred + s);
+        b[0] = (int16_t)((unsigned)pred << Al);
     }
     static void dc_refine(Bits& br, int16_t* b, int Al) {
         if (br.get(1)) b[0] = (int16_t)(b[0] | (1 << Al));

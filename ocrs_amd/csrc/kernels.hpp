@@ -242,22 +242,6 @@ void crop_lines(const float* const* d_pages, const int32_t* d_page_hw /*[pages][
 // kernels_peaks.hip
 void measure_peaks(double* mfma_tflops, double* copy_gbps);
 
-// kernels_tail.hip — the deep levels of the detection U-Net (every operator below ~50 x 38 pixels) as ONE persistent launch
-enum { TAIL_POOL = 0, TAIL_DW = 1, TAIL_PW = 2, TAIL_CONVT = 3 };
-struct TailPhase {       // one operator; tensors are [n][h][w][c] fp32, every page of the request in one buffer
-    int type;
-    int h, w;            // output grid (PW / CONVT: the INPUT grid — ConvT writes [2h][2w])
-    int cin, cout;       // DW over a concatenation: cin = channels of `src` (the skip), cout = all channels
-    int relu;
-    int h2, w2, c2;      // POOL: the input grid; DW with src2: grid and channels of the (centre-padded) second source
-    int pad_;
-    const float *src, *src2, *wt, *bias;
-    float* dst;
-};
-constexpr int kTailMaxPhases = 40;
-struct TailArgs { TailPhase ph[kTailMaxPhases]; };   // passed by value: 3.2 KB of kernel arguments, no upload
-// d_bar: n_pages words, zeroed by the caller on the same stream
-void det_tail(const TailArgs& phases, int n_phases, int n_pages, uint32_t* d_bar, hipStream_t s);
 
 // kernels_jpeg.hip — the GPU half of the JPEG hand-off (jpeg.hpp)
 size_t jpeg_sample_bytes(const jpeg::Coefficients& c);

@@ -724,13 +724,13 @@ bool double_conv_fused(const DoubleConvArgs& a, int cs, int cx, int cmid, int co
     // option "det_rows" (default 1): the row-streaming workgroup kernels of kernels_det_rows.hip where the shape has one and
     // the request is one they take (up to 8 pages under option value 1); then option "det_stream" (default 1): the wave
     // kernels of kernels_det_stream.hip; then the LDS-tiled blocks below
-    if (option(OPT_DET_ROWS) >= 1 && fuse_level >= 1 && (!launch || a.rtape) && double_conv_rows_takes(a, cx) &&
+    if (option(OPT_DET_ROWS) >= 1 && fuse_level >= 1 && ((!launch && a.n == 0) || a.rtape) && double_conv_rows_takes(a, cx) &&
         double_conv_rows(a, cs, cx, cmid, cout, pool, final_conv, launch, s)) {
         if (on_mfma) *on_mfma = true;
         if (path) *path = 2;
         return true;
     }
-    if (option(OPT_DET_STREAM) >= 1 && fuse_level >= 1 && (!launch || a.tape) && double_conv_stream(a, cs, cx, cmid, cout, pool, final_conv, launch, s)) {
+    if (option(OPT_DET_STREAM) >= 1 && fuse_level >= 1 && ((!launch && a.n == 0) || a.tape) && double_conv_stream(a, cs, cx, cmid, cout, pool, final_conv, launch, s)) {
         if (on_mfma) *on_mfma = false;
         if (path) *path = 1;
         return true;

@@ -436,8 +436,11 @@ bool double_conv_rows(const DoubleConvArgs& a, int cs, int cx, int cmid, int cou
         const int64_t cap = (int64_t)occ * (launch ? ctx().cu_count() : 256);
         return groups(8) <= cap ? 8 : groups(14) <= cap ? 14 : groups(20) <= cap ? 20 : 32;
     };
-    if (launch && !double_conv_rows_takes(a, cx)) return false;
-    if (launch && ((int64_t)a.h * a.w * cs * 4 >= kOobOffset || (int64_t)a.h1 * a.w1 * cx * 4 >= kOobOffset)) return false;
+    // the request-dependent conditions also apply to a query made with the request's arguments (a.n > 0): the caller may
+    // have no other fused kernel for the shape and must know before it commits to the fused path
+    const bool real = launch || a.n > 0;
+    if (real && !double_conv_rows_takes(a, cx)) return false;
+    if (real && ((int64_t)a.h * a.w * cs * 4 >= kOobOffset || (int64_t)a.h1 * a.w1 * cx * 4 >= kOobOffset)) return false;
 #define OCRS_RW(CS, CX, CM, CO, P, OCC)                                                           \
     if (cs == CS && cx == CX && cmid == CM && cout == CO && pool == P) {                            \
         typedef RwCfg<CS, CX, CM, CO, P, 32> Cfg;                                                  \

@@ -394,7 +394,7 @@ static void launch_gemm_tiled(const GemmDesc& d, hipStream_t s) {
     const bool pair = !d.im2col && (d.K % (2 * TG_BK)) == 0 && (d.ldb & 3) == 0 && (((uintptr_t)d.B) & 15) == 0 &&
                       (d.strideB & 3) == 0 && (d.N & 3) == 0 && d.N >= 4;
     if (d.im2col) hipLaunchKernelGGL((gemm_tiled_kernel<BN, true, false>), grid, dim3(256), lds, s, d);
-    else if (pair && grid.y > 1 && option(OPT_GEMM_NFAST)) {
+    else if (pair && grid.y > 1) {   // column tiles of a row tile side by side on one XCD
         GemmDesc e = d;
         e.nfast = 1; e.nx = (int)grid.x; e.ny = (int)grid.y;
         const dim3 g1((unsigned)((grid.x + 7) / 8 * 8 * grid.y), 1, grid.z);

@@ -740,13 +740,7 @@ bool conv3x3_ragged(const float* x, const RaggedView& rv, int cin, const float* 
     const int ntiles = flat ? (pw == 2 ? rv.ntiles2d_flat2 : rv.ntiles2d_flat) : rv.ntiles2d;
     if (ntiles <= 0) return true;
     const bool n64 = cout <= 64;
-    size_t lds = (size_t)(2 * RG_BK * RG_LDA + 2 * RG_BK * (n64 ? 64 : 128)) * sizeof(float);
-    // Four of these blocks fill every SIMD's register file (4 waves x 128 VGPRs) for ~0.5 ms at a time: a small
-    // kernel of another request — and a request's detection stage is a chain of ~50 of them — then waits for a block
-    // to retire before EVERY launch (measured: detect_words 0.8 ms alone, 14 ms beside the conv stacks of other
-    // requests).  Option "conv_occupancy" = 3 pads the LDS request so that three blocks fit per CU: a quarter of
-    // each SIMD's registers stays free for whatever else is queued, at 3-4 % of this kernel's own rate.
-    if (option(OPT_CONV_OCCUPANCY) == 3) lds = std::max<size_t>(lds, 53 * 1024);
+    const size_t lds = (size_t)(2 * RG_BK * RG_LDA + 2 * RG_BK * (n64 ? 64 : 128)) * sizeof(float);
     const dim3 grid(ntiles, (cout + (n64 ? 63 : 127)) / (n64 ? 64 : 128));
 #define OCRS_LAUNCH_CONV(BN_, TW_, PH_, PW_)                                                                            \
     do {                                                                                                                \

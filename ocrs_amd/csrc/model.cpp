@@ -383,35 +383,6 @@ float* HipModel::run_device(Workspace& ws, const float* d_in, int n, int h, int 
 
     std::vector<char> covered(ops.size(), 0);   // ops already done by a fused DoubleConv launch
     const int det_fuse = option(OPT_DET_FUSE);
-    const int det_tail = option(OPT_DET_TAIL);
-    // operators the one-launch tail (kernels_tail.hip) takes: pool 2x2, depthwise 3x3 (also over a concatenation read in
-    // place), pointwise 1x1, ConvTranspose 2x2/s2, channel counts in fours, at most kTailMaxPx output pixels per page, and not
-    // part of a fused DoubleConv block
-    constexpr int64_t kTailMaxPx = 2048;
-    std::vector<char> in_block(ops.size(), 0);
-    if (det_fuse)
-        for (const DcBlock& b : dc_blocks)
-            for (int q = b.first; q >= 0 && q <= b.last && q < (int)ops.size(); q++) in_block[q] = 1;
-    auto tail_ok = [&](size_t j) -> bool {
-        if (j >= n_run || covered[j] || in_block[j]) return false;
-        const GraphOp& q = ops[j];
-        if (q.fused_into_prev || q.fuse_next_pw || q.done_by_prev) return false;
-        const TensorShape qi = shp[q.in0], qo = shp[q.out];
-        if (qi.seq || qo.seq || (int64_t)qo.h * qo.w > kTailMaxPx || (int64_t)qi.h * qi.w > 4 * kTailMaxPx + 4096) return false;
-        switch (q.type) {
-            case OP_MAXPOOL: return q.kh == 2 && q.kw == 2 && (qi.c % 4) == 0 && qo.h == qi.h / 2 && qo.w == qi.w / 2;
-            case OP_DWCONV3:
-                if (q.reads_cat && j > 0 && cat_fused(j - 1)) {
-                    const TensorShape sk = shp[ops[j - 1].in0], up = shp[ops[j - 1].in1];
-                    return (sk.c % 4) == 0 && (up.c % 4) == 0 && up.h <= sk.h && up.w <= sk.w;
-                }
-                return (qi.c % 4) == 0;
-            case OP_PADCAT: return cat_fused(j);
-            case OP_CONV: return q.kh == 1 && q.kw == 1 && (q.cin % 4) == 0 && (q.cout % 4) == 0;
-            case OP_CONVT2: return (q.cin % 4) == 0 && (q.cout % 4) == 0 && q.aux0 && q.aux1;
-            default: return false;
-        }
-    };
     for (size_t i = 0; i < n_run; i++) {
         const GraphOp& op = ops[i];
         const TensorShape a = shp[op.in0];
@@ -422,7 +393,6 @@ float* HipModel::run_device(Workspace& ws, const float* d_in, int n, int h, int 
         else if (op.type == OP_LINEAR || op.type == OP_LOGSOFTMAX) enter_stage(seen_seq ? ST_REC_HEAD : ST_REC_CONV);
         else enter_stage(seen_seq ? ST_REC_GRU : ST_REC_CONV);
         if (op.type == OP_TOSEQ) seen_seq = true;
-        if (covered[i] == 2) continue;   // part of a one-launch tail run: its buffers were handled there
         if (covered[i]) {
             for (int sl = 1; sl < (int)n_slots; sl++)   // any slot whose last reader this op was (incl. a skipped PADCAT's inputs)
                 if (last_use[sl] == (int)i && ptr[sl] && cap[sl]) {
@@ -433,80 +403,9 @@ float* HipModel::run_device(Workspace& ws, const float* d_in, int n, int h, int 
             if (print_timing) OCRS_HIP(hipEventRecord(ev[i + 1], st));
             continue;
         }
-        // ---- the deep levels of a detection U-Net as ONE launch (kernels_tail.hip): a maximal run of small operators
-        if (kind == 0 && det_tail && !print_timing) {
-            size_t j_end = i;
-            while (tail_ok(j_end)) j_end++;
-            while (j_end > i && ops[j_end - 1].type == OP_PADCAT) j_end--;   // a concatenation needs its consumer in the run
-            size_t n_real = 0;
-            for (size_t j = i; j < j_end; j++) n_real += ops[j].type != OP_PADCAT;
-            if (n_real >= 6 && n_real <= (size_t)k::kTailMaxPhases) {
-                k::TailArgs ta{};
-                int np = 0;
-                double fl = 0, by = 0;
-                std::vector<std::pair<size_t, float*>> release_later;   // nothing freed inside the run is handed out again inside it:
-                                                                        // pages advance through the phases independently
-                const int pages = shp[ops[i].in0].n;
-                for (size_t j = i; j < j_end; j++) {
-                    const GraphOp& q = ops[j];
-                    const TensorShape qi = shp[q.in0], qo = shp[q.out];
-                    if (q.type != OP_PADCAT) {
-                        auto r = get((size_t)qo.count());
-                        ptr[q.out] = r.first;
-                        cap[q.out] = r.second;
-                        k::TailPhase& ph = ta.ph[np++];
-                        ph.dst = r.first;
-                        ph.src = ptr[q.in0];
-                        ph.relu = q.relu;
-                        switch (q.type) {
-                            case OP_MAXPOOL:
-                                ph.type = k::TAIL_POOL; ph.h = qo.h; ph.w = qo.w; ph.cout = qo.c; ph.cin = qo.c; ph.h2 = qi.h; ph.w2 = qi.w; ph.relu = 0;
-                                by += 4.0 * (qi.count() + qo.count());
-                                break;
-                            case OP_DWCONV3:
-                                ph.type = k::TAIL_DW; ph.h = qo.h; ph.w = qo.w; ph.cout = qo.c; ph.cin = qo.c; ph.wt = q.w[0]; ph.bias = q.w[1];
-                                if (q.reads_cat && j > 0 && cat_fused(j - 1)) {
-                                    const GraphOp& cat = ops[j - 1];
-                                    const TensorShape sk = shp[cat.in0], up = shp[cat.in1];
-                                    ph.src = ptr[cat.in0]; ph.cin = sk.c;
-                                    ph.src2 = ptr[cat.in1]; ph.h2 = up.h; ph.w2 = up.w; ph.c2 = up.c;
-                                }
-                                fl += 18.0 * qo.count(); by += 8.0 * qo.count();
-                                break;
-                            case OP_CONV:
-                                ph.type = k::TAIL_PW; ph.h = qi.h; ph.w = qi.w; ph.cin = q.cin; ph.cout = q.cout; ph.wt = q.w[0]; ph.bias = q.w[1];
-                                fl += 2.0 * (double)qi.n * qi.h * qi.w * q.cin * q.cout; by += 4.0 * (qi.count() + qo.count()) + wbytes(q, 0);
-                                break;
-                            case OP_CONVT2:
-                                ph.type = k::TAIL_CONVT; ph.h = qi.h; ph.w = qi.w; ph.cin = q.cin; ph.cout = q.cout; ph.wt = q.aux0; ph.bias = q.aux1; ph.relu = 0;
-                                fl += 2.0 * (double)qi.n * qi.h * qi.w * q.cin * q.cout * 4; by += 4.0 * (qi.count() + qo.count()) + wbytes(q, 0);
-                                break;
-                            default: break;
-                        }
-                        if (!ph.src || !ph.dst) fail(OCRS_ERR_RUN_FAILED, "model run failed: internal (tail run reads an unset slot)");
-                    }
-                    std::vector<int> dying = {q.in0, q.in1};
-                    if (q.type == OP_DWCONV3 && q.reads_cat && j > 0 && cat_fused(j - 1)) { dying.push_back(ops[j - 1].in0); dying.push_back(ops[j - 1].in1); }
-                    for (int sl : dying)
-                        if (sl > 0 && last_use[sl] == (int)j && ptr[sl] && cap[sl]) {
-                            release_later.emplace_back(cap[sl], ptr[sl]);
-                            ptr[sl] = nullptr;
-                            cap[sl] = 0;
-                        }
-                    if (j > i) covered[j] = 2;   // (2: bookkeeping already done here)
-                }
-                uint32_t* d_bar = ws.alloc_n<uint32_t>((size_t)pages);
-                OCRS_HIP(hipMemsetAsync(d_bar, 0, (size_t)pages * sizeof(uint32_t), st));
-                timed(KC_DET_BLOCK, fl, by, [&] { k::det_tail(ta, np, pages, d_bar, st); }, 0.0);
-                for (auto& r : release_later) free_local.emplace(r.first, r.second);
-                i = j_end - 1;
-                continue;
-            }
-        }
         if (det_fuse && op.dc_block >= 0) {
             const DcBlock& b = dc_blocks[op.dc_block];
-            bool ok = (size_t)b.last < n_run &&
-                      k::double_conv_fused(k::DoubleConvArgs{}, b.cs, b.cx, b.cmid, b.cout, b.pool >= 0, b.fin >= 0, det_fuse, false, nullptr);
+            bool ok = (size_t)b.last < n_run;
             for (int q = b.first; ok && q < b.last; q++)   // no intermediate may be what this run returns
                 if ((uint32_t)ops[q].out == ret_slot && q != b.pw2) ok = false;
             if (ok && b.fin >= 0 && (uint32_t)ops[b.pw2].out == ret_slot) ok = false;
@@ -530,6 +429,13 @@ float* HipModel::run_device(Workspace& ws, const float* d_in, int n, int h, int 
                 da.wd2 = d2.w[0]; da.bd2 = d2.w[1]; da.wp2 = p2.w[0]; da.bp2 = p2.w[1];
                 da.relu_d1 = d1.relu; da.relu_p1 = p1.relu; da.relu_d2 = d2.relu; da.relu_p2 = p2.relu;
                 da.tape = b.tape; da.tape_len = b.tape_len; da.rtape = b.rtape; da.rtape_len = b.rtape_len;
+                // Is there a fused kernel for THIS request (its page count and sizes, not just the block's channel counts)?  A
+                // query with the real arguments: the row-streaming kernels decline some requests (more than 8 pages, an odd pad
+                // offset) and two block shapes have no other fused kernel when option det_mfma is 0 — those fall through to the
+                // per-operator kernels below.
+                bool on_mfma = false;
+                int path = 0;   // which kernel family will take it (nothing is launched by the query)
+                if (ok) ok = k::double_conv_fused(da, b.cs, b.cx, b.cmid, b.cout, b.pool >= 0, b.fin >= 0, det_fuse, false, nullptr, &on_mfma, &path);
                 const double px = (double)sk.n * sk.h * sk.w;
                 double out_floats = 0;
                 if (ok) {
@@ -557,12 +463,11 @@ float* HipModel::run_device(Workspace& ws, const float* d_in, int n, int h, int 
                     // of which dense contractions (pointwise convs, ConvTranspose) — on the matrix cores if the block's MFMA variant runs
                     const double fl_dense = 2.0 * px * ((double)cin * b.cmid + (double)b.cmid * b.cout) +
                                             2.0 * px * (b.convt >= 0 ? (double)b.cx * b.cs : 0.0);
-                    bool on_mfma = false;
-                    int path = 0;   // which kernel family will take it (a query: nothing is launched)
-                    k::double_conv_fused(da, b.cs, b.cx, b.cmid, b.cout, b.pool >= 0, b.fin >= 0, det_fuse, false, nullptr, &on_mfma, &path);
+                    bool launched = false;
                     timed(path == 1 ? KC_DET_STREAM_WAVE : path == 2 ? KC_DET_STREAM_ROWS : KC_DET_BLOCK, fl, 4.0 * (px * b.cs + px1 * b.cx + out_floats), [&] {
-                        k::double_conv_fused(da, b.cs, b.cx, b.cmid, b.cout, b.pool >= 0, b.fin >= 0, det_fuse, true, st);
+                        launched = k::double_conv_fused(da, b.cs, b.cx, b.cmid, b.cout, b.pool >= 0, b.fin >= 0, det_fuse, true, st);
                     }, on_mfma ? fl_dense : 0.0);
+                    if (!launched) fail(OCRS_ERR_RUN_FAILED, "model run failed: internal (no fused kernel took the DoubleConv block its query accepted)");
                     for (int q = b.first + 1; q <= b.last; q++) covered[q] = 1;
                     for (int sl = 1; sl < (int)n_slots; sl++)
                         if (last_use[sl] == (int)i && ptr[sl] && cap[sl]) {
@@ -1096,17 +1001,10 @@ int HipModel::run_recognition_packed(Workspace& ws, const std::vector<PackedGrou
     int C0 = 0;
     {
         // all conv stacks of a device go through ONE stream, in request order.  The lock is taken by the hook, i.e. after
-        // the request's geometry has been worked out and its metadata uploads are queued.  With option "gx_heavy" the
-        // hook first waits (on the host) until everything the conv stack reads — crops, metadata — is on the device: a
-        // conv stack whose inputs are late would stall the shared stream for every request behind it, and under a
-        // saturating conv stack of another request small kernels and copies ARE late (they wait for CU slots).
+        // the request's geometry has been worked out and its metadata uploads are queued.
         std::unique_lock<std::mutex> heavy(ctx().heavy_phase, std::defer_lock);
-        const bool wait_inputs = option(OPT_GX_HEAVY) != 0;
         try {
-            X = run_prefix_ragged(ws, heavy_stream(), groups, plan, h, ts, timers, &C0, [&] {
-                if (wait_inputs) ws.stream.sync();
-                heavy.lock();
-            });
+            X = run_prefix_ragged(ws, heavy_stream(), groups, plan, h, ts, timers, &C0, [&] { heavy.lock(); });
         } catch (...) {
             // Kernels of this request may already be queued on the shared stream, reading and writing scratch
             // that ~Workspace hands back to the pool after draining only the request's OWN stream: make that
@@ -1157,34 +1055,15 @@ int HipModel::run_recognition_packed(Workspace& ws, const std::vector<PackedGrou
             float* y = ws.alloc_n<float>((size_t)R * 2 * H);
             const bool fused = (H == 256 || H == 128 || H == 64);
             const bool persistent = fused && gru_mode() == GRU_PERSISTENT && k::gru_persistent_supported(M, plan.Tmax, R, H);
-            const bool gx_on_heavy = option(OPT_GX_HEAVY) && R >= 4096;
-            if (persistent && !gx_on_heavy) OCRS_HIP(k::gru_persistent_prepare(y, R, H, st));  // "unwritten" marks; ahead of the input GEMM
+            if (persistent) OCRS_HIP(k::gru_persistent_prepare(y, R, H, st));  // "unwritten" marks; ahead of the input GEMM
             k::GemmDesc d{};
             d.A = cur; d.lda = I; d.B = op.aux0; d.ldb = 3 * H; d.bias = op.aux1; d.C = gx; d.ldc = 3 * H;
             d.M = (int)R; d.N = 3 * H; d.K = I; d.batch = 2;
             d.strideA = 0; d.strideB = (int64_t)I * 3 * H; d.strideBias = 3 * H; d.strideC = R * 3 * H;
             const double gx_flops = 2.0 * 2 * R * (double)d.N * d.K, gx_bytes = 4.0 * ((double)R * I + 2.0 * R * d.N + 2.0 * d.K * d.N);
-            if (gx_on_heavy) {
-                // The input projections are MFMA-bound like the conv stacks: run them on the device's conv-stack stream,
-                // one after the other with the conv stacks of all requests, instead of beside them.  A projection whose
-                // input is not ready would block that stream for everybody, so the host waits for its input first (layer
-                // 1: the request's own conv stack, already queued there; layer 2: the first layer's recurrence).
-                if (gru_layer > 0) ws.stream.sync();
-                DeviceContext& dc = ctx();
-                std::lock_guard<std::mutex> heavy(dc.heavy_phase);
-                hipStream_t hs = dc.heavy_stream();
-                hipEvent_t ready = ws.make_event(), done = ws.make_event();
-                OCRS_HIP(hipEventRecord(ready, st));
-                OCRS_HIP(hipStreamWaitEvent(hs, ready, 0));
-                if (persistent) OCRS_HIP(k::gru_persistent_prepare(y, R, H, hs));   // (a fill kernel: it too would wait for CU slots elsewhere)
-                int gtok = timers ? timers->kbegin(KC_GEMM_GRU_INPUT, hs, gx_flops, gx_bytes) : -1;
-                k::gemm(d, hs);
-                if (gtok >= 0) timers->end(gtok, hs);
-                OCRS_HIP(hipEventRecord(done, hs));
-                OCRS_HIP(hipStreamWaitEvent(st, done, 0));
-            } else {
-                timed(KC_GEMM_GRU_INPUT, gx_flops, gx_bytes, [&] { k::gemm(d, st); });
-            }
+            // (round 3's option gx_heavy queued these projections on the conv-stack stream: every MFMA class then ran at its
+            // alone speed at the same or slightly lower pages/s — a zero-sum trade, removed in round 5)
+            timed(KC_GEMM_GRU_INPUT, gx_flops, gx_bytes, [&] { k::gemm(d, st); });
             bool ran_persistent = false;
             if (persistent) {
                 // ONE launch for all Tmax steps of both directions (kernels_gru.hip).  Its workgroups wait on

@@ -215,19 +215,18 @@ def test_oversized_recognition_request_is_split_into_sub_requests(engine):
     res = {}
     try:
         for budget in (64 * 1200 * 12, 64 * 50):   # ~12 lines per sub-request; one line per sub-request
-            _lib.set_option("rec_max_pixels", budget)
+            engine.set_option("rec_max_pixels", budget)
             res[budget] = [(str(t), [c.rect for c in t.chars()]) if t else None for t in engine.recognize_text(inp, lines)]
     finally:
-        _lib.set_option("rec_max_pixels", 0)
+        engine.set_option("rec_max_pixels", 0)
     assert sum(1 for t in ref if t) > 60
     for budget, got in res.items():
         assert got == ref, budget
 
 
-@pytest.mark.parametrize("waves,extra", [(4, 512), (16, 2560)])
-def test_more_lines_than_one_grid_holds_second_wave_of_gru_clusters(engine, waves, extra):
-    """More row tiles than the slots of a 256-workgroup grid hold (2 560 lines for the general kernel, 4 608 for the
-    teams kernel): the persistent GRU kernel is launched with 512 workgroups — the second half becomes
+@pytest.mark.parametrize("extra", [512])
+def test_more_lines_than_one_grid_holds_second_wave_of_gru_clusters(engine, extra):
+    """More row tiles than the slots of a 256-workgroup grid hold (2 560 lines): the persistent GRU kernel is launched with 512 workgroups — the second half becomes
     resident as workgroups of the first exit (clusters never depend on each other).  Chars and boxes must equal the
     per-step kernel's, and the first 2 048 lines (same crops, lines are independent) the golden request's."""
     g = np.load(os.path.join(GOLD, "bench_crops_2048.npz"))
@@ -238,13 +237,11 @@ def test_more_lines_than_one_grid_holds_second_wave_of_gru_clusters(engine, wave
     loffs = np.arange(m + 1, dtype=np.uintp)
     res = {}
     try:
-        _lib.set_option("gru_waves", waves)
         for mode in (0, 1):
-            _lib.set_option("gru_mode", mode)
+            engine.set_option("gru_mode", mode)
             res[mode] = engine.recognize_text_batch_raw([inp], rects2, loffs, np.array([0, m], dtype=np.uintp))
     finally:
-        _lib.set_option("gru_mode", 0)
-        _lib.set_option("gru_waves", 4)
+        engine.set_option("gru_mode", 0)
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
     chars, coffs = res[0]
     coffs = np.asarray(coffs, np.int64)
@@ -266,41 +263,27 @@ def test_gru_modes_give_identical_bits(engine):
     rng = np.random.default_rng(0)
     short = [l[: max(1, int(rng.integers(1, len(l) + 1)))] for l in lines[:40]]   # ragged: prefixes of lines
     req = lines + short
-    req2 = lines + short + lines[:70]      # 9-16 row tiles: the packed gate-per-wave kernel's range (mode 7)
+    req2 = lines + short + lines[:70]      # 9-16 row tiles: just beyond the gate-per-wave kernel's range
     cinp, crects, n = _crops_request(engine)
     cl = np.arange(n + 1, dtype=np.uintp)
     res = {}
     try:
-        # mode 0 = persistent kernel, 1 = per-step launches; 2, 3 = persistent with the hand-off forced to
-        # write-through stores (gru_local 0) and with clusters spread over all XCDs (gru_scatter 1: the in-kernel
-        # placement census must then choose write-through by itself)
-        # 4 = without the gate-per-wave kernel (gru_gates 0): the one-page request then runs on the general kernel;
-        # 5, 6 = the gate-per-wave kernel with forced write-through / scattered clusters
-        # 7 = gate-per-wave kernel packed two workgroups per CU (gru_gates_pack 2): applies to requests of 9-16 row tiles
-        # 8 = the background (lean, multi-tile gate-per-wave) kernel for requests beyond one tile per cluster; 9 = the same
-        #     with forced write-through hand-offs
-        # 10, 11 = round 4's teams kernel (gru_waves 16: four gate-per-wave teams per workgroup, state through LDS) for every
-        # request beyond the gate-per-wave kernel's size / everywhere, the latter with scattered clusters
-        for mode in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11):
-            _lib.set_option("gru_waves", 16 if mode in (10, 11) else 4)
-            _lib.set_option("gru_gates_pack", 2 if mode == 7 else 1)
-            _lib.set_option("gru_background", 1 if mode in (8, 9) else 0)
-            _lib.set_option("gru_mode", 1 if mode == 1 else 0)
-            _lib.set_option("gru_local", 0 if mode in (2, 5, 9) else 1)
-            _lib.set_option("gru_scatter", 1 if mode in (3, 6, 11) else 0)
-            _lib.set_option("gru_gates", 0 if mode in (2, 3, 4, 11) else 1)
+        # mode 0 = persistent kernels (general + gate-per-wave for the one-page requests), 1 = per-step launches,
+        # 2 = general kernel only (gru_gates 0) with the hand-off forced to write-through stores (gru_local 0),
+        # 3 = general kernel only, hand-offs through the XCD's L2 where the placement census allows,
+        # 4 = gate-per-wave kernel with forced write-through hand-offs
+        for mode in (0, 1, 2, 3, 4):
+            engine.set_option("gru_mode", 1 if mode == 1 else 0)
+            engine.set_option("gru_local", 0 if mode in (2, 4) else 1)
+            engine.set_option("gru_gates", 0 if mode in (2, 3) else 1)
             a = engine.recognize_text(inp, req) + engine.recognize_text(inp, req2)
             b = engine.recognize_text_batch_raw([cinp], crects, cl, np.array([0, n], dtype=np.uintp))
             res[mode] = ([(str(t), [c.rect for c in t.chars()]) if t else None for t in a], b)
     finally:
-        _lib.set_option("gru_mode", 0)
-        _lib.set_option("gru_local", 1)
-        _lib.set_option("gru_scatter", 0)
-        _lib.set_option("gru_gates", 1)
-        _lib.set_option("gru_gates_pack", 1)
-        _lib.set_option("gru_background", 0)
-        _lib.set_option("gru_waves", 4)
-    for mode in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11):
+        engine.set_option("gru_mode", 0)
+        engine.set_option("gru_local", 1)
+        engine.set_option("gru_gates", 1)
+    for mode in (1, 2, 3, 4):
         assert res[0][0] == res[mode][0], mode
         assert np.array_equal(res[0][1][0], res[mode][1][0]) and np.array_equal(res[0][1][1], res[mode][1][1]), mode
     assert sum(1 for t in res[0][0] if t) > 80
@@ -338,3 +321,29 @@ def test_fused_double_conv_blocks_equal_unfused_and_oracle(in_hw, depths):
         assert np.array_equal(o, ref), key
     if in_hw[0] <= 256:
         assert np.array_equal(got, OracleGraph(dbuf).run_exact(x))
+
+
+@pytest.mark.parametrize("n", [9, 16])
+def test_blocks_without_a_fused_kernel_for_the_request_fall_back_to_the_per_operator_kernels(n):
+    """det_mfma = 0 with det_fuse = 1: the (32, 32, 32, 32) and (32, 64, 32, 32) decoder blocks then have ONE fused kernel, the
+    row-streaming one, and it declines requests of more than 8 pages.  The executor's query must be made with the request's
+    arguments so that those blocks run on the per-operator kernels (round 4 queried with empty arguments, marked the
+    operators as done and launched nothing: garbage, silently).  Same bits as det_fuse = 0 and as the defaults."""
+    dbuf = M.detection_model_bytes((232, 184), (8, 16, 32, 32, 64))
+    model = Model.load_bytes(dbuf)
+    rng = np.random.default_rng(n)
+    x = (rng.random((n, 1, 232, 184), dtype=np.float32) - np.float32(0.5))
+    try:
+        ref = model.run(x)                       # defaults
+        _lib.set_option("det_fuse", 0)
+        unfused = model.run(x)
+        _lib.set_option("det_fuse", 1)
+        _lib.set_option("det_mfma", 0)
+        got = model.run(x)
+        _lib.set_option("det_rows", 32)          # and with the row kernels forced on for every request size
+        forced = model.run(x)
+    finally:
+        _lib.set_option("det_fuse", 1)
+        _lib.set_option("det_mfma", 1)
+        _lib.set_option("det_rows", 1)
+    assert np.array_equal(unfused, ref) and np.array_equal(got, ref) and np.array_equal(forced, ref)

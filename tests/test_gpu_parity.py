@@ -691,16 +691,16 @@ def test_beam_search_gpu_and_host_paths_of_the_engine_agree():
     res = {}
     try:
         for mode in (1, 0):
-            _lib.set_option("beam_gpu", mode)
+            eng.set_option("beam_gpu", mode)
             got = eng.recognize_text(inp, lines)
             res[mode] = [(str(t), [c.rect for c in t.chars()]) if t else None for t in got]
         # and with the request split into sub-requests of ~2 lines by the engine (beam search on the GPU)
-        _lib.set_option("beam_gpu", 1)
-        _lib.set_option("rec_max_pixels", 64 * 700 * 2)
+        eng.set_option("beam_gpu", 1)
+        eng.set_option("rec_max_pixels", 64 * 700 * 2)
         res["split"] = [(str(t), [c.rect for c in t.chars()]) if t else None for t in eng.recognize_text(inp, lines)]
     finally:
-        _lib.set_option("beam_gpu", 1)
-        _lib.set_option("rec_max_pixels", 0)
+        eng.set_option("beam_gpu", 1)
+        eng.set_option("rec_max_pixels", 0)
     assert res[1] == res[0]
     assert res["split"] == res[1]
     assert sum(1 for t in res[1] if t) >= 5

@@ -64,12 +64,11 @@ def _check_all_golden(out, digests, n=N_PAGES):
 # ------------------------------------------------------------------ engine group
 def test_group_of_two_members_on_one_device_gives_golden_bits(bufs, pages16):
     """devices [0, 0]: two engines (two weight replicas, two host threads per call) on the one GPU of the box; with
-    group_shared_block = 1 the pages of a call are split between them in two contiguous blocks.  The per-request gather
+    ocrs_group_params.shared_block = 1 the pages of a call are split between them in two contiguous blocks.  The per-request gather
     is the host transport (AUTO inside one process)."""
     dbuf, rbuf, digests = bufs
-    _lib.set_option("group_shared_block", 1)
-    try:
-        group = EngineGroup([0, 0], dbuf, rbuf, gather="auto")
+    if True:
+        group = EngineGroup([0, 0], dbuf, rbuf, gather="auto", shared_block=1)
         assert len(group) == 2 and group.member(1)[1] == 0
         out = _group_pipeline(group, pages16)
         _check_all_golden(out, digests)
@@ -87,8 +86,6 @@ def test_group_of_two_members_on_one_device_gives_golden_bits(bufs, pages16):
         # uneven dealing: 5 pages -> 3 + 2
         out5 = _group_pipeline(group, pages16[:5])
         _check_all_golden(out5, digests, n=5)
-    finally:
-        _lib.set_option("group_shared_block", 16)
 
 
 def test_group_rccl_gather_one_member(bufs, pages16):
@@ -160,12 +157,12 @@ def test_concurrent_one_page_calls_are_merged_and_keep_their_bits(bufs, pages16)
         batches, reqs = s1[stage][0] - s0[stage][0], s1[stage][1] - s0[stage][1]
         assert reqs == 48 and batches < reqs, (stage, batches, reqs)
     try:
-        _lib.set_option("coalesce", 0)
+        engine.set_option("coalesce", 0)
         with ThreadPoolExecutor(max_workers=6) as ex:
             outs = list(ex.map(lambda k: (k % 4, _one_page(engine, pages[k % 4])), range(12)))
         assert engine.coalesce_stats() == s1   # nothing went through the queues
     finally:
-        _lib.set_option("coalesce", 2)
+        engine.set_option("coalesce", 2)
     for pi, (w, t) in outs:
         assert np.array_equal(w, ref[pi][0]) and t == ref[pi][1]
 
@@ -190,12 +187,12 @@ def test_an_error_in_a_merged_batch_reaches_only_its_caller(bufs, pages16):
         return "raised"
 
     try:
-        _lib.set_option("coalesce_window_us", 20000)   # make sure the calls meet in one batch
+        engine.set_option("coalesce_window_us", 20000)   # make sure the calls meet in one batch
         with ThreadPoolExecutor(max_workers=8) as ex:
             futs = [ex.submit(bad if k % 4 == 1 else good, k) for k in range(16)]
             res = [f.result() for f in futs]
     finally:
-        _lib.set_option("coalesce_window_us", 300)
+        engine.set_option("coalesce_window_us", 300)
     assert res.count("raised") == 4
     assert all(r == ref for r in res if r != "raised")
 
@@ -358,7 +355,7 @@ def test_recurrence_paths_by_hidden_size_and_mode(hidden):
     assert sum(1 for t in exp if t is not None) >= 5
 
     def run(mode):
-        _lib.set_option("gru_mode", mode)
+        gpu.set_option("gru_mode", mode)
         gpu.enable_timing(2)
         gpu.kernel_stats(reset=True)
         got = gpu.recognize_text(inp, [rects_of(l) for l in lines])
@@ -374,7 +371,7 @@ def test_recurrence_paths_by_hidden_size_and_mode(hidden):
         hid0, gates0 = run(0)
         hid1, gates1 = run(1)
     finally:
-        _lib.set_option("gru_mode", 0)
+        gpu.set_option("gru_mode", 0)
     if hidden == 32:
         assert gates0 > 0 and gates0 == hid0 and (hid1, gates1) == (hid0, gates0)   # two launches per step either way
     else:
@@ -403,13 +400,13 @@ def test_narrow_lines_sharing_conv_patches():
     try:
         # conv12_fuse: conv1 + pool + conv2 + pool as one kernel (its patches leave an empty column between images)
         for flat, fuse12 in ((1, 1), (0, 1), (1, 0), (0, 0)):
-            _lib.set_option("conv_flat", flat)
-            _lib.set_option("conv12_fuse", fuse12)
+            gpu.set_option("conv_flat", flat)
+            gpu.set_option("conv12_fuse", fuse12)
             got = gpu.recognize_text(inp, [rects_of(l) for l in lines])
             for a, b in zip(got, exp):
                 assert (a is None) == (b is None)
                 if a is not None:
                     assert str(a) == str(b) and [c.rect for c in a.chars()] == [c.rect.tlbr() for c in b.chars]
     finally:
-        _lib.set_option("conv_flat", 1)
-        _lib.set_option("conv12_fuse", 1)
+        gpu.set_option("conv_flat", 1)
+        gpu.set_option("conv12_fuse", 1)

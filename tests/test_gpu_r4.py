@@ -39,9 +39,8 @@ def test_group_rccl_gather_with_several_members_through_the_librccl_double(bufs,
     of pages 0-15 come back, raw gathers are byte-exact (incl. empty and unequal payloads), three calls in flight."""
     dbuf, rbuf, digests = bufs
     before = rccl_stub()
-    _lib.set_option("group_shared_block", 16 // members)
-    try:
-        group = EngineGroup([0] * members, dbuf, rbuf, gather="rccl")
+    if True:
+        group = EngineGroup([0] * members, dbuf, rbuf, gather="rccl", shared_block=16 // members)
         out = _group_pipeline(group, pages16)
         _check_all_golden(out, digests)
         lg = group.last_gather()
@@ -61,8 +60,6 @@ def test_group_rccl_gather_with_several_members_through_the_librccl_double(bufs,
         # uneven shares: 5 pages
         out5 = _group_pipeline(group, pages16[:5])
         _check_all_golden(out5, digests, n=5)
-    finally:
-        _lib.set_option("group_shared_block", 16)
     after = rccl_stub()
     assert after["inits"] == before["inits"] + 1 and after["max_ranks"] >= members
     assert after["gathers"] - before["gathers"] >= members * (2 * 5 + 4)     # G all-gathers per gather, 2 gathers per pipeline
@@ -202,40 +199,6 @@ def test_mixed_load_soak_20_seconds():
     assert r.returncode == 0 and "errors: none" in r.stdout, (r.stdout + r.stderr)[-3000:]
 
 
-# ------------------------------------------------------------------ the detection U-Net's deep levels in one launch
-@pytest.mark.parametrize("in_hw,depths", [((800, 600), (8, 16, 32, 32, 64, 128, 256)), ((320, 256), (8, 16, 32, 64, 128)),
-                                          ((160, 128), (8, 16, 32, 32))])
-def test_one_launch_detection_tail_equals_the_per_operator_kernels_and_the_oracle(in_hw, depths):
-    """option det_tail = 1: pools, depthwise / pointwise convs, ConvTransposes and in-place concatenations of the levels below
-    2 048 pixels per page run as ONE persistent launch (kernels_tail.hip; an experiment, off by default).  Same
-    probability-map bits as one launch per operator, for 1, 3 and 9 pages per request (9 = two page groups), and equal
-    to the oracle's exact chain."""
-    import models_util as M
-    from oracle import pipeline as OP
-    from oracle.nn import OracleGraph, OracleModel
-    from ocrs_amd import synth
-    dbuf = M.detection_model_bytes(in_hw, depths)
-    eng = OcrEngine(detection_model=Model.load_bytes(dbuf))
-    pages = [synth.synthetic_page(40 + s, 317, 409, lines=10, columns=1) for s in range(9)]
-    inputs = [eng.prepare_input(ImageSource.from_tensor(p, DimOrder.Hwc)) for p in pages]
-    res = {}
-    try:
-        for tail in (1, 0):
-            _lib.set_option("det_tail", tail)
-            res[tail] = ([eng.detect_text_pixels(i) for i in inputs[:3]],
-                         eng.detect_words_batch(inputs[:1]), eng.detect_words_batch(inputs[:3]), eng.detect_words_batch(inputs))
-    finally:
-        _lib.set_option("det_tail", 0)
-    for a, b in zip(res[1][0], res[0][0]):
-        assert np.array_equal(a, b)
-    for k in (1, 2, 3):
-        assert all(np.array_equal(a, b) for a, b in zip(res[1][k], res[0][k]))
-    assert all(np.array_equal(a, b) for a, b in zip(res[1][3][:3], res[1][2]))   # a page's result does not depend on its batch
-    ora = OP.OcrEngine(detection_model=OracleModel(OracleGraph(dbuf), "exact"))
-    oin = ora.prepare_input(OP.ImageSource.from_tensor(pages[0], "hwc"))
-    assert np.array_equal(res[1][0][0], ora.detect_text_pixels(oin))
-
-
 # ------------------------------------------------------------------ row-streaming DoubleConv blocks (kernels_det_stream.hip)
 @pytest.mark.parametrize("in_hw,n,depths", [((96, 64), 3, (8, 16, 32, 32)), ((131, 157), 2, (8, 16, 32, 32)), ((61, 59), 1, (8, 16)),
                                             ((240, 121), 5, (8, 16, 32)), ((176, 272), 2, (8, 16, 32, 32, 64)), ((402, 250), 1, (8, 16, 32, 32, 64))])
@@ -320,11 +283,11 @@ def test_quad_pixel_component_kernels_equal_the_byte_kernels_and_the_oracle(h, w
             box["prob"] = mask.astype(np.float32)
             exp = rects_of(ora.detect_words(page))
             for quad in (1, 0):
-                _lib.set_option("ccl_quad", quad)
+                gpu.set_option("ccl_quad", quad)
                 got = gpu.detect_words(inp)
                 assert got.shape == exp.shape and np.array_equal(got, exp), (name, quad)
     finally:
-        _lib.set_option("ccl_quad", 1)
+        gpu.set_option("ccl_quad", 1)
 
 
 def test_quad_pixel_component_kernels_on_page_sized_masks():
@@ -347,11 +310,11 @@ def test_quad_pixel_component_kernels_on_page_sized_masks():
             exp = rects_of(ora.detect_words(page))
             assert len(exp) > 100, name
             for quad in (1, 0):
-                _lib.set_option("ccl_quad", quad)
+                gpu.set_option("ccl_quad", quad)
                 got = gpu.detect_words(inp)
                 assert got.shape == exp.shape and np.array_equal(got, exp), (name, quad)
     finally:
-        _lib.set_option("ccl_quad", 1)
+        gpu.set_option("ccl_quad", 1)
 
 
 def test_streaming_detection_kernels_at_bench_scale_give_the_golden_word_rects(bufs, pages16):
@@ -367,14 +330,14 @@ def test_streaming_detection_kernels_at_bench_scale_give_the_golden_word_rects(b
     assert sum(g is not None for g in golden) >= 2
     try:
         for mode in ((1, 1), (8, 8), (32, 32), (14, 20), (0, 0), (1, 0), (0, 1)):
-            _lib.set_option("det_stream", mode[0])
-            _lib.set_option("det_rows", mode[1])
+            eng.set_option("det_stream", mode[0])
+            eng.set_option("det_rows", mode[1])
             for lo, hi in ((0, 16), (0, 8), (8, 11)):
                 words = eng.detect_words_batch(inputs[lo:hi])
                 for pi in range(lo, hi):
                     if golden[pi] is not None:
                         assert np.array_equal(words[pi - lo], golden[pi]["word_rects"]), (mode, lo, hi, pi)
     finally:
-        _lib.set_option("det_stream", 1)
-        _lib.set_option("det_rows", 1)
+        eng.set_option("det_stream", 1)
+        eng.set_option("det_rows", 1)
 

@@ -296,15 +296,7 @@ def test_beam_search_host_equals_oracle(lib):
         assert abs(OP.beam_lse(a, b) - (max(a, b) + math.log1p(math.exp(-abs(a - b))))) < 1e-14
 
 
-def _gru_plan(lib, lengths, hidden=256, waves=4):
-    assert lib.ocrs_set_option(b"gru_waves", C.c_long(waves)) == 0
-    try:
-        return _gru_plan_now(lib, lengths, hidden)
-    finally:
-        lib.ocrs_set_option(b"gru_waves", C.c_long(4))
-
-
-def _gru_plan_now(lib, lengths, hidden):
+def _gru_plan(lib, lengths, hidden=256):
     a = np.ascontiguousarray(np.asarray(lengths, np.int32))
     ncl, waves = C.c_int32(0), C.c_int32(0)
     tiles = np.full(512, -2, np.int16)
@@ -319,22 +311,20 @@ def _wave_cost(lens, c, L):
     return sum((ls[i] - ls[i + 1]) * max((i + 1) * c, L) for i in range(len(ls) - 1))
 
 
-@pytest.mark.parametrize("waves", [4, 16])
 @pytest.mark.parametrize("n_lines", [1, 16, 17, 77, 1232, 2048, 2049, 4096, 8192])
-def test_gru_tile_plan_covers_every_tile_once_and_balances(lib, n_lines, waves):
-    """Host side of the persistent GRU kernels (kernels_gru.hip::gru_assign_tiles): every 16-line tile of the
-    length-sorted batch goes to exactly one slot (general kernel: 4 waves per cluster, at most 4 tiles each; teams
-    kernel: 4 teams per cluster, at most 8 tiles each), longest first; the slowest slot of the deal is no slower (cost
-    model of the kernel) than under the contiguous deal it replaced."""
+def test_gru_tile_plan_covers_every_tile_once_and_balances(lib, n_lines):
+    """Host side of the persistent GRU kernel (kernels_gru.hip::gru_assign_tiles): every 16-line tile of the
+    length-sorted batch goes to exactly one slot (4 waves per cluster, at most 4 tiles each), longest first; the slowest
+    slot of the deal is no slower (cost model of the kernel) than under the contiguous deal it replaced."""
     rng = np.random.default_rng(n_lines)
     lengths = np.sort(rng.integers(25, 601, n_lines))[::-1]
-    st, ncl, tiles, W = _gru_plan(lib, lengths, waves=waves)
-    if waves == 4 and n_lines > 4096:
+    st, ncl, tiles, W = _gru_plan(lib, lengths)
+    if n_lines > 4096:
         assert st == 9                                         # OCRS_ERR_CAPACITY: the general kernel holds 4 096 lines
         return
-    assert st == 0 and W == waves
-    S, per = 4, (8 if waves == 16 else 4)                      # slots per cluster, tiles per slot
-    c, L = (3.0, 4.6) if waves == 16 else (4.7, 6.6)
+    assert st == 0 and W == 4
+    S, per = 4, 4                                              # slots per cluster, tiles per slot
+    c, L = 4.7, 6.6
     ntiles = (n_lines + 15) // 16
     assert 1 <= ncl <= (8 if ntiles <= 32 * per else 16)
     used = tiles[: per * S * ncl].reshape(-1, per)
@@ -356,7 +346,6 @@ def test_gru_tile_plan_covers_every_tile_once_and_balances(lib, n_lines, waves):
 
 def test_gru_tile_plan_rejects_what_the_kernel_cannot_hold(lib):
     assert _gru_plan(lib, np.full(4097, 50, np.int32))[0] == 9      # OCRS_ERR_CAPACITY: > 4096 lines at H = 256 (general kernel)
-    assert _gru_plan(lib, np.full(8193, 50, np.int32), waves=16)[0] == 9   # > 8192 lines (teams kernel)
     assert _gru_plan(lib, np.full(64, 50, np.int32), hidden=96)[0] == 9  # unsupported hidden size
     assert _gru_plan(lib, [10, 20])[0] == 1                  # OCRS_ERR_INVALID_ARGUMENT: not descending
 
@@ -385,12 +374,12 @@ def test_coalescer_runs_every_request_once_and_merges_under_load(lib, threads, m
 
 # ---------------------------------------------------------------- engine group: dealing and packing (host side)
 def test_group_deals_pages_in_contiguous_blocks(lib):
-    """block = max(ceil(n / G), min(group_min_block = 8, n)); page i -> member (i / block) mod G: a 16-page call on 8
+    """block = max(ceil(n / G), min(min_block = 8, n)); page i -> member (i / block) mod G: a 16-page call on 8
     members uses two of them (8 pages each), 10 000 pages on 8 members 1 250 each, in order."""
     for n, g in [(0, 1), (7, 3), (16, 8), (5, 8), (10000, 8), (16, 2), (24, 2), (9, 2), (64, 8), (65, 8)]:
         mo = (C.c_size_t * max(n, 1))()
         pp = (C.c_size_t * g)()
-        assert lib.ocrs_group_deal(C.c_size_t(n), C.c_size_t(g), mo, pp) == 0
+        assert lib.ocrs_group_deal(C.c_size_t(n), C.c_size_t(g), C.c_size_t(0), mo, pp) == 0
         block = max(-(-n // g), min(8, n)) if n else 1
         assert [mo[i] for i in range(n)] == [(i // block) % g for i in range(n)]
         assert [pp[m] for m in range(g)] == [sum(1 for i in range(n) if (i // block) % g == m) for m in range(g)]
@@ -399,7 +388,9 @@ def test_group_deals_pages_in_contiguous_blocks(lib):
             assert max(pp) - min(pp) <= block and min(pp) > 0            # large calls use every member
         elif n:
             assert min(v for v in pp if v) >= min(8, n) or sum(1 for v in pp if v) == 1 or n % block
-    assert lib.ocrs_group_deal(C.c_size_t(4), C.c_size_t(0), None, None) == 1
+    assert lib.ocrs_group_deal(C.c_size_t(4), C.c_size_t(0), C.c_size_t(0), None, None) == 1
+    mo = (C.c_size_t * 6)()   # an explicit min_block (ocrs_group_params.min_block)
+    assert lib.ocrs_group_deal(C.c_size_t(6), C.c_size_t(3), C.c_size_t(1), mo, None) == 0 and list(mo) == [0, 0, 1, 1, 2, 2]
 
 
 def test_group_host_gather_concatenates_member_payloads_in_member_order(lib):
@@ -457,19 +448,34 @@ def test_group_auto_gather_is_host_per_request_and_rccl_problems_are_never_fatal
         _lib.check(lib.ocrs_group_final_gather(g1._h, C.c_int(7), None, None, None, None))
 
 
-def test_every_option_of_the_library_is_documented_in_the_header():
-    """ocrs_set_option names: the table in common.cpp and the comment block of include/ocrs_amd.h list the same options."""
+def test_every_option_of_the_library_is_documented_in_the_header(lib):
+    """ocrs_set_option names: the table in common.cpp, ocrs_option_name and the comment block of include/ocrs_amd.h list the
+    same options, at most twelve of them (round 5: the experiment switches are gone); the per-engine configuration fields
+    are fields of ocrs_engine_params, not options; no getenv outside the once-per-process initialisers."""
     import re
+    from ocrs_amd import _lib
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     src = open(os.path.join(root, "ocrs_amd", "csrc", "common.cpp")).read()
     names = re.findall(r'\{"([a-z0-9_]+)",\s*"OCRS_[A-Z0-9_]+",', src)
-    assert len(names) >= 19
+    assert 8 <= len(names) <= 12
+    assert _lib.option_names() == names
     hdr = open(os.path.join(root, "include", "ocrs_amd.h")).read()
     missing = [n for n in names if '"%s"' % n not in hdr]
     assert not missing, missing
+    fields = re.findall(r'\{"([a-z0-9_]+)",\s*nullptr,', src)
+    params = re.search(r"typedef struct ocrs_engine_params \{(.*?)\} ocrs_engine_params;", hdr, re.S).group(1)
+    assert fields and all(re.search(r"\b%s;" % f, params) for f in fields), fields
     # the table is indexed by `enum Option`: entry i must be the option enumerator i names (a det_tail / gru_waves swap once
     # made one option read the other's value)
     chp = open(os.path.join(root, "ocrs_amd", "csrc", "common.hpp")).read()
-    enum = re.search(r"enum Option \{(.*?)OPT_COUNT", chp, re.S).group(1)
+    enum = re.search(r"enum Option \{(.*?)OPT_COUNT \}", chp, re.S).group(1)
+    enum = re.sub(r"//[^\n]*", "", enum)
     ids = [x.split("=")[0].strip() for x in enum.replace("\n", " ").split(",") if x.strip()]
-    assert ["OPT_" + n.upper() for n in names] == ids
+    ids = [i for i in ids if i != "OPT_PUBLIC_COUNT"]
+    assert ["OPT_" + n.upper() for n in names + fields] == ids
+    assert lib.ocrs_set_option(b"coalesce", C.c_long(1)) == 1 and lib.ocrs_set_option(b"det_tail", C.c_long(1)) == 1   # not process options
+    # environment variables are read by initialisers that run once (options, pool cap, the RCCL library name), never on a launch path
+    for f in sorted(os.listdir(os.path.join(root, "ocrs_amd", "csrc"))):
+        body = open(os.path.join(root, "ocrs_amd", "csrc", f)).read()
+        n = len(re.findall(r"\bgetenv\(", body))
+        assert n <= {"common.cpp": 2, "group.cpp": 1}.get(f, 0), (f, n)

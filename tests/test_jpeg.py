@@ -97,6 +97,33 @@ def test_malformed_and_unsupported_streams_are_refused_not_crashed():
 
 
 # ------------------------------------------------------------------------------------------------ GPU
+def test_decompression_bombs_are_refused_before_any_allocation():
+    """A tiny file whose SOF claims 65535 x 65535 (12 GiB of samples), a stream with hundreds of scans, a sequential stream
+    whose scan is repeated: OCRS_ERR_IMAGE_SOURCE at once (the reference's `image` crate enforces a 512 MiB allocation limit)."""
+    import time
+    data = _encode(synth.synthetic_page(1, 64, 64, lines=2, columns=1), quality=80)
+    sof = data.index(b"\xff\xc0")
+    huge = data[: sof + 5] + b"\xff\xff\xff\xff" + data[sof + 9:]
+    t0 = time.perf_counter()
+    for fn in (_lib.jpeg_info, _lib.jpeg_coefficients):
+        with pytest.raises(_lib.OcrsError, match="too large") as ei:
+            fn(huge)
+        assert ei.value.status == 6
+    assert time.perf_counter() - t0 < 1.0
+    big_ok = data[: sof + 5] + bytes([0x2E, 0xE0, 0x2E, 0xE0]) + data[sof + 9:]      # 12000 x 12000 x 3 = 412 MiB: within budget
+    assert _lib.jpeg_info(big_ok)["height"] == 12000
+    # the scan of a sequential stream repeated: the second one names components that are already decoded
+    sos, eoi = data.index(b"\xff\xda"), data.rindex(b"\xff\xd9")
+    with pytest.raises(_lib.OcrsError, match="two scans"):
+        _lib.jpeg_coefficients(data[:eoi] + data[sos:eoi] + b"\xff\xd9")
+    # a progressive stream with its last scan repeated 600 times
+    prog = _encode(synth.synthetic_page(1, 64, 64, lines=2, columns=1), quality=80, progressive=True)
+    last, eoi = prog.rindex(b"\xff\xda"), prog.rindex(b"\xff\xd9")
+    with pytest.raises(_lib.OcrsError, match="too many scans"):
+        _lib.jpeg_coefficients(prog[:eoi] + prog[last:eoi] * 600 + b"\xff\xd9")
+    assert _lib.jpeg_coefficients(prog[:eoi] + prog[last:eoi] * 3 + b"\xff\xd9") is not None   # a few repeats are legal refinements or harmless
+
+
 @pytest.mark.gpu
 def test_gpu_decode_equals_pil_and_the_oracle_in_every_mode():
     _lib.require_gpu()
