@@ -195,7 +195,7 @@ OCRS_API void ocrs_model_free(ocrs_model* m);
 typedef struct ocrs_engine ocrs_engine;
 typedef struct ocrs_page ocrs_page; /* OcrInput */
 
-typedef enum ocrs_numerics { OCRS_NUMERICS_EXACT = 0, OCRS_NUMERICS_RELAXED = 1 } ocrs_numerics;
+typedef enum ocrs_numerics { OCRS_NUMERICS_EXACT = 0, OCRS_NUMERICS_RELAXED = 1, OCRS_NUMERICS_REDUCED = 2 } ocrs_numerics;
 
 typedef enum ocrs_decode_method { /* DecodeMethod, recognition.rs:198-205 */
     OCRS_DECODE_GREEDY = 0,
@@ -214,9 +214,12 @@ typedef struct ocrs_engine_params {
     const char* allowed_chars; /* UTF-8 */
     /* --- no reference counterpart (RTen is fp32 on the CPU, one page per call) --- */
     ocrs_numerics numerics;    /* OCRS_NUMERICS_EXACT (0, default): every kernel follows the numeric spec, results are
-                                * bit-identical to the CPU oracle.  OCRS_NUMERICS_RELAXED: hardware transcendentals, operands
-                                * split into bf16 terms on the 16x faster bf16 matrix cores, free accumulation order — boxes
-                                * and tokens are expected, not guaranteed, to match (DESIGN.md "what exactness costs") */
+                                * bit-identical to the CPU oracle.  OCRS_NUMERICS_RELAXED: fp32-class arithmetic that is not
+                                * reproducible on a CPU — hardware exp / rcp in the recurrence's gates, the recognition convs'
+                                * operands cut into three bf16 terms on the bf16 matrix cores (products good to 2^-23), the
+                                * matrix core's accumulation order.  OCRS_NUMERICS_REDUCED: the same with two bf16 terms per
+                                * operand (products good to 2^-15: a 16-bit significand).  Boxes and tokens are expected, not
+                                * guaranteed, to match the exact mode: DESIGN.md "what exactness costs" has the measured flips */
     int coalesce;              /* one-page calls that wait at the same time are merged into one ragged request per stage
                                 * (lines are independent: nobody's bits change).  Merged batches in flight per stage:
                                 * 0 = default (2), negative = every call runs on its own */
@@ -324,6 +327,13 @@ OCRS_API ocrs_status ocrs_engine_recognize_text_batch(const ocrs_engine* e, cons
 OCRS_API ocrs_status ocrs_engine_recognize_tokens(const ocrs_engine* e, const ocrs_page* page, const float* line_rects,
                                          const size_t* line_offsets, size_t n_lines, uint32_t** labels,
                                          uint32_t** positions, size_t** token_offsets);
+
+/* The recognition model's output for the same lines, before masking and decoding (TextRecognizer::run,
+ * recognition.rs:341-360): line i owns rows [row_offsets[i], row_offsets[i+1]) of the [rows][classes] matrix *logp — its
+ * T_i time steps.  One request, never coalesced.  For tolerance checks between numerics modes. */
+OCRS_API ocrs_status ocrs_engine_recognize_logits(const ocrs_engine* e, const ocrs_page* page, const float* line_rects,
+                                         const size_t* line_offsets, size_t n_lines, float** logp, size_t** row_offsets,
+                                         int* classes);
 
 /* TextItem::rotated_rect (text_items.rs:18-30) for a TextLine / TextWord given its characters'
  * rects (n x {top,left,bottom,right}): minimum-area rectangle of the box corners, oriented

@@ -171,7 +171,7 @@ class Model:
             pass
 
 
-NUMERICS = {"exact": 0, "relaxed": 1}   # ocrs_numerics
+NUMERICS = {"exact": 0, "relaxed": 1, "reduced": 2}   # ocrs_numerics
 
 
 class OcrEngineParams:  # lib.rs:38-71
@@ -548,6 +548,25 @@ class OcrEngine:
             out.append([(int(lab[k]), int(pos[k])) for k in range(toff[i], toff[i + 1])])
         for p in (lab, pos, toff):
             lib().ocrs_buffer_free(p)
+        return out
+
+    def recognize_logits(self, inp, lines):
+        """The recognition model's log-probabilities per line, [T_i, classes] each (ocrs_engine_recognize_logits)."""
+        rects, offs = _pack_lines(lines)
+        lp = C.POINTER(C.c_float)()
+        roff = C.POINTER(C.c_size_t)()
+        ncls = C.c_int(0)
+        check(lib().ocrs_engine_recognize_logits(self._h, inp._h, rects.ctypes.data_as(C.POINTER(C.c_float)),
+                                                 offs.ctypes.data_as(C.POINTER(C.c_size_t)), C.c_size_t(len(lines)),
+                                                 C.byref(lp), C.byref(roff), C.byref(ncls)))
+        c = ncls.value
+        out = []
+        for i in range(len(lines)):
+            a, b = roff[i], roff[i + 1]
+            out.append(np.ctypeslib.as_array(lp, shape=(roff[len(lines)] * c,))[a * c:b * c].reshape(b - a, c).copy() if b > a
+                       else np.zeros((0, c), np.float32))
+        lib().ocrs_buffer_free(lp)
+        lib().ocrs_buffer_free(roff)
         return out
 
     # ---- lib.rs:268-278

@@ -628,6 +628,24 @@ ocrs_status ocrs_engine_recognize_tokens(const ocrs_engine* e, const ocrs_page* 
     });
 }
 
+ocrs_status ocrs_engine_recognize_logits(const ocrs_engine* e, const ocrs_page* page, const float* line_rects,
+                                         const size_t* line_offsets, size_t n_lines, float** logp, size_t** row_offsets, int* classes) {
+    return guarded_engine(e, [&] {
+        if (!e || !page || !line_offsets || !logp || !row_offsets || !classes) fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
+        check_pages_on(e, &page, 1);
+        std::vector<std::vector<float>> per_line;
+        e->recognize_logits(page, unpack_lines(line_rects, line_offsets, 0, n_lines), &per_line, classes);
+        std::vector<float> flat;
+        std::vector<size_t> offs{0};
+        for (const auto& l : per_line) {
+            flat.insert(flat.end(), l.begin(), l.end());
+            offs.push_back(flat.size() / (size_t)*classes);
+        }
+        *logp = dup_buffer(flat);
+        *row_offsets = dup_buffer(offs);
+    });
+}
+
 ocrs_status ocrs_text_item_rotated_rect(const int32_t* rects_tlbr, size_t n_chars, float out6[6]) {
     return guarded([&] {
         if (!rects_tlbr || !out6 || n_chars == 0) fail(OCRS_ERR_INVALID_ARGUMENT, "expected valid rect");

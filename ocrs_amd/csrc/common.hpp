@@ -162,7 +162,7 @@ inline hipStream_t recurrent_stream() { return ctx().recurrent_stream(); }
 // The entries after OPT_PUBLIC_COUNT are not options: they are fields of ocrs_engine_params that travel the same way.
 enum Option { OPT_GRU_MODE = 0, OPT_GRU_GATES, OPT_GRU_LOCAL, OPT_DET_FUSE, OPT_DET_MFMA, OPT_DET_STREAM, OPT_DET_ROWS, OPT_CCL_QUAD,
               OPT_CONV12_FUSE, OPT_CONV_FLAT, OPT_BEAM_GPU, OPT_PUBLIC_COUNT,
-              OPT_NUMERICS = OPT_PUBLIC_COUNT,   // ocrs_engine_params.numerics: 0 exact (the numeric spec), 1 relaxed
+              OPT_NUMERICS = OPT_PUBLIC_COUNT,   // ocrs_engine_params.numerics: 0 exact (the numeric spec), 1 relaxed, 2 reduced
               OPT_COALESCE, OPT_COALESCE_PAGES, OPT_COALESCE_WINDOW_US,   // ocrs_engine_params.coalesce*
               OPT_LAYOUT_THREADS, OPT_REC_MAX_PIXELS,                     // ocrs_engine_params.layout_threads / rec_max_pixels
               OPT_COUNT };

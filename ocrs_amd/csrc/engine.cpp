@@ -447,9 +447,23 @@ void ocrs_engine::recognize_now(const ocrs_page* const* pages, size_t n_pages,
     *rec_lines_out = std::move(lines);
 }
 
+void ocrs_engine::recognize_logits(const ocrs_page* page, const std::vector<std::vector<RotatedRect>>& lines_in,
+                                   std::vector<std::vector<float>>* logp, int* classes) const {
+    if (!recognition) fail(OCRS_ERR_MODEL_NOT_LOADED, "Recognition model not loaded");
+    if (recognition->is_callback()) fail(OCRS_ERR_INVALID_ARGUMENT, "recognize_logits needs a model of the fixed-graph executor");
+    std::vector<RecLine> lines;
+    for (const auto& words : lines_in) lines.push_back(make_rec_line(words, 0, lines.size()));
+    std::vector<std::vector<CtcStep>> steps;
+    std::vector<uint32_t> ctc_len;
+    recognize_lines(&page, 1, lines, &steps, &ctc_len, logp);
+    *classes = (int)alphabet.size() + 1;
+}
+
 void ocrs_engine::recognize_lines(const ocrs_page* const* pages, size_t n_pages, const std::vector<RecLine>& lines,
-                                  std::vector<std::vector<CtcStep>>* steps_out, std::vector<uint32_t>* ctc_len_out) const {
+                                  std::vector<std::vector<CtcStep>>* steps_out, std::vector<uint32_t>* ctc_len_out,
+                                  std::vector<std::vector<float>>* logp_out) const {
     const bool beam = decode_method == OCRS_DECODE_BEAM_SEARCH;
+    if (logp_out) logp_out->assign(lines.size(), {});
     const uint32_t rec_h = rec_input_height();
     const size_t alphabet_len = alphabet.size();
 
@@ -636,8 +650,8 @@ void ocrs_engine::recognize_lines(const ocrs_page* const* pages, size_t n_pages,
             int Tmax = 0;
             uint32_t gru_status[8] = {0};  // time-out words of the persistent GRU kernels (0 = fine)
             bool gpu_beam = false;         // beam search already done on the GPU: hl/hp/hc hold its steps
-            std::vector<float> logp;      // beam search only: packed [R][C]
-            std::vector<int32_t> off;     // beam search only
+            std::vector<float> logp;      // beam search on the host / logits wanted: packed [R][C]
+            std::vector<int32_t> off;     // with logp
         };
         const int T_SPLIT = 160;
         size_t first_long = chunks.size();
@@ -691,7 +705,12 @@ void ocrs_engine::recognize_lines(const ocrs_page* const* pages, size_t n_pages,
                                                        d_meta + pos_at[c - c0]});
             int32_t* d_labels = w.alloc_n<int32_t>((size_t)plan.R);
             float* d_logp = nullptr;
-            hm->run_recognition_packed(w, pg, plan, (int)rec_h, T, d_excl, d_labels, beam ? &d_logp : nullptr);
+            hm->run_recognition_packed(w, pg, plan, (int)rec_h, T, d_excl, d_labels, (beam || logp_out) ? &d_logp : nullptr);
+            if (logp_out) {
+                sub.logp.resize((size_t)plan.R * C);
+                sub.off = hoff;
+                w.download(sub.logp.data(), d_logp, sub.logp.size() * sizeof(float), sst);
+            }
             if (beam && option(OPT_BEAM_GPU) && k::ctc_beam_supported(C, (int)beam_width)) {
                 // rten decode_beam (recognition.rs:512-514) on the GPU, one workgroup per line (kernels_beam.hip)
                 const int Tmax = plan.Tmax;
@@ -717,10 +736,12 @@ void ocrs_engine::recognize_lines(const ocrs_page* const* pages, size_t n_pages,
                 return;
             }
             if (beam) {
-                sub.logp.resize((size_t)plan.R * C);
-                sub.off = hoff;
                 sub.Tmax = plan.Tmax;
-                w.download(sub.logp.data(), d_logp, sub.logp.size() * sizeof(float), sst);
+                if (!logp_out) {
+                    sub.logp.resize((size_t)plan.R * C);
+                    sub.off = hoff;
+                    w.download(sub.logp.data(), d_logp, sub.logp.size() * sizeof(float), sst);
+                }
                 return;
             }
             // greedy CTC (recognition.rs:511)
@@ -743,6 +764,13 @@ void ocrs_engine::recognize_lines(const ocrs_page* const* pages, size_t n_pages,
         auto unpack = [&](const Sub& sub) {
             for (uint32_t st8 : sub.gru_status)
                 if (st8) fail(OCRS_ERR_DEVICE, "GRU recurrence kernel timed out waiting for a peer workgroup (status 0x%x)", st8);
+            if (logp_out)
+                for (size_t m = 0; m < sub.slots.size(); m++) {
+                    auto& dst = (*logp_out)[sub.slots[m].line];
+                    dst.resize((size_t)sub.slots[m].T * C);
+                    for (int t = 0; t < sub.slots[m].T; t++)
+                        memcpy(&dst[(size_t)t * C], &sub.logp[((size_t)sub.off[t] + m) * C], (size_t)C * sizeof(float));
+                }
             if (beam && !sub.gpu_beam) {  // rten decode_beam (recognition.rs:512-514), host side, one thread per slice of lines
                 const size_t M = sub.slots.size();
                 const unsigned nth = (unsigned)std::max<size_t>(1, std::min<size_t>({(size_t)std::thread::hardware_concurrency(), (size_t)32, M}));

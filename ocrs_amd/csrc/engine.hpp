@@ -99,8 +99,13 @@ struct ocrs_engine {
     mutable std::unique_ptr<ocrs::Coalescer<ocrs::DetRequest>> det_queue;
     mutable std::unique_ptr<ocrs::Coalescer<ocrs::RecRequest>> rec_queue;
     // one sub-request of `recognize` (within the activation budget); outputs indexed like `lines`
+    // logp (optional): per line the model's log-probabilities [T][C] (TextRecognizer::run, recognition.rs:341-360), unmasked
     void recognize_lines(const ocrs_page* const* pages, size_t n_pages, const std::vector<ocrs::RecLine>& lines,
-                         std::vector<std::vector<ocrs::CtcStep>>* steps, std::vector<uint32_t>* ctc_input_len) const;
+                         std::vector<std::vector<ocrs::CtcStep>>* steps, std::vector<uint32_t>* ctc_input_len,
+                         std::vector<std::vector<float>>* logp = nullptr) const;
+    // the recognition model's output for the lines of one page, one request, no coalescing (parity / tolerance checks)
+    void recognize_logits(const ocrs_page* page, const std::vector<std::vector<ocrs::geom::RotatedRect>>& lines,
+                          std::vector<std::vector<float>>* logp, int* classes) const;
 
     std::vector<ocrs::TextChar> text_line_from_result(const ocrs::RecLine& line, uint32_t ctc_input_len,
                                                       const std::vector<ocrs::CtcStep>& steps) const;

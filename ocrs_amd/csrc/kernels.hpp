@@ -221,8 +221,10 @@ void avgpool_to_seq_ragged(const float* x, const RaggedView& in, const RaggedVie
 bool conv12_fused_ragged(const float* x, const RaggedView& in0, const RaggedView& mid, const float* w1, const float* b1,
                          int c1, const float* w2, const float* b2, int c2, float* y, const RaggedView& out, hipStream_t s);
 // returns false if the shape is not supported (caller falls back to the per-group path)
+// wsplit: the weights cut into bf16 terms (conv_split_weights) or null; used when the calling engine's numerics are relaxed
 bool conv3x3_ragged(const float* x, const RaggedView& rv, int cin, const float* wt, const float* bias, int cout, int relu,
-                    int ph, int pw, float* y, const RaggedView& out, hipStream_t s);
+                    int ph, int pw, float* y, const RaggedView& out, hipStream_t s, const uint16_t* wsplit = nullptr);
+void conv_split_weights(const float* w_host, int K, int cout, std::vector<uint16_t>* out);   // host; cout % 128 == 0, K % 16 == 0
 
 // ---- kernels_lines.hip ----------------------------------------------------
 struct LineDesc {      // one text line to crop (recognition.rs:91-126)

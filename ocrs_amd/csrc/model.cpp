@@ -162,6 +162,19 @@ std::unique_ptr<HipModel> HipModel::load(const void* data, size_t len, int devic
         else if (fx.which == 2) op.aux2 = p;
         else op.aux3 = p;
     }
+    // Relaxed numerics (ocrs_engine_params.numerics): the 3x3 convs of a recognition stack whose contraction can run on the
+    // bf16 matrix cores carry their weights a second time, cut into three bf16 terms in the kernel's LDS layout
+    // (kernels_rec.hip conv_split_weights; 1.5x the fp32 bytes, a few MB per model).
+    for (uint32_t i = 0; i < hd.n_ops; i++) {
+        GraphOp& op = m->ops[i];
+        if (m->kind == 1 && op.type == OP_CONV && op.kh == 3 && op.kw == 3 && (op.cin % 32) == 0 && (op.cout % 128) == 0) {
+            std::vector<uint16_t> img;
+            k::conv_split_weights(slab.data() + fops[i].w[0].off, 9 * op.cin, op.cout, &img);
+            m->tapes.emplace_back(img.size() * sizeof(uint16_t));
+            OCRS_HIP(hipMemcpy(m->tapes.back().p, img.data(), img.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+            op.wsplit = m->tapes.back().as<uint16_t>();
+        }
+    }
     // Fold SIGMOID into a directly preceding Cout==1 pointwise conv.
     for (size_t i = 0; i + 1 < m->ops.size(); i++) {
         GraphOp& a = m->ops[i];
@@ -914,7 +927,7 @@ float* HipModel::run_prefix_ragged(Workspace& ws, hipStream_t exec, const std::v
             bool ok = false;
             timed(KC_GEMM_CONV3X3, 2.0 * vin.pixels * 9.0 * op.cin * op.cout,
                   4.0 * (vin.pixels * op.cin + vout.pixels * op.cout) + 4.0 * op.wcount[0],
-                  [&] { ok = k::conv3x3_ragged(cur, vin, op.cin, op.w[0], op.w[1], op.cout, op.relu, ph, pw, y, vout, st); });
+                  [&] { ok = k::conv3x3_ragged(cur, vin, op.cin, op.w[0], op.w[1], op.cout, op.relu, ph, pw, y, vout, st, op.wsplit); });
             if (!ok) fail(OCRS_ERR_RUN_FAILED, "model run failed: ragged conv %d->%d at height %d not supported", op.cin, op.cout, vin.H);
             curC = op.cout;
             if (fuse) i += 1;

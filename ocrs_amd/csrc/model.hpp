@@ -27,6 +27,7 @@ struct GraphOp {
     const float* aux1 = nullptr;  // convT: bias x4; GRU: bi [2][3H]
     const float* aux2 = nullptr;  // GRU: Wh [2][H][3H]
     const float* aux3 = nullptr;  // GRU: bh [2][3H]
+    const uint16_t* wsplit = nullptr;   // 3x3 conv / GRU input weights cut into bf16 terms for the relaxed-numerics kernels (or null)
     bool fused_into_prev = false; // e.g. SIGMOID folded into the preceding Cout==1 conv
     bool fuse_next_pw = false;    // DWCONV3 whose only consumer is the next op, a 1x1 CONV (8 <= C <= 32): one fused launch
     bool done_by_prev = false;    // that 1x1 CONV

@@ -1,0 +1,121 @@
+"""GPU tests of the round-5 work, through the C ABI:
+
+  * per-engine tuning options: two engines in one process differ, a process default never reaches an existing engine;
+  * relaxed numerics (ocrs_engine_params.numerics): tokens and boxes against the exact engine, log-probs within a stated tolerance;
+  * memory: pool statistics stay bounded over requests of varied sizes, results equal the sequential run's.
+"""
+import os
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+import models_util as M
+from ocrs_amd import DimOrder, ImageSource, Model, OcrEngine, _lib, numerics_report as NR, synth
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+# Relaxed numerics, recognition log-probs: |relaxed - exact| on the values that are finite in both.  The relaxed contraction
+# is fp32-accurate term by term (bf16 x 3 split, fp32 accumulate) but sums in another order, and the gates use the 1-ulp
+# hardware exp / rcp: differences are those of two correct fp32 evaluations, amplified by the 600-step recurrence.
+LOGPROB_TOL = 2e-3
+
+
+@pytest.fixture(scope="module")
+def pair():
+    _lib.require_gpu()
+    det, rec = Model.load_bytes(M.detection_model_bytes()), Model.load_bytes(M.recognition_model_bytes())
+    return (OcrEngine(detection_model=det, recognition_model=rec), OcrEngine(detection_model=det, recognition_model=rec, numerics="relaxed"))
+
+
+def test_two_engines_in_one_process_own_their_options(pair):
+    """ocrs_engine_set_option changes one engine; ocrs_set_option (the process default) only what is created afterwards; two
+    engines with different kernel selections run concurrently and return the same bits."""
+    exact, _ = pair
+    det, rec = Model.load_bytes(M.detection_model_bytes()), Model.load_bytes(M.recognition_model_bytes())
+    other = OcrEngine(detection_model=det, recognition_model=rec, options={"gru_mode": 1, "det_stream": 0, "det_rows": 0, "ccl_quad": 0, "conv12_fuse": 0})
+    assert other.get_option("gru_mode") == 1 and exact.get_option("gru_mode") == 0
+    assert other.get_option("numerics") == 0 and pair[1].get_option("numerics") == 1
+    with pytest.raises(_lib.OcrsError):
+        other.set_option("numerics", 1)                      # fixed at creation
+    with pytest.raises(_lib.OcrsError):
+        other.set_option("gru_waves", 16)                    # removed in round 5
+    try:
+        _lib.set_option("det_fuse", 0)
+        assert exact.get_option("det_fuse") == 1            # an existing engine keeps its copy
+        third = OcrEngine(detection_model=det)
+        assert third.get_option("det_fuse") == 0            # a new one starts from the default
+    finally:
+        _lib.set_option("det_fuse", 1)
+    px = synth.synthetic_page(21, 700, 900, lines=40)
+    def run(eng):
+        inp = eng.prepare_input(ImageSource.from_tensor(px, DimOrder.Hwc))
+        words = eng.detect_words(inp)
+        return words, eng.recognize_tokens(inp, eng.find_text_lines(inp, words))
+    ref = run(exact)
+    with ThreadPoolExecutor(4) as ex:
+        outs = list(ex.map(run, [exact, other, exact, other]))
+    for w, t in outs:
+        assert np.array_equal(w, ref[0]) and t == ref[1]
+    assert len(ref[1]) > 20
+
+
+def test_relaxed_numerics_keep_boxes_and_tokens_and_stay_within_the_logprob_tolerance(pair):
+    """Two bench pages and 256 crops through an exact and a relaxed engine: word boxes identical (detection runs the same
+    kernels in both modes), CTC tokens and char boxes identical — or the flips printed and at most 1 line in 1 000 —, log-probs
+    within LOGPROB_TOL.  The relaxed engine really runs other kernels: its log-probs are NOT bit-identical."""
+    exact, relaxed = pair
+    pages = [synth.synthetic_page(s, 1024, 1024, lines=80) for s in (0, 5)]
+    rep = NR.compare_pixels(exact, relaxed, pages)
+    inp, lines = NR.crops_request(exact, synth, n=256)
+    rc = NR.compare_page(exact, relaxed, inp, lines=lines)
+    tot = NR.merge([rep, rc])
+    print("relaxed vs exact:", {k: v for k, v in tot.items() if k != "flipped"}, tot["flipped"][:3])
+    assert tot["lines"] > 350 and tot["tokens"] > 5000
+    assert rep["box_flips"] == 0 and rep["max_abs_dprob_map"] == 0.0
+    assert tot["nonfinite_mismatch"] == 0
+    assert tot["token_flip_lines"] <= max(1, tot["lines"] // 1000), tot["flipped"]
+    assert tot["char_box_flips"] <= tot["token_flip_lines"] * 4
+    assert 0.0 < tot["max_abs_dlogprob"] < LOGPROB_TOL
+    # the exact engine is still exact: page 0 against the oracle's golden fixture
+    g = np.load(os.path.join(GOLD, "bench_page_seed0.npz"))
+    i0 = exact.prepare_input(ImageSource.from_tensor(pages[0], DimOrder.Hwc))
+    assert np.array_equal(exact.detect_words(i0), g["word_rects"])
+
+
+def test_pools_stay_bounded_over_requests_of_varied_sizes():
+    """Pages of random sizes (200-1 600 pixels a side, 1-120 lines) from four threads for a few seconds, with small caps on the
+    cached bytes: device and pinned memory in use return to their idle level, the caches respect their caps (blocks above them
+    go back to the driver on the trimmer thread), and every result equals the sequential run's."""
+    _lib.require_gpu()
+    det, rec = Model.load_bytes(M.detection_model_bytes((320, 256), (8, 16, 32, 32, 64))), Model.load_bytes(M.recognition_model_bytes())
+    eng = OcrEngine(detection_model=det, recognition_model=rec)
+    rng = np.random.default_rng(11)
+    cases = []
+    for s in range(24):
+        h, w = int(rng.integers(200, 1601)), int(rng.integers(200, 1601))
+        cases.append(synth.synthetic_page(100 + s, h, w, lines=int(rng.integers(1, max(2, min(120, h // 14)))), columns=1 + (w > 900)))
+    def run(px):
+        inp = eng.prepare_input(ImageSource.from_tensor(px, DimOrder.Hwc))
+        words = eng.detect_words(inp)
+        return words, eng.recognize_tokens(inp, eng.find_text_lines(inp, words))
+    ref = [run(px) for px in cases]
+    base = _lib.pool_stats()
+    cap_dev, cap_pin = 256 << 20, 8 << 20
+    _lib.pool_configure(device_cached_cap=cap_dev, pinned_cached_cap=cap_pin)
+    try:
+        peak_cached = 0
+        with ThreadPoolExecutor(4) as ex:
+            for rep in range(3):
+                outs = list(ex.map(run, cases))
+                for (w, t), (rw, rt) in zip(outs, ref):
+                    assert np.array_equal(w, rw) and t == rt
+                st = _lib.pool_stats()
+                peak_cached = max(peak_cached, st["device_cached"])
+                assert st["device_cached"] <= cap_dev and st["pinned_cached"] <= cap_pin, st
+        st = _lib.pool_stats()
+        assert st["device_live"] <= base["device_live"] + (1 << 20) and st["pinned_live"] <= base["pinned_live"] + (1 << 16), (base, st)
+        assert st["device_driver_frees"] > base["device_driver_frees"]      # the cap was reached and blocks went back
+        assert st["device_cap"] == cap_dev and st["pinned_cap"] == cap_pin
+    finally:
+        _lib.pool_configure(device_cached_cap=base["device_cap"], pinned_cached_cap=base["pinned_cap"])
