@@ -464,6 +464,19 @@ OCRS_API ocrs_status ocrs_group_gather(ocrs_engine_group* g, const void* const* 
  * when the group has two or more members and RCCL can be had, else host — never an error for lack of RCCL). */
 OCRS_API ocrs_status ocrs_group_final_gather(ocrs_engine_group* g, ocrs_gather_mode mode, const void* const* payloads,
                                              const size_t* bytes, void** out, size_t* offsets);
+/* What member m has done so far, for diagnosing a multi-GPU run (the host side is the expected scaling
+ * limiter): out = {shares of calls it ran, pages those carried, CPU nanoseconds of the host threads that ran them, their wall
+ * nanoseconds, NUMA node of its GPU + 1 (0 = the host does not say), CPUs of that node (0 = no binding), shares that ran
+ * bound to those CPUs, its device}.  A member's share of a call binds its thread to the CPUs of the NUMA node the member's
+ * GPU hangs off (hipDeviceGetPCIBusId -> sysfs numa_node / cpulist) for the duration of the share and restores the thread's
+ * mask afterwards; its page-locked staging is first touched from there.  Hosts without that information: no binding. */
+OCRS_API ocrs_status ocrs_group_member_stats(const ocrs_engine_group* g, size_t m, uint64_t out[8]);
+/* Host-only helpers behind that placement, exported for tests: a sysfs cpu list ("0-3,8") parsed into cpu numbers (cpus may
+ * be NULL; *n_cpus = how many the list names); and: node of a PCI device under `sysfs_root` (NULL = "/sys"), the calling
+ * thread bound to that node's CPUs inside a scope (*cpus_inside = CPUs in its mask there, -1 = not bound) and restored
+ * (*cpus_after). */
+OCRS_API ocrs_status ocrs_numa_parse_cpulist(const char* list, int32_t* cpus, size_t capacity, size_t* n_cpus);
+OCRS_API ocrs_status ocrs_numa_bind_selftest(const char* sysfs_root, const char* pci_bus_id, int* node, int* cpus_inside, int* cpus_after);
 /* Worker threads the group has created so far (they are kept between calls). */
 OCRS_API ocrs_status ocrs_group_worker_threads(const ocrs_engine_group* g, size_t* n);
 /* Transport of the group's most recent gather: 1 host, 2 RCCL (0: none yet), the payload bytes it moved, and — when it

@@ -692,6 +692,13 @@ class EngineGroup:
         check(lib().ocrs_engine_group_member(self._h, C.c_size_t(i), C.byref(e), C.byref(d)))
         return OcrEngine._borrowed(e, self), d.value
 
+    def member_stats(self, i):
+        """ocrs_group_member_stats as a dict."""
+        v = (C.c_uint64 * 8)()
+        check(lib().ocrs_group_member_stats(self._h, C.c_size_t(i), v))
+        return {"device": int(v[7]), "shares": int(v[0]), "pages": int(v[1]), "host_cpu_s": v[2] / 1e9, "busy_wall_s": v[3] / 1e9,
+                "numa_node": int(v[4]) - 1 if v[4] else None, "node_cpus": int(v[5]), "bound_shares": int(v[6])}
+
     def set_option(self, name, value):
         """ocrs_engine_set_option on every member."""
         for i in range(len(self)):

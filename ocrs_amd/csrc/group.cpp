@@ -29,6 +29,7 @@
 
 #include "abi_util.hpp"
 #include "host_pool.hpp"
+#include "numa.hpp"
 #include "kernels.hpp"
 
 using namespace ocrs;
@@ -102,6 +103,16 @@ struct ocrs_engine_group {
         int device = 0;
         std::unique_ptr<ocrs_model> detection, recognition;
         std::unique_ptr<ocrs_engine> engine;
+        // host placement (numa.hpp): the NUMA node the member's GPU hangs off and that node's CPUs; a share binds its thread
+        // to them for its duration (its page-locked staging is then first touched there); empty = unknown, no binding
+        int numa_node = -1;
+        std::vector<int> cpus;
+        // accounting for ocrs_group_member_stats (the first multi-GPU run must be diagnosable): shares run, pages they
+        // carried, CPU time of the threads that ran them (CLOCK_THREAD_CPUTIME_ID deltas), their wall time, shares that ran bound
+        std::atomic<uint64_t> shares{0}, pages{0}, cpu_ns{0}, wall_ns{0}, bound_shares{0};
+        Member() = default;
+        Member(Member&& o) noexcept : device(o.device), detection(std::move(o.detection)), recognition(std::move(o.recognition)),
+                                      engine(std::move(o.engine)), numa_node(o.numa_node), cpus(std::move(o.cpus)) {}
     };
     std::vector<Member> members;
     std::vector<int> devices;                          // distinct devices, in order of first appearance
@@ -214,8 +225,24 @@ void for_each_member(ocrs_engine_group* g, const std::vector<std::vector<size_t>
     for (size_t m = 0; m < g->size(); m++) has_work[m] = !of_member[m].empty();
     std::vector<std::exception_ptr> errs;
     run_shares(g->workers, has_work, errs, [&](size_t m) {
-        DeviceScope bind(g->members[m].device);
-        TuningScope tune(&g->members[m].engine->tuning);   // the member engine's own options, on whichever thread runs its share
+        auto& mem = g->members[m];
+        numa::BindScope place(mem.cpus);
+        timespec c0{}, c1{};
+        (void)clock_gettime(CLOCK_THREAD_CPUTIME_ID, &c0);
+        const auto w0 = std::chrono::steady_clock::now();
+        struct Account {   // also when the share throws
+            ocrs_engine_group::Member& mem; timespec& c0; timespec& c1; std::chrono::steady_clock::time_point w0; size_t n; bool bound;
+            ~Account() {
+                (void)clock_gettime(CLOCK_THREAD_CPUTIME_ID, &c1);
+                mem.shares++;
+                mem.pages += n;
+                mem.bound_shares += bound ? 1 : 0;
+                mem.cpu_ns += (uint64_t)((c1.tv_sec - c0.tv_sec) * 1000000000ll + (c1.tv_nsec - c0.tv_nsec));
+                mem.wall_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - w0).count();
+            }
+        } account{mem, c0, c1, w0, of_member[m].size(), place.bound()};
+        DeviceScope bind(mem.device);
+        TuningScope tune(&mem.engine->tuning);   // the member engine's own options, on whichever thread runs its share
         fn(m);
     });
 }
@@ -462,6 +489,15 @@ ocrs_status ocrs_engine_group_new(const ocrs_group_params* params, ocrs_engine_g
             ep.rec_max_pixels = params->rec_max_pixels;
             mem.engine = make_engine(ep);
             mem.engine->device = mem.device;   // (an engine without weights has nothing else to pin it to its device)
+            {   // where the member's host side should run: the NUMA node of its GPU (silent when the host does not say)
+                char bus[64] = {0};
+                if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, mem.device) == hipSuccess) {
+                    mem.numa_node = numa::node_of_pci(bus);
+                    if (!numa::cpus_of_node(mem.numa_node, &mem.cpus)) mem.cpus.clear();
+                } else {
+                    (void)hipGetLastError();
+                }
+            }
         }
         *out = g.release();
     });
@@ -698,6 +734,43 @@ ocrs_status ocrs_group_final_gather(ocrs_engine_group* g, ocrs_gather_mode mode,
         if (mode != OCRS_GATHER_AUTO && mode != OCRS_GATHER_HOST && mode != OCRS_GATHER_RCCL)
             fail(OCRS_ERR_INVALID_ARGUMENT, "unknown gather mode %d", (int)mode);
         gather_entry(g, mode, payloads, bytes, out, offsets);
+    });
+}
+
+ocrs_status ocrs_group_member_stats(const ocrs_engine_group* g, size_t m, uint64_t out[8]) {
+    return guarded([&] {
+        if (!g || !out || m >= g->size()) fail(OCRS_ERR_INVALID_ARGUMENT, "no such member");
+        const auto& mem = g->members[m];
+        out[0] = mem.shares.load(); out[1] = mem.pages.load(); out[2] = mem.cpu_ns.load(); out[3] = mem.wall_ns.load();
+        out[4] = (uint64_t)(mem.numa_node + 1);   // 0 = unknown
+        out[5] = mem.cpus.size();
+        out[6] = mem.bound_shares.load();
+        out[7] = (uint64_t)mem.device;
+    });
+}
+
+ocrs_status ocrs_numa_parse_cpulist(const char* list, int32_t* cpus, size_t capacity, size_t* n_cpus) {
+    return guarded([&] {
+        if (!list || !n_cpus) fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
+        std::vector<int> v;
+        if (!numa::parse_cpulist(list, &v)) fail(OCRS_ERR_INVALID_ARGUMENT, "malformed cpu list");
+        *n_cpus = v.size();
+        for (size_t i = 0; i < v.size() && i < capacity && cpus; i++) cpus[i] = v[i];
+    });
+}
+
+ocrs_status ocrs_numa_bind_selftest(const char* sysfs_root, const char* pci_bus_id, int* node, int* cpus_inside, int* cpus_after) {
+    return guarded([&] {
+        if (!node || !cpus_inside || !cpus_after) fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
+        const char* root = sysfs_root && *sysfs_root ? sysfs_root : "/sys";
+        *node = numa::node_of_pci(pci_bus_id, root);
+        std::vector<int> cpus;
+        if (!numa::cpus_of_node(*node, &cpus, root)) cpus.clear();
+        {
+            numa::BindScope place(cpus);
+            *cpus_inside = place.bound() ? numa::affinity_count() : -1;
+        }
+        *cpus_after = numa::affinity_count();
     });
 }
 

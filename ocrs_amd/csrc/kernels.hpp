@@ -65,6 +65,8 @@ struct GemmDesc {
     int batch; int64_t strideA, strideB, strideBias, strideC;
     // set by the launcher (gemm_tiled, dense A): 1-D grid, the column tiles of a row tile run side by side on one XCD
     int nfast = 0, nx = 0, ny = 0;
+    // relaxed / reduced numerics: B cut into bf16 terms (split_mfma.hpp split_weights), per batch strideBsplit uint16 apart; or null
+    const uint16_t* Bsplit = nullptr; int64_t strideBsplit = 0;
 };
 void gemm(const GemmDesc& d, hipStream_t s);
 // Direct conv (k x k, same padding, Cout % 4 == 0) for tiny contractions / odd shapes.
@@ -221,10 +223,10 @@ void avgpool_to_seq_ragged(const float* x, const RaggedView& in, const RaggedVie
 bool conv12_fused_ragged(const float* x, const RaggedView& in0, const RaggedView& mid, const float* w1, const float* b1,
                          int c1, const float* w2, const float* b2, int c2, float* y, const RaggedView& out, hipStream_t s);
 // returns false if the shape is not supported (caller falls back to the per-group path)
-// wsplit: the weights cut into bf16 terms (conv_split_weights) or null; used when the calling engine's numerics are relaxed
+// wsplit: the weights cut into bf16 terms (split_mfma.hpp split_weights) or null; used when the calling engine's numerics are not exact
 bool conv3x3_ragged(const float* x, const RaggedView& rv, int cin, const float* wt, const float* bias, int cout, int relu,
                     int ph, int pw, float* y, const RaggedView& out, hipStream_t s, const uint16_t* wsplit = nullptr);
-void conv_split_weights(const float* w_host, int K, int cout, std::vector<uint16_t>* out);   // host; cout % 128 == 0, K % 16 == 0
+void split_weights(const float* w_host, int K, int N, int ldw, std::vector<uint16_t>* out);   // host; N % 128 == 0, K % 16 == 0 (split_mfma.hpp)
 
 // ---- kernels_lines.hip ----------------------------------------------------
 struct LineDesc {      // one text line to crop (recognition.rs:91-126)

@@ -13,6 +13,7 @@
 // Built with -ffp-contract=off: an fma happens only where fmaf() is written.
 #include "common.hpp"
 #include "kernels.hpp"
+#include "split_mfma.hpp"
 #include "spec_math.hpp"
 
 namespace ocrs {
@@ -403,6 +404,104 @@ static void launch_gemm_tiled(const GemmDesc& d, hipStream_t s) {
     else hipLaunchKernelGGL((gemm_tiled_kernel<BN, false, false>), grid, dim3(256), lds, s, d);
 }
 
+// ---------------------------------------------------------------------------
+// Relaxed / reduced numerics (ocrs_engine_params.numerics) of the dense GEMM C = A . B + bias with pre-cut weights: the
+// GRU input projections.  Tiles, operand layout, arithmetic and pipeline: split_mfma.hpp.  A [M][lda] fp32 row-major,
+// d.Bsplit the weights' split image per batch, K % 64 == 0, N % 128 == 0.  1-D grid, the column tiles of a row tile side by
+// side on one XCD (as gemm_tiled_kernel's nfast form).
+// ---------------------------------------------------------------------------
+template <int NP>
+__global__ void __launch_bounds__(256, NP == 3 ? 2 : 3) gemm_split_kernel(GemmDesc d) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int PL = split::PLANE;
+    float* As = lds;                     // [2][NP][PLANE]
+    float* Bs = lds + 2 * NP * PL;       // [4][NP][PLANE]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int z = blockIdx.z;
+    const float* __restrict__ A = d.A + (int64_t)z * d.strideA;
+    const float* __restrict__ bias = d.bias ? d.bias + (int64_t)z * d.strideBias : nullptr;
+    float* __restrict__ C = d.C + (int64_t)z * d.strideC;
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int nblk = q % d.ny;
+    const int mblk = (q / d.ny) * 8 + xcd;
+    if (mblk >= d.nx) return;
+    const int64_t m0 = (int64_t)mblk * split::BM;
+    const int n0 = nblk * split::BN;
+    const int nchunks = d.K / split::BK;
+    const float* __restrict__ img = reinterpret_cast<const float*>(d.Bsplit + (int64_t)z * d.strideBsplit) +
+                                    (int64_t)nblk * nchunks * split::image_floats;
+    const int ar = tid >> 2, akq = tid & 3;
+    const float* arow[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        int64_t row = m0 + ar + 64 * j;
+        if (row >= d.M) row = d.M - 1;
+        arow[j] = A + row * d.lda + akq * 4;
+    }
+    split::f32x16s acc[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        const int col = n0 + wn * 64 + t * 32 + l31;
+        const float bv = bias ? bias[col] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) { acc[0][t][r] = bv; acc[1][t][r] = bv; }
+    }
+    split::pipeline<NP>(nchunks,
+        [&](int k0, split::f32x4s (&d0)[2], split::f32x4s (&d1)[2]) {
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                d0[j] = *reinterpret_cast<const split::f32x4s*>(arow[j] + k0);
+                d1[j] = *reinterpret_cast<const split::f32x4s*>(arow[j] + k0 + split::BK);
+            }
+        },
+        [&](int k0, int ring) { split::load_weights<NP>(img + (int64_t)(k0 / split::BK) * split::image_floats, Bs + ring * NP * PL, wave, lane); },
+        [&](int abuf, const split::f32x4s (&v)[2]) {
+            char* base = reinterpret_cast<char*>(As + abuf * NP * PL);
+#pragma unroll
+            for (int j = 0; j < 2; j++) split::commit4<NP>(base, ar + 64 * j, akq, v[j][0], v[j][1], v[j][2], v[j][3]);
+        },
+        [&](int abuf, int ring) {
+            split::mma_chunk<NP>(reinterpret_cast<const char*>(As + abuf * NP * PL), reinterpret_cast<const char*>(Bs + ring * NP * PL),
+                                 wm, wn, l31, half, acc);
+        });
+    // epilogue (32x32 C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5))
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            const int col = n0 + wn * 64 + t * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int64_t rr = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (rr >= d.M) continue;
+                float v = acc[i][t][r];
+                if (d.relu) v = v > 0.0f ? v : 0.0f;
+                C[rr * d.ldc + col] = v;
+            }
+        }
+}
+
+// false: the shape has no split form (the caller runs the exact kernel)
+static bool launch_gemm_split(const GemmDesc& d, int numerics, hipStream_t s) {
+    if (!d.Bsplit || d.im2col || d.convt || (d.K % 64) != 0 || (d.N % 128) != 0 || (d.lda & 3) != 0 || (((uintptr_t)d.A) & 15) != 0 ||
+        (d.strideA & 3) != 0 || d.M < 1) return false;
+    GemmDesc e = d;
+    e.nx = (int)((d.M + split::BM - 1) / split::BM);
+    e.ny = d.N / split::BN;
+    const dim3 grid((unsigned)((e.nx + 7) / 8 * 8 * e.ny), 1, (unsigned)(d.batch > 0 ? d.batch : 1));
+    static std::atomic<uint64_t> ok3{0}, ok2{0};
+    if (numerics == 2) {
+        allow_dynamic_lds(reinterpret_cast<const void*>(&gemm_split_kernel<2>), ok2);
+        hipLaunchKernelGGL((gemm_split_kernel<2>), grid, dim3(256), split::lds_bytes(2), s, e);
+    } else {
+        allow_dynamic_lds(reinterpret_cast<const void*>(&gemm_split_kernel<3>), ok3);
+        hipLaunchKernelGGL((gemm_split_kernel<3>), grid, dim3(256), split::lds_bytes(3), s, e);
+    }
+    return true;
+}
+
 template <int NT>
 static void launch_gemm(const GemmDesc& d, hipStream_t s) {
     dim3 grid((unsigned)((d.M + 127) / 128), (unsigned)((d.N + 32 * NT - 1) / (32 * NT)), (unsigned)(d.batch > 0 ? d.batch : 1));
@@ -520,6 +619,10 @@ static bool gemm_small_ok(const GemmDesc& d) {
 
 void gemm(const GemmDesc& d, hipStream_t s) {
     if (d.M <= 0 || d.N <= 0) return;
+    if (d.Bsplit && d.M >= 256) {   // relaxed / reduced numerics of the calling engine
+        const int numerics = option(OPT_NUMERICS);
+        if (numerics != 0 && launch_gemm_split(d, numerics, s)) return;
+    }
     if (gemm_small_ok(d)) {
         const dim3 grid((unsigned)((d.M + 127) / 128), (unsigned)((d.N + 31) / 32));
         const size_t lds = (size_t)d.K * 32 * sizeof(float);

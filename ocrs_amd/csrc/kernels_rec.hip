@@ -12,6 +12,7 @@
 
 #include "common.hpp"
 #include "kernels.hpp"
+#include "split_mfma.hpp"
 
 namespace ocrs {
 namespace k {
@@ -285,22 +286,9 @@ constexpr int RG_BM = 128, RG_BK = OCRS_CONV_BK, RG_LDA = RG_BM + 1;
 // FLAT: the patches of a group tile the strip of ALL its images side by side (flat column c = img * Wp + x, Wp = W
 // rounded up to PW) instead of each image on its own, so only the last patch of a GROUP is ragged, not the last
 // patch of every image (group widths are multiples of 50: W / 4 = 87, 112, 137 ... wasted 7 % of the MFMA rows).
-// SPLIT (the engine's relaxed / reduced numerics, BN = 128 only): the same patches, loads and epilogue, but the contraction
-// runs on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16, 16x the fp32 rate).  An fp32 value is cut into bf16 terms by
-// round-to-nearest (v_cvt_pk_bf16_f32) of the running residual: x = hi + mid + lo with |mid| <= 2^-8 |x|, |lo| <= 2^-16 |x|,
-// residual <= 2^-24 |x|; every bf16 x bf16 product is exact in the fp32 accumulator, the sum runs in the matrix core's own
-// order (NOT the numeric spec's k-ascending fmaf chain).
-//   SPLIT = 3 (relaxed): a.b ~ ah.bh + ah.bm + am.bh + am.bm + ah.bl + al.bh, dropped terms <= 2^-23 |a.b|: fp32-class
-//                        products; six bf16 MFMAs of K = 16 replace eight fp32 MFMAs of K = 2 (192 vs 512 pipe cycles);
-//   SPLIT = 2 (reduced): a.b ~ ah.bh + ah.bm + am.bh, dropped terms <= 1.5 x 2^-15 |a.b| (a 16-bit significand, between
-//                        fp16's 11 and fp32's 24 bits); three MFMAs, the lo planes are neither built nor loaded.
-// Measured (profiles/r5_relaxed_*): the relaxed kernel sustains 1.23 PFLOP/s of bf16 work — what the matrix pipe delivers
-// under the power budget on real data (MI355X_MICROARCH.md "DVFS give-back": 1.25 PFLOP/s for a tuned 8192^3 GEMM).
-//   A: cut by the thread that stages it (4 VALU per value, once per block instead of once per consuming wave), stored as
-//      three planes [row][16 k] of bf16, 32 bytes per row, the two 16-byte halves of a row swapped on rows with bit 3 set so
-//      that the 16-byte operand reads (lane = row, half of the wave = k half) are bank-conflict free;
-//   B: cut once when the model is loaded (conv_split_weights), laid out in global memory as the exact LDS image of every
-//      (column block, chunk): global_load_lds copies it without touching a register.
+// SPLIT = 3 / 2 (the engine's relaxed / reduced numerics, BN = 128 only): the same patches, activation loads and epilogue,
+// the contraction on the bf16 matrix cores with both operands cut into SPLIT bf16 terms — split_mfma.hpp has the arithmetic,
+// the LDS layout and the pipeline.  Bw is then the weights' split image (split_weights).
 template <int BN, int TW, int PH, int PW, bool FLAT, int SPLIT = 0>   // SPLIT: 0 exact; 3 / 2 = bf16 planes per operand (relaxed / reduced numerics)
 __global__ void __launch_bounds__(256, SPLIT == 3 ? 2 : SPLIT == 2 ? 3 : OCRS_CONV_WAVES)   // (split: 72 / 48 KB of LDS per block)
 conv3x3_ragged_kernel(const float* __restrict__ X, RaggedView rv, int cin, const float* __restrict__ Bw,
@@ -313,7 +301,7 @@ conv3x3_ragged_kernel(const float* __restrict__ X, RaggedView rv, int cin, const
     static_assert(!SPLIT || (BN == 128 && RG_BK == 16), "split mode: 128-column blocks, 16-deep chunks");
     constexpr int NP = SPLIT ? SPLIT : 1;               // bf16 planes per operand
     // exact: As [2][BK][LDA] fp32, Bs [2][BK][BN] fp32.  split: As [2][NP planes][128 rows][16 bf16], Bs [4][NP][128 columns][16]
-    constexpr int SP_PLANE = RG_BM * 8;                 // floats per plane (128 rows x 32 bytes)
+    constexpr int SP_PLANE = split::PLANE;              // floats per plane (128 rows x 32 bytes)
     float* As = lds;
     float* Bs = lds + (SPLIT ? 2 * NP * SP_PLANE : 2 * RG_BK * RG_LDA);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -423,14 +411,10 @@ conv3x3_ragged_kernel(const float* __restrict__ X, RaggedView rv, int cin, const
     // address): the [k][BN] tile is row-major and contiguous in LDS, so chunk element idx lands at float 4 * idx.
     // No staging registers and no ds_write for B; the barrier that ends the chunk drains the copies (vmcnt(0)).
     auto load_b = [&](int k0, int buf) {
-        if (SPLIT) {
+        if constexpr (SPLIT != 0) {
             // Bw = the split image: [column block][chunk][3 planes x 128 columns x 32 bytes] = 12 KB per (block, chunk)
-            const float* __restrict__ img = Bw + ((int64_t)blockIdx.y * (K / RG_BK) + k0 / RG_BK) * (3 * SP_PLANE);   // (the image always holds 3 planes)
-            float* bdst = Bs + buf * NP * SP_PLANE + wave * 256;
-#pragma unroll
-            for (int j = 0; j < NP; j++)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(img + 1024 * j + wave * 256 + lane * 4),
-                                                 (__attribute__((address_space(3))) void*)(bdst + 1024 * j), 16, 0, 0);
+            split::load_weights<NP>(Bw + ((int64_t)blockIdx.y * (K / RG_BK) + k0 / RG_BK) * split::image_floats,
+                                    Bs + buf * NP * SP_PLANE, wave, lane);
             return;
         }
         const float* __restrict__ bk = Bw + (int64_t)k0 * cout;
@@ -441,27 +425,10 @@ conv3x3_ragged_kernel(const float* __restrict__ X, RaggedView rv, int cin, const
                                              (__attribute__((address_space(3))) void*)(bdst + 1024 * j), 16, 0, 0);
     };
     auto commit = [&](int buf, const f32x4 (&pa)[AV]) {
-        if (SPLIT) {
-            // the thread's four consecutive k of row r -> 8 bytes in each plane
+        if constexpr (SPLIT != 0) {
             char* base = reinterpret_cast<char*>(As + buf * NP * SP_PLANE);
-            auto cut = [](float x0, float x1) { return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{x0, x1}, bf16x2)); };   // v_cvt_pk_bf16_f32 (RNE)
-            auto lo_f = [](unsigned pk) { return __uint_as_float(pk << 16); };
-            auto hi_f = [](unsigned pk) { return __uint_as_float(pk & 0xFFFF0000u); };
 #pragma unroll
-            for (int j = 0; j < AV; j++) {
-                const int r = ar + AROWS * j;
-                const int off = r * 32 + ((((akq >> 1) ^ (r >> 3)) & 1) << 4) + ((akq & 1) << 3);
-                const float x0 = pa[j][0], x1 = pa[j][1], x2 = pa[j][2], x3 = pa[j][3];
-                u32x2 ph = {cut(x0, x1), cut(x2, x3)};
-                const float r0 = x0 - lo_f(ph[0]), r1 = x1 - hi_f(ph[0]), r2 = x2 - lo_f(ph[1]), r3 = x3 - hi_f(ph[1]);   // exact
-                u32x2 pm = {cut(r0, r1), cut(r2, r3)};
-                *reinterpret_cast<u32x2*>(base + off) = ph;
-                *reinterpret_cast<u32x2*>(base + SP_PLANE * 4 + off) = pm;
-                if (NP == 3) {
-                    u32x2 pl = {cut(r0 - lo_f(pm[0]), r1 - hi_f(pm[0])), cut(r2 - lo_f(pm[1]), r3 - hi_f(pm[1]))};
-                    *reinterpret_cast<u32x2*>(base + 2 * SP_PLANE * 4 + off) = pl;
-                }
-            }
+            for (int j = 0; j < AV; j++) split::commit4<NP>(base, ar + AROWS * j, akq, pa[j][0], pa[j][1], pa[j][2], pa[j][3]);
             return;
         }
         float* a = As + buf * RG_BK * RG_LDA;
@@ -484,33 +451,9 @@ conv3x3_ragged_kernel(const float* __restrict__ X, RaggedView rv, int cin, const
         for (int r = 0; r < 16; r++) { acc[0][t][r] = bv; acc[1][t][r] = bv; }
     }
     auto compute = [&](int buf, int bbuf = -1) {
-        if (SPLIT) {
-            const char* abase = reinterpret_cast<const char*>(As + buf * NP * SP_PLANE);
-            const char* bbase = reinterpret_cast<const char*>(Bs + (bbuf < 0 ? buf : bbuf) * NP * SP_PLANE);
-            bf16x8 af[2][3], bfr[NTW][3];   // (planes NP.. unused)
-#pragma unroll
-            for (int i = 0; i < 2; i++) {
-                const int r = wm * 64 + i * 32 + l31;
-                const int off = r * 32 + (((half ^ (r >> 3)) & 1) << 4);
-#pragma unroll
-                for (int pl = 0; pl < NP; pl++) af[i][pl] = *reinterpret_cast<const bf16x8*>(abase + pl * SP_PLANE * 4 + off);
-            }
-#pragma unroll
-            for (int t = 0; t < NTW; t++) {
-                const int n = wn * (BN / 2) + t * 32 + l31;
-                const int off = n * 32 + (((half ^ (n >> 3)) & 1) << 4);
-#pragma unroll
-                for (int pl = 0; pl < NP; pl++) bfr[t][pl] = *reinterpret_cast<const bf16x8*>(bbase + pl * SP_PLANE * 4 + off);
-            }
-            // smallest terms first; consecutive MFMAs go to different accumulators (no back-to-back dependency)
-#define OCRS_TERM(PA, PB)                                                                                                   \
-            _Pragma("unroll") for (int t = 0; t < NTW; t++) {                                                               \
-                acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][PA], bfr[t][PB], acc[0][t], 0, 0, 0);             \
-                acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][PA], bfr[t][PB], acc[1][t], 0, 0, 0);             \
-            }
-            if (NP == 3) { OCRS_TERM(NP - 1, 0) OCRS_TERM(0, NP - 1) OCRS_TERM(1, 1) }
-            OCRS_TERM(1, 0) OCRS_TERM(0, 1) OCRS_TERM(0, 0)
-#undef OCRS_TERM
+        if constexpr (SPLIT != 0) {
+            split::mma_chunk<NP>(reinterpret_cast<const char*>(As + buf * NP * SP_PLANE),
+                                 reinterpret_cast<const char*>(Bs + (bbuf < 0 ? buf : bbuf) * NP * SP_PLANE), wm, wn, l31, half, acc);
             return;
         }
         const float* a = As + buf * RG_BK * RG_LDA + wm * 64 + l31;
@@ -528,63 +471,13 @@ conv3x3_ragged_kernel(const float* __restrict__ X, RaggedView rv, int cin, const
         }
     };
     const int nchunks = K / RG_BK;  // even: cin % (2*RG_BK) == 0
-    if (SPLIT) {
-        // A chunk's matrix work is 2.7x shorter than in the exact kernel (768 pipe cycles per wave) while the memory latencies
-        // are what they were, so a one-chunk look-ahead no longer covers them (first version, one chunk ahead and
-        // __syncthreads: 1.57x the fp32 kernel, the matrix pipe half idle).  Here the weights travel three chunks ahead
-        // through a ring of four LDS buffers and the activations two to three chunks ahead in two register sets (one per
-        // chunk pair, used alternately); a half-step ends with the bare barrier instruction behind COUNTED waits — only the
-        // copies of the chunk that is consumed next have to have landed, the younger ones stay in flight (vmcnt retires in
-        // order: "at most N outstanding" = everything older than the N youngest has arrived).
-        f32x4 sa[2][2][AV];                     // [set = pair parity][chunk of the pair][row pass]
-        // VMEM instructions per weight chunk: NP (one global_load_lds per plane); per activation pair: 2 * AV = 4 buffer loads.
-        // s_waitcnt immediates (gfx9 encoding: vmcnt = bits 3:0 and 15:14, expcnt = bits 6:4, lgkmcnt = bits 11:8):
-        static_assert(AV == 2, "the counted waits below assume four activation loads per chunk pair");
-#define OCRS_END_HALF(VMCNT_IMM)                                                                                  \
-        do {                                                                                                      \
-            if (tail) __builtin_amdgcn_s_waitcnt(0x0070);            /* vmcnt(0) lgkmcnt(0) */                   \
-            else { __builtin_amdgcn_s_waitcnt(VMCNT_IMM); __builtin_amdgcn_s_waitcnt(0xC07F); /* lgkmcnt(0) */ } \
-            __builtin_amdgcn_s_barrier();                                                                         \
-        } while (0)
-        // B(c+1) landed — younger: B(c+2) NP, A(p+1) 4, B(c+3) NP;  B(c+2) landed — younger: A(p+1) 4, B(c+3) NP, B(c+4) NP, A(p+2) 4
-        constexpr int kWaitB1 = 0x0F70 | (NP == 3 ? 10 : 8);    // vmcnt(10) / vmcnt(8)
-        constexpr int kWaitB2 = 0x0F70 | (NP == 3 ? 14 : 12);   // vmcnt(14) / vmcnt(12)
-        const int npairs = nchunks / 2;         // even (cin % 64 == 0: the host checks)
-        // prologue, issued in the order of the steady state so that the counted waits below hold from the first half-step on
-        load_a_into(0, sa[0][0], sa[0][1]);
-        load_b(0, 0);
-        commit(0, sa[0][0]);
-        { const bool tail = true; OCRS_END_HALF(0); }
-        load_b(1 * RG_BK, 1);
-        load_b(2 * RG_BK, 2);
-        load_a_into(2 * RG_BK, sa[1][0], sa[1][1]);
-        for (int p = 0; p < npairs; p += 2) {
-            const int c = 2 * p;
-            const bool tail = c + 4 >= nchunks;   // the last iteration skips loads: counted waits would be too lax — drain instead
-            // pair p (set 0), even chunk c: ring 0 -> fetch ring 3
-            if (c + 3 < nchunks) load_b((c + 3) * RG_BK, 3);
-            compute(0, 0);
-            commit(1, sa[0][1]);
-            OCRS_END_HALF(kWaitB1);
-            // odd chunk c+1: ring 1 -> fetch ring 0; commit chunk c+2 (pair p+1, set 1); set 0 is free: fetch pair p+2 into it
-            if (c + 4 < nchunks) load_b((c + 4) * RG_BK, 0);
-            compute(1, 1);
-            commit(0, sa[1][0]);
-            if (p + 2 < npairs) load_a_into((c + 4) * RG_BK, sa[0][0], sa[0][1]);
-            OCRS_END_HALF(kWaitB2);
-            // pair p+1 (set 1), even chunk c+2: ring 2 -> fetch ring 1
-            if (c + 5 < nchunks) load_b((c + 5) * RG_BK, 1);
-            compute(0, 2);
-            commit(1, sa[1][1]);
-            OCRS_END_HALF(kWaitB1);
-            // odd chunk c+3: ring 3 -> fetch ring 2; commit chunk c+4 (pair p+2, set 0); fetch pair p+3 into set 1
-            if (c + 6 < nchunks) load_b((c + 6) * RG_BK, 2);
-            compute(1, 3);
-            if (p + 2 < npairs) commit(0, sa[0][0]);
-            if (p + 3 < npairs) load_a_into((c + 6) * RG_BK, sa[1][0], sa[1][1]);
-            OCRS_END_HALF(kWaitB2);
-        }
-#undef OCRS_END_HALF
+    if constexpr (SPLIT != 0) {
+        static_assert(AV == 2, "split::pipeline counts four activation loads per chunk pair");
+        split::pipeline<NP>(nchunks,   // nchunks % 4 == 0 (cin % 64 == 0: the host checks)
+                            [&](int k0, f32x4 (&d0)[AV], f32x4 (&d1)[AV]) { load_a_into(k0, d0, d1); },
+                            [&](int k0, int ring) { load_b(k0, ring); },
+                            [&](int abuf, const f32x4 (&d)[AV]) { commit(abuf, d); },
+                            [&](int abuf, int ring) { compute(abuf, ring); });
     } else {
     load_a_pair(0);
     load_b(0, 0);
@@ -877,10 +770,9 @@ bool conv12_fused_ragged(const float* x, const RaggedView& in0, const RaggedView
 
 // rv carries the 2-D tiling of the INPUT geometry (toff2d / ntiles2d / tw); `out` is the geometry after the
 // fused pool (== rv when ph == pw == 1).  Returns false if the shape is not supported.
-// The split image of a [K][cout] weight matrix (conv3x3_ragged_kernel, SPLIT): per (128-column block, 16-row chunk) three
-// planes (hi, mid, lo) of [column][16 k] bf16 with the swizzle of the LDS layout.  cout % 128 == 0, K % 16 == 0.
-void conv_split_weights(const float* w, int K, int cout, std::vector<uint16_t>* out) {
-    const int nblk = cout / 128, nch = K / 16;
+// (split_mfma.hpp) the split image of a row-major [K][N] weight matrix with row pitch ldw
+void split_weights(const float* w, int K, int N, int ldw, std::vector<uint16_t>* out) {
+    const int nblk = N / 128, nch = K / 16;
     out->assign((size_t)nblk * nch * 3 * 128 * 16, 0);
     auto bits = [](float f) { uint32_t u; memcpy(&u, &f, 4); return u; };
     auto from = [](uint32_t u) { float f; memcpy(&f, &u, 4); return f; };
@@ -890,7 +782,7 @@ void conv_split_weights(const float* w, int K, int cout, std::vector<uint16_t>* 
             uint16_t* img = out->data() + ((size_t)nb * nch + c) * 3 * 128 * 16;
             for (int n = 0; n < 128; n++)
                 for (int kl = 0; kl < 16; kl++) {
-                    const float x = w[(size_t)(c * 16 + kl) * cout + nb * 128 + n];
+                    const float x = w[(size_t)(c * 16 + kl) * ldw + nb * 128 + n];
                     const uint32_t hb = rne(x);
                     const float r1 = x - from(hb << 16);          // exact
                     const uint32_t mb = rne(r1);
@@ -922,7 +814,7 @@ bool conv3x3_ragged(const float* x, const RaggedView& rv, int cin, const float* 
     // relaxed numerics (ocrs_engine_params.numerics): the bf16-split contraction, where the model carries the split weights
     const int numerics = option(OPT_NUMERICS);   // 0 exact, 1 relaxed (three bf16 planes), 2 reduced (two)
     const bool split = wsplit && !n64 && (cout % 128) == 0 && (cin % 64) == 0 && numerics != 0;
-    const size_t lds = split ? (size_t)((2 + 4) * (numerics == 2 ? 2 : 3) * RG_BM * 8) * sizeof(float)   // A: 2 buffers, B: ring of 4; 4 KB per plane
+    const size_t lds = split ? split::lds_bytes(numerics == 2 ? 2 : 3)   // A: 2 buffers, B: ring of 4; 4 KB per plane
                              : (size_t)(2 * RG_BK * RG_LDA + 2 * RG_BK * (n64 ? 64 : 128)) * sizeof(float);
     const dim3 grid(ntiles, (cout + (n64 ? 63 : 127)) / (n64 ? 64 : 128));
 #define OCRS_LAUNCH_SPLIT(TW_, PH_, PW_, FLAT_, NP_, SLOT_)                                                              \

@@ -164,16 +164,30 @@ std::unique_ptr<HipModel> HipModel::load(const void* data, size_t len, int devic
     }
     // Relaxed numerics (ocrs_engine_params.numerics): the 3x3 convs of a recognition stack whose contraction can run on the
     // bf16 matrix cores carry their weights a second time, cut into three bf16 terms in the kernel's LDS layout
-    // (kernels_rec.hip conv_split_weights; 1.5x the fp32 bytes, a few MB per model).
+    // (split_mfma.hpp split_weights; 1.5x the fp32 bytes, a few MB per model).
     for (uint32_t i = 0; i < hd.n_ops; i++) {
         GraphOp& op = m->ops[i];
         if (m->kind == 1 && op.type == OP_CONV && op.kh == 3 && op.kw == 3 && (op.cin % 32) == 0 && (op.cout % 128) == 0) {
             std::vector<uint16_t> img;
-            k::conv_split_weights(slab.data() + fops[i].w[0].off, 9 * op.cin, op.cout, &img);
+            k::split_weights(slab.data() + fops[i].w[0].off, 9 * op.cin, op.cout, op.cout, &img);
             m->tapes.emplace_back(img.size() * sizeof(uint16_t));
             OCRS_HIP(hipMemcpy(m->tapes.back().p, img.data(), img.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
             op.wsplit = m->tapes.back().as<uint16_t>();
         }
+    }
+    // the same for the GRU input projections ([I][3H] per direction; derived tensor aux0 = [2][I][3H] in the slab)
+    for (const Fix& fx : fixes) {
+        GraphOp& op = m->ops[fx.op];
+        if (fx.which != 0 || op.type != OP_GRU || (op.cin % 64) != 0 || ((3 * op.hidden) % 128) != 0) continue;
+        std::vector<uint16_t> both;
+        for (int dir = 0; dir < 2; dir++) {
+            std::vector<uint16_t> img;
+            k::split_weights(slab.data() + fx.off + (size_t)dir * op.cin * 3 * op.hidden, op.cin, 3 * op.hidden, 3 * op.hidden, &img);
+            both.insert(both.end(), img.begin(), img.end());
+        }
+        m->tapes.emplace_back(both.size() * sizeof(uint16_t));
+        OCRS_HIP(hipMemcpy(m->tapes.back().p, both.data(), both.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+        op.wsplit = m->tapes.back().as<uint16_t>();
     }
     // Fold SIGMOID into a directly preceding Cout==1 pointwise conv.
     for (size_t i = 0; i + 1 < m->ops.size(); i++) {
@@ -1073,6 +1087,7 @@ int HipModel::run_recognition_packed(Workspace& ws, const std::vector<PackedGrou
             d.A = cur; d.lda = I; d.B = op.aux0; d.ldb = 3 * H; d.bias = op.aux1; d.C = gx; d.ldc = 3 * H;
             d.M = (int)R; d.N = 3 * H; d.K = I; d.batch = 2;
             d.strideA = 0; d.strideB = (int64_t)I * 3 * H; d.strideBias = 3 * H; d.strideC = R * 3 * H;
+            d.Bsplit = op.wsplit; d.strideBsplit = (int64_t)(3 * H / 128) * (I / 16) * 3 * 128 * 16;   // (uint16 units per direction)
             const double gx_flops = 2.0 * 2 * R * (double)d.N * d.K, gx_bytes = 4.0 * ((double)R * I + 2.0 * R * d.N + 2.0 * d.K * d.N);
             // (round 3's option gx_heavy queued these projections on the conv-stack stream: every MFMA class then ran at its
             // alone speed at the same or slightly lower pages/s — a zero-sum trade, removed in round 5)

@@ -191,3 +191,31 @@ def test_oracle_reproduces_the_cheap_stages_of_the_reference_image_goldens(name)
     lines = OL.find_text_lines(words)
     assert np.array_equal(np.cumsum([0] + [len(l) for l in lines]), g["line_offsets"])
     assert np.array_equal(np.array([x.to_array() for l in lines for x in l], np.float32).reshape(-1, 6), g["line_rects"])
+
+
+@pytest.mark.parametrize("name,angle", [("why-rust", 3), ("polar-bears", -10), ("rust-book", 90), ("polar-bears", 90), ("why-rust", -10)])
+def test_oracle_reproduces_the_cheap_stages_of_the_rotated_page_goldens(name, angle):
+    """tests/golden/rotated/ (make_golden_rotated.py): the rotated pixels are rebuilt with the same PIL call and their CRC
+    checked; grey conversion, mask -> contours -> rotated rects and the line grouping re-derived with the oracle."""
+    import sys
+    import zlib
+    from oracle import clib
+    from oracle.geometry import RotatedRect
+    from oracle import layout as OL
+    sys.path.insert(0, G)
+    from make_golden_rotated import rotated_pixels
+    g = np.load(os.path.join(G, "rotated", "%s_%+d.npz" % (name, angle)))
+    base = np.load(os.path.join(G, "reference", name + ".npz"))
+    px = rotated_pixels(base["pixels"], name, angle)
+    if zlib.crc32(px.tobytes()) != int(g["pixel_crc"][0]):
+        pytest.skip("this PIL build resamples differently from the one that made the fixture")
+    grey = OP.prepare_image(OP.ImageSource.from_tensor(px, "hwc"))
+    assert _bits_sum(grey) == int(g["grey_bits_sum"][0])
+    h, w = [int(v) for v in g["mask_shape"]]
+    mask = np.unpackbits(g["mask"])[: h * w].reshape(h, w).astype(np.uint8)
+    rects = clib.component_rects(mask, 3.0, 100.0)
+    assert np.array_equal(np.asarray(rects, np.float32).reshape(-1, 6), g["word_rects"])
+    words = [RotatedRect.from_array(r) for r in g["word_rects"]]
+    lines = OL.find_text_lines(words)
+    assert np.array_equal(np.cumsum([0] + [len(l) for l in lines]), g["line_offsets"])
+    assert np.array_equal(np.array([x.to_array() for l in lines for x in l], np.float32).reshape(-1, 6), g["line_rects"])

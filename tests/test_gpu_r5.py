@@ -119,3 +119,68 @@ def test_pools_stay_bounded_over_requests_of_varied_sizes():
         assert st["device_cap"] == cap_dev and st["pinned_cap"] == cap_pin
     finally:
         _lib.pool_configure(device_cached_cap=base["device_cap"], pinned_cached_cap=base["pinned_cap"])
+
+
+# ------------------------------------------------------------------ rotated / skewed pages end to end
+ROT_CASES = [(n, a) for n in ("why-rust", "polar-bears", "rust-book") for a in (3, -3, 10, -10, 90)]
+
+
+def _rot_case(name, angle):
+    import sys
+    import zlib
+    sys.path.insert(0, GOLD)
+    from make_golden_rotated import rotated_pixels
+    g = np.load(os.path.join(GOLD, "rotated", "%s_%+d.npz" % (name, angle)))
+    base = np.load(os.path.join(GOLD, "reference", name + ".npz"))
+    px = rotated_pixels(base["pixels"], name, angle)
+    if zlib.crc32(px.tobytes()) != int(g["pixel_crc"][0]) or px.shape != tuple(g["pixel_shape"]):
+        pytest.skip("this PIL build resamples differently from the one that made the fixture")
+    dbuf, rbuf = M.detection_model_bytes(ink=tuple(g["ink"])), M.recognition_model_bytes()
+    assert [M.digest(dbuf), M.digest(rbuf)] == list(g["model_digests"]), "synthetic model files changed: re-run make_golden_rotated.py"
+    return g, px, OcrEngine(detection_model=Model.load_bytes(dbuf), recognition_model=Model.load_bytes(rbuf))
+
+
+def _bits_sum(a):
+    return int(np.frombuffer(np.ascontiguousarray(a).tobytes(), np.uint32).sum(dtype=np.uint64))
+
+
+@pytest.mark.parametrize("name,angle", ROT_CASES)
+def test_rotated_page_through_the_one_page_api_equals_the_oracle_golden(name, angle):
+    """The reference's images rotated by +-3, +-10 and 90 degrees (tests/golden/make_golden_rotated.py): word rects with real
+    `up` vectors, lines grouped along a slope (or in vertical columns at 90 degrees), slanted line polygons, crops resampled
+    from rotated boxes, char boxes cut from slanted polygons — every stage equal to the oracle's exact golden."""
+    g, px, eng = _rot_case(name, angle)
+    inp = eng.prepare_input(ImageSource.from_tensor(px, DimOrder.Hwc))
+    assert _bits_sum(inp.image()) == int(g["grey_bits_sum"][0])
+    prob = eng.detect_text_pixels(inp)
+    assert prob.shape == tuple(g["mask_shape"])
+    assert np.array_equal(np.packbits(prob > np.float32(eng.detection_threshold())), g["mask"])
+    assert _bits_sum(prob) == int(g["prob_bits_sum"][0])
+    words = eng.detect_words(inp)
+    assert np.array_equal(words, g["word_rects"])
+    up = words[:, 2:4]
+    if angle != 90 and len(words) > 20:
+        assert np.count_nonzero(np.abs(up[:, 0]) > 0.02) > len(words) // 2      # the rects really are rotated
+    lines = eng.find_text_lines(inp, words)
+    assert np.array_equal(np.cumsum([0] + [len(l) for l in lines]), g["line_offsets"])
+    assert np.array_equal(np.concatenate(lines) if lines else np.zeros((0, 6), np.float32), g["line_rects"])
+    for i, (shape, bits) in enumerate(zip(g["crop_shapes"], g["crop_bits_sums"])):
+        crop = eng.prepare_recognition_input(inp, lines[i])
+        assert crop.shape == tuple(shape) and _bits_sum(crop) == int(bits), (name, angle, i)
+    toks = eng.recognize_tokens(inp, lines)
+    assert np.array_equal(np.array([t for ts in toks for t in ts], np.int32).reshape(-1, 2), g["tokens"])
+    assert np.array_equal(np.cumsum([0] + [len(t) for t in toks]), g["token_offsets"])
+    assert eng.get_text(inp) == str(g["text"][0])
+
+
+@pytest.mark.parametrize("name,angle", [("why-rust", 3), ("polar-bears", -10), ("rust-book", 90), ("polar-bears", 90)])
+def test_rotated_page_through_the_batch_api_equals_the_oracle_golden(name, angle):
+    """Three copies of a rotated page in one batch request: golden word rects, line grouping and char boxes for every copy."""
+    from test_gpu_bench_scale import _check_page_against_golden
+    g, px, eng = _rot_case(name, angle)
+    inputs = [eng.prepare_input(ImageSource.from_tensor(px, DimOrder.Hwc)) for _ in range(3)]
+    words = eng.detect_words_batch(inputs)
+    rects, loffs, poffs = eng.find_text_lines_batch_raw(words)
+    chars, coffs = eng.recognize_text_batch_raw(inputs, rects, loffs, poffs)
+    for pi in range(3):
+        _check_page_against_golden(g, words[pi], rects, loffs, int(poffs[pi]), int(poffs[pi + 1]), chars, coffs)

@@ -479,3 +479,35 @@ def test_every_option_of_the_library_is_documented_in_the_header(lib):
         body = open(os.path.join(root, "ocrs_amd", "csrc", f)).read()
         n = len(re.findall(r"\bgetenv\(", body))
         assert n <= {"common.cpp": 2, "group.cpp": 1}.get(f, 0), (f, n)
+
+
+def test_numa_placement_helpers_parse_bind_and_restore(lib, tmp_path):
+    """numa.hpp behind ocrs_group_member_stats: sysfs cpu lists, the node of a PCI device from a (fake) sysfs tree, and the
+    scope that binds a member's share to its GPU's node and puts the thread's mask back — silently doing nothing when the
+    host does not say (node -1, no file, CPUs outside the thread's mask)."""
+    n, arr = C.c_size_t(0), (C.c_int32 * 32)()
+    assert lib.ocrs_numa_parse_cpulist(b"0-3,8,10-11\n", arr, 32, C.byref(n)) == 0 and list(arr)[: n.value] == [0, 1, 2, 3, 8, 10, 11]
+    assert lib.ocrs_numa_parse_cpulist(b"", None, 0, C.byref(n)) == 0 and n.value == 0
+    assert lib.ocrs_numa_parse_cpulist(b"0-255", None, 0, C.byref(n)) == 0 and n.value == 256     # cpus may be NULL: count only
+    for bad in (b"3-1", b"a", b"1,,2", b"1-", b"70000"):
+        assert lib.ocrs_numa_parse_cpulist(bad, None, 0, C.byref(n)) == 1, bad
+    mine = sorted(os.sched_getaffinity(0))
+    root = tmp_path / "sys"
+    dev = root / "bus" / "pci" / "devices" / "0000:c1:00.0"
+    dev.mkdir(parents=True)
+    (dev / "numa_node").write_text("1\n")
+    node1 = root / "devices" / "system" / "node" / "node1"
+    node1.mkdir(parents=True)
+    (node1 / "cpulist").write_text("%d\n" % mine[0])
+    node, inside, after = C.c_int(-9), C.c_int(0), C.c_int(0)
+    assert lib.ocrs_numa_bind_selftest(str(root).encode(), b"0000:C1:00.0", C.byref(node), C.byref(inside), C.byref(after)) == 0
+    assert (node.value, inside.value, after.value) == (1, 1, len(mine))          # bound to the one CPU inside, restored after
+    assert sorted(os.sched_getaffinity(0)) == mine
+    (node1 / "cpulist").write_text("4000-4001\n")                                  # CPUs this thread may not use: no binding
+    assert lib.ocrs_numa_bind_selftest(str(root).encode(), b"0000:c1:00.0", C.byref(node), C.byref(inside), C.byref(after)) == 0
+    assert (node.value, inside.value, after.value) == (1, -1, len(mine))
+    (dev / "numa_node").write_text("-1\n")                                         # single-node hosts say -1
+    assert lib.ocrs_numa_bind_selftest(str(root).encode(), b"0000:c1:00.0", C.byref(node), C.byref(inside), C.byref(after)) == 0
+    assert (node.value, inside.value) == (-1, -1)
+    assert lib.ocrs_numa_bind_selftest(str(root).encode(), b"0000:99:00.0", C.byref(node), C.byref(inside), C.byref(after)) == 0
+    assert (node.value, inside.value, after.value) == (-1, -1, len(mine))         # unknown device
