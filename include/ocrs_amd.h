@@ -139,6 +139,10 @@ OCRS_API ocrs_status ocrs_device_pool_stats(int device, uint64_t out[12]);
  * OCRS_POOL_CAP_GB, read once per device, overrides) and 1 GiB of pinned host memory.  Blocks above a cap are returned
  * to the driver by a background thread, never on a request's thread (hipFree waits for the device). */
 OCRS_API ocrs_status ocrs_device_pool_configure(int device, uint64_t device_cached_cap_bytes, uint64_t pinned_cached_cap_bytes);
+/* Gives back what the library holds for re-use on `device`: every cached block and the activation arena the recognition conv
+ * stacks of all requests share (kept at the size of the largest request seen).  Bytes in use afterwards = weights, pages the
+ * caller still holds, requests in flight.  Waits for the conv stacks in flight; for idle moments, not for the request path. */
+OCRS_API ocrs_status ocrs_device_pool_trim(int device);
 
 /* ------------------------------------------------------------------------
  * L2 seam: `trait Model` (ocrs/src/model.rs:6-17) and its rten impl

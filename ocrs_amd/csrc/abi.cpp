@@ -149,6 +149,19 @@ ocrs_status ocrs_device_pool_stats(int device, uint64_t out[12]) {
     });
 }
 
+ocrs_status ocrs_device_pool_trim(int device) {
+    return guarded([&] {
+        DeviceContext& c = device_context(device < 0 ? default_device() : device);
+        DeviceScope bind(c.device);
+        {   // the conv stacks' shared activation arena (kept at its high-water mark between requests): no request may be inside
+            std::lock_guard<std::mutex> heavy(c.heavy_phase);
+            OCRS_HIP(hipStreamSynchronize(c.heavy_stream()));
+            c.heavy_arena.clear();
+        }
+        c.pool.trim();
+    });
+}
+
 ocrs_status ocrs_device_pool_configure(int device, uint64_t device_cached_cap_bytes, uint64_t pinned_cached_cap_bytes) {
     return guarded([&] {
         DeviceContext& c = device_context(device < 0 ? default_device() : device);

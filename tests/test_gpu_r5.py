@@ -100,7 +100,8 @@ def test_pools_stay_bounded_over_requests_of_varied_sizes():
         words = eng.detect_words(inp)
         return words, eng.recognize_tokens(inp, eng.find_text_lines(inp, words))
     ref = [run(px) for px in cases]
-    base = _lib.pool_stats()
+    _lib.pool_trim()
+    base = _lib.pool_stats()          # weights only: nothing cached, no activation arena
     cap_dev, cap_pin = 256 << 20, 8 << 20
     _lib.pool_configure(device_cached_cap=cap_dev, pinned_cached_cap=cap_pin)
     try:
@@ -113,8 +114,10 @@ def test_pools_stay_bounded_over_requests_of_varied_sizes():
                 st = _lib.pool_stats()
                 peak_cached = max(peak_cached, st["device_cached"])
                 assert st["device_cached"] <= cap_dev and st["pinned_cached"] <= cap_pin, st
+        _lib.pool_trim()                 # cached blocks and the conv stacks' shared arena (kept at its high-water mark) given back
         st = _lib.pool_stats()
         assert st["device_live"] <= base["device_live"] + (1 << 20) and st["pinned_live"] <= base["pinned_live"] + (1 << 16), (base, st)
+        assert st["device_cached"] == 0
         assert st["device_driver_frees"] > base["device_driver_frees"]      # the cap was reached and blocks went back
         assert st["device_cap"] == cap_dev and st["pinned_cap"] == cap_pin
     finally:
