@@ -67,6 +67,8 @@ def parse(argv=None):
     ap.add_argument("--numerics", choices=("exact", "relaxed", "reduced"), default="exact",
                     help="ocrs_engine_params.numerics of the timed engine (the headline is exact; the default run reports "
                          "the other two as extras)")
+    ap.add_argument("--coalesce", type=int, default=0,
+                    help="ocrs_engine_params.coalesce: merged batches of one-page calls in flight per stage (0 = default 2, -1 = off)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pages", type=int, default=2, help="pages in the bounded CPU-baseline sample")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -246,7 +248,7 @@ def main():
         devices = [int(x) for x in args.devices.split(",")] if args.devices else list(range(args.gpus))
         group = EngineGroup(devices, models.synthetic_detection_bytes(), models.synthetic_recognition_bytes(),
                             gather="rccl" if args.gather == "rccl" else "host", layout_threads=layout_threads_for(per_rank_cores),
-                            numerics=args.numerics)
+                            numerics=args.numerics, coalesce=args.coalesce)
         engine = group.member(0)[0]     # stage / kernel timers: member 0's
         G = len(devices)
     else:
@@ -254,7 +256,7 @@ def main():
         det = Model.load_bytes(models.synthetic_detection_bytes())
         rec = Model.load_bytes(models.synthetic_recognition_bytes())
         engine = OcrEngine(detection_model=det, recognition_model=rec, layout_threads=layout_threads_for(per_rank_cores),
-                           numerics=args.numerics)
+                           numerics=args.numerics, coalesce=args.coalesce)
         G = 1
 
     # ---- synthetic pages, resident in HBM before the timed region (in group mode: a step's pages in contiguous blocks of

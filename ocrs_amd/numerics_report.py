@@ -5,7 +5,8 @@ identical, detection logits and recognition log-probs within a tolerance).
 Everything goes through the public API of `OcrEngine`; used by bench.py (extras.relaxed), tools/relaxed_report.py and the
 `-m gpu` tests.  A "flip" is an output that differs between the two modes:
     box flips    word rects that differ (any of the 6 floats), or a differing number of words
-    token flips  recognised lines whose greedy-CTC (label, position) sequence differs
+    token flips  recognised lines whose greedy-CTC (label, position) sequence differs; label flips: lines whose LABEL sequence (the
+                 decoded text) differs, with the edit distance between the two sequences
     char-box flips  characters whose decoded rect differs (lines with equal tokens only)
 """
 import numpy as np
@@ -20,10 +21,21 @@ def _finite_absdiff(a, b):
     return (float(np.max(np.abs(a[both] - b[both]))) if both.any() else 0.0), odd
 
 
+def _edit_distance(a, b):
+    """Levenshtein distance between two label sequences."""
+    prev = list(range(len(b) + 1))
+    for i, x in enumerate(a, 1):
+        cur = [i]
+        for j, y in enumerate(b, 1):
+            cur.append(min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (x != y)))
+        prev = cur
+    return prev[-1]
+
+
 def compare_page(exact, relaxed, inp, lines=None, want_prob_map=True):
     """One prepared page (OcrInput) through both engines.  lines: use these text lines (lists of word rects) instead of
     detecting them (recognition-only inputs)."""
-    out = {"words": 0, "box_flips": 0, "lines": 0, "tokens": 0, "token_flip_lines": 0, "label_flips": 0, "chars": 0, "char_box_flips": 0,
+    out = {"words": 0, "box_flips": 0, "lines": 0, "tokens": 0, "token_flip_lines": 0, "label_flip_lines": 0, "label_edits": 0, "chars": 0, "char_box_flips": 0,
            "max_abs_dlogprob": 0.0, "nonfinite_mismatch": 0, "max_abs_dprob_map": 0.0, "flipped": []}
     if lines is None:
         we, wr = exact.detect_words(inp), relaxed.detect_words(inp)
@@ -47,7 +59,9 @@ def compare_page(exact, relaxed, inp, lines=None, want_prob_map=True):
         if a != b:
             out["token_flip_lines"] += 1
             la, lb = [x[0] for x in a], [x[0] for x in b]
-            out["label_flips"] += sum(1 for x, y in zip(la, lb) if x != y) + abs(len(la) - len(lb))
+            if la != lb:   # the decoded TEXT differs (otherwise only the time step a token is attributed to moved)
+                out["label_flip_lines"] += 1
+                out["label_edits"] += _edit_distance(la, lb)
             if len(out["flipped"]) < 8:
                 out["flipped"].append({"line": i, "exact": a[:40], "relaxed": b[:40]})
         same.append(a == b)

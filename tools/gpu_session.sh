@@ -1,6 +1,6 @@
 #!/bin/bash
 # One gpurun call = one session: tools/gpu_session.sh <tag> <section>...   (outputs under gpurun_out/<tag>/)
-# Sections: tests_new tests_r3 tests_all ab lat serial16 det detprof detpmc full multi group stream stream10k conc single prof pmc
+# Sections: tests_new tests_r3 tests_all ab lat serial16 det detprof detpmc full multi group stream stream10k conc single prof pmc relaxedprof
 set -u
 export TMPDIR=/tmp
 TAG=$1; shift
@@ -90,7 +90,7 @@ single)
   while IFS='|' read -r envs infl; do
     [ -z "$infl" ] && continue
     tag=$(echo "$envs$infl" | tr -c 'A-Za-z0-9' '_')
-    env $envs timeout 300 python bench.py --pages 1 --inflight $infl --steps 360 --warmup 36 --settle-s 1 --no-cpu-baseline --no-extras > $OUT/bench_single_$tag.json 2> $OUT/bench_single_$tag.err; rc=$?
+    eval "$envs"; timeout 300 python bench.py ${BENCH_EXTRA:-} --pages 1 --inflight $infl --steps 360 --warmup 36 --settle-s 1 --no-cpu-baseline --no-extras > $OUT/bench_single_$tag.json 2> $OUT/bench_single_$tag.err; rc=$?
     say "[$envs] inflight=$infl rc=$rc"; jsum $OUT/bench_single_$tag.json "[$envs] inflight=$infl"
     [ $rc -ne 0 ] && tail -2 $OUT/bench_single_$tag.err | cut -c1-300 | tee -a $S
     python - $OUT/bench_single_$tag.json <<'PY' | tee -a $S
@@ -100,9 +100,9 @@ try:
 except Exception as e: print("parse failed", e)
 PY
   done <<EOF_SINGLE
-${SINGLE_CASES:-OCRS_COALESCE=2|12
-OCRS_COALESCE=0|12
-OCRS_COALESCE=2|24}
+${SINGLE_CASES:-BENCH_EXTRA=--coalesce=2|12
+BENCH_EXTRA=--coalesce=-1|12
+BENCH_EXTRA=--coalesce=2|24}
 EOF_SINGLE
   ;;
 stream10k)
@@ -135,6 +135,14 @@ pmc)
   (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE -d $ROOT/$OUT/pmc -o mfma -- $BENCH > $ROOT/$OUT/pmc_mfma.log 2>&1); say "mfma rc=$?"
   python tools/pmc_summary.py $OUT/pmc $OUT/${TAG}_pmc_hbm.txt $OUT/${TAG}_pmc.json > /dev/null 2>$OUT/pmc_summary.err; head -40 $OUT/${TAG}_pmc_hbm.txt | cut -c1-220 | tee -a $S
   find $OUT/pmc -size +30M -delete;;
+relaxedprof)
+  say "== rocprofv3 kernel trace, serial 16 pages, numerics relaxed and reduced (isolated kernels of the split matrix path)"
+  for m in relaxed reduced; do
+    (cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats -d $ROOT/$OUT/prof -o serial_$m -- python $ROOT/bench.py --numerics $m --steps 3 --warmup 1 --settle-s 0 --inflight 1 --no-pipeline --no-cpu-baseline --no-extras --no-kernel-timing > /dev/null 2> $ROOT/$OUT/prof_serial_$m.err); say "$m rc=$?"
+    db=$(find $OUT/prof -name "serial_${m}*.db" | head -1)
+    [ -n "$db" ] && python tools/rocprof_summary.py "$db" $OUT/${TAG}_${m}_serial_kernel_stats.txt > /dev/null && head -14 $OUT/${TAG}_${m}_serial_kernel_stats.txt | cut -c1-200 | tee -a $S
+  done
+  find $OUT/prof -size +30M -delete;;
 conc)
   say "== small requests in flight: 1 and 2 pages per request, 6 and 12 in flight (gate-per-wave GRU kernel under concurrency)"
   for a in "--pages 1 --inflight 6" "--pages 1 --inflight 12" "--pages 2 --inflight 6"; do
