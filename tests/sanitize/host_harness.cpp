@@ -12,6 +12,7 @@
 //   host_harness text_items                text_item_rotated_rect (text_items.cpp) on random character boxes
 //   host_harness jpeg <streams.bin>        the JPEG marker parser and Huffman decoders (jpeg_host.cpp) on valid, truncated and
 //                                          corrupted streams: every one must come back as coefficients or as an ocrs::Error
+#include "../../ocrs_amd/csrc/numa.hpp"
 #include <cinttypes>
 #include <cstdio>
 #include <cstdlib>
@@ -226,6 +227,50 @@ static int run_jpeg(const char* path) {
     return check(decoded > 0, "at least the intact streams decode");
 }
 
+// numa.hpp: cpu-list parsing on hostile strings and BindScope from several threads at once (each binds to one of the CPUs the
+// process may use and must find its own mask restored).
+static int run_numa() {
+    using namespace ocrs::numa;
+    std::vector<int> v;
+    const char* good[] = {"0-3,8,10-11\n", "", "7", " 1 , 2 ", "0-0"};
+    const char* bad[] = {"3-1", "a", "1,,2", "1-", "70000", "-1", "1-2-3", ","};
+    for (const char* g : good) if (!parse_cpulist(g, &v)) return check(false, "a good cpu list was refused");
+    for (const char* b : bad) if (parse_cpulist(b, &v)) return check(false, "a malformed cpu list was accepted");
+    if (parse_cpulist(nullptr, &v)) return check(false, "null list accepted");
+    std::mt19937 rng(7);
+    for (int i = 0; i < 20000; i++) {   // random bytes from the list alphabet: must never crash or loop
+        std::string sx;
+        const int n = rng() % 24;
+        for (int k = 0; k < n; k++) sx.push_back("0123456789,- \n"[rng() % 15]);
+        (void)parse_cpulist(sx.c_str(), &v);
+        if (v.size() > 70000) return check(false, "implausible cpu count");
+    }
+    if (node_of_pci("0000:ff:1f.7", "/nonexistent") != -1 || cpus_of_node(0, &v, "/nonexistent")) return check(false, "missing sysfs must mean unknown");
+    cpu_set_t mine;
+    if (sched_getaffinity(0, sizeof mine, &mine) != 0) return check(true, "no affinity call here: nothing to test");
+    std::vector<int> allowed;
+    for (int c = 0; c < CPU_SETSIZE; c++) if (CPU_ISSET(c, &mine)) allowed.push_back(c);
+    std::atomic<int> wrong{0};
+    std::vector<std::thread> th;
+    for (int t = 0; t < 8; t++)
+        th.emplace_back([&, t] {
+            for (int i = 0; i < 200; i++) {
+                const int before = affinity_count();
+                {
+                    BindScope b({allowed[(t + i) % allowed.size()]});
+                    if (b.bound() && affinity_count() != 1) wrong++;
+                    BindScope none(std::vector<int>{});          // empty list: no binding
+                    BindScope outside({CPU_SETSIZE - 1 == allowed.back() ? -5 : CPU_SETSIZE - 1});   // a CPU we may not use: no binding
+                    if (none.bound() || outside.bound()) wrong++;
+                }
+                if (affinity_count() != before) wrong++;
+            }
+        });
+    for (auto& x : th) x.join();
+    printf("numa: %zu cpus allowed, %d wrong\n", allowed.size(), wrong.load());
+    return check(wrong.load() == 0, "bind scopes restore the thread's mask");
+}
+
 int main(int argc, char** argv) {
     const std::string mode = argc > 1 ? argv[1] : "";
     int bad = 0;
@@ -234,8 +279,9 @@ int main(int argc, char** argv) {
     else if (mode == "layout" && argc > 3) bad = run_layout(argv[2], atoi(argv[3]));
     else if (mode == "beam") bad = run_beam();
     else if (mode == "text_items") bad = run_text_items();
+    else if (mode == "numa") bad = run_numa();
     else if (mode == "jpeg" && argc > 2) bad = run_jpeg(argv[2]);
-    else { fprintf(stderr, "usage: host_harness coalescer|shares|layout <pages.bin> <threads>|beam|text_items|jpeg <streams.bin>\n"); return 2; }
+    else { fprintf(stderr, "usage: host_harness coalescer|shares|layout <pages.bin> <threads>|beam|text_items|numa|jpeg <streams.bin>\n"); return 2; }
     printf("%s: %s\n", mode.c_str(), bad ? "FAILED" : "ok");
     return bad ? 1 : 0;
 }

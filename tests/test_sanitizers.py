@@ -54,7 +54,7 @@ SAN = ["thread", "address,undefined"]
 
 
 @pytest.mark.parametrize("kind", SAN)
-@pytest.mark.parametrize("mode", ["coalescer", "shares", "beam", "text_items"])
+@pytest.mark.parametrize("mode", ["coalescer", "shares", "beam", "text_items", "numa"])
 def test_host_code_is_clean_under_sanitizers(kind, mode):
     assert mode + ": ok" in run(kind, mode)
 
