@@ -220,5 +220,27 @@ def test_export_for_reference_tool_runs_end_to_end(tmp_path):
     spec.loader.exec_module(mod)
     mod.main(str(tmp_path))
     names = sorted(p.name for p in tmp_path.iterdir())
-    assert names == ["det.ocrsm", "det.onnx", "page.png", "rec.ocrsm", "rec.onnx"]
+    refs = ("polar-bears", "rust-book", "why-rust")
+    assert names == sorted(["det.ocrsm", "det.onnx", "page.png", "rec.ocrsm", "rec.onnx", "check_against_reference.sh", "compare_json.py"] +
+                           [f % n for n in refs for f in ("%s.png", "%s.expected.json", "det_%s.onnx", "det_%s.ocrsm")])
     assert (tmp_path / "rec.onnx").stat().st_size > 9_000_000 and (tmp_path / "page.png").stat().st_size > 100_000
+    # round 5: what this engine's spec gives for the reference's own images, in the reference CLI's JSON format, and the
+    # comparison script a maintainer with cargo runs against `ocrs --json`
+    import json
+    import subprocess
+    import sys
+    exp = json.load(open(tmp_path / "why-rust.expected.json"))
+    g = np.load(os.path.join(root, "tests", "golden", "reference", "why-rust.npz"))
+    lines = exp["paragraphs"][0]["lines"]
+    assert (exp["image_height"], exp["image_width"]) == g["pixels"].shape[:2]
+    assert "\n".join(l["text"] for l in lines) == str(g["text"][0])
+    assert all(len(l["vertices"]) == 4 and all(len(w["vertices"]) == 4 for w in l["words"]) for l in lines)
+    same = subprocess.run([sys.executable, str(tmp_path / "compare_json.py"), str(tmp_path / "why-rust.expected.json"),
+                           str(tmp_path / "why-rust.expected.json")], capture_output=True, text=True)
+    assert same.returncode == 0 and "OK: %d lines identical" % len(lines) in same.stdout
+    lines[3]["text"] += "x"
+    lines[5]["words"][0]["vertices"][0][0] += 1
+    json.dump(exp, open(tmp_path / "changed.json", "w"))
+    diff = subprocess.run([sys.executable, str(tmp_path / "compare_json.py"), str(tmp_path / "why-rust.expected.json"),
+                           str(tmp_path / "changed.json")], capture_output=True, text=True)
+    assert diff.returncode == 1 and "line 3 text" in diff.stdout and "line 5 word 0" in diff.stdout
