@@ -220,8 +220,11 @@ void to_seq_packed_ragged(const float* x, const RaggedView& in, int c, const int
 void avgpool_to_seq_ragged(const float* x, const RaggedView& in, const RaggedView& seq, int c, const int32_t* d_pos,
                            const int32_t* d_off, float* y, hipStream_t s);
 // conv1 (Cin = 1) + ReLU + pool 2x2 + conv2 + ReLU + pool 2x2 in one launch; false = not this shape (run the two ops)
+// w2split: conv2's weights cut into bf16 terms (conv12_split_weights) or null; used when the calling engine's numerics are not exact
 bool conv12_fused_ragged(const float* x, const RaggedView& in0, const RaggedView& mid, const float* w1, const float* b1,
-                         int c1, const float* w2, const float* b2, int c2, float* y, const RaggedView& out, hipStream_t s);
+                         int c1, const float* w2, const float* b2, int c2, float* y, const RaggedView& out, hipStream_t s,
+                         const uint16_t* w2split = nullptr);
+void conv12_split_weights(const float* w2_host /* [288][64] */, std::vector<uint16_t>* out);   // host
 // returns false if the shape is not supported (caller falls back to the per-group path)
 // wsplit: the weights cut into bf16 terms (split_mfma.hpp split_weights) or null; used when the calling engine's numerics are not exact
 bool conv3x3_ragged(const float* x, const RaggedView& rv, int cin, const float* wt, const float* bias, int cout, int relu,

@@ -754,8 +754,235 @@ conv12_fused_kernel(const float* __restrict__ X0, RaggedView in0, RaggedView mid
         }
 }
 
+// ---------------------------------------------------------------------------
+// The same launch with conv2's contraction on the bf16 matrix cores (relaxed / reduced numerics, split_mfma.hpp): conv1 is
+// computed exactly as above (fp32 VALU, the spec's chain) and CUT as it is written — the tile holds NP planes of
+// [position][32 channels] bf16 instead of fp32 values — conv2's weights come pre-cut from the model (conv12_split_weights:
+// per tap, per plane, [64 columns][32 k]), one tap (K = 32, two MFMA k-steps) per barrier through a ring of three LDS
+// buffers.  Tile rows are 20 positions apart (18 used) and the 16-byte slot of a position's 64-byte row is XORed with
+// (hx >> 2) & 3; the weight rows with (n >> 2) & 3: both operand reads (ds_read_b128, lane = pixel or column, half-wave = k
+// half) are bank-conflict free for every tap.
+// ---------------------------------------------------------------------------
+constexpr int F12S_RS = 20;                                   // tile row stride in positions
+constexpr int F12S_TILE = F12_HH * F12S_RS * 64;              // bytes per plane of the tile
+constexpr int F12S_BTAP = F12_COUT * 64;                      // bytes per plane of one tap's weights
+constexpr size_t f12s_lds(int np) { return (size_t)np * (F12S_TILE + 3 * F12S_BTAP); }   // 74.4 KB (NP 3) / 49.6 KB (NP 2)
+
+template <int NP>
+__global__ void __launch_bounds__(256, NP == 3 ? 2 : 3)
+conv12_fused_split_kernel(const float* __restrict__ X0, RaggedView in0, RaggedView mid, const float* __restrict__ w1,
+                          const float* __restrict__ b1, const uint16_t* __restrict__ Bimg, const float* __restrict__ bias,
+                          float* __restrict__ Y, const int64_t* __restrict__ out_poff) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int BN = F12_COUT, TW = F12_TW, TH = F12_TH;
+    char* T = reinterpret_cast<char*>(lds);                  // [NP][HH * RS][64 B]
+    char* Bs = T + NP * F12S_TILE;                           // [3 taps][NP][64 columns][64 B]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int gtile = xcd_remap(blockIdx.x, gridDim.x);
+    const int g = find_group(mid.toff2d_gap, mid.G, gtile);
+    const int tile = gtile - mid.toff2d_gap[g];
+    const int H = mid.H, W = mid.W[g];
+    const int H0 = in0.H, W0 = in0.W[g];
+    const int tiles_h = H / TH;
+    const int Wg = (W + 2) & ~1;
+    const int nimg = mid.n[g];
+    const int rb = tile % tiles_h;
+    const int c0 = (tile / tiles_h) * TW;
+    const int img = c0 / Wg;
+    const int x0 = c0 - img * Wg;
+    const int span = min(nimg - img, (x0 + TW - 1) / Wg + 1);
+    const int y0 = rb * TH;
+
+    // conv2 weights of tap t -> ring buffer t % 3: NP planes of 4 KB, one 16-byte piece per thread and plane
+    auto load_b = [&](int tap) {
+        const char* src = reinterpret_cast<const char*>(Bimg) + (size_t)tap * 3 * F12S_BTAP;     // (the image always holds 3 planes)
+        char* dst = Bs + (tap % 3) * NP * F12S_BTAP;
+#pragma unroll
+        for (int p = 0; p < NP; p++)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + p * F12S_BTAP + wave * 1024 + lane * 16),
+                                             (__attribute__((address_space(3))) void*)(dst + p * F12S_BTAP + wave * 1024), 16, 0, 0);
+    };
+    load_b(0);
+    load_b(1);
+
+    // ---- stage 1: conv1 + ReLU + pool for the halo positions (the exact kernel's arithmetic), cut into the planes
+    {
+        const int q = tid & 7;
+        f32x2 wq[9][2], bq[2];
+#pragma unroll
+        for (int t = 0; t < 9; t++)
+#pragma unroll
+            for (int c = 0; c < 2; c++) wq[t][c] = f32x2{w1[t * F12_MID + 4 * q + 2 * c], w1[t * F12_MID + 4 * q + 2 * c + 1]};
+#pragma unroll
+        for (int c = 0; c < 2; c++) bq[c] = f32x2{b1[4 * q + 2 * c], b1[4 * q + 2 * c + 1]};
+        const float* __restrict__ xg = X0 + in0.poff[g];
+        auto cut = [](float a, float b) { return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, bf16x2)); };
+        auto lo_f = [](unsigned pk) { return __uint_as_float(pk << 16); };
+        auto hi_f = [](unsigned pk) { return __uint_as_float(pk & 0xFFFF0000u); };
+        for (int p = tid >> 3; p < F12_NPOS; p += 32) {
+            const int hy = p / F12_HW, hx = p - hy * F12_HW;
+            const int y = y0 - 1 + hy;
+            int x = x0 - 1 + hx, ir = 0;
+#pragma unroll
+            for (int k = 0; k < 3; k++) { const bool nx = x >= Wg; x -= nx ? Wg : 0; ir += nx; }
+            f32x2 m[2] = {f32x2{0.0f, 0.0f}, f32x2{0.0f, 0.0f}};
+            if ((unsigned)y < (unsigned)H && x >= 0 && x < W && ir < span) {
+                const float* xi = xg + (int64_t)(img + ir) * H0 * W0;
+                float pt[4][4];
+                const int iy0 = 2 * y - 1, ix0 = 2 * x - 1;
+                if (iy0 >= 0 && iy0 + 3 < H0 && ix0 >= 0 && ix0 + 3 < W0) {
+                    const float* pp = xi + (int64_t)iy0 * W0 + ix0;
+#pragma unroll
+                    for (int a = 0; a < 4; a++)
+#pragma unroll
+                        for (int b = 0; b < 4; b++) pt[a][b] = pp[a * W0 + b];
+                } else {
+#pragma unroll
+                    for (int a = 0; a < 4; a++)
+#pragma unroll
+                        for (int b = 0; b < 4; b++) {
+                            const int iy = iy0 + a, ix = ix0 + b;
+                            pt[a][b] = ((unsigned)iy < (unsigned)H0 && (unsigned)ix < (unsigned)W0) ? xi[(int64_t)iy * W0 + ix] : 0.0f;
+                        }
+                }
+#pragma unroll
+                for (int py = 0; py < 2; py++)
+#pragma unroll
+                    for (int px = 0; px < 2; px++) {
+                        f32x2 acc[2] = {bq[0], bq[1]};
+#pragma unroll
+                        for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+                            for (int kx = 0; kx < 3; kx++) {
+                                const float xs = pt[py + ky][px + kx];
+                                const f32x2 xv = f32x2{xs, xs};
+#pragma unroll
+                                for (int c = 0; c < 2; c++) acc[c] = __builtin_elementwise_fma(xv, wq[ky * 3 + kx][c], acc[c]);
+                            }
+#pragma unroll
+                        for (int c = 0; c < 2; c++) m[c] = (py == 0 && px == 0) ? acc[c] : __builtin_elementwise_max(acc[c], m[c]);
+                    }
+#pragma unroll
+                for (int c = 0; c < 2; c++) {
+                    m[c].x = m[c].x > 0.0f ? m[c].x : 0.0f;
+                    m[c].y = m[c].y > 0.0f ? m[c].y : 0.0f;
+                }
+            }
+            // channels 4q .. 4q + 3 of position (hy, hx): 8 bytes per plane, slot (q >> 1) ^ ((hx >> 2) & 3)
+            const int off = (hy * F12S_RS + hx) * 64 + ((((q >> 1) ^ (hx >> 2)) & 3) << 4) + ((q & 1) << 3);
+            u32x2 ph = {cut(m[0].x, m[0].y), cut(m[1].x, m[1].y)};
+            const float r0 = m[0].x - lo_f(ph[0]), r1 = m[0].y - hi_f(ph[0]), r2 = m[1].x - lo_f(ph[1]), r3 = m[1].y - hi_f(ph[1]);
+            u32x2 pm = {cut(r0, r1), cut(r2, r3)};
+            *reinterpret_cast<u32x2*>(T + off) = ph;
+            *reinterpret_cast<u32x2*>(T + F12S_TILE + off) = pm;
+            if (NP == 3) {
+                u32x2 pl = {cut(r0 - lo_f(pm[0]), r1 - hi_f(pm[0])), cut(r2 - lo_f(pm[1]), r3 - hi_f(pm[1]))};
+                *reinterpret_cast<u32x2*>(T + 2 * F12S_TILE + off) = pl;
+            }
+        }
+    }
+
+    // ---- stage 2: conv2 on the bf16 matrix cores
+    f32x16 acc[2];
+    {
+        const float bv = bias[wn * 32 + l31];
+#pragma unroll
+        for (int r = 0; r < 16; r++) { acc[0][r] = bv; acc[1][r] = bv; }
+    }
+    const int mx = l31 & 15;
+    int pos0[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int m = wm * 64 + i * 32 + l31;
+        pos0[i] = (m / TW) * F12S_RS + mx;
+    }
+    const int nb = wn * 32 + l31;
+    const int boff = nb * 64, bsw = (nb >> 2) & 3;
+    __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) lgkmcnt(0): taps 0 and 1 landed, this thread's tile writes done
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int tap = 0; tap < 9; tap++) {
+        if (tap + 2 < 9) load_b(tap + 2);
+        const int ky = tap / 3, kx = tap % 3;
+        const int asw = ((mx + kx) >> 2) & 3;
+        const char* bb = Bs + (tap % 3) * NP * F12S_BTAP + boff;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; s2++) {
+            const int qa = (((2 * s2 + half) ^ asw) & 3) << 4, qb = (((2 * s2 + half) ^ bsw) & 3) << 4;
+            bf16x8 af[2][3], bfr[3];
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int p = 0; p < NP; p++) af[i][p] = *reinterpret_cast<const bf16x8*>(T + p * F12S_TILE + (pos0[i] + ky * F12S_RS + kx) * 64 + qa);
+#pragma unroll
+            for (int p = 0; p < NP; p++) bfr[p] = *reinterpret_cast<const bf16x8*>(bb + p * F12S_BTAP + qb);
+#define OCRS_TERM12(PA, PB)                                                                                   \
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][PA], bfr[PB], acc[0], 0, 0, 0);            \
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][PA], bfr[PB], acc[1], 0, 0, 0);
+            if (NP == 3) { OCRS_TERM12(NP - 1, 0) OCRS_TERM12(0, NP - 1) OCRS_TERM12(1, 1) }
+            OCRS_TERM12(1, 0) OCRS_TERM12(0, 1) OCRS_TERM12(0, 0)
+#undef OCRS_TERM12
+        }
+        // the next tap's weights must have landed (the tap after it, just requested, may stay in flight); every wave is
+        // done with this tap's buffer before it is overwritten two taps from now
+        if (tap + 2 < 9) __builtin_amdgcn_s_waitcnt(0x0F70 | NP);   // vmcnt(NP)
+        else __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0)
+        __builtin_amdgcn_s_barrier();
+    }
+
+    // ---- epilogue: as conv12_fused_kernel
+    const int Ho = H / 2, Wo = W / 2;
+    float* __restrict__ C = Y + (out_poff[g] + (int64_t)img * Ho * Wo) * BN;
+    auto act = [&](float v) { return v > 0.0f ? v : 0.0f; };
+    const int col = wn * 32 + l31;
+    int xo_off[8];
+#pragma unroll
+    for (int jx = 0; jx < 8; jx++) {
+        if (jx & 1) { xo_off[jx] = -1; continue; }
+        int x = x0 + (jx & 3) + 8 * (jx >> 2) + 4 * half, ir = 0;
+#pragma unroll
+        for (int k = 0; k < 3; k++) { const bool nx = x >= Wg; x -= nx ? Wg : 0; ir += nx; }
+        xo_off[jx] = (x + 1 < W && ir < span) ? (ir * Ho * Wo + x / 2) * BN : -1;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int r = 0; r < 8; r += 2) {
+            if (xo_off[r & 7] < 0) continue;
+            const float m = act(__builtin_fmaxf(__builtin_fmaxf(acc[i][r], acc[i][r + 1]), __builtin_fmaxf(acc[i][r + 8], acc[i][r + 9])));
+            const int yo = (y0 + 4 * wm + 2 * i) / 2;
+            C[xo_off[r & 7] + yo * Wo * BN + col] = m;
+        }
+}
+
+// conv2's weights [9 taps x 32 channels][64 columns] for conv12_fused_split_kernel: per tap three planes (hi, mid, lo) of
+// [column][32 k] bf16, the 16-byte slots of a column's 64-byte row XORed with (column >> 2) & 3.  Host.
+void conv12_split_weights(const float* w, std::vector<uint16_t>* out) {
+    out->assign((size_t)9 * 3 * F12_COUT * 32, 0);
+    auto bits = [](float f) { uint32_t u; memcpy(&u, &f, 4); return u; };
+    auto from = [](uint32_t u) { float f; memcpy(&f, &u, 4); return f; };
+    auto rne = [&](float f) { const uint32_t u = bits(f); return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16; };
+    for (int tap = 0; tap < 9; tap++)
+        for (int n = 0; n < F12_COUT; n++)
+            for (int k = 0; k < 32; k++) {
+                const float x = w[(size_t)(tap * 32 + k) * F12_COUT + n];
+                const uint32_t hb = rne(x);
+                const float r1 = x - from(hb << 16);
+                const uint32_t mb = rne(r1);
+                const uint32_t lb = rne(r1 - from(mb << 16));
+                const size_t e = (size_t)n * 32 + (size_t)((((k >> 3) ^ (n >> 2)) & 3) * 8) + (k & 7);
+                uint16_t* img = out->data() + (size_t)tap * 3 * F12_COUT * 32;
+                img[e] = (uint16_t)hb;
+                img[F12_COUT * 32 + e] = (uint16_t)mb;
+                img[2 * F12_COUT * 32 + e] = (uint16_t)lb;
+            }
+}
+
 bool conv12_fused_ragged(const float* x, const RaggedView& in0, const RaggedView& mid, const float* w1, const float* b1,
-                         int c1, const float* w2, const float* b2, int c2, float* y, const RaggedView& out, hipStream_t s) {
+                         int c1, const float* w2, const float* b2, int c2, float* y, const RaggedView& out, hipStream_t s,
+                         const uint16_t* w2split) {
     // x == nullptr: only asks whether the shape has this kernel
     if (option(OPT_CONV12_FUSE) == 0) return false;
     if (c1 != F12_MID || c2 != F12_COUT || mid.H % F12_TH != 0 || in0.H != 2 * mid.H || out.H * 2 != mid.H) return false;
@@ -764,6 +991,18 @@ bool conv12_fused_ragged(const float* x, const RaggedView& in0, const RaggedView
     if (mid.max_tile_px_ * 4 * (int64_t)sizeof(float) >= (int64_t)1 << 30 ||
         mid.max_tile_px_ * F12_COUT * (int64_t)sizeof(float) >= (int64_t)1 << 30) return false;
     if (!x) return true;
+    const int numerics = option(OPT_NUMERICS);
+    if (numerics != 0 && w2split) {   // relaxed / reduced: conv2's contraction on the bf16 matrix cores
+        static std::atomic<uint64_t> ok3{0}, ok2{0};
+        if (numerics == 2) {
+            allow_dynamic_lds(reinterpret_cast<const void*>(&conv12_fused_split_kernel<2>), ok2);
+            hipLaunchKernelGGL((conv12_fused_split_kernel<2>), dim3(mid.ntiles2d_gap), dim3(256), f12s_lds(2), s, x, in0, mid, w1, b1, w2split, b2, y, out.poff);
+        } else {
+            allow_dynamic_lds(reinterpret_cast<const void*>(&conv12_fused_split_kernel<3>), ok3);
+            hipLaunchKernelGGL((conv12_fused_split_kernel<3>), dim3(mid.ntiles2d_gap), dim3(256), f12s_lds(3), s, x, in0, mid, w1, b1, w2split, b2, y, out.poff);
+        }
+        return true;
+    }
     hipLaunchKernelGGL(conv12_fused_kernel, dim3(mid.ntiles2d_gap), dim3(256), F12_LDS, s, x, in0, mid, w1, b1, w2, b2, y, out.poff);
     return true;
 }

@@ -174,6 +174,14 @@ std::unique_ptr<HipModel> HipModel::load(const void* data, size_t len, int devic
             OCRS_HIP(hipMemcpy(m->tapes.back().p, img.data(), img.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
             op.wsplit = m->tapes.back().as<uint16_t>();
         }
+        // conv2 of the fused conv1 + conv2 launch (32 -> 64 channels): its own image (one tap per barrier)
+        if (m->kind == 1 && op.type == OP_CONV && op.kh == 3 && op.kw == 3 && op.cin == 32 && op.cout == 64) {
+            std::vector<uint16_t> img;
+            k::conv12_split_weights(slab.data() + fops[i].w[0].off, &img);
+            m->tapes.emplace_back(img.size() * sizeof(uint16_t));
+            OCRS_HIP(hipMemcpy(m->tapes.back().p, img.data(), img.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+            op.wsplit = m->tapes.back().as<uint16_t>();
+        }
     }
     // the same for the GRU input projections ([I][3H] per direction; derived tensor aux0 = [2][I][3H] in the slab)
     for (const Fix& fx : fixes) {
@@ -910,7 +918,7 @@ float* HipModel::run_prefix_ragged(Workspace& ws, hipStream_t exec, const std::v
                 // counted as conv2's launch with conv2's FLOPs (the matrix-core work); conv1's VALU work rides along
                 timed(KC_GEMM_CONV3X3, 2.0 * vmid.pixels * 9.0 * op2.cin * op2.cout,
                       4.0 * (vin.pixels + vout.pixels * op2.cout) + 4.0 * op2.wcount[0],
-                      [&] { k::conv12_fused_ragged(cur, vin, vmid, op.w[0], op.w[1], op.cout, op2.w[0], op2.w[1], op2.cout, y2, vout, st); });
+                      [&] { k::conv12_fused_ragged(cur, vin, vmid, op.w[0], op.w[1], op.cout, op2.w[0], op2.w[1], op2.cout, y2, vout, st, op2.wsplit); });
                 y = y2;
                 ybytes = (size_t)vout.pixels * op2.cout * sizeof(float);
                 curC = op2.cout;

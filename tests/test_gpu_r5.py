@@ -77,6 +77,18 @@ def test_relaxed_numerics_keep_boxes_and_tokens_and_stay_within_the_logprob_tole
     assert tot["token_flip_lines"] <= max(1, tot["lines"] // 1000) and tot["label_flip_lines"] == 0, tot["flipped"]
     assert tot["char_box_flips"] <= tot["token_flip_lines"] * 4
     assert 0.0 < tot["max_abs_dlogprob"] < LOGPROB_TOL
+    # the other kernel selections under relaxed / reduced numerics (unfused conv1 + conv2, per-image conv patches, per-step GRU):
+    # same tokens as the exact engine on page 0
+    det, rec = Model.load_bytes(M.detection_model_bytes()), Model.load_bytes(M.recognition_model_bytes())
+    i0 = exact.prepare_input(ImageSource.from_tensor(pages[0], DimOrder.Hwc))
+    lines0 = exact.find_text_lines(i0, exact.detect_words(i0))
+    want = exact.recognize_tokens(i0, lines0)
+    for mode in ("relaxed", "reduced"):
+        for opts in ({"conv12_fuse": 0}, {"conv_flat": 0}, {"gru_mode": 1}, {"gru_gates": 0, "gru_local": 0}):
+            alt = OcrEngine(detection_model=det, recognition_model=rec, numerics=mode, options=opts)
+            got = alt.recognize_tokens(i0, lines0)
+            differ = sum(1 for a, b in zip(got, want) if [x[0] for x in a] != [x[0] for x in b])
+            assert differ <= (0 if mode == "relaxed" else 1), (mode, opts, differ)
     # the exact engine is still exact: page 0 against the oracle's golden fixture
     g = np.load(os.path.join(GOLD, "bench_page_seed0.npz"))
     i0 = exact.prepare_input(ImageSource.from_tensor(pages[0], DimOrder.Hwc))
