@@ -135,6 +135,19 @@ pmc)
   (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE -d $ROOT/$OUT/pmc -o mfma -- $BENCH > $ROOT/$OUT/pmc_mfma.log 2>&1); say "mfma rc=$?"
   python tools/pmc_summary.py $OUT/pmc $OUT/${TAG}_pmc_hbm.txt $OUT/${TAG}_pmc.json > /dev/null 2>$OUT/pmc_summary.err; head -40 $OUT/${TAG}_pmc_hbm.txt | cut -c1-220 | tee -a $S
   find $OUT/pmc -size +30M -delete;;
+group8)
+  say "== eight members on this one GPU (devices 0 x 8, 2 pages per member per step = the 16-page step), final gather through the librccl test double, against the single engine on the same box"
+  STUB=$(python -c "import sys; sys.path.insert(0, 'tests'); import stub_util; print(stub_util.rccl_stub_path())")
+  for rep in 1 2; do
+    timeout 300 python bench.py --steps 36 --warmup 12 --no-cpu-baseline --no-extras > $OUT/bench_single_$rep.json 2> $OUT/bench_single_$rep.err; jsum $OUT/bench_single_$rep.json "single engine"
+    OCRS_RCCL_LIB=$STUB timeout 300 python bench.py --gpus 8 --devices 0,0,0,0,0,0,0,0 --pages 2 --gather rccl-final --steps 36 --warmup 12 --no-cpu-baseline --no-extras > $OUT/bench_group8_$rep.json 2> $OUT/bench_group8_$rep.err; jsum $OUT/bench_group8_$rep.json "group 0x8"
+  done
+  python - $OUT/bench_group8_2.json <<'PY' | tee -a $S
+import json, sys
+d = json.loads([l for l in open(sys.argv[1]).read().splitlines() if l.startswith("{")][-1])
+print("   members:", json.dumps(d.get("members"))[:1200]); print("   final_gather:", d.get("final_gather"))
+PY
+  ;;
 relaxedprof)
   say "== rocprofv3 kernel trace, serial 16 pages, numerics relaxed and reduced (isolated kernels of the split matrix path)"
   for m in relaxed reduced; do
