@@ -100,11 +100,14 @@ static size_t round_size(size_t n) {
 // ---- the trimmer: one detached thread per process that returns memory to the driver.  hipFree / hipHostFree wait for
 // the device to go idle, which under load takes as long as the queued work: a request's thread never pays that.
 namespace {
+struct Trimmer;
+Trimmer& trimmer();
 struct Trimmer {
     std::mutex mu;
     std::condition_variable cv;
     std::deque<std::pair<int, void*>> q;   // (device or -1 for pinned host memory, pointer)
     bool started = false;
+    std::atomic<bool> exiting{false};   // set by an atexit handler: the HIP runtime may be tearing down, leave the blocks to the OS
     void run() {
         for (;;) {
             std::pair<int, void*> it;
@@ -114,6 +117,7 @@ struct Trimmer {
                 it = q.front();
                 q.pop_front();
             }
+            if (exiting.load()) continue;
             if (it.first >= 0) {
                 if (hipSetDevice(it.first) == hipSuccess) (void)hipFree(it.second);
             } else {
@@ -126,6 +130,7 @@ struct Trimmer {
         std::lock_guard<std::mutex> lk(mu);
         if (!started) {
             started = true;
+            std::atexit([] { trimmer().exiting.store(true); });
             try {
                 std::thread([this] { run(); }).detach();
             } catch (const std::system_error&) {
