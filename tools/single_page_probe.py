@@ -17,8 +17,10 @@ from ocrs_amd import DimOrder, Model, OcrEngine, _lib, models, synth  # noqa: E4
 threads = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 n_req = int(sys.argv[2]) if len(sys.argv) > 2 else 360
 L = _lib.lib()
+# optional: coalesce=N coalesce_pages=N coalesce_window_us=N (ocrs_engine_params fields) as further arguments
+kw = {a.split("=")[0]: int(a.split("=")[1]) for a in sys.argv[3:] if "=" in a}
 eng = OcrEngine(detection_model=Model.load_bytes(models.synthetic_detection_bytes()),
-                recognition_model=Model.load_bytes(models.synthetic_recognition_bytes()))
+                recognition_model=Model.load_bytes(models.synthetic_recognition_bytes()), **kw)
 dptrs = []
 for s in range(16):
     pg = synth.synthetic_page(s, 1024, 1024, lines=80)
