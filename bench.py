@@ -319,6 +319,7 @@ def main():
     prepare, rest = make_stages(engine, group, args.resident)
 
     step_latency = []   # seconds per whole step (request latency), appended by every in-flight host thread
+    handover_latency = []   # the same measured from the moment the request's host pixels were handed to the uploader
 
     from concurrent.futures import ThreadPoolExecutor
 
@@ -341,10 +342,13 @@ def main():
                     prepped[i] = up.submit(prepare, i)
 
             def one(i):
+                t_start = time.perf_counter()          # a step thread takes the request (its upload may still be running)
                 inputs = prepped.pop(i).result()
                 submit_prepare(i + ahead)
                 out = rest(inputs)
-                latency.append(time.perf_counter() - t_sub.pop(i))
+                t_end = time.perf_counter()
+                latency.append(t_end - t_start)
+                handover_latency.append(t_end - t_sub.pop(i))   # from the hand-over of the host pixels: includes the look-ahead queue
                 return out
             if args.no_pipeline or args.inflight <= 1:
                 outs = []
@@ -393,6 +397,7 @@ def main():
     engine.stage_times(reset=True)
     sync_all()
     del step_latency[:]
+    del handover_latency[:]
     members0 = [group.member_stats(m) for m in range(G)] if group_mode else None
     cpu0 = time.process_time()
     t0 = time.perf_counter()
@@ -503,7 +508,12 @@ def main():
         "lines_per_s": round(n_lines_all / elapsed, 1),
         "request_latency_ms": ({"p50": round(1e3 * float(np.percentile(step_latency, 50)), 2),
                                 "p99": round(1e3 * float(np.percentile(step_latency, 99)), 2),
-                                "pages_per_request": BG, "requests_in_flight": max(1, args.inflight)} if step_latency else None),
+                                "pages_per_request": BG, "requests_in_flight": max(1, args.inflight),
+                                "from_hand_over_of_the_host_pixels_p50": (round(1e3 * float(np.percentile(handover_latency, 50)), 2)
+                                                                          if handover_latency else None),
+                                "how": "from the moment a step thread takes the request (waiting for its upload if that is still running) to its "
+                                       "TextLines; from_hand_over…: from the moment its pixels were given to the uploader, i.e. including the "
+                                       "look-ahead queue of inflight + 1 requests"} if step_latency else None),
         "host_cpu_cores_busy_per_gpu": round(host_cpu_s / elapsed, 2),
         "device_memory_in_use_gb": dev_mem_gb,
         "host_cores_budget_per_rank": per_rank_cores,
