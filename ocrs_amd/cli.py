@@ -46,6 +46,9 @@ def main(argv=None):
     ap.add_argument("--debug", action="store_true")
     ap.add_argument("--text-map", action="store_true", help="write text-map.png (detect_text_pixels)")
     ap.add_argument("--text-mask", action="store_true", help="write text-mask.png (text map > detection threshold)")
+    ap.add_argument("--numerics", choices=("exact", "relaxed", "reduced"), default="exact",
+                    help="ocrs_engine_params.numerics (no reference counterpart): exact = bits of the CPU restatement (default); "
+                         "relaxed / reduced = faster arithmetic whose outputs are expected, not guaranteed, to match (DESIGN.md 4.4)")
     ap.add_argument("--text-line-images", action="store_true",
                     help="write lines/line-N.png: the pre-processed recognition input of every text line")
     args = ap.parse_args(argv)
@@ -55,7 +58,7 @@ def main(argv=None):
     det = Model.load_file(args.detect_model) if args.detect_model else Model.load_bytes(models.synthetic_detection_bytes())
     rec = Model.load_file(args.rec_model) if args.rec_model else Model.load_bytes(models.synthetic_recognition_bytes())
     engine = OcrEngine(detection_model=det, recognition_model=rec, debug=args.debug, alphabet=args.alphabet,
-                       allowed_chars=args.allowed_chars,
+                       allowed_chars=args.allowed_chars, numerics=args.numerics,
                        decode_method=DecodeMethod.BeamSearch(100) if args.beam else DecodeMethod.Greedy)
     # JPEG files: Huffman decoding here, everything per-sample on the GPU (include/ocrs_amd.h "JPEG hand-off"); flavours
     # the hand-off does not cover, and every other format, are decoded on the host as the reference does (main.rs:312-323)

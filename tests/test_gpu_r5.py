@@ -199,3 +199,35 @@ def test_rotated_page_through_the_batch_api_equals_the_oracle_golden(name, angle
     chars, coffs = eng.recognize_text_batch_raw(inputs, rects, loffs, poffs)
     for pi in range(3):
         _check_page_against_golden(g, words[pi], rects, loffs, int(poffs[pi]), int(poffs[pi + 1]), chars, coffs)
+
+
+def test_relaxed_numerics_on_rotated_pages_and_with_beam_search(tmp_path):
+    """The numerics modes beyond the upright greedy case: a rotated reference image (slanted polygons, resampled crops) and
+    DecodeMethod::BeamSearch on the GPU — relaxed gives the exact engine's text, reduced at most one differing line; and the
+    CLI's --numerics switch reaches the engine."""
+    from ocrs_amd import DecodeMethod
+    g, px, exact = _rot_case("polar-bears", -10)
+    dbuf, rbuf = M.detection_model_bytes(ink=tuple(g["ink"])), M.recognition_model_bytes()
+    det, rec = Model.load_bytes(dbuf), Model.load_bytes(rbuf)
+    inp = exact.prepare_input(ImageSource.from_tensor(px, DimOrder.Hwc))
+    lines = exact.find_text_lines(inp, exact.detect_words(inp))
+    want = [str(t) if t else None for t in exact.recognize_text(inp, lines)]
+    assert "\n".join(t for t in want if t is not None) == str(g["text"][0])
+    for mode, allowed in (("relaxed", 0), ("reduced", 1)):
+        eng = OcrEngine(detection_model=det, recognition_model=rec, numerics=mode)
+        got = [str(t) if t else None for t in eng.recognize_text(inp, lines)]
+        assert sum(1 for a, b in zip(got, want) if a != b) <= allowed, mode
+    beam_exact = OcrEngine(detection_model=det, recognition_model=rec, decode_method=DecodeMethod.BeamSearch(20))
+    beam_relaxed = OcrEngine(detection_model=det, recognition_model=rec, decode_method=DecodeMethod.BeamSearch(20), numerics="relaxed")
+    be = [str(t) if t else None for t in beam_exact.recognize_text(inp, lines[:20])]
+    br = [str(t) if t else None for t in beam_relaxed.recognize_text(inp, lines[:20])]
+    assert sum(1 for a, b in zip(be, br) if a != b) <= 1 and sum(1 for t in be if t) >= 10
+    # the CLI with --numerics relaxed on the same pixels (PNG on disk, synthetic default models of the CLI)
+    from PIL import Image
+    from ocrs_amd import cli
+    Image.fromarray(synth.synthetic_page(3, 300, 640, lines=10, columns=1), "RGB").save(tmp_path / "page.png")
+    outs = {}
+    for mode in ("exact", "relaxed"):
+        assert cli.main([str(tmp_path / "page.png"), "--numerics", mode, "-o", str(tmp_path / (mode + ".txt"))]) == 0
+        outs[mode] = open(tmp_path / (mode + ".txt")).read()
+    assert outs["exact"] == outs["relaxed"] and len(outs["exact"]) > 20
