@@ -17,7 +17,7 @@ OBJ = os.path.join(HERE, "_build")
 LIB = os.path.join(HERE, "libocrs_amd.so")
 
 SOURCES = ["common.cpp", "layout.cpp", "model.cpp", "engine.cpp", "ctc_beam.cpp", "text_items.cpp", "abi.cpp", "abi_util.cpp", "group.cpp", "jpeg_host.cpp", "kernels_jpeg.hip", "kernels_image.hip", "kernels_ccl.hip",
-           "kernels_nn.hip", "kernels_det.hip", "kernels_det_stream.hip", "kernels_det_rows.hip", "kernels_gru.hip", "kernels_lines.hip", "kernels_beam.hip", "kernels_rec.hip", "kernels_peaks.hip"]
+           "kernels_nn.hip", "kernels_det.hip", "kernels_det_stream.hip", "kernels_det_rows.hip", "kernels_gru.hip", "kernels_gru_split.hip", "kernels_lines.hip", "kernels_beam.hip", "kernels_rec.hip", "kernels_peaks.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-fvisibility=hidden", "-Wall", "-Wno-unused-function", "-Wno-pass-failed"]
 

@@ -686,6 +686,13 @@ bool gru_tile_plan(const int32_t* h_Tm, int M, int H, int* ncl, int* waves, int1
     return true;
 }
 
+// The same geometry and deal for a kernel with `cap` resident workgroups (kernels_gru_split.hip shares the decomposition).
+bool gru_general_tile_plan(const int32_t* h_Tm, int M, int Tmax, int H, int cap, int* ncl, int16_t* tiles) {
+    if (M <= 0 || !gru_plan(M, Tmax, H, ncl, cap)) return false;
+    if (tiles) gru_assign_tiles(h_Tm, M, *ncl, tiles);
+    return true;
+}
+
 bool gru_persistent_supported(int M, int Tmax, int64_t R, int H) {
     int ncl;
     if (H != 256 && H != 128 && H != 64) return false;

@@ -231,3 +231,58 @@ def test_relaxed_numerics_on_rotated_pages_and_with_beam_search(tmp_path):
         assert cli.main([str(tmp_path / "page.png"), "--numerics", mode, "-o", str(tmp_path / (mode + ".txt"))]) == 0
         outs[mode] = open(tmp_path / (mode + ".txt")).read()
     assert outs["exact"] == outs["relaxed"] and len(outs["exact"]) > 20
+
+
+# ------------------------------------------------------------------ the recurrence of the relaxed modes (kernels_gru_split.hip)
+def _rec_model(hidden):
+    from ocrs_amd import modelfile as mf
+    from oracle.nn import OracleGraph
+    g = mf.build_recognition(n_classes=97, in_h=64, seed=40 + hidden, hidden=hidden, chans=(32, 64, 64, 64, 64, 64))
+    cal = synth.synthetic_line_crops(9, n=8)
+    xp = np.full((8, 1, 64, 300), -0.5, np.float32)
+    xp[:, 0, :, :cal.shape[2]] = cal
+    return mf.calibrate_recognition_head(g, lambda buf, x: OracleGraph(buf).run_torch(x), xp).to_bytes()
+
+
+@pytest.mark.parametrize("hidden", [64, 128, 256])
+def test_split_recurrence_by_hidden_size_and_request_shape(hidden):
+    """numerics = relaxed / reduced run the recurrence with the state cut into 3 / 2 bf16 planes, in one persistent launch per
+    layer, for the hidden sizes the exact persistent kernel serves.  Requests of one line, of 10 ragged lines and of 330 lines
+    (21 row tiles: several per wave, lengths 8 .. 170 steps): labels equal to the exact engine's but for near-ties (relaxed: at most
+    1 line of the 330, reduced: 1 in 100), log-probs within the tolerance — and NOT the bits of the same mode with one fp32 launch per step (gru_mode = 1),
+    which shares every other kernel: the split kernel really ran."""
+    _lib.require_gpu()
+    rec = Model.load_bytes(_rec_model(hidden))
+    exact = OcrEngine(recognition_model=rec)
+    px = synth.synthetic_page(8, 460, 760, lines=10, columns=1)
+    inp = exact.prepare_input(ImageSource.from_tensor(px, DimOrder.Hwc))
+    def rect(i, ww, hh):   # one upright word per line: centre, up vector, width, height
+        return np.array([[10 + ww / 2, 30 + 40 * (i % 10), 0.0, 1.0, ww, hh]], np.float32)
+    ten = [rect(i, 60 + 70 * i, 14 + (i % 5) * 3) for i in range(10)]
+    many = [rect(i, 30 + (i * 37) % 700, 14 + (i % 5) * 3) for i in range(330)]
+    # (random weights: many near-ties between classes; with every log-prob within tol a label can only flip where the exact margin is < 2 tol)
+    for mode, tol, flip_rate in (("relaxed", LOGPROB_TOL, 0.004), ("reduced", 20 * LOGPROB_TOL, 0.01)):
+        split = OcrEngine(recognition_model=rec, numerics=mode)
+        steps = OcrEngine(recognition_model=rec, numerics=mode, options={"gru_mode": 1})
+        for lines in (ten[:1], ten, many):
+            split.enable_timing(2)
+            split.kernel_stats(reset=True)
+            got = split.recognize_tokens(inp, lines)
+            ks = split.kernel_stats(reset=True)
+            split.enable_timing(0)
+            # one launch per layer and sub-request (the 330 lines go as two), like the input projections
+            assert ks["gemm_gru_hidden_mfma"]["launches"] == ks["gemm_gru_input_mfma"]["launches"] in (2, 4) and ks["gru_gates"]["launches"] == 0
+            want = exact.recognize_tokens(inp, lines)
+            differ = sum(1 for a, b in zip(got, want) if [x[0] for x in a] != [x[0] for x in b])
+            flips_allowed = int(flip_rate * len(lines)) if len(lines) > 100 else 0
+            le, ls, lp = exact.recognize_logits(inp, lines), split.recognize_logits(inp, lines), steps.recognize_logits(inp, lines)
+            worst, same_bits = 0.0, True
+            for a, b, c in zip(le, ls, lp):
+                assert a.shape == b.shape == c.shape and np.array_equal(np.isfinite(a), np.isfinite(b))
+                fin = np.isfinite(a)
+                worst = max(worst, float(np.max(np.abs(a[fin] - b[fin]))) if fin.any() else 0.0)
+                same_bits = same_bits and np.array_equal(b, c)
+            assert worst < tol, (mode, len(lines), worst)
+            assert differ <= flips_allowed, (mode, len(lines), differ, worst)
+            assert not same_bits, (mode, len(lines))
+        assert sum(len(t) for t in want) > 300
