@@ -173,9 +173,9 @@ bool gru_general_tile_plan(const int32_t* h_Tm, int M, int Tmax, int H, int cap,
 // ---- kernels_gru_split.hip: the same launch for numerics != exact: hidden contraction on the bf16 matrix cores with the state
 // cut into np (2: reduced, 3: relaxed) bf16 planes.  hx: gru_split_exchange_bytes() of scratch, marked by gru_split_prepare on a
 // stream ordered before; y needs no marks.  d_sync as above.
-size_t gru_split_exchange_bytes(int64_t R, int H, int np);
-bool gru_split_supported(int M, int Tmax, int64_t R, int H, int np);
-hipError_t gru_split_prepare(uint16_t* hx, int64_t R, int H, int np, hipStream_t s);
+size_t gru_split_exchange_bytes(const int32_t* h_Tm, int M, int H, int np);
+bool gru_split_supported(const int32_t* h_Tm, int M, int Tmax, int64_t R, int H, int np);
+hipError_t gru_split_prepare(uint16_t* hx, const int32_t* h_Tm, int M, int H, int np, hipStream_t s);
 bool gru_persistent_split(const float* gx, const float* wh, const float* bh, float* y, uint16_t* hx, const int32_t* d_Tm, const int32_t* d_off,
                           const int32_t* h_Tm, int64_t R, int M, int Tmax, int H, int np, uint32_t* d_sync, hipStream_t s);
 void ctc_collapse_packed(const int32_t* labels, const int32_t* d_Tm, const int32_t* d_off, int M, int Tmax,

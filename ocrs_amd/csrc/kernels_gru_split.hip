@@ -5,9 +5,14 @@
 //
 //   * the state travels CUT: a wave stores the new state of its 16 rows x 16 units twice — fp32 into the layer's output y
 //     (what the next layer reads; no longer the hand-off) and as NP bf16 planes (hi, mid[, lo]: split_mfma.hpp's cut) into an
-//     exchange buffer hx[plane][row][2H] that the host pre-fills with 0xFFFFFFFF words.  A consumer's B operand of
-//     v_mfma_f32_16x16x32_bf16 — lane (row, kq) feeds k = 32 s + 8 kq .. + 7 — is then ONE 16-byte load per k-step and plane:
-//     no cutting on the consumer's side and none of the 64 lane swaps the fp32 kernel needs for the 16x16x4 layout;
+//     exchange buffer that the host pre-fills with 0xFFFFFFFF words.  A consumer's B operand of v_mfma_f32_16x16x32_bf16 —
+//     lane (row, kq) feeds k = 32 s + 8 kq .. + 7 — is then ONE 16-byte load per k-step and plane: no cutting on the
+//     consumer's side and none of the 64 lane swaps the fp32 kernel needs for the 16x16x4 layout;
+//   * the exchange buffer is laid out for the memory system, not for a reader of rows: hx[plane][direction][block][ub][16 rows]
+//     [16 units], one 8 KB block per (row tile, step) — tile k's blocks start at tbase[k] = the sum of the longer tiles'
+//     lengths.  A wave's store instruction then writes 512 contiguous bytes = four WHOLE 128-byte lines per plane (in the
+//     row-major layout of y a line is pieced together from four workgroups' partial writes, and the L2 has to fetch the rest
+//     of it before it can serve a read), and a consumer's load instruction reads 1 KB contiguous (two workgroups' pieces);
 //   * Wh is cut once per launch by the workgroup itself while it stages its slice into LDS (NP planes of 3 gates x H/32
 //     k-steps x 64 lanes x 16 bytes: 48 KB at NP = 2, H = 256 — what the fp32 slice takes);
 //   * per (tile, step) item 3 gates x H/32 k-steps x {3, 6} terms = 72 / 144 MFMAs of 16 pipe cycles instead of 192 of 32;
@@ -16,6 +21,7 @@
 //
 // A pair of bf16 values equal to 0xFFFFFFFF cannot be data: NaN states are stored as the canonical 0x7FC0 | 0.
 #include <atomic>
+#include <vector>
 
 #include "common.hpp"
 #include "kernels.hpp"
@@ -43,7 +49,7 @@ struct SplitParams {
     const float* wh;     // [2][H][3H]
     const float* bh;     // [2][3H]
     float* y;            // [R][2H] fp32 layer output
-    uint16_t* hx;        // [NP][R][2H] bf16 planes: the hand-off; pre-filled with 0xFFFFFFFF words
+    uint16_t* hx;        // [NP][2][TB][H / 16][16][16] bf16 planes: the hand-off; pre-filled with 0xFFFFFFFF words
     const int32_t* Tm;
     const int32_t* off;
     uint32_t* sync;
@@ -51,7 +57,9 @@ struct SplitParams {
     int64_t R;
     int M, ncl, Tmax;
     int allow_local;
+    int TB;              // blocks per direction and plane: the sum of the tiles' lengths
     int16_t tiles[kMaxSlots * 4];
+    int32_t tbase[kMaxSlots * 4];   // first block of tiles[..]
     uint32_t spin_limit;
 };
 
@@ -61,12 +69,12 @@ struct Loaded {
     f32x4 gr, gz, gn;
     uint32_t y_off;         // byte offset in y of this lane's 4 output units
     uint32_t hx_off;        // byte offset inside a plane of this lane's 4 units (8 bytes)
-    uint32_t prev_off;      // byte offset inside a plane of the row's previous-step state (this direction's half)
+    uint32_t prev_off;      // byte offset inside a plane of the row's piece of the previous step's block (ub = 0, units 0..7)
     bool has_prev, active;
 };
 
 template <int H, int NP>
-__device__ __forceinline__ void issue_meta(const SplitParams& p, int dir, int ub, int tile, int tm, const int* off_l, int s, int i16,
+__device__ __forceinline__ void issue_meta(const SplitParams& p, int dir, int ub, int tile, int tbase, int tm, const int* off_l, int s, int i16,
                                            int kq, Loaded<H, NP>& L) {
     const int m = tile * 16 + i16;
     L.active = tm > s;
@@ -74,7 +82,8 @@ __device__ __forceinline__ void issue_meta(const SplitParams& p, int dir, int ub
     const int64_t row = L.active ? (int64_t)off_l[t] + m : 0;
     const int64_t col = dir * H + ub * 16 + kq * 4;
     L.y_off = (uint32_t)((row * 2 * H + col) * sizeof(float));
-    L.hx_off = (uint32_t)((row * 2 * H + col) * 2);
+    const uint32_t blk = (uint32_t)(dir * p.TB + tbase + s);          // (tile, step) block of this direction
+    L.hx_off = (blk * (H / 16) + ub) * 512u + i16 * 32u + kq * 8u;
     const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
     L.gr = L.gz = L.gn = zero;
     L.has_prev = L.active && s > 0;
@@ -84,7 +93,7 @@ __device__ __forceinline__ void issue_meta(const SplitParams& p, int dir, int ub
         L.gr = *reinterpret_cast<const f32x4*>(g);
         L.gz = *reinterpret_cast<const f32x4*>(g + H);
         L.gn = *reinterpret_cast<const f32x4*>(g + 2 * H);
-        if (s > 0) L.prev_off = (uint32_t)((((int64_t)off_l[dir ? tm - s : s - 1] + m) * 2 * H + dir * H) * 2);
+        if (s > 0) L.prev_off = (blk - 1u) * (H / 16) * 512u + i16 * 32u;
     }
 }
 
@@ -95,7 +104,7 @@ __device__ __forceinline__ void issue_state(__amdgpu_buffer_rsrc_t hx, uint32_t 
         for (int s = 0; s < H / 32; s++)
 #pragma unroll
             for (int pl = 0; pl < NP; pl++)
-                L.hq[s][pl] = __builtin_amdgcn_raw_buffer_load_b128(hx, (int)(pl * plane_bytes + L.prev_off + (32 * s + 8 * kq) * 2), 0, kAuxSc1);
+                L.hq[s][pl] = __builtin_amdgcn_raw_buffer_load_b128(hx, (int)(pl * plane_bytes + L.prev_off + (2 * s + (kq >> 1)) * 512 + (kq & 1) * 16), 0, kAuxSc1);
     } else {
         const u32x4 zero = {0u, 0u, 0u, 0u};
 #pragma unroll
@@ -196,12 +205,13 @@ gru_split_kernel(SplitParams p) {
     const int slot = cl * WV + wave;
     const int t0 = p.tiles[slot * 4 + 0], t1 = p.tiles[slot * 4 + 1], t2 = p.tiles[slot * 4 + 2], t3 = p.tiles[slot * 4 + 3];
     auto tile_of = [&](int i) { return i == 0 ? t0 : i == 1 ? t1 : i == 2 ? t2 : t3; };
-    int tmr[4], tT[4];
+    int tmr[4], tT[4], tB[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const int m = tile_of(i) * 16 + i16;
         tmr[i] = (tile_of(i) >= 0 && m < p.M) ? p.Tm[m] : 0;
         tT[i] = __builtin_amdgcn_readfirstlane(tmr[i]);
+        tB[i] = p.tbase[slot * 4 + i];
     }
     auto sel = [](const int (&a)[4], int i) { return i == 0 ? a[0] : i == 1 ? a[1] : i == 2 ? a[2] : i == 3 ? a[3] : 0; };
     __syncthreads();
@@ -222,21 +232,28 @@ gru_split_kernel(SplitParams p) {
         }
         local = !__any(v != xcc + 1u) && p.allow_local;
     }
-    const uint32_t plane_bytes = (uint32_t)(p.R * 2 * H * 2);
+    const uint32_t plane_bytes = (uint32_t)p.TB * 2u * (H / 16) * 512u;
     const __amdgpu_buffer_rsrc_t hxb = __builtin_amdgcn_make_buffer_rsrc(p.hx, 0, (int)(uint32_t)((uint64_t)NP * plane_bytes), 0x00020000);
     const __amdgpu_buffer_rsrc_t yb = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)(uint32_t)(p.R * 2 * H * sizeof(float)), 0x00020000);
     f32x4 hp0 = {0.f, 0.f, 0.f, 0.f}, hp1 = hp0, hp2 = hp0, hp3 = hp0;   // previous state of the lane's own units, per tile slot
     int s = 0, i = 0;
+#ifdef OCRS_GRU_PROBE
+    uint64_t pr_wait = 0, pr_mma = 0, pr_gate = 0, pr_store = 0, pr_items = 0, pr_polls = 0, pr_t0 = __builtin_readcyclecounter();
+#define PROBE_T() __builtin_readcyclecounter()
+#endif
     Loaded<H, NP> bufA, bufB;
-    issue_meta<H, NP>(p, dir, ub, tile_of(0), tmr[0], off_l, 0, i16, kq, bufA);
+    issue_meta<H, NP>(p, dir, ub, tile_of(0), tB[0], tmr[0], off_l, 0, i16, kq, bufA);
     issue_state<H, NP>(hxb, plane_bytes, kq, bufA);
     auto item = [&](Loaded<H, NP>& cur, Loaded<H, NP>& nxt) -> int {
         int ns = s, ni = i + 1;
         if (sel(tT, ni) <= s) { ns = s + 1; ni = 0; }
         const bool have_next = sel(tT, ni) > ns;
         const bool early = have_next && ni != i;
-        if (have_next) issue_meta<H, NP>(p, dir, ub, tile_of(ni), sel(tmr, ni), off_l, ns, i16, kq, nxt);
+        if (have_next) issue_meta<H, NP>(p, dir, ub, tile_of(ni), sel(tB, ni), sel(tmr, ni), off_l, ns, i16, kq, nxt);
         if (early) issue_state<H, NP>(hxb, plane_bytes, kq, nxt);
+#ifdef OCRS_GRU_PROBE
+        const uint64_t pt0 = PROBE_T();
+#endif
         // three interleaved chains (r, z, n); A from LDS one k-step ahead
         f32x4 acc_r = br, acc_z = bz, acc_n = bn;
         const u32x4* ap = reinterpret_cast<const u32x4*>(lds_w) + lane;
@@ -257,6 +274,10 @@ gru_split_kernel(SplitParams p) {
             OCRS_GTERM(1, 0) OCRS_GTERM(0, 1) OCRS_GTERM(0, 0)
 #undef OCRS_GTERM
         }
+#ifdef OCRS_GRU_PROBE
+        asm volatile("" :: "v"(acc_r), "v"(acc_z), "v"(acc_n));
+        const uint64_t pt1 = PROBE_T();
+#endif
         // gates (hardware exp / rcp), new state from the lane's own uncut previous state
         const f32x4 hp = i == 0 ? hp0 : i == 1 ? hp1 : i == 2 ? hp2 : hp3;
         f32x4 hn;
@@ -270,6 +291,10 @@ gru_split_kernel(SplitParams p) {
             const float hv = fmaf(zg, hp[r] - ng, ng);
             hn[r] = hv != hv ? __uint_as_float(0x7FC00000u) : hv;   // canonical NaN: its bf16 planes are 0x7FC0 | 0, never the flag
         }
+#ifdef OCRS_GRU_PROBE
+        asm volatile("" :: "v"(hn));
+        const uint64_t pt2 = PROBE_T();
+#endif
         const bool st = cur.active;
         if (st) {   // (wave-uniform per 16-lane row group is not guaranteed: per-lane predication)
             if (i == 0) hp0 = hn; else if (i == 1) hp1 = hn; else if (i == 2) hp2 = hn; else hp3 = hn;
@@ -297,9 +322,19 @@ gru_split_kernel(SplitParams p) {
             if (local) __builtin_amdgcn_raw_buffer_store_b64(pl3, hxb, (int)o3, 0, 0);
             else __builtin_amdgcn_raw_buffer_store_b64(pl3, hxb, (int)o3, 0, kAuxSc1);
         }
+#ifdef OCRS_GRU_PROBE
+        const uint64_t pt3 = PROBE_T();
+        pr_mma += pt1 - pt0; pr_gate += pt2 - pt1; pr_store += pt3 - pt2; pr_items++;
+#endif
         if (!have_next) return 0;
         if (!early) issue_state<H, NP>(hxb, plane_bytes, kq, nxt);
+#ifdef OCRS_GRU_PROBE
+        if (!state_ready<H, NP>(nxt)) pr_polls++;
+#endif
         if (!await_state<H, NP>(p, hxb, plane_bytes, kq, nxt)) return -1;
+#ifdef OCRS_GRU_PROBE
+        pr_wait += PROBE_T() - pt3;
+#endif
         s = ns;
         i = ni;
         return 1;
@@ -308,6 +343,13 @@ gru_split_kernel(SplitParams p) {
         if (item(bufA, bufB) <= 0) break;
         if (item(bufB, bufA) <= 0) break;
     }
+#ifdef OCRS_GRU_PROBE
+    if (cid < 2 && ub == 0 && lane == 0)
+        printf("probe cid %d wave %d local %d tiles %d: items %llu total %llu | mma %llu gate %llu store %llu wait %llu (first-miss %llu) cycles per item\n", cid, wave, (int)local,
+               (t0 >= 0) + (t1 >= 0) + (t2 >= 0) + (t3 >= 0), (unsigned long long)pr_items, (unsigned long long)((PROBE_T() - pr_t0) / (pr_items ? pr_items : 1)),
+               (unsigned long long)(pr_mma / pr_items), (unsigned long long)(pr_gate / pr_items), (unsigned long long)(pr_store / pr_items),
+               (unsigned long long)(pr_wait / pr_items), (unsigned long long)pr_polls);
+#endif
 }
 
 template <int H, int NP>
@@ -344,12 +386,18 @@ void launch(const SplitParams& p, size_t lds, hipStream_t s) {
 
 }  // namespace
 
-size_t gru_split_exchange_bytes(int64_t R, int H, int np) { return (size_t)np * (size_t)R * 2 * H * 2; }
+// blocks per direction: every row tile holds one per step of its longest (= first) line
+static int64_t tile_blocks(const int32_t* h_Tm, int M) {
+    int64_t tb = 0;
+    for (int m = 0; m < M; m += 16) tb += h_Tm[m];
+    return tb;
+}
+size_t gru_split_exchange_bytes(const int32_t* h_Tm, int M, int H, int np) { return (size_t)np * 2 * (size_t)tile_blocks(h_Tm, M) * 16 * H * 2; }
 
-bool gru_split_supported(int M, int Tmax, int64_t R, int H, int np) {
+bool gru_split_supported(const int32_t* h_Tm, int M, int Tmax, int64_t R, int H, int np) {
     if (M <= 0 || (H != 256 && H != 128 && H != 64) || (np != 2 && np != 3)) return false;
     // y and the exchange buffer are each addressed through one buffer resource: < 4 GiB
-    if ((uint64_t)np * (uint64_t)R * 2 * H * 2 >= (uint64_t(1) << 32) || (uint64_t)R * 2 * H * sizeof(float) >= (uint64_t(1) << 32)) return false;
+    if ((uint64_t)gru_split_exchange_bytes(h_Tm, M, H, np) >= (uint64_t(1) << 32) || (uint64_t)R * 2 * H * sizeof(float) >= (uint64_t(1) << 32)) return false;
     const size_t lds = split_lds_bytes(H, np, Tmax);
     if (lds > 150 * 1024) return false;
     int ncl = 0;
@@ -358,15 +406,15 @@ bool gru_split_supported(int M, int Tmax, int64_t R, int H, int np) {
 }
 
 // every word of the exchange buffer "unwritten"; any stream ordered before the recurrence
-hipError_t gru_split_prepare(uint16_t* hx, int64_t R, int H, int np, hipStream_t s) {
-    return R > 0 ? hipMemsetAsync(hx, 0xFF, gru_split_exchange_bytes(R, H, np), s) : hipSuccess;
+hipError_t gru_split_prepare(uint16_t* hx, const int32_t* h_Tm, int M, int H, int np, hipStream_t s) {
+    return M > 0 ? hipMemsetAsync(hx, 0xFF, gru_split_exchange_bytes(h_Tm, M, H, np), s) : hipSuccess;
 }
 
 // false: no plan for this shape on this device, nothing launched (gru_split_supported says so beforehand)
 bool gru_persistent_split(const float* gx, const float* wh, const float* bh, float* y, uint16_t* hx, const int32_t* d_Tm, const int32_t* d_off,
                           const int32_t* h_Tm, int64_t R, int M, int Tmax, int H, int np, uint32_t* d_sync, hipStream_t s) {
     if (M <= 0) return true;
-    if (!hx || !gru_split_supported(M, Tmax, R, H, np)) return false;
+    if (!hx || !gru_split_supported(h_Tm, M, Tmax, R, H, np)) return false;
     SplitParams p{};
     p.gx = gx; p.wh = wh; p.bh = bh; p.y = y; p.hx = hx; p.Tm = d_Tm; p.off = d_off;
     p.place = d_sync;
@@ -376,6 +424,12 @@ bool gru_persistent_split(const float* gx, const float* wh, const float* bh, flo
     p.spin_limit = 1u << 21;
     const size_t lds = split_lds_bytes(H, np, Tmax);
     if (!gru_general_tile_plan(h_Tm, M, Tmax, H, capacity(H, np, lds), &p.ncl, p.tiles)) return false;
+    {
+        std::vector<int32_t> base((M + 15) / 16 + 1, 0);
+        for (size_t k = 0; k + 1 < base.size(); k++) base[k + 1] = base[k] + h_Tm[k * 16];
+        p.TB = base.back();
+        for (int i = 0; i < kMaxSlots * 4; i++) p.tbase[i] = i < 16 * p.ncl && p.tiles[i] >= 0 ? base[p.tiles[i]] : 0;
+    }
     OCRS_HIP(hipMemsetAsync(d_sync, 0, ((size_t)kMaxGrid + 1) * sizeof(uint32_t), s));
     if (np == 2) { if (H == 256) launch<256, 2>(p, lds, s); else if (H == 128) launch<128, 2>(p, lds, s); else launch<64, 2>(p, lds, s); }
     else { if (H == 256) launch<256, 3>(p, lds, s); else if (H == 128) launch<128, 3>(p, lds, s); else launch<64, 3>(p, lds, s); }

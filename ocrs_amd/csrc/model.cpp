@@ -1092,9 +1092,9 @@ int HipModel::run_recognition_packed(Workspace& ws, const std::vector<PackedGrou
             const bool persistent = fused && gru_mode() == GRU_PERSISTENT && k::gru_persistent_supported(M, plan.Tmax, R, H);
             // numerics != exact: the recurrence on the bf16 matrix cores (kernels_gru_split.hip), state cut into 3 / 2 planes
             const int np = option(OPT_NUMERICS) == 1 ? 3 : option(OPT_NUMERICS) == 2 ? 2 : 0;
-            const bool split = persistent && np != 0 && k::gru_split_supported(M, plan.Tmax, R, H, np);
-            uint16_t* hx = split ? ws.alloc_n<uint16_t>(k::gru_split_exchange_bytes(R, H, np) / 2) : nullptr;
-            if (split) OCRS_HIP(k::gru_split_prepare(hx, R, H, np, st));
+            const bool split = persistent && np != 0 && k::gru_split_supported(plan.h_Tm.data(), M, plan.Tmax, R, H, np);
+            uint16_t* hx = split ? ws.alloc_n<uint16_t>(k::gru_split_exchange_bytes(plan.h_Tm.data(), M, H, np) / 2) : nullptr;
+            if (split) OCRS_HIP(k::gru_split_prepare(hx, plan.h_Tm.data(), M, H, np, st));
             else if (persistent) OCRS_HIP(k::gru_persistent_prepare(y, R, H, st));  // "unwritten" marks; ahead of the input GEMM
             k::GemmDesc d{};
             d.A = cur; d.lda = I; d.B = op.aux0; d.ldb = 3 * H; d.bias = op.aux1; d.C = gx; d.ldc = 3 * H;
