@@ -160,14 +160,15 @@ bool gru_step_fused(const float* gx, const float* wh, const float* bh, const flo
 // afterwards if a wait inside the kernel timed out.  Returns false (nothing launched) if the shape is not
 // supported (H, more than 4096 lines, Tmax beyond the LDS table, a device that cannot keep a whole group of clusters
 // resident): the caller then runs gru_step_fused per step.
-// gru_persistent_prepare marks every word of y "unwritten" (the kernel's hand-off protocol reads y as its own
-// flag); call it on a stream ordered before gru_persistent.
+// hx: gru_persistent_exchange_bytes() of scratch, the hand-off buffer between the workgroups; gru_persistent_prepare marks
+// every word of it "unwritten" (the data is its own flag); call it on a stream ordered before gru_persistent.
 size_t gru_persistent_sync_words(int M);
-bool gru_persistent_supported(int M, int Tmax, int64_t R, int H);
+size_t gru_persistent_exchange_bytes(const int32_t* h_Tm, int M, int H);
+bool gru_persistent_supported(const int32_t* h_Tm, int M, int Tmax, int64_t R, int H);
 bool gru_tile_plan(const int32_t* h_Tm, int M, int H, int* ncl, int* waves, int16_t* tiles /* [512] */);  // host only: the deal of row tiles to waves
-hipError_t gru_persistent_prepare(float* y, int64_t R, int H, hipStream_t s);
+hipError_t gru_persistent_prepare(float* hx, const int32_t* h_Tm, int M, int H, hipStream_t s);
 // h_Tm: the same lengths as d_Tm on the host (descending) — the deal of row tiles to waves is computed from them.
-bool gru_persistent(const float* gx, const float* wh, const float* bh, float* y, const int32_t* d_Tm, const int32_t* d_off,
+bool gru_persistent(const float* gx, const float* wh, const float* bh, float* y, float* hx, const int32_t* d_Tm, const int32_t* d_off,
                     const int32_t* h_Tm, int64_t R, int M, int Tmax, int H, uint32_t* d_sync, hipStream_t s);
 bool gru_general_tile_plan(const int32_t* h_Tm, int M, int Tmax, int H, int cap, int* ncl, int16_t* tiles /* [512] or null */);
 // ---- kernels_gru_split.hip: the same launch for numerics != exact: hidden contraction on the bf16 matrix cores with the state

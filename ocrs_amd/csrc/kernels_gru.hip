@@ -12,17 +12,23 @@
 // ones: gru_assign_tiles, a longest-first deal that balances the waves' run times).  The UB workgroups that own the
 // slices of the same rows form a "cluster"; the only data they exchange is the new hidden state of their rows.
 //
-// Exchange = the layer's own output, and the data is its own flag.  y[row(t, m)][dir*H + unit] has to be
-// written anyway; the host pre-fills y with the word 0xFFFFFFFF (a NaN no result can be: the epilogue maps that one
-// bit pattern to the canonical NaN).  A wave writes its 16 rows x 16 units with 16-byte WRITE-THROUGH stores and
-// moves on — no drain, no counter.  The UB waves that need the tile's full state for the next step read the y rows
-// of the previous step with cache-bypassing loads and look at every 32-bit word: any 0xFFFFFFFF left means "not yet
+// Exchange: the data is its own flag.  The host pre-fills the hand-off buffer with the word 0xFFFFFFFF (a NaN no result can
+// be: the epilogue maps that one bit pattern to the canonical NaN).  A wave writes its 16 rows x 16 units with 16-byte
+// WRITE-THROUGH stores and moves on — no drain, no counter.  The UB waves that need the tile's full state for the next step
+// read the previous step with cache-bypassing loads and look at every 32-bit word: any 0xFFFFFFFF left means "not yet
 // written", and the wave re-reads (MI355X_MICROARCH.md "inter-workgroup visibility", form R2 — the payload is the
 // flag — checked per 32-bit word, so no assumption about the atomicity of wider accesses is made).  The loads of
 // the next item are issued before the current item is computed whenever it belongs to another tile, so that by the
 // time they are checked the round trip is long over.  No grid barrier: tiles never wait for each other, and nothing
 // depends on workgroup placement or order (blocks of a cluster are merely steered to one XCD for speed).  Every
 // wait is bounded: on a time-out the kernel raises the error word and returns, the host reports OCRS_ERR_DEVICE.
+// The hand-off buffer is NOT the layer output (round 5; it was until then): hx[direction][block][ub]
+// [16 rows][16 units], one 16 KB block (at H = 256) per (row tile, step), tile k's blocks starting at tbase[k] = the sum of
+// the longer tiles' lengths.  A wave's store instruction writes 1 KB contiguous = eight WHOLE 128-byte lines, and a load
+// instruction of a consumer reads 1 KB contiguous.  In the row-major y a line is pieced together from two workgroups'
+// partial writes — the L2 has to fetch the rest before it can serve a read — and a load instruction touches 16 lines half
+// each; a CU moves bypassing loads at ~10 bytes per clock whatever they hit, so the wasted halves were time
+// (tools/gru_round_probe.py: 7.6 -> x us per step with one tile per wave, 24.7 -> x with four).  y gets a second, plain store.
 //
 // MFMA roles.  D = A.B with A = Wh^T (16 units x 4 k, from LDS) and B = h^T (4 k x 16 rows, from
 // registers), so a lane ends up with 4 CONSECUTIVE units of one row: the epilogue's gx reads and
@@ -53,6 +59,7 @@ struct GruParams {
     const float* wh;     // [2][H][3H]
     const float* bh;     // [2][3H]
     float* y;            // [R][2H]
+    float* hx;           // the hand-off buffer [2][TB][H / 16][16][16], pre-filled with 0xFFFFFFFF words
     const int32_t* Tm;   // [M] sequence length of line m (descending)
     const int32_t* off;  // [Tmax + 1] first packed row of time t
     uint32_t* sync;      // [1] error word; zeroed before the launch
@@ -62,14 +69,16 @@ struct GruParams {
     int prio;            // s_setprio level of the waves (0..3)
     int allow_local;     // 0: write-through hand-offs whatever the placement (option gru_local = 0)
     int16_t tiles[kMaxSlots * 4];  // row tiles of wave slot (cluster-in-direction * 4 + wave), longest first; -1 = none
+    int32_t tbase[kMaxSlots * 4];  // first hand-off block of tiles[..] (gate-per-wave kernel: of tile [..])
+    int TB;                        // hand-off blocks per direction: the sum of the tiles' lengths
     uint32_t spin_limit;
 };
 
-// Hand-off accesses to y: 16-byte raw-buffer loads/stores with the sc1 (agent-scope) cache bit — the store is
+// Hand-off accesses: 16-byte raw-buffer loads/stores with the sc1 (agent-scope) cache bit — the store is
 // written through to memory, the load bypasses the CU's L1 (MI355X_MICROARCH.md: "`sc1` loads may replace the
 // acquire when the producer stored `sc1`").  Buffer intrinsics rather than `volatile` accesses: the compiler
 // follows a volatile access with s_waitcnt vmcnt(0), which would serialise the 17 loads of an item.  The buffer
-// resource spans y (< 4 GiB, checked by gru_plan); offsets are bytes.
+// resources span y and the hand-off buffer (each < 4 GiB, checked on the host); offsets are bytes.
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr int kAuxSc1 = 16;
 __device__ __forceinline__ f32x4 load_bypass(__amdgpu_buffer_rsrc_t y, uint32_t byte_off) {
@@ -110,7 +119,8 @@ struct Loaded {             // everything one (tile, step) item reads from memor
     f32x4 hp;               // previous state of this lane's own 4 units
     f32x4 gr, gz, gn;       // gx of this lane's 4 units
     uint32_t out_off;       // byte offset in y of this lane's 4 output units
-    uint32_t prev_off;      // byte offset in y of the row's previous-step output (this direction's half)
+    uint32_t hx_off;        // byte offset in hx of the same 4 units
+    uint32_t prev_off;      // byte offset in hx of the row's previous state (its piece of ub = 0)
     bool has_prev;          // false: h = 0 (first step / idle lane)
     bool active;
 };
@@ -118,8 +128,9 @@ struct Loaded {             // everything one (tile, step) item reads from memor
 // row bookkeeping + the gx operands of the epilogue (independent of the recurrence).  tm = length of the lane's
 // row (0: no such row); off_l = the packed-row table off[] in LDS.  No global load here other than gx: a wait on
 // one would also wait for the write-through store of the previous item (vmcnt retires in order).
+// tbase = first hand-off block of the tile.
 template <int H>
-__device__ __forceinline__ void issue_meta(const GruParams& p, int dir, int ub, int tile, int tm, const int* off_l, int s,
+__device__ __forceinline__ void issue_meta(const GruParams& p, int dir, int ub, int tile, int tbase, int tm, const int* off_l, int s,
                                            int i16, int kq, Loaded<H>& L) {
     const int m = tile * 16 + i16;
     L.active = tm > s;
@@ -131,22 +142,25 @@ __device__ __forceinline__ void issue_meta(const GruParams& p, int dir, int ub, 
                                  // of zeros alive across the MFMA chain when the state loads are issued after it)
     L.has_prev = L.active && s > 0;
     L.prev_off = 0;
+    const uint32_t blk = (uint32_t)(dir * p.TB + tbase + s);   // (tile, step) block of this direction
+    L.hx_off = (blk * (H / 16) + ub) * 1024u + i16 * 64u + kq * 16u;
     if (L.active) {
         const float* g = p.gx + ((int64_t)dir * p.R + row) * 3 * H + ub * 16 + kq * 4;
         L.gr = *reinterpret_cast<const f32x4*>(g);
         L.gz = *reinterpret_cast<const f32x4*>(g + H);
         L.gn = *reinterpret_cast<const f32x4*>(g + 2 * H);
-        if (s > 0) L.prev_off = (uint32_t)((((int64_t)off_l[dir ? tm - s : s - 1] + m) * 2 * H + dir * H) * sizeof(float));
+        if (s > 0) L.prev_off = (blk - 1u) * (H / 16) * 1024u + i16 * 64u;
     }
 }
 
 // the previous state of the lane's row (no wait: the loads are checked by state_ready())
 template <int H>
 __device__ __forceinline__ void issue_state(__amdgpu_buffer_rsrc_t y, int ub, int kq, Loaded<H>& L) {
+    constexpr uint32_t kPiece = 1024u;   // bytes between the row's pieces of consecutive 16-unit slices (workgroups)
     if (L.has_prev) {
 #pragma unroll
-        for (int j = 0; j < H / 16; j++) L.h[j] = load_bypass(y, L.prev_off + (16 * j + 4 * kq) * 4);
-        L.hp = load_bypass(y, L.prev_off + (ub * 16 + kq * 4) * 4);
+        for (int j = 0; j < H / 16; j++) L.h[j] = load_bypass(y, L.prev_off + j * kPiece + kq * 16);
+        L.hp = load_bypass(y, L.prev_off + ub * kPiece + kq * 16);
     } else {   // first step of the row / idle lane: h = 0
         const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
@@ -267,8 +281,8 @@ __device__ __forceinline__ float tanh_g(float x) {
 
 // gates + new state of the lane's 4 units; `store` = this lane's row is live at this step
 template <int H, bool FAST>
-__device__ __forceinline__ void epilogue_store(__amdgpu_buffer_rsrc_t y, const GateAcc& a, const f32x4& gr, const f32x4& gz,
-                                               const f32x4& gn, const f32x4& hp, uint32_t out_off, bool store, bool local) {
+__device__ __forceinline__ f32x4 epilogue_store(__amdgpu_buffer_rsrc_t y, const GateAcc& a, const f32x4& gr, const f32x4& gz,
+                                                const f32x4& gn, const f32x4& hp, uint32_t out_off, bool store, bool local) {
     f32x4 hn;
 #pragma unroll
     for (int r = 0; r < 4; r++) {
@@ -284,6 +298,7 @@ __device__ __forceinline__ void epilogue_store(__amdgpu_buffer_rsrc_t y, const G
     const uint32_t o = store ? out_off : 0xFFFFFFF0u;
     if (local) store_local(y, o, hn);  // wave-uniform
     else store_through(y, o, hn);
+    return hn;
 }
 
 template <int H, bool FAST>
@@ -367,12 +382,15 @@ gru_persistent_kernel(GruParams p) {
     // items in (step, tile) order; the state loads of the NEXT item are issued before the current one is
     // computed whenever it belongs to another tile (its inputs cannot depend on the current item)
     const __amdgpu_buffer_rsrc_t yb = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)(uint32_t)(p.R * 2 * H * sizeof(float)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t hxb = __builtin_amdgcn_make_buffer_rsrc(p.hx, 0, (int)((uint32_t)p.TB * 2u * (H / 16) * 1024u), 0x00020000);
+    const int tb0 = p.tbase[slot * 4 + 0], tb1 = p.tbase[slot * 4 + 1], tb2 = p.tbase[slot * 4 + 2], tb3 = p.tbase[slot * 4 + 3];
+    auto tbase_of = [&](int i) { return i == 0 ? tb0 : i == 1 ? tb1 : i == 2 ? tb2 : tb3; };
     // Two register sets used alternately (A holds the current item while B receives the next one's loads, then
     // the roles swap): copying a set would make the wave wait for loads that are still in flight.
     int s = 0, i = 0;
     Loaded<H> bufA, bufB;
-    issue_meta<H>(p, dir, ub, tile_of(0), tmr[0], off_l, 0, i16, kq, bufA);
-    issue_state<H>(yb, ub, kq, bufA);   // step 0: no previous state, h = 0
+    issue_meta<H>(p, dir, ub, tile_of(0), tbase_of(0), tmr[0], off_l, 0, i16, kq, bufA);
+    issue_state<H>(hxb, ub, kq, bufA);   // step 0: no previous state, h = 0
     // one item: returns 0 = done, 1 = go on, -1 = timed out
     auto item = [&](Loaded<H>& cur, Loaded<H>& nxt) -> int {
         int ns = s, ni = i + 1;
@@ -384,13 +402,15 @@ gru_persistent_kernel(GruParams p) {
         float w[H / 4];
 #pragma unroll
         for (int j = 0; j < H / 16; j++) transpose4(cur.h[j], &w[4 * j]);
-        if (have_next) issue_meta<H>(p, dir, ub, tile_of(ni), sel(tmr, ni), off_l, ns, i16, kq, nxt);
-        if (early) issue_state<H>(yb, ub, kq, nxt);
+        if (have_next) issue_meta<H>(p, dir, ub, tile_of(ni), tbase_of(ni), sel(tmr, ni), off_l, ns, i16, kq, nxt);
+        if (early) issue_state<H>(hxb, ub, kq, nxt);
         const GateAcc acc = mfma_chain<H>(lane, w, lds_w, br, bz, bn);
-        epilogue_store<H, FAST>(yb, acc, cur.gr, cur.gz, cur.gn, cur.hp, cur.out_off, cur.active, local);
+        // the hand-off store first (what the cluster waits for), then the layer output: a plain store, read by the next launch
+        const f32x4 hn = epilogue_store<H, FAST>(hxb, acc, cur.gr, cur.gz, cur.gn, cur.hp, cur.hx_off, cur.active, local);
+        store_local(yb, cur.active ? cur.out_off : 0xFFFFFFF0u, hn);
         if (!have_next) return 0;
-        if (!early) issue_state<H>(yb, ub, kq, nxt);
-        if (!await_state<H>(p, yb, ub, kq, nxt)) return -1;
+        if (!early) issue_state<H>(hxb, ub, kq, nxt);
+        if (!await_state<H>(p, hxb, ub, kq, nxt)) return -1;
         s = ns;
         i = ni;
         return 1;
@@ -500,6 +520,8 @@ gru_gates_kernel(GruParams p) {
         local = !__any(v != xcc + 1u) && p.allow_local;
     }
     const __amdgpu_buffer_rsrc_t yb = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)(uint32_t)(p.R * 2 * H * sizeof(float)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t hxb = __builtin_amdgcn_make_buffer_rsrc(p.hx, 0, (int)((uint32_t)p.TB * 2u * (H / 16) * 1024u), 0x00020000);
+    const uint32_t blk0 = (uint32_t)(dir * p.TB + p.tbase[tile]);   // the tile's hand-off block of step 0 (tbase by tile here)
     if (wave < 3) {
         const f32x4 bias = *reinterpret_cast<const f32x4*>(bhd + wave * H + j0 + kq * 4);
         Loaded<H> L;
@@ -512,9 +534,9 @@ gru_gates_kernel(GruParams p) {
             L.hp = zero;
 #pragma unroll
             for (int j = 0; j < H / 16; j++) L.h[j] = zero;
-            L.prev_off = L.has_prev ? (uint32_t)((((int64_t)off_l[dir ? tm - s : s - 1] + m) * 2 * H + dir * H) * sizeof(float)) : 0u;
-            issue_state<H>(yb, ub, kq, L);
-            if (!await_state<H>(p, yb, ub, kq, L)) *abort_w = 1;
+            L.prev_off = L.has_prev ? (blk0 + s - 1u) * (H / 16) * 1024u + i16 * 64u : 0u;
+            issue_state<H>(hxb, ub, kq, L);
+            if (!await_state<H>(p, hxb, ub, kq, L)) *abort_w = 1;
             float w[H / 4];
 #pragma unroll
             for (int j = 0; j < H / 16; j++) transpose4(L.h[j], &w[4 * j]);
@@ -557,9 +579,10 @@ gru_gates_kernel(GruParams p) {
                 const float hv = fmaf(zg, hp[r] - ng, ng);
                 hn[r] = __float_as_uint(hv) == kUnwritten ? __uint_as_float(0x7FC00000u) : hv;
             }
-            const uint32_t o = active ? out_off : 0xFFFFFFF0u;
-            if (local) store_local(yb, o, hn);
-            else store_through(yb, o, hn);
+            const uint32_t o = active ? ((blk0 + s) * (H / 16) + ub) * 1024u + i16 * 64u + kq * 16u : 0xFFFFFFF0u;
+            if (local) store_local(hxb, o, hn);
+            else store_through(hxb, o, hn);
+            store_local(yb, active ? out_off : 0xFFFFFFF0u, hn);   // the layer output: read by the next launch only
             if (active) hp = hn;    // what the next step would read back as this row's previous state
             gr = ngr; gz = ngz; gn = ngn; out_off = nout_off; active = nactive;
         }
@@ -576,9 +599,17 @@ static size_t gru_gates_lds_bytes(int H, int Tmax) {   // Wh slice | off table (
 static size_t gru_general_lds_bytes(int H, int Tmax) { return (size_t)H * 48 * sizeof(float) + ((size_t)Tmax + 1) * sizeof(int); }
 size_t gru_persistent_sync_words(int) { return kMaxGrid + 1; }  // placement table + error word (last)
 
-// y -> all words "unwritten"; any stream that is ordered before the recurrence (it does not depend on gx)
-hipError_t gru_persistent_prepare(float* y, int64_t R, int H, hipStream_t s) {
-    return R > 0 ? hipMemsetAsync(y, 0xFF, (size_t)R * 2 * H * sizeof(float), s) : hipSuccess;
+// hand-off blocks per direction: every row tile holds one per step of its longest (= first) line
+static int64_t gru_tile_blocks(const int32_t* h_Tm, int M) {
+    int64_t tb = 0;
+    for (int m = 0; m < M; m += 16) tb += h_Tm[m];
+    return tb;
+}
+size_t gru_persistent_exchange_bytes(const int32_t* h_Tm, int M, int H) { return (size_t)2 * (size_t)gru_tile_blocks(h_Tm, M) * 16 * H * sizeof(float); }
+
+// hand-off buffer -> all words "unwritten"; any stream that is ordered before the recurrence (it does not depend on gx)
+hipError_t gru_persistent_prepare(float* hx, const int32_t* h_Tm, int M, int H, hipStream_t s) {
+    return M > 0 ? hipMemsetAsync(hx, 0xFF, gru_persistent_exchange_bytes(h_Tm, M, H), s) : hipSuccess;
 }
 
 // How many workgroups of the recurrence kernels the CURRENT device keeps resident at once: CUs x workgroups per CU
@@ -693,11 +724,11 @@ bool gru_general_tile_plan(const int32_t* h_Tm, int M, int Tmax, int H, int cap,
     return true;
 }
 
-bool gru_persistent_supported(int M, int Tmax, int64_t R, int H) {
+bool gru_persistent_supported(const int32_t* h_Tm, int M, int Tmax, int64_t R, int H) {
     int ncl;
     if (H != 256 && H != 128 && H != 64) return false;
-    // y is addressed through one buffer resource: < 4 GiB
-    return M > 0 && (uint64_t)R * 2 * H * sizeof(float) < (uint64_t(1) << 32) &&
+    // y and the hand-off buffer are each addressed through one buffer resource: < 4 GiB
+    return M > 0 && (uint64_t)R * 2 * H * sizeof(float) < (uint64_t(1) << 32) && (uint64_t)gru_persistent_exchange_bytes(h_Tm, M, H) < (uint64_t(1) << 32) &&
            gru_plan(M, Tmax, H, &ncl, gru_resident_capacity(H, false, gru_general_lds_bytes(H, Tmax)));
 }
 
@@ -728,13 +759,16 @@ static void launch_general(bool fast, dim3 grid, size_t lds, hipStream_t s, cons
     else hipLaunchKernelGGL((gru_persistent_kernel<H, false>), grid, dim3(256), lds, s, g);
 }
 
-bool gru_persistent(const float* gx, const float* wh, const float* bh, float* y, const int32_t* d_Tm, const int32_t* d_off,
+bool gru_persistent(const float* gx, const float* wh, const float* bh, float* y, float* hx, const int32_t* d_Tm, const int32_t* d_off,
                     const int32_t* h_Tm, int64_t R, int M, int Tmax, int H, uint32_t* d_sync, hipStream_t s) {
     if (M <= 0) return true;
-    if (H != 256 && H != 128 && H != 64) return false;
+    if (!hx || !gru_persistent_supported(h_Tm, M, Tmax, R, H)) return false;
     const bool fast = option(OPT_NUMERICS) != 0;
     GruParams p{};
-    p.gx = gx; p.wh = wh; p.bh = bh; p.y = y; p.Tm = d_Tm; p.off = d_off;
+    p.gx = gx; p.wh = wh; p.bh = bh; p.y = y; p.hx = hx; p.Tm = d_Tm; p.off = d_off;
+    std::vector<int32_t> base((M + 15) / 16 + 1, 0);
+    for (size_t k = 0; k + 1 < base.size(); k++) base[k + 1] = base[k] + h_Tm[k * 16];
+    p.TB = base.back();
     p.place = d_sync;
     p.sync = d_sync + kMaxGrid;
     p.R = R; p.M = M; p.Tmax = Tmax;
@@ -743,6 +777,7 @@ bool gru_persistent(const float* gx, const float* wh, const float* bh, float* y,
     p.allow_local = option(OPT_GRU_LOCAL) != 0;
     const int UB = H / 16;
     if (option(OPT_GRU_GATES) && gru_gates_plan(M, Tmax, H, &p.ncl)) {
+        for (int k = 0; k < p.ncl; k++) p.tbase[k] = base[k];   // one tile per cluster
         const dim3 grid(8 * UB * ((2 * p.ncl + 7) / 8));
         const size_t lds = gru_gates_lds_bytes(H, Tmax);
         OCRS_HIP(hipMemsetAsync(d_sync, 0, gru_persistent_sync_words(M) * sizeof(uint32_t), s));
@@ -753,10 +788,11 @@ bool gru_persistent(const float* gx, const float* wh, const float* bh, float* y,
     }
     if (!gru_plan(M, Tmax, H, &p.ncl, gru_resident_capacity(H, false, gru_general_lds_bytes(H, Tmax)))) return false;
     gru_assign_tiles(h_Tm, M, p.ncl, p.tiles);
+    for (int i = 0; i < 16 * p.ncl; i++) p.tbase[i] = p.tiles[i] >= 0 ? base[p.tiles[i]] : 0;
     const dim3 grid(8 * UB * ((2 * p.ncl + 7) / 8));
     if (grid.x > (unsigned)kMaxGrid) return false;
     const size_t lds = gru_general_lds_bytes(H, Tmax);
-    OCRS_HIP(hipMemsetAsync(d_sync, 0, gru_persistent_sync_words(M) * sizeof(uint32_t), s));  // (y: gru_persistent_prepare)
+    OCRS_HIP(hipMemsetAsync(d_sync, 0, gru_persistent_sync_words(M) * sizeof(uint32_t), s));  // (hx: gru_persistent_prepare)
     if (H == 256) launch_general<256>(fast, grid, lds, s, p);
     else if (H == 128) launch_general<128>(fast, grid, lds, s, p);
     else launch_general<64>(fast, grid, lds, s, p);

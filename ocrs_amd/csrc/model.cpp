@@ -1089,13 +1089,15 @@ int HipModel::run_recognition_packed(Workspace& ws, const std::vector<PackedGrou
             float* gx = gx_buf;
             float* y = ws.alloc_n<float>((size_t)R * 2 * H);
             const bool fused = (H == 256 || H == 128 || H == 64);
-            const bool persistent = fused && gru_mode() == GRU_PERSISTENT && k::gru_persistent_supported(M, plan.Tmax, R, H);
+            const bool persistent = fused && gru_mode() == GRU_PERSISTENT && k::gru_persistent_supported(plan.h_Tm.data(), M, plan.Tmax, R, H);
             // numerics != exact: the recurrence on the bf16 matrix cores (kernels_gru_split.hip), state cut into 3 / 2 planes
             const int np = option(OPT_NUMERICS) == 1 ? 3 : option(OPT_NUMERICS) == 2 ? 2 : 0;
             const bool split = persistent && np != 0 && k::gru_split_supported(plan.h_Tm.data(), M, plan.Tmax, R, H, np);
+            // the hand-off buffer of the launch, every word marked "unwritten" ahead of the input GEMM
             uint16_t* hx = split ? ws.alloc_n<uint16_t>(k::gru_split_exchange_bytes(plan.h_Tm.data(), M, H, np) / 2) : nullptr;
+            float* hxf = persistent && !split ? ws.alloc_n<float>(k::gru_persistent_exchange_bytes(plan.h_Tm.data(), M, H) / sizeof(float)) : nullptr;
             if (split) OCRS_HIP(k::gru_split_prepare(hx, plan.h_Tm.data(), M, H, np, st));
-            else if (persistent) OCRS_HIP(k::gru_persistent_prepare(y, R, H, st));  // "unwritten" marks; ahead of the input GEMM
+            else if (persistent) OCRS_HIP(k::gru_persistent_prepare(hxf, plan.h_Tm.data(), M, H, st));
             k::GemmDesc d{};
             d.A = cur; d.lda = I; d.B = op.aux0; d.ldb = 3 * H; d.bias = op.aux1; d.C = gx; d.ldc = 3 * H;
             d.M = (int)R; d.N = 3 * H; d.K = I; d.batch = 2;
@@ -1122,7 +1124,7 @@ int HipModel::run_recognition_packed(Workspace& ws, const std::vector<PackedGrou
                     OCRS_HIP(hipStreamWaitEvent(rs, ready, 0));
                     int ktok = timers ? timers->kbegin(KC_GEMM_GRU_HIDDEN, rs, fl, 4.0 * ((double)R * (2.0 * 3 * H + 2.0 * 2 * H) + 2.0 * 3 * H * H)) : -1;
                     ran_persistent = split ? k::gru_persistent_split(gx, op.aux2, op.aux3, y, hx, plan.d_Tm, plan.d_off, plan.h_Tm.data(), R, M, plan.Tmax, H, np, d_sync, rs)
-                                           : k::gru_persistent(gx, op.aux2, op.aux3, y, plan.d_Tm, plan.d_off, plan.h_Tm.data(), R, M, plan.Tmax, H, d_sync, rs);
+                                           : k::gru_persistent(gx, op.aux2, op.aux3, y, hxf, plan.d_Tm, plan.d_off, plan.h_Tm.data(), R, M, plan.Tmax, H, d_sync, rs);
                     if (ktok >= 0) timers->end(ktok, rs);
                     if (ran_persistent && plan.h_status && gru_layer < 8)
                         ws.download(plan.h_status + gru_layer, d_sync + k::gru_persistent_sync_words(M) - 1, sizeof(uint32_t), rs);
