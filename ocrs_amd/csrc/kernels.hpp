@@ -170,7 +170,7 @@ hipError_t gru_persistent_prepare(float* hx, const int32_t* h_Tm, int M, int H, 
 // h_Tm: the same lengths as d_Tm on the host (descending) — the deal of row tiles to waves is computed from them.
 bool gru_persistent(const float* gx, const float* wh, const float* bh, float* y, float* hx, const int32_t* d_Tm, const int32_t* d_off,
                     const int32_t* h_Tm, int64_t R, int M, int Tmax, int H, uint32_t* d_sync, hipStream_t s);
-bool gru_general_tile_plan(const int32_t* h_Tm, int M, int Tmax, int H, int cap, int* ncl, int16_t* tiles /* [512] or null */);
+bool gru_general_tile_plan(const int32_t* h_Tm, int M, int Tmax, int H, int cap, int* ncl, int16_t* tiles /* [512] or null */, int kernel /* 0 fp32, 1 / 2: split with 3 / 2 planes */);
 // ---- kernels_gru_split.hip: the same launch for numerics != exact: hidden contraction on the bf16 matrix cores with the state
 // cut into np (2: reduced, 3: relaxed) bf16 planes.  hx: gru_split_exchange_bytes() of scratch, marked by gru_split_prepare on a
 // stream ordered before; y needs no marks.  d_sync as above.

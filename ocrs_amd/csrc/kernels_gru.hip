@@ -28,7 +28,7 @@
 // instruction of a consumer reads 1 KB contiguous.  In the row-major y a line is pieced together from two workgroups'
 // partial writes — the L2 has to fetch the rest before it can serve a read — and a load instruction touches 16 lines half
 // each; a CU moves bypassing loads at ~10 bytes per clock whatever they hit, so the wasted halves were time
-// (tools/gru_round_probe.py: 7.6 -> x us per step with one tile per wave, 24.7 -> x with four).  y gets a second, plain store.
+// (tools/gru_round_probe.py: 7.6 -> 6.3 us per step with one tile per wave, 24.7 -> 20.0 with four).  y gets a second, plain store.
 //
 // MFMA roles.  D = A.B with A = Wh^T (16 units x 4 k, from LDS) and B = h^T (4 k x 16 rows, from
 // registers), so a lane ends up with 4 CONSECUTIVE units of one row: the epilogue's gx reads and
@@ -388,6 +388,9 @@ gru_persistent_kernel(GruParams p) {
     // Two register sets used alternately (A holds the current item while B receives the next one's loads, then
     // the roles swap): copying a set would make the wave wait for loads that are still in flight.
     int s = 0, i = 0;
+#ifdef OCRS_GRU_PROBE   // where an item's cycles go (tools/gru_round_probe.py --once)
+    uint64_t pr_tr = 0, pr_mma = 0, pr_gate = 0, pr_wait = 0, pr_items = 0, pr_t0 = __builtin_readcyclecounter();
+#endif
     Loaded<H> bufA, bufB;
     issue_meta<H>(p, dir, ub, tile_of(0), tbase_of(0), tmr[0], off_l, 0, i16, kq, bufA);
     issue_state<H>(hxb, ub, kq, bufA);   // step 0: no previous state, h = 0
@@ -399,18 +402,36 @@ gru_persistent_kernel(GruParams p) {
         const bool early = EARLY && have_next && ni != i;
         // B operand: lane (row, kq) feeds h[row][4*s4 + kq].  Turned BEFORE the next item's loads are issued so
         // that those can land in the registers the pieces leave behind.
+#ifdef OCRS_GRU_PROBE
+        const uint64_t pt0 = __builtin_readcyclecounter();
+#endif
         float w[H / 4];
 #pragma unroll
         for (int j = 0; j < H / 16; j++) transpose4(cur.h[j], &w[4 * j]);
         if (have_next) issue_meta<H>(p, dir, ub, tile_of(ni), tbase_of(ni), sel(tmr, ni), off_l, ns, i16, kq, nxt);
         if (early) issue_state<H>(hxb, ub, kq, nxt);
+#ifdef OCRS_GRU_PROBE
+        asm volatile("" :: "v"(w[0]), "v"(w[H / 4 - 1]));
+        const uint64_t pt1 = __builtin_readcyclecounter();
+#endif
         const GateAcc acc = mfma_chain<H>(lane, w, lds_w, br, bz, bn);
+#ifdef OCRS_GRU_PROBE
+        asm volatile("" :: "v"(acc.r), "v"(acc.z), "v"(acc.n));
+        const uint64_t pt2 = __builtin_readcyclecounter();
+#endif
         // the hand-off store first (what the cluster waits for), then the layer output: a plain store, read by the next launch
         const f32x4 hn = epilogue_store<H, FAST>(hxb, acc, cur.gr, cur.gz, cur.gn, cur.hp, cur.hx_off, cur.active, local);
         store_local(yb, cur.active ? cur.out_off : 0xFFFFFFF0u, hn);
+#ifdef OCRS_GRU_PROBE
+        const uint64_t pt3 = __builtin_readcyclecounter();
+        pr_tr += pt1 - pt0; pr_mma += pt2 - pt1; pr_gate += pt3 - pt2; pr_items++;
+#endif
         if (!have_next) return 0;
         if (!early) issue_state<H>(hxb, ub, kq, nxt);
         if (!await_state<H>(p, hxb, ub, kq, nxt)) return -1;
+#ifdef OCRS_GRU_PROBE
+        pr_wait += __builtin_readcyclecounter() - pt3;
+#endif
         s = ns;
         i = ni;
         return 1;
@@ -419,6 +440,12 @@ gru_persistent_kernel(GruParams p) {
         if (item(bufA, bufB) <= 0) break;
         if (item(bufB, bufA) <= 0) break;
     }
+#ifdef OCRS_GRU_PROBE
+    if (cid == 0 && ub == 0 && lane == 0)
+        printf("probe fp32 wave %d local %d tiles %d: items %llu, cycles per item %llu = transposes + issue %llu | chain %llu | gates + stores %llu | wait %llu\n", wave, (int)local,
+               (t0 >= 0) + (t1 >= 0) + (t2 >= 0) + (t3 >= 0), (unsigned long long)pr_items, (unsigned long long)((__builtin_readcyclecounter() - pr_t0) / pr_items),
+               (unsigned long long)(pr_tr / pr_items), (unsigned long long)(pr_mma / pr_items), (unsigned long long)(pr_gate / pr_items), (unsigned long long)(pr_wait / pr_items));
+#endif
 }
 
 
@@ -645,7 +672,9 @@ static int gru_resident_capacity(int H, bool gates, size_t lds) {
                      : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gru_persistent_kernel<64, false>, 256, lds);
     }
     if (e != hipSuccess) { (void)hipGetLastError(); per_cu = 0; }
-    const int cap = prop.multiProcessorCount * (per_cu > 0 ? 1 : 0);   // one workgroup per CU by design
+    // one workgroup per CU by design (two per CU of the general kernel, 216 registers without the look-ahead loads: the same
+    // 18.7 vs 20.0 us per round of 128 equal tiles, 265 vs 269 pages/s in the bench — profiles/r5_gru_kernel_experiments.txt)
+    const int cap = prop.multiProcessorCount * (per_cu > 0 ? 1 : 0);
     std::lock_guard<std::mutex> g(mu);
     cache[key] = cap;
     return cap;
@@ -672,14 +701,17 @@ static bool gru_plan(int M, int Tmax, int H, int* ncl, int max_blocks = 256) {
 
 // Deal the row tiles (tile k = lines 16k .. 16k+15 of the length-sorted batch, so len[k] >= len[k + 1]) to the
 // 4 * ncl waves of a direction, at most 4 per wave.  A wave steps its tiles round-robin; a round of n live tiles
-// costs max(n * c, L): c = the wave's own work per item (MFMA chain + epilogue), L = the store -> visible -> re-read
-// latency of the state exchange that a single tile cannot hide.  Its time is the sum over rounds, and the kernel
-// ends with the slowest wave: longest-tile-first greedy on that cost (the longest tiles end up alone or with one
-// short partner, the mid-length ones in twos and threes).  Dealing consecutive tiles to a cluster took 8.4 ms per
-// layer on 1 232 lines of 100..600 steps, a snake deal 6.5 ms, this 4.7 ms.
-static void gru_assign_tiles(const int32_t* h_Tm, int M, int ncl, int16_t* tiles) {
+// costs round[n]: measured per kernel with equal-length requests (tools/gru_round_probe.py, profiles/r5_gru_round_probe.json;
+// units of 0.1 us, all four waves of the workgroups busy) — one tile cannot hide the store -> visible -> re-read latency of
+// the state exchange, two hide most of it, from there every further tile adds a whole item.  A wave's time is the sum over
+// its rounds, and the kernel ends with the slowest wave: longest-tile-first greedy on that cost (the longest tiles end up
+// alone or with one short partner, the mid-length ones in twos and threes).  Dealing consecutive tiles to a cluster took
+// 8.4 ms per layer on 1 232 lines of 100..600 steps, a snake deal 6.5 ms, this 4.7 ms (round 3's kernel).
+// kernel: 0 = fp32 (this file), 1 / 2 = kernels_gru_split.hip with 3 / 2 planes.
+static const int kRoundCost[3][5] = {{0, 63, 101, 150, 200}, {0, 54, 91, 128, 170}, {0, 44, 68, 99, 135}};
+static void gru_assign_tiles(const int32_t* h_Tm, int M, int ncl, int16_t* tiles, int kernel = 0) {
     const int ntiles = (M + 15) / 16, nslots = 4 * ncl;
-    const int64_t c = 47, L = 66;   // units of 0.1 us: 4.7 us per item, 6.6 us per lone step (measured)
+    const int* round = kRoundCost[kernel >= 0 && kernel < 3 ? kernel : 0];
     for (int i = 0; i < nslots * 4; i++) tiles[i] = -1;
     std::vector<int> cnt(nslots, 0);
     auto cost = [&](int slot, int extra_len) {   // lengths are descending within a slot, extra_len <= all of them
@@ -688,8 +720,7 @@ static void gru_assign_tiles(const int32_t* h_Tm, int M, int ncl, int16_t* tiles
         for (int i = 0; i < n; i++) len[i] = h_Tm[tiles[slot * 4 + i] * 16];
         if (extra_len > 0) len[n++] = extra_len;
         for (int i = n - 1, below = 0; i >= 0; i--) {   // rounds in which exactly i + 1 tiles are live
-            const int64_t round = (i + 1) * c > L ? (i + 1) * c : L;
-            tot += (int64_t)(len[i] - below) * round;
+            tot += (int64_t)(len[i] - below) * round[i + 1];
             below = len[i];
         }
         return tot;
@@ -718,9 +749,9 @@ bool gru_tile_plan(const int32_t* h_Tm, int M, int H, int* ncl, int* waves, int1
 }
 
 // The same geometry and deal for a kernel with `cap` resident workgroups (kernels_gru_split.hip shares the decomposition).
-bool gru_general_tile_plan(const int32_t* h_Tm, int M, int Tmax, int H, int cap, int* ncl, int16_t* tiles) {
+bool gru_general_tile_plan(const int32_t* h_Tm, int M, int Tmax, int H, int cap, int* ncl, int16_t* tiles, int kernel) {
     if (M <= 0 || !gru_plan(M, Tmax, H, ncl, cap)) return false;
-    if (tiles) gru_assign_tiles(h_Tm, M, *ncl, tiles);
+    if (tiles) gru_assign_tiles(h_Tm, M, *ncl, tiles, kernel);
     return true;
 }
 

@@ -401,7 +401,7 @@ bool gru_split_supported(const int32_t* h_Tm, int M, int Tmax, int64_t R, int H,
     const size_t lds = split_lds_bytes(H, np, Tmax);
     if (lds > 150 * 1024) return false;
     int ncl = 0;
-    if (!gru_general_tile_plan(nullptr, M, Tmax, H, capacity(H, np, lds), &ncl, nullptr)) return false;
+    if (!gru_general_tile_plan(nullptr, M, Tmax, H, capacity(H, np, lds), &ncl, nullptr, 0)) return false;
     return 8 * (H / 16) * ((2 * ncl + 7) / 8) <= kMaxGrid;
 }
 
@@ -423,7 +423,7 @@ bool gru_persistent_split(const float* gx, const float* wh, const float* bh, flo
     p.allow_local = option(OPT_GRU_LOCAL) != 0;
     p.spin_limit = 1u << 21;
     const size_t lds = split_lds_bytes(H, np, Tmax);
-    if (!gru_general_tile_plan(h_Tm, M, Tmax, H, capacity(H, np, lds), &p.ncl, p.tiles)) return false;
+    if (!gru_general_tile_plan(h_Tm, M, Tmax, H, capacity(H, np, lds), &p.ncl, p.tiles, np == 3 ? 1 : 2)) return false;
     {
         std::vector<int32_t> base((M + 15) / 16 + 1, 0);
         for (size_t k = 0; k + 1 < base.size(); k++) base[k + 1] = base[k] + h_Tm[k * 16];
