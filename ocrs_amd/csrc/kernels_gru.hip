@@ -455,8 +455,10 @@ gru_persistent_kernel(GruParams p) {
 // direction at H = 256: a single page).  There the recurrence is a pure latency chain — T dependent steps, nothing to
 // interleave — and the longest link of a step is the wave's 192 MFMAs.  Here the three gates of a step run on three
 // waves (three SIMDs) at once, 64 MFMAs each, and the fourth wave does the gate arithmetic and the store:
-//   waves 0..2 (gate r, z, n):  previous state of the tile (polled as above) -> 4x4 transposes -> 64-MFMA chain of
-//                               their gate -> accumulators to LDS -> workgroup barrier
+//   waves 0..2 (gate r, z, n):  previous state of the tile (polled as above) -> 64-MFMA chain of their gate (no transposes:
+//                               wave 3 stores the hand-off piece already turned, lane (row, kq) holding units 16 ub + 4 j + kq,
+//                               its consumers' operands of the k-steps 4 ub + j; one transpose per step instead of 3 x H / 16) ->
+//                               accumulators to LDS -> workgroup barrier
 //   wave 3:                     gx of the step (prefetched one step ahead) and the previous state of its own 4 units
 //                               (kept in registers: it wrote them) -> barrier -> gates from LDS -> sigma / tanh -> store
 // Same arithmetic per output (each gate's chain is the k-ascending fmaf chain), so the bits equal the other paths'.
@@ -566,7 +568,9 @@ gru_gates_kernel(GruParams p) {
             if (!await_state<H>(p, hxb, ub, kq, L)) *abort_w = 1;
             float w[H / 4];
 #pragma unroll
-            for (int j = 0; j < H / 16; j++) transpose4(L.h[j], &w[4 * j]);
+            for (int j = 0; j < H / 16; j++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) w[4 * j + e] = L.h[j][e];
             xch[wave * 64 + lane] = gate_chain<H>(lane, w, lds_w, wave, bias);
             __syncthreads();
             if (*abort_w) return;
@@ -607,8 +611,11 @@ gru_gates_kernel(GruParams p) {
                 hn[r] = __float_as_uint(hv) == kUnwritten ? __uint_as_float(0x7FC00000u) : hv;
             }
             const uint32_t o = active ? ((blk0 + s) * (H / 16) + ub) * 1024u + i16 * 64u + kq * 16u : 0xFFFFFFF0u;
-            if (local) store_local(hxb, o, hn);
-            else store_through(hxb, o, hn);
+            float t[4];
+            transpose4(hn, t);   // the hand-off piece in the gate waves' operand order (the 4 lanes of a row are live or idle together)
+            const f32x4 ht = {t[0], t[1], t[2], t[3]};
+            if (local) store_local(hxb, o, ht);
+            else store_through(hxb, o, ht);
             store_local(yb, active ? out_off : 0xFFFFFFF0u, hn);   // the layer output: read by the next launch only
             if (active) hp = hn;    // what the next step would read back as this row's previous state
             gr = ngr; gz = ngz; gn = ngn; out_off = nout_off; active = nactive;
