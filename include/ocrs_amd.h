@@ -102,7 +102,8 @@ OCRS_API ocrs_status ocrs_coalescer_selftest(int n_threads, int requests_per_thr
  *
  *   "gru_mode"        0 = one persistent kernel per GRU layer (default), 1 = one launch per time step
  *   "gru_gates"       1 = requests small enough that every 16-line row tile gets its own cluster of workgroups run the
- *                     gate-per-wave recurrence kernel (default), 0 = always the general persistent kernel
+ *                     gate-per-wave recurrence kernel (default), 0 = always the general persistent kernel (exact numerics
+ *                     only: the relaxed / reduced modes have one persistent recurrence kernel for every request size)
  *   "gru_local"       persistent GRU kernels: 1 = a cluster of workgroups that finds itself on one XCD hands its state
  *                     over through that XCD's L2 (default), 0 = always through write-through stores
  *   "det_fuse"        1 = fused DoubleConv blocks of the detection U-Net where they win (default), 2 = for every block
@@ -219,9 +220,10 @@ typedef struct ocrs_engine_params {
     /* --- no reference counterpart (RTen is fp32 on the CPU, one page per call) --- */
     ocrs_numerics numerics;    /* OCRS_NUMERICS_EXACT (0, default): every kernel follows the numeric spec, results are
                                 * bit-identical to the CPU oracle.  OCRS_NUMERICS_RELAXED: fp32-class arithmetic that is not
-                                * reproducible on a CPU — hardware exp / rcp in the recurrence's gates, the recognition convs'
-                                * operands cut into three bf16 terms on the bf16 matrix cores (products good to 2^-23), the
-                                * matrix core's accumulation order.  OCRS_NUMERICS_REDUCED: the same with two bf16 terms per
+                                * reproducible on a CPU — hardware exp / rcp in the recurrence's gates; the operands of the
+                                * recognition convs, the GRU input projections and the recurrence's own contraction cut
+                                * into three bf16 terms on the bf16 matrix cores (products good to 2^-23), the matrix core's
+                                * accumulation order.  OCRS_NUMERICS_REDUCED: the same with two bf16 terms per
                                 * operand (products good to 2^-15: a 16-bit significand).  Boxes and tokens are expected, not
                                 * guaranteed, to match the exact mode: DESIGN.md "what exactness costs" has the measured flips */
     int coalesce;              /* one-page calls that wait at the same time are merged into one ragged request per stage
