@@ -343,6 +343,7 @@ hipStream_t DeviceContext::heavy_stream() {
 }
 
 hipStream_t DeviceContext::recurrent_stream() {
+    if (serialized()) return heavy_stream();
     std::lock_guard<std::mutex> g(lazy_mu_);
     if (!recurrent_) {
         DeviceScope bind(device);
@@ -448,6 +449,12 @@ bool get_option(const Tuning& t, const char* name, long* value) {
 // ---------------------------------------------------------------- streams
 StreamLease::StreamLease(bool high_priority) : ctx_(&ctx()), high_(high_priority) {
     high_ = true;  // every request stream outranks nothing and is outranked by nothing: all at the highest priority (see heavy_stream())
+    if (ctx_->serialized()) {   // one stream for everything on this device; the lease owns only its event
+        s_ = ctx_->heavy_stream();
+        shared_ = true;
+        OCRS_HIP(hipEventCreateWithFlags(&done_, hipEventBlockingSync | hipEventDisableTiming));
+        return;
+    }
     {
         std::lock_guard<std::mutex> g(ctx_->stream_mu);
         auto& v = ctx_->streams;
@@ -465,6 +472,7 @@ StreamLease::StreamLease(bool high_priority) : ctx_(&ctx()), high_(high_priority
 }
 
 StreamLease::~StreamLease() {
+    if (shared_) { (void)hipEventDestroy(done_); return; }
     std::lock_guard<std::mutex> g(ctx_->stream_mu);
     ctx_->streams.emplace_back(s_, done_);
 }

@@ -111,6 +111,11 @@ struct DeviceContext {
     std::mutex heavy_phase, rec_phase;
     hipStream_t heavy_stream();
     hipStream_t recurrent_stream();
+    // Engines with relaxed / reduced numerics alive on this device.  While there is one, every API call on the device enqueues
+    // on ONE stream (the conv-stack stream), so that no two kernels of this process ever run at the same time.  Why: DESIGN.md
+    // §6.5 "concurrency" — other kernels' results were seen to change while the split kernels' bf16 MFMAs ran beside them.
+    std::atomic<int> relaxed_engines{0};
+    bool serialized() const { return relaxed_engines.load(std::memory_order_relaxed) > 0; }
     int cu_count();
     // intermediate activations of the conv stacks that run on heavy_stream(): shared by all requests (stream order is
     // the exclusion), guarded by heavy_phase; see HipModel::run_prefix_ragged
@@ -259,6 +264,7 @@ class StreamLease {
 
   private:
     DeviceContext* ctx_;   // the pool the stream goes back to
+    bool shared_ = false;  // s_ is the device's one serial stream (DeviceContext::serialize), not a leased one
     hipStream_t s_;
     hipEvent_t done_;
     bool high_;

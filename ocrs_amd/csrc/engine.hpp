@@ -75,6 +75,8 @@ struct ocrs_engine {
     // the engine's copy of the tuning options (common.hpp): the process defaults at creation + ocrs_engine_params +
     // ocrs_engine_set_option; installed for the calling thread by every entry point (abi_util.hpp guarded_engine)
     ocrs::Tuning tuning{};
+    bool counted_relaxed = false;   // numerics != exact: counted in its device's DeviceContext::relaxed_engines
+    ~ocrs_engine() { if (counted_relaxed) ocrs::device_context(device).relaxed_engines.fetch_sub(1); }
 
     ocrs::StageTimers* tm() const { return timers.enabled ? &timers : nullptr; }
 

@@ -619,7 +619,8 @@ static bool gemm_small_ok(const GemmDesc& d) {
 
 void gemm(const GemmDesc& d, hipStream_t s) {
     if (d.M <= 0 || d.N <= 0) return;
-    if (d.Bsplit && d.M >= 256) {   // relaxed / reduced numerics of the calling engine
+    if (d.Bsplit) {   // relaxed / reduced numerics of the calling engine — for every M: what a line's result is must not depend on
+                      // how many rows share its launch (small requests alone vs merged with others: tools/soak_varied.py --numerics)
         const int numerics = option(OPT_NUMERICS);
         if (numerics != 0 && launch_gemm_split(d, numerics, s)) return;
     }

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Memory behaviour under requests of varied sizes (round 5, verdict item 6):  python tools/soak_varied.py [seconds] [threads]
+"""Memory behaviour under requests of varied sizes (round 5, verdict item 6):  python tools/soak_varied.py [seconds] [threads] [--numerics relaxed|reduced]
 
 Pages of random sizes (200-3000 pixels a side, 1-200 lines, one or two columns) through the one-page pipeline from several
 threads for a while.  Asserts: every result equals the sequential run's (bytes of the word rects, tokens); the bytes in use
@@ -16,10 +16,15 @@ import numpy as np  # noqa: E402
 
 from ocrs_amd import DimOrder, ImageSource, Model, OcrEngine, _lib, models, synth  # noqa: E402
 
+numerics = "exact"
+if "--numerics" in sys.argv:   # the same check for the relaxed modes' kernels: a mode's results do not depend on what shares its launches
+    i = sys.argv.index("--numerics")
+    numerics = sys.argv[i + 1]
+    del sys.argv[i:i + 2]
 seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 n_threads = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 eng = OcrEngine(detection_model=Model.load_bytes(models.synthetic_detection_bytes()),
-                recognition_model=Model.load_bytes(models.synthetic_recognition_bytes()))
+                recognition_model=Model.load_bytes(models.synthetic_recognition_bytes()), numerics=numerics)
 rng = np.random.default_rng(2025)
 cases = []
 for s in range(48):
