@@ -225,7 +225,9 @@ typedef struct ocrs_engine_params {
                                 * into three bf16 terms on the bf16 matrix cores (products good to 2^-23), the matrix core's
                                 * accumulation order.  OCRS_NUMERICS_REDUCED: the same with two bf16 terms per
                                 * operand (products good to 2^-15: a 16-bit significand).  Boxes and tokens are expected, not
-                                * guaranteed, to match the exact mode: DESIGN.md "what exactness costs" has the measured flips */
+                                * guaranteed, to match the exact mode: DESIGN.md "what exactness costs" has the measured flips.
+                                * While an engine of these modes exists, every call on its device (of any engine of the
+                                * process) runs its kernels one at a time on one stream: create it before serving traffic */
     int coalesce;              /* one-page calls that wait at the same time are merged into one ragged request per stage
                                 * (lines are independent: nobody's bits change).  Merged batches in flight per stage:
                                 * 0 = default (2), negative = every call runs on its own */
