@@ -178,7 +178,8 @@ class OcrEngineParams:  # lib.rs:38-71
     def __init__(self, detection_model=None, recognition_model=None, debug=False, decode_method=DecodeMethod.Greedy,
                  alphabet=None, allowed_chars=None, numerics="exact", coalesce=0, coalesce_pages=0, coalesce_window_us=0,
                  layout_threads=0, rec_max_pixels=0, options=None):
-        # numerics / coalesce*: ocrs_engine_params fields without a reference counterpart (0 = default);
+        # numerics / coalesce*: ocrs_engine_params fields without a reference counterpart (0 = default); while an engine with
+        # numerics != "exact" is alive, every call on its device runs its kernels one at a time (include/ocrs_amd.h);
         # options: {name: value} applied to the new engine with ocrs_engine_set_option
         self.numerics = numerics
         self.coalesce = coalesce
