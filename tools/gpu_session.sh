@@ -1,6 +1,6 @@
 #!/bin/bash
 # One gpurun call = one session: tools/gpu_session.sh <tag> <section>...   (outputs under gpurun_out/<tag>/)
-# Sections: tests_new tests_r3 tests_all ab lat serial16 det detprof detpmc full multi group stream stream10k conc single prof pmc relaxedprof
+# Sections: tests_new tests_r3 tests_all ab lat serial16 det detprof detpmc full multi group stream stream10k conc single prof pmc relaxedprof soak
 set -u
 export TMPDIR=/tmp
 TAG=$1; shift
@@ -161,6 +161,11 @@ conc)
   for a in "--pages 1 --inflight 6" "--pages 1 --inflight 12" "--pages 2 --inflight 6"; do
     timeout 300 python bench.py $a --steps 120 --warmup 20 --settle-s 1 --no-cpu-baseline --no-extras > $OUT/bench_conc.json 2> $OUT/bench_conc.err; rc=$?
     say "$a rc=$rc"; jsum $OUT/bench_conc.json "$a"; [ $rc -ne 0 ] && tail -2 $OUT/bench_conc.err | cut -c1-300 | tee -a $S
+  done;;
+soak)
+  say "== pages of varied sizes from six threads against the sequential run, memory caps in force: exact, relaxed, reduced"
+  for m in exact relaxed reduced; do
+    timeout 300 python tools/soak_varied.py ${SOAK_SECONDS:-20} 6 --numerics $m > $OUT/soak_$m.txt 2>&1; say "$m rc=$?"; tail -1 $OUT/soak_$m.txt | tee -a $S
   done;;
 *) say "unknown section $sec";;
 esac

@@ -17,6 +17,9 @@ import numpy as np  # noqa: E402
 from ocrs_amd import DimOrder, ImageSource, Model, OcrEngine, _lib, models, synth  # noqa: E402
 
 numerics = "exact"
+if "--numerics" in sys.argv and sys.argv[sys.argv.index("--numerics") + 1] == "exact":
+    i = sys.argv.index("--numerics")
+    del sys.argv[i:i + 2]
 if "--numerics" in sys.argv:   # the same check for the relaxed modes' kernels: a mode's results do not depend on what shares its launches
     i = sys.argv.index("--numerics")
     numerics = sys.argv[i + 1]
