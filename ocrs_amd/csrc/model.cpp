@@ -1076,6 +1076,8 @@ int HipModel::run_recognition_packed(Workspace& ws, const std::vector<PackedGrou
     int gru_layer = 0;
     float* gx_buf = nullptr;
     size_t gx_cap = 0;
+    void* hx_buf = nullptr;   // the recurrences' hand-off buffer: likewise one for all layers (a layer's marks are written after the
+    size_t hx_cap = 0;        // previous layer's recurrence has finished: this stream waits for it)
     for (size_t i = ts + 1; i < ops.size(); i++) {
         const GraphOp& op = ops[i];
         if (op.type == OP_GRU) {
@@ -1094,8 +1096,10 @@ int HipModel::run_recognition_packed(Workspace& ws, const std::vector<PackedGrou
             const int np = option(OPT_NUMERICS) == 1 ? 3 : option(OPT_NUMERICS) == 2 ? 2 : 0;
             const bool split = persistent && np != 0 && k::gru_split_supported(plan.h_Tm.data(), M, plan.Tmax, R, H, np);
             // the hand-off buffer of the launch, every word marked "unwritten" ahead of the input GEMM
-            uint16_t* hx = split ? ws.alloc_n<uint16_t>(k::gru_split_exchange_bytes(plan.h_Tm.data(), M, H, np) / 2) : nullptr;
-            float* hxf = persistent && !split ? ws.alloc_n<float>(k::gru_persistent_exchange_bytes(plan.h_Tm.data(), M, H) / sizeof(float)) : nullptr;
+            const size_t hx_bytes = split ? k::gru_split_exchange_bytes(plan.h_Tm.data(), M, H, np) : persistent ? k::gru_persistent_exchange_bytes(plan.h_Tm.data(), M, H) : 0;
+            if (hx_bytes > hx_cap) { hx_buf = ws.alloc(hx_bytes); hx_cap = hx_bytes; }
+            uint16_t* hx = split ? static_cast<uint16_t*>(hx_buf) : nullptr;
+            float* hxf = persistent && !split ? static_cast<float*>(hx_buf) : nullptr;
             if (split) OCRS_HIP(k::gru_split_prepare(hx, plan.h_Tm.data(), M, H, np, st));
             else if (persistent) OCRS_HIP(k::gru_persistent_prepare(hxf, plan.h_Tm.data(), M, H, st));
             k::GemmDesc d{};
