@@ -882,7 +882,8 @@ float* HipModel::run_prefix_ragged(Workspace& ws, hipStream_t exec, const std::v
     // (under heavy_phase, held here since before_launch), so every request's stack can use the same few buffers — with
     // six 16-page requests in flight that is ~5 GB once instead of ~5 GB per request.  Buffers are never handed back while
     // the process runs (an earlier request's kernels may still be using them); the arena grows to the largest request seen.
-    const bool shared_arena = exec != ws.s();
+    // (a device that runs one kernel at a time — DeviceContext::serialized() — has exec == the request's stream: same rule)
+    const bool shared_arena = exec != ws.s() || (ctx().serialized() && before_launch);
     std::vector<char> arena_taken;
     auto get = [&](size_t floats) -> float* {
         const size_t bytes = floats * sizeof(float);
