@@ -328,3 +328,31 @@ def test_relaxed_results_do_not_depend_on_what_runs_beside_them(mode):
     [t.start() for t in ths]
     [t.join() for t in ths]
     assert not bad, (mode, sorted(set(bad)))
+
+
+@pytest.mark.parametrize("hidden", [64, 128, 256])
+def test_blocked_handoff_of_the_exact_recurrence_kernels_by_hidden_size(hidden):
+    """The exact persistent kernels (general and gate-per-wave) hand the state over through the blocked exchange buffer of round 5:
+    for every hidden size they serve, requests of 1 line (one step tile, one row live), 10 ragged lines (gate-per-wave kernel: every
+    tile its own cluster) and 330 lines (general kernel, several tiles per wave, tiles with idle rows) give the bits of the
+    per-step kernels (gru_mode = 1), with L2 and with write-through hand-offs."""
+    _lib.require_gpu()
+    rec = Model.load_bytes(_rec_model(hidden))
+    step = OcrEngine(recognition_model=rec, options={"gru_mode": 1})
+    px = synth.synthetic_page(8, 460, 760, lines=10, columns=1)
+    inp = step.prepare_input(ImageSource.from_tensor(px, DimOrder.Hwc))
+    def rect(i, ww, hh):
+        return np.array([[10 + ww / 2, 30 + 40 * (i % 10), 0.0, 1.0, ww, hh]], np.float32)
+    ten = [rect(i, 60 + 70 * i, 14 + (i % 5) * 3) for i in range(10)]
+    many = [rect(i, 30 + (i * 37) % 700, 14 + (i % 5) * 3) for i in range(330)]
+    for opts in ({}, {"gru_local": 0}, {"gru_gates": 0}):
+        eng = OcrEngine(recognition_model=rec, options=opts)
+        for lines in (ten[:1], ten, many):
+            want, got = step.recognize_logits(inp, lines), eng.recognize_logits(inp, lines)
+            assert all(np.array_equal(a, b) for a, b in zip(want, got)), (hidden, opts, len(lines))
+            eng.enable_timing(2)
+            eng.kernel_stats(reset=True)
+            eng.recognize_tokens(inp, lines)
+            ks = eng.kernel_stats(reset=True)
+            eng.enable_timing(0)
+            assert ks["gemm_gru_hidden_mfma"]["launches"] == ks["gemm_gru_input_mfma"]["launches"]   # persistent: one launch per layer
