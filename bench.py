@@ -69,6 +69,8 @@ def parse(argv=None):
                          "the other two as extras)")
     ap.add_argument("--coalesce", type=int, default=0,
                     help="ocrs_engine_params.coalesce: merged batches of one-page calls in flight per stage (0 = default 2, -1 = off)")
+    ap.add_argument("--no-steady-state", action="store_true",
+                    help="time the K steps from an EMPTY pipeline to an empty pipeline (the rounds 1-5 form) instead of in steady state")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pages", type=int, default=2, help="pages in the bounded CPU-baseline sample")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -323,8 +325,8 @@ def main():
 
     from concurrent.futures import ThreadPoolExecutor
 
-    def run_steps(k, collect=False, prepare=prepare, rest=rest, latency=step_latency):
-        """k full steps, `--inflight` of them in flight (one host thread + HIP stream each: the library is thread-safe).  The
+    def run_steps(k, collect=False, prepare=prepare, rest=rest, latency=step_latency, stamps=None):
+        """k full steps (`stamps`: a list that receives the host time at which each step's TextLines were complete), `--inflight` of them in flight (one host thread + HIP stream each: the library is thread-safe).  The
         uploads run ONE REQUEST AHEAD on a thread of their own, as a decoder thread feeding the engine would: step i's pages
         are uploaded and converted while the steps before it compute, inside the timed region like everything else."""
         if args.stream_pages:
@@ -349,6 +351,8 @@ def main():
                 t_end = time.perf_counter()
                 latency.append(t_end - t_start)
                 handover_latency.append(t_end - t_sub.pop(i))   # from the hand-over of the host pixels: includes the look-ahead queue
+                if stamps is not None:
+                    stamps.append(t_end)
                 return out
             if args.no_pipeline or args.inflight <= 1:
                 outs = []
@@ -356,6 +360,8 @@ def main():
                     t0 = time.perf_counter()
                     outs.append(rest(prepare(i)))
                     latency.append(time.perf_counter() - t0)
+                    if stamps is not None:
+                        stamps.append(time.perf_counter())
                 return outs if collect else outs[-1]
             for i in range(min(ahead, k)):
                 submit_prepare(i)
@@ -399,23 +405,42 @@ def main():
     del step_latency[:]
     del handover_latency[:]
     members0 = [group.member_stats(m) for m in range(G)] if group_mode else None
-    cpu0 = time.process_time()
+    cpu0 = time.perf_counter(), time.process_time()
+    # The timed region.  K steps are timed in STEADY STATE: the request pipeline (`--inflight` steps on their own host threads
+    # and streams, uploads one request ahead) is already full when the clock starts and stays full until it stops — P untimed
+    # priming steps, the K timed steps and D untimed trailing steps are ONE uninterrupted stream of requests, bracketed by a
+    # barrier + device synchronize on both sides; the clock runs from the moment the P-th request's TextLines are complete to
+    # the moment the (P + K)-th request's are: exactly K requests complete inside the window and every one of them does all of
+    # its work (upload, prepare, detect, layout, recognise).  A K-step region that starts and ends with an EMPTY pipeline — the
+    # form rounds 1-5 reported, a quarter of whose 1.2 s at K = 20 is fill and drain — is measured right after it and reported
+    # as `value_incl_fill_drain`.  A page stream (--stream-pages) is timed whole: its fill and drain belong to the job.
+    steady = not args.stream_pages and not args.no_steady_state
+    prime = (2 * max(args.inflight, 1)) if steady else 0
+    trail = max(args.inflight, 1) if steady else 0
+    stamps = []
     t0 = time.perf_counter()
-    outs = run_steps(args.steps, collect=True)
+    outs = run_steps(prime + args.steps + trail, collect=True, stamps=stamps)
     sync_all()
-    elapsed = time.perf_counter() - t0
+    wall = time.perf_counter() - t0
+    if steady:
+        stamps.sort()
+        elapsed = stamps[prime + args.steps - 1] - stamps[prime - 1]
+        outs = outs[prime:prime + args.steps]
+    else:
+        elapsed = wall
+    steps_under_timers = prime + args.steps + trail
     members = None
     if group_mode:   # what every member did in the timed region (the first multi-GPU run must be diagnosable)
         members = []
         for m in range(G):
             a, b = members0[m], group.member_stats(m)
             members.append({"member": m, "device": b["device"], "pages": b["pages"] - a["pages"],
-                            "pages_per_s": round((b["pages"] - a["pages"]) / 3.0 / elapsed, 2),   # a page passes 3 shares: prepare, detect, recognise
+                            "pages_per_s": round((b["pages"] - a["pages"]) / 3.0 / wall, 2),   # a page passes 3 shares: prepare, detect, recognise
                             "host_thread_cpu_s": round(b["host_cpu_s"] - a["host_cpu_s"], 3),
                             "busy_wall_s": round(b["busy_wall_s"] - a["busy_wall_s"], 3),
                             "numa_node": b["numa_node"], "node_cpus": b["node_cpus"],
                             "shares": b["shares"] - a["shares"], "shares_bound_to_node": b["bound_shares"] - a["bound_shares"]})
-    host_cpu_s = time.process_time() - cpu0  # all host threads of this rank (layout analysis dominates)
+    host_cpu_s = (time.process_time() - cpu0[1]) * elapsed / max(time.perf_counter() - cpu0[0], 1e-9)  # all host threads of this rank (layout analysis dominates), scaled to the timed window
     try:   # device memory in use by this process's pools after the timed region (cached blocks included)
         free_b, total_b = torch.cuda.mem_get_info(dev_index)
         dev_mem_gb = round((total_b - free_b) / 2**30, 1)
@@ -424,6 +449,14 @@ def main():
     stages = engine.stage_times(reset=False)
     kstats = engine.kernel_stats(reset=True)
     engine.enable_timing(0)
+    # the same K steps from an empty pipeline to an empty pipeline (fill and drain inside the clock): the form of rounds 1-5
+    elapsed_fd = None
+    if steady:
+        sync_all()
+        t0 = time.perf_counter()
+        run_steps(args.steps, latency=[])
+        sync_all()
+        elapsed_fd = reduce_over_ranks(time.perf_counter() - t0, (0,), world, red_dev)[0]
 
     outs = [o for o in outs if o is not None]
     n_lines = sum(len(o[1][1]) - 1 for o in outs)
@@ -472,6 +505,8 @@ def main():
         "warmup": args.warmup,
         "extra_untimed_settle_steps": settle_steps,
         "ms_per_step": round(1000.0 * elapsed / args.steps, 3),
+        "value_incl_fill_drain": round(n_pages_all / elapsed_fd, 3) if elapsed_fd else None,
+        "ms_per_step_incl_fill_drain": round(1000.0 * elapsed_fd / args.steps, 3) if elapsed_fd else None,
         "higher_is_better": True,
         "scaling": "strong" if args.stream_pages else "weak",
         "vs_baseline": None,
@@ -486,6 +521,12 @@ def main():
                          "one request ahead of the compute") +
                         ", ~%d lines/page; prepare_input -> detect_words (U-Net @800x600 + threshold + components->rects) "
                         "-> find_text_lines (host) -> recognize_text (crops, CRNN, greedy CTC)" % args.lines,
+            "timing": (("steady state: %d untimed priming steps, the %d timed steps and %d untimed trailing steps are one uninterrupted "
+                        "stream of requests (%d in flight) between two barrier + device-synchronize points; the clock runs from the completion "
+                        "of the last priming step to the completion of the last timed step, so exactly %d steps complete inside it and each "
+                        "does all of its work, uploads included; value_incl_fill_drain = the same %d steps from an empty pipeline to an empty "
+                        "pipeline (the rounds 1-5 form)" % (prime, args.steps, trail, max(args.inflight, 1), args.steps, args.steps))
+                       if steady else "whole region between two barrier + device-synchronize points (pipeline fill and drain inside the clock)"),
             "pages_per_step_per_gpu": B,
             "coalesce": ("concurrent small requests share launches (ocrs_engine_params.coalesce -> %d): %s" % (
                 engine.get_option("coalesce"), json.dumps(engine.coalesce_stats()))),
@@ -527,7 +568,7 @@ def main():
         result["final_gather"] = final_gather
 
     # ---- stage table + rooflines (HIP events, timed region)
-    result["stages_ms_per_step"] = {k: round(v[0] / args.steps, 4) for k, v in stages.items() if v[0] > 0}
+    result["stages_ms_per_step"] = {k: round(v[0] / steps_under_timers, 4) for k, v in stages.items() if v[0] > 0}
     kt = {k: v for k, v in kstats.items() if v["launches"] > 0}
     if kt:
         total_cal_ms = max(1e-9, sum(v["ms"] for v in cal.values()))
@@ -544,7 +585,7 @@ def main():
                 roof = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": PEAK_HBM_GBS,
                         "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBS, 4)}
             roof["avg_launch_ms"] = round(avg_ms, 5)
-            roof["launches_per_step"] = round(dom["launches"] / args.steps, 2)
+            roof["launches_per_step"] = round(dom["launches"] / steps_under_timers, 2)
             roof["share_of_gpu_kernel_time_in_calibration_step"] = round(cal[name]["ms"] / total_cal_ms, 3) if name in cal else None
             # the same kernels with the GPU to themselves (the untimed calibration step runs one request alone):
             # `frac` above is measured LIVE, i.e. while the other in-flight requests' kernels share the CUs
@@ -575,15 +616,15 @@ def main():
                                   "mfma_classes_tflop_per_step": {k: round(v["flops"] / 1e12, 3) for k, v in
                                                                   sorted(cal.items(), key=lambda kv: -kv[1]["flops"])
                                                                   if v["flops"] > 1e9}}
-        result["kernels_ms_per_step"] = {k: round(v["ms"] / args.steps, 4) for k, v in sorted(kt.items(), key=lambda kv: -kv[1]["ms"])}
+        result["kernels_ms_per_step"] = {k: round(v["ms"] / steps_under_timers, 4) for k, v in sorted(kt.items(), key=lambda kv: -kv[1]["ms"])}
         if args.profile_hint:
             for k, v in sorted(kt.items(), key=lambda kv: -kv[1]["ms"]):
                 tf = v["flops"] / max(v["ms"], 1e-9) / 1e9
                 gb = v["bytes"] / max(v["ms"], 1e-9) / 1e6
                 print("%-24s %8.3f ms/step %8.1f launches/step %8.2f TFLOP/s %8.1f GB/s" % (
-                    k, v["ms"] / args.steps, v["launches"] / args.steps, tf, gb), file=sys.stderr)
+                    k, v["ms"] / steps_under_timers, v["launches"] / steps_under_timers, tf, gb), file=sys.stderr)
             for k, v in stages.items():
-                print("stage %-18s %8.3f ms/step" % (k, v[0] / args.steps), file=sys.stderr)
+                print("stage %-18s %8.3f ms/step" % (k, v[0] / steps_under_timers), file=sys.stderr)
 
     # ---- extra legs named by BASELINE.json (rank 0, N=1 only; not part of `value`)
     if world == 1 and not group_mode and not args.no_extras:
