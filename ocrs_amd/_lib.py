@@ -71,6 +71,7 @@ DECLARED_SYMBOLS = [
     "ocrs_group_prepare_input_batch", "ocrs_group_prepare_input_device_batch", "ocrs_group_detect_words_batch",
     "ocrs_group_recognize_text_batch", "ocrs_group_gather", "ocrs_group_final_gather", "ocrs_group_worker_threads", "ocrs_group_last_gather", "ocrs_device_malloc_on", "ocrs_engine_coalesce_stats", "ocrs_coalescer_selftest", "ocrs_engine_kernel_mfma_flops", "ocrs_engine_prepare_input_jpeg", "ocrs_jpeg_decode_rgb", "ocrs_jpeg_info", "ocrs_jpeg_coefficients",
     "ocrs_group_member_stats", "ocrs_numa_parse_cpulist", "ocrs_numa_bind_selftest", "ocrs_engine_recognize_logits", "ocrs_engine_set_option", "ocrs_engine_get_option", "ocrs_option_name", "ocrs_device_pool_stats", "ocrs_device_pool_configure", "ocrs_device_pool_trim",
+    "ocrs_device_set_isolation", "ocrs_device_isolation",
 ]
 
 _lib = None
@@ -150,6 +151,20 @@ def pool_trim(device=-1):
 
 def pool_configure(device=-1, device_cached_cap=0, pinned_cached_cap=0):
     check(lib().ocrs_device_pool_configure(int(device), C.c_uint64(int(device_cached_cap)), C.c_uint64(int(pinned_cached_cap))))
+
+
+ISOLATION = {"auto": 0, "none": 1, "partition": 2}
+
+
+def set_isolation(policy="auto", split_cus=0, device=-1):
+    """ocrs_device_set_isolation: how kernels of engines with numerics != exact are kept away from other requests' kernels."""
+    check(lib().ocrs_device_set_isolation(int(device), int(ISOLATION[policy]), int(split_cus)))
+
+
+def isolation(device=-1):
+    v = (C.c_int * 4)()
+    check(lib().ocrs_device_isolation(int(device), v))
+    return {"mode": ("free", "serial", "partition")[v[0]], "relaxed_engines": int(v[1]), "split_cus": int(v[2]), "cus": int(v[3])}
 
 
 def ctc_beam_search(logp, width, impl=0):

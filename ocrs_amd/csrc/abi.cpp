@@ -162,6 +162,29 @@ ocrs_status ocrs_device_pool_trim(int device) {
     });
 }
 
+ocrs_status ocrs_device_set_isolation(int device, ocrs_isolation policy, int split_cus) {
+    return guarded([&] {
+        if (policy != OCRS_ISOLATION_AUTO && policy != OCRS_ISOLATION_NONE && policy != OCRS_ISOLATION_CU_PARTITION)
+            fail(OCRS_ERR_INVALID_ARGUMENT, "unknown isolation policy %d", (int)policy);
+        DeviceContext& c = device_context(device < 0 ? default_device() : device);
+        DeviceScope bind(c.device);
+        c.set_isolation(policy == OCRS_ISOLATION_NONE ? DeviceContext::ISO_NONE : policy == OCRS_ISOLATION_CU_PARTITION ? DeviceContext::ISO_PARTITION
+                                                                                                                        : DeviceContext::ISO_AUTO, split_cus);
+    });
+}
+
+ocrs_status ocrs_device_isolation(int device, int out[4]) {
+    return guarded([&] {
+        if (!out) fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
+        DeviceContext& c = device_context(device < 0 ? default_device() : device);
+        DeviceScope bind(c.device);
+        out[0] = (int)c.current_mode();
+        out[1] = c.relaxed_engine_count();
+        out[2] = c.current_mode() == DeviceContext::MODE_PARTITION ? c.partition_cus() : 0;
+        out[3] = c.cu_count();
+    });
+}
+
 ocrs_status ocrs_device_pool_configure(int device, uint64_t device_cached_cap_bytes, uint64_t pinned_cached_cap_bytes) {
     return guarded([&] {
         DeviceContext& c = device_context(device < 0 ? default_device() : device);

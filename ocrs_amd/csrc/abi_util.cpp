@@ -93,7 +93,7 @@ std::unique_ptr<ocrs_engine> make_engine(const ocrs_engine_params& params) {
     if (params.numerics != OCRS_NUMERICS_EXACT && params.numerics != OCRS_NUMERICS_RELAXED && params.numerics != OCRS_NUMERICS_REDUCED)
         fail(OCRS_ERR_INVALID_ARGUMENT, "unknown numerics mode %d", (int)params.numerics);
     e->tuning.v[OPT_NUMERICS] = (long)params.numerics;
-    if (params.numerics != OCRS_NUMERICS_EXACT) { device_context(e->device).relaxed_engines.fetch_add(1); e->counted_relaxed = true; }
+    if (params.numerics != OCRS_NUMERICS_EXACT) e->count_relaxed(device_context(e->device));   // waits for the device's requests in flight
     // coalescing fields: 0 = default, negative = off / zero
     if (params.coalesce) e->tuning.v[OPT_COALESCE] = params.coalesce < 0 ? 0 : params.coalesce;
     if (params.coalesce_pages) e->tuning.v[OPT_COALESCE_PAGES] = params.coalesce_pages < 0 ? 1 : params.coalesce_pages;

@@ -342,16 +342,114 @@ hipStream_t DeviceContext::heavy_stream() {
     return heavy_;
 }
 
-hipStream_t DeviceContext::recurrent_stream() {
-    if (serialized()) return heavy_stream();
+hipStream_t DeviceContext::recurrent_stream(int mode) {
+    if (mode == MODE_SERIAL) return heavy_stream();
     std::lock_guard<std::mutex> g(lazy_mu_);
-    if (!recurrent_) {
+    hipStream_t& r = mode == MODE_PARTITION ? recurrent_masked_ : recurrent_;
+    if (!r) {
         DeviceScope bind(device);
-        int least = 0, greatest = 0;
-        OCRS_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        OCRS_HIP(hipStreamCreateWithPriority(&recurrent_, hipStreamNonBlocking, greatest));
+        if (mode == MODE_PARTITION) {
+            r = masked_stream(false);
+        } else {
+            int least = 0, greatest = 0;
+            OCRS_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+            OCRS_HIP(hipStreamCreateWithPriority(&r, hipStreamNonBlocking, greatest));
+        }
     }
-    return recurrent_;
+    return r;
+}
+
+// ---- MODE_PARTITION: the device's compute units split in two sets, a stream confined to either.  Bit i of the mask is
+// compute unit i in the driver's numbering (on this 8-XCD part consecutive bits go round the XCDs, so a prefix of the mask is
+// the same number of units on every XCD; nothing here depends on that — any split is disjoint).
+hipStream_t DeviceContext::masked_stream(bool split_side) {
+    const int total = cu_count(), a = part_cus_;
+    std::vector<uint32_t> mask((size_t)(total + 31) / 32, 0u);
+    for (int i = split_side ? 0 : a; i < (split_side ? a : total); i++) mask[(size_t)i / 32] |= 1u << (i % 32);
+    hipStream_t s = nullptr;
+    DeviceScope bind(device);
+    OCRS_HIP(hipExtStreamCreateWithCUMask(&s, (uint32_t)mask.size(), mask.data()));
+    return s;
+}
+
+hipStream_t DeviceContext::split_stream() {
+    std::lock_guard<std::mutex> g(lazy_mu_);
+    if (!split_) split_ = masked_stream(true);
+    return split_;
+}
+
+// per host thread and device: leases the thread already holds (a nested lease must not wait for a switch that waits for it)
+static thread_local int t_lease_depth[kMaxDevices] = {0};
+
+// ---- isolation regime changes.  `change` runs with no request in flight on the device, new ones held back, the device idle.
+template <class F> void DeviceContext::switch_isolation(F&& change) {
+    if (t_lease_depth[device] > 0) fail(OCRS_ERR_INVALID_ARGUMENT, "the isolation regime of device %d cannot change from inside one of its requests", device);
+    std::unique_lock<std::mutex> lk(iso_mu_);
+    iso_cv_.wait(lk, [&] { return !switching_; });
+    const Mode before = mode_locked();
+    switching_ = true;                                   // from here on lease_begin() waits
+    struct Done { DeviceContext* c; ~Done() { c->switching_ = false; c->iso_cv_.notify_all(); } } done{this};
+    // what changes for a request is known only after `change`; try it on a copy first so that a no-op costs no drain
+    const Isolation p0 = policy_;
+    const int r0 = relaxed_, c0 = part_cus_;
+    change();
+    const bool same = mode_locked() == before && (before != MODE_PARTITION || part_cus_ == c0);
+    if (same) return;
+    // put the old regime back while the requests that were told about it finish, then flip
+    const Isolation p1 = policy_;
+    const int r1 = relaxed_, c1 = part_cus_;
+    policy_ = p0; relaxed_ = r0; part_cus_ = c0;
+    iso_cv_.wait(lk, [&] { return leases_ == 0; });
+    {
+        DeviceScope bind(device);
+        if (hipDeviceSynchronize() != hipSuccess) (void)hipGetLastError();
+        // streams confined to an old partition are useless to a new one
+        std::lock_guard<std::mutex> g(lazy_mu_);
+        std::lock_guard<std::mutex> g2(stream_mu);
+        for (auto& se : masked_streams_) { (void)hipStreamDestroy(se.first); (void)hipEventDestroy(se.second); }
+        masked_streams_.clear();
+        if (split_) { (void)hipStreamDestroy(split_); split_ = nullptr; }
+        if (recurrent_masked_) { (void)hipStreamDestroy(recurrent_masked_); recurrent_masked_ = nullptr; }
+    }
+    policy_ = p1; relaxed_ = r1; part_cus_ = c1;
+}
+
+DeviceContext::Mode DeviceContext::lease_begin() {
+    std::unique_lock<std::mutex> lk(iso_mu_);
+    if (t_lease_depth[device] == 0) iso_cv_.wait(lk, [&] { return !switching_; });
+    t_lease_depth[device]++;
+    leases_++;
+    return mode_locked();
+}
+
+void DeviceContext::lease_end() {
+    std::lock_guard<std::mutex> lk(iso_mu_);
+    t_lease_depth[device]--;
+    if (--leases_ == 0) iso_cv_.notify_all();
+}
+
+void DeviceContext::add_relaxed_engine(int delta) {
+    switch_isolation([&] { relaxed_ += delta; });
+}
+
+void DeviceContext::set_isolation(Isolation policy, int cus) {
+    if (policy == ISO_PARTITION) {
+        const int total = cu_count();
+        // the recurrence kernels need one whole group of clusters resident on their side (kernels_gru.hip: 128 workgroups at
+        // hidden 256), the split kernels at least an XCD's worth on theirs
+        if (cus < 8 || total - cus < 8) fail(OCRS_ERR_INVALID_ARGUMENT, "CU partition %d / %d of %d compute units: each side needs at least 8", cus, total - cus, total);
+    }
+    switch_isolation([&] { policy_ = policy; part_cus_ = policy == ISO_PARTITION ? cus : 0; });
+}
+
+DeviceContext::Mode DeviceContext::current_mode() {
+    std::lock_guard<std::mutex> lk(iso_mu_);
+    return mode_locked();
+}
+
+int DeviceContext::relaxed_engine_count() {
+    std::lock_guard<std::mutex> lk(iso_mu_);
+    return relaxed_;
 }
 
 int DeviceContext::cu_count() {
@@ -362,6 +460,12 @@ int DeviceContext::cu_count() {
         cus_ = prop.multiProcessorCount;
     }
     return cus_;
+}
+
+int DeviceContext::recurrence_cus() {
+    const int total = cu_count();
+    std::lock_guard<std::mutex> lk(iso_mu_);
+    return mode_locked() == MODE_PARTITION ? total - part_cus_ : total;
 }
 
 // ---------------------------------------------------------------- options
@@ -449,32 +553,46 @@ bool get_option(const Tuning& t, const char* name, long* value) {
 // ---------------------------------------------------------------- streams
 StreamLease::StreamLease(bool high_priority) : ctx_(&ctx()), high_(high_priority) {
     high_ = true;  // every request stream outranks nothing and is outranked by nothing: all at the highest priority (see heavy_stream())
-    if (ctx_->serialized()) {   // one stream for everything on this device; the lease owns only its event
-        s_ = ctx_->heavy_stream();
-        shared_ = true;
-        OCRS_HIP(hipEventCreateWithFlags(&done_, hipEventBlockingSync | hipEventDisableTiming));
-        return;
-    }
-    {
-        std::lock_guard<std::mutex> g(ctx_->stream_mu);
-        auto& v = ctx_->streams;
-        if (!v.empty()) {
-            s_ = v.back().first;
-            done_ = v.back().second;
-            v.pop_back();
+    mode_ = ctx_->lease_begin();
+    try {
+        if (mode_ == DeviceContext::MODE_SERIAL) {   // one stream for everything on this device; the lease owns only its event
+            s_ = ctx_->heavy_stream();
+            shared_ = true;
+            OCRS_HIP(hipEventCreateWithFlags(&done_, hipEventBlockingSync | hipEventDisableTiming));
             return;
         }
+        {
+            std::lock_guard<std::mutex> g(ctx_->stream_mu);
+            auto& v = mode_ == DeviceContext::MODE_PARTITION ? ctx_->masked_streams_ : ctx_->streams;
+            if (!v.empty()) {
+                s_ = v.back().first;
+                done_ = v.back().second;
+                v.pop_back();
+                return;
+            }
+        }
+        if (mode_ == DeviceContext::MODE_PARTITION) {
+            s_ = ctx_->masked_stream(false);
+        } else {
+            int least = 0, greatest = 0;
+            OCRS_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+            OCRS_HIP(hipStreamCreateWithPriority(&s_, hipStreamNonBlocking, greatest));
+        }
+        OCRS_HIP(hipEventCreateWithFlags(&done_, hipEventBlockingSync | hipEventDisableTiming));
+    } catch (...) {
+        ctx_->lease_end();
+        throw;
     }
-    int least = 0, greatest = 0;
-    OCRS_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-    OCRS_HIP(hipStreamCreateWithPriority(&s_, hipStreamNonBlocking, greatest));
-    OCRS_HIP(hipEventCreateWithFlags(&done_, hipEventBlockingSync | hipEventDisableTiming));
 }
 
 StreamLease::~StreamLease() {
-    if (shared_) { (void)hipEventDestroy(done_); return; }
-    std::lock_guard<std::mutex> g(ctx_->stream_mu);
-    ctx_->streams.emplace_back(s_, done_);
+    if (shared_) {
+        (void)hipEventDestroy(done_);
+    } else {
+        std::lock_guard<std::mutex> g(ctx_->stream_mu);
+        (mode_ == DeviceContext::MODE_PARTITION ? ctx_->masked_streams_ : ctx_->streams).emplace_back(s_, done_);
+    }
+    ctx_->lease_end();
 }
 
 // ---------------------------------------------------------------- timers

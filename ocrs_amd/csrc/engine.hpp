@@ -75,8 +75,16 @@ struct ocrs_engine {
     // the engine's copy of the tuning options (common.hpp): the process defaults at creation + ocrs_engine_params +
     // ocrs_engine_set_option; installed for the calling thread by every entry point (abi_util.hpp guarded_engine)
     ocrs::Tuning tuning{};
-    bool counted_relaxed = false;   // numerics != exact: counted in its device's DeviceContext::relaxed_engines
-    ~ocrs_engine() { if (counted_relaxed) ocrs::device_context(device).relaxed_engines.fetch_sub(1); }
+    // numerics != exact: the device context this engine is counted in (DeviceContext::add_relaxed_engine) — remembered, because
+    // `device` may be reassigned after creation (a group member without weights) and the count must come off where it went on
+    ocrs::DeviceContext* counted_relaxed = nullptr;
+    void count_relaxed(ocrs::DeviceContext& c) { uncount_relaxed(); c.add_relaxed_engine(+1); counted_relaxed = &c; }
+    void uncount_relaxed() noexcept {
+        if (!counted_relaxed) return;
+        try { counted_relaxed->add_relaxed_engine(-1); } catch (...) {}
+        counted_relaxed = nullptr;
+    }
+    ~ocrs_engine() { uncount_relaxed(); }
 
     ocrs::StageTimers* tm() const { return timers.enabled ? &timers : nullptr; }
 

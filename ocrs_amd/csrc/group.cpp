@@ -489,6 +489,8 @@ ocrs_status ocrs_engine_group_new(const ocrs_group_params* params, ocrs_engine_g
             ep.rec_max_pixels = params->rec_max_pixels;
             mem.engine = make_engine(ep);
             mem.engine->device = mem.device;   // (an engine without weights has nothing else to pin it to its device)
+            if (mem.engine->counted_relaxed && mem.engine->counted_relaxed != &device_context(mem.device))
+                mem.engine->count_relaxed(device_context(mem.device));   // ... and is counted where it runs
             {   // where the member's host side should run: the NUMA node of its GPU (silent when the host does not say)
                 char bus[64] = {0};
                 if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, mem.device) == hipSuccess) {

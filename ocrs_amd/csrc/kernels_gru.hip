@@ -35,6 +35,7 @@
 // the y store are one 16-byte access per gate / per lane in the natural layouts.  The B operand
 // wants lane (row, kq) to hold h[row][4*s + kq]; rows are fetched as 16-byte pieces and turned by a
 // 4x4 transpose across the four 16-lane groups (v_permlane16_swap / v_permlane32_swap).
+#include <algorithm>
 #include <cstdlib>
 #include <map>
 #include <mutex>
@@ -660,10 +661,11 @@ static int gru_resident_capacity(int H, bool gates, size_t lds) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 0;
     const int key = dev * 8 + (gates ? 4 : 0) + (H == 256 ? 2 : H == 128 ? 1 : 0);
+    const int side = ctx().recurrence_cus();   // fewer than the device's when the compute units are partitioned (common.hpp)
     {
         std::lock_guard<std::mutex> g(mu);
         auto it = cache.find(key);
-        if (it != cache.end()) return it->second;
+        if (it != cache.end()) return std::min(it->second, side);
     }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
@@ -684,7 +686,7 @@ static int gru_resident_capacity(int H, bool gates, size_t lds) {
     const int cap = prop.multiProcessorCount * (per_cu > 0 ? 1 : 0);
     std::lock_guard<std::mutex> g(mu);
     cache[key] = cap;
-    return cap;
+    return std::min(cap, side);
 }
 
 // Grid geometry: ncl clusters per direction (UB workgroups each); false if the shape is not supported.

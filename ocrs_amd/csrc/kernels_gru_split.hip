@@ -20,6 +20,7 @@
 //     evaluated on the uncut values; gates with hardware exp / rcp.
 //
 // A pair of bf16 values equal to 0xFFFFFFFF cannot be data: NaN states are stored as the canonical 0x7FC0 | 0.
+#include <algorithm>
 #include <atomic>
 #include <vector>
 
@@ -368,7 +369,7 @@ int resident_capacity(size_t lds) {   // see gru_resident_capacity (kernels_gru.
         cap = per_cu > 0 ? prop.multiProcessorCount : -1;
         cache[dev].store(cap, std::memory_order_relaxed);
     }
-    return cap > 0 ? cap : 0;
+    return cap > 0 ? std::min(cap, ctx().recurrence_cus()) : 0;   // (a partitioned device: the recurrences' side only)
 }
 
 size_t split_lds_bytes(int H, int np, int Tmax) { return (size_t)3 * (H / 32) * np * 1024 + ((size_t)Tmax + 1) * sizeof(int); }

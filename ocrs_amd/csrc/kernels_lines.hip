@@ -43,6 +43,9 @@ crop_lines_kernel(const float* const* __restrict__ pages, const int32_t* __restr
                   float* __restrict__ batch) {
     __shared__ int xs[2][MAX_LDS_EDGES];
     __shared__ int cnt[2];
+#ifdef OCRS_CROP_SETPRIO   // probe builds only (tools/build_hazard_repro.sh): the victim of the co-residency hazard at a raised wave priority
+    __builtin_amdgcn_s_setprio(OCRS_CROP_SETPRIO);
+#endif
     const LineDesc ln = lines[blockIdx.y];
     const int oy = blockIdx.x;
     const int out_w = ln.out_w;

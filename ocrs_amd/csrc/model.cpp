@@ -882,8 +882,8 @@ float* HipModel::run_prefix_ragged(Workspace& ws, hipStream_t exec, const std::v
     // (under heavy_phase, held here since before_launch), so every request's stack can use the same few buffers — with
     // six 16-page requests in flight that is ~5 GB once instead of ~5 GB per request.  Buffers are never handed back while
     // the process runs (an earlier request's kernels may still be using them); the arena grows to the largest request seen.
-    // (a device that runs one kernel at a time — DeviceContext::serialized() — has exec == the request's stream: same rule)
-    const bool shared_arena = exec != ws.s() || (ctx().serialized() && before_launch);
+    // (a request of a device that runs one kernel at a time — StreamLease::serial() — has exec == its own stream: same rule)
+    const bool shared_arena = exec != ws.s() || (ws.stream.serial() && before_launch);
     std::vector<char> arena_taken;
     auto get = [&](size_t floats) -> float* {
         const size_t bytes = floats * sizeof(float);
@@ -1039,8 +1039,9 @@ int HipModel::run_recognition_packed(Workspace& ws, const std::vector<PackedGrou
         // all conv stacks of a device go through ONE stream, in request order.  The lock is taken by the hook, i.e. after
         // the request's geometry has been worked out and its metadata uploads are queued.
         std::unique_lock<std::mutex> heavy(ctx().heavy_phase, std::defer_lock);
+        const hipStream_t conv = ws.stream.conv_stream();   // the device's conv-stack stream (MODE_PARTITION: confined to the split kernels' units)
         try {
-            X = run_prefix_ragged(ws, heavy_stream(), groups, plan, h, ts, timers, &C0, [&] { heavy.lock(); });
+            X = run_prefix_ragged(ws, conv, groups, plan, h, ts, timers, &C0, [&] { heavy.lock(); });
         } catch (...) {
             // Kernels of this request may already be queued on the shared stream, reading and writing scratch
             // that ~Workspace hands back to the pool after draining only the request's OWN stream: make that
@@ -1048,10 +1049,10 @@ int HipModel::run_recognition_packed(Workspace& ws, const std::vector<PackedGrou
             hipEvent_t e = nullptr;
             if (hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess) {
                 ws.events.push_back(e);
-                if (hipEventRecord(e, heavy_stream()) != hipSuccess || hipStreamWaitEvent(ws.s(), e, 0) != hipSuccess)
-                    (void)hipStreamSynchronize(heavy_stream());
+                if (hipEventRecord(e, conv) != hipSuccess || hipStreamWaitEvent(ws.s(), e, 0) != hipSuccess)
+                    (void)hipStreamSynchronize(conv);
             } else {
-                (void)hipStreamSynchronize(heavy_stream());
+                (void)hipStreamSynchronize(conv);
             }
             throw;
         }
@@ -1111,6 +1112,21 @@ int HipModel::run_recognition_packed(Workspace& ws, const std::vector<PackedGrou
             const double gx_flops = 2.0 * 2 * R * (double)d.N * d.K, gx_bytes = 4.0 * ((double)R * I + 2.0 * R * d.N + 2.0 * d.K * d.N);
             // (round 3's option gx_heavy queued these projections on the conv-stack stream: every MFMA class then ran at its
             // alone speed at the same or slightly lower pages/s — a zero-sum trade, removed in round 5)
+            if (ws.stream.mode() == DeviceContext::MODE_PARTITION && np != 0 && d.Bsplit) {
+                // the projection is a bf16-split kernel too: it belongs on the compute units set aside for them, i.e. on the
+                // conv-stack stream, in request order like the conv stacks (events both ways, no host wait)
+                DeviceContext& dc = ctx();
+                std::lock_guard<std::mutex> g(dc.heavy_phase);
+                const hipStream_t cs = ws.stream.conv_stream();
+                hipEvent_t ready = ws.make_event(), done = ws.make_event();
+                OCRS_HIP(hipEventRecord(ready, st));
+                OCRS_HIP(hipStreamWaitEvent(cs, ready, 0));
+                int ktok = timers ? timers->kbegin(KC_GEMM_GRU_INPUT, cs, gx_flops, gx_bytes) : -1;
+                k::gemm(d, cs);
+                if (ktok >= 0) timers->end(ktok, cs);
+                OCRS_HIP(hipEventRecord(done, cs));
+                OCRS_HIP(hipStreamWaitEvent(st, done, 0));
+            } else
             timed(KC_GEMM_GRU_INPUT, gx_flops, gx_bytes, [&] { k::gemm(d, st); });
             bool ran_persistent = false;
             if (persistent) {
@@ -1123,7 +1139,7 @@ int HipModel::run_recognition_packed(Workspace& ws, const std::vector<PackedGrou
                 {
                     DeviceContext& dc = ctx();
                     std::lock_guard<std::mutex> g(dc.rec_phase);
-                    hipStream_t rs = dc.recurrent_stream();
+                    hipStream_t rs = ws.stream.recurrent_stream();
                     hipEvent_t ready = ws.make_event(), done = ws.make_event();
                     OCRS_HIP(hipEventRecord(ready, st));
                     OCRS_HIP(hipStreamWaitEvent(rs, ready, 0));

@@ -1,0 +1,133 @@
+"""Round 6 GPU tests: the standing concurrency canary, the isolation regimes of the bf16-split kernels and their safe switch.
+
+The canary (tools/hazard_canary.py) calls every stage of the pipeline through the C ABI from six threads and compares EVERY
+element of every stage's output — grey page, probability map, word rects, every line crop, every log-probability, every CTC
+step — with what the same engine computed for the same input alone on the device.  The reference's contract is concurrent
+`Model::run` (recognition.rs:465-485); that results do not depend on what runs beside them is a test here, not an absence of
+reports.
+"""
+import os
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+import models_util as M  # noqa: E402
+from ocrs_amd import DimOrder, ImageSource, Model, OcrEngine, _lib, synth  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def _assert_clean(rep, min_checks):
+    assert not rep["errors"], rep["errors"]
+    assert rep["mismatching_checks"] == 0, {k: v for k, v in rep["classes"].items() if v["bad_checks"]}
+    assert rep["sequential_pass_after_differs_on_pages"] == 0
+    for cls, n in min_checks.items():
+        assert rep["classes"][cls]["checks"] >= n, (cls, rep["classes"][cls])
+
+
+def test_exact_mode_canary_every_stage_every_element_six_threads_twenty_seconds():
+    """Exact engine, isolation untouched (every call on its own stream, conv stacks and recurrences on the shared ones): 20 s of
+    six threads, every victim class — prepare, resize + detection CNN, threshold + components + contours, line crops, conv stack
+    + projections + recurrence + head, CTC — equal to the quiet run, element for element."""
+    import hazard_canary as HC
+    _lib.require_gpu()
+    rep = HC.run(numerics="exact", isolation="auto", seconds=20.0, threads=6)
+    assert rep["isolation"]["mode"] == "free"
+    _assert_clean(rep, {"prepare": 20, "text_map": 20, "words": 20, "crop": 500, "logits": 20, "tokens": 20})
+
+
+@pytest.mark.parametrize("mode", ["relaxed", "reduced"])
+def test_relaxed_modes_canary_under_the_default_isolation(mode):
+    """numerics != exact with the default policy (one stream per device while such an engine exists): the same canary, clean."""
+    import hazard_canary as HC
+    _lib.require_gpu()
+    rep = HC.run(numerics=mode, isolation="auto", seconds=8.0, threads=6)
+    assert rep["isolation"]["mode"] == "serial" and rep["isolation"]["relaxed_engines"] == 1
+    _assert_clean(rep, {"crop": 100, "logits": 5})
+    assert _lib.isolation()["mode"] == "free" and _lib.isolation()["relaxed_engines"] == 0   # the engine is gone, so is the regime
+
+
+def test_cu_partition_runs_the_pipeline_with_golden_bits_of_the_serial_regime():
+    """OCRS_ISOLATION_CU_PARTITION: split kernels on a stream confined to 128 compute units, everything else (the persistent
+    recurrence included: its grid is planned for the 128 units of its side) on the complementary ones.  Same bits as the
+    one-stream regime, sequentially and from four threads."""
+    _lib.require_gpu()
+    det, rec = Model.load_bytes(M.detection_model_bytes()), Model.load_bytes(M.recognition_model_bytes())
+    px = [synth.synthetic_page(40 + s, 700 + 90 * s, 900 + 60 * s, lines=20 + 7 * s, columns=1) for s in range(4)]
+    try:
+        eng = OcrEngine(detection_model=det, recognition_model=rec, numerics="relaxed")
+        assert _lib.isolation()["mode"] == "serial"
+        want = []
+        for p in px:
+            inp = eng.prepare_input(ImageSource.from_tensor(p, DimOrder.Hwc))
+            words = eng.detect_words(inp)
+            lines = eng.find_text_lines(inp, words)
+            want.append((inp, words, lines, eng.recognize_logits(inp, lines)))
+        _lib.set_isolation("partition", 128)
+        info = _lib.isolation()
+        assert info["mode"] == "partition" and info["split_cus"] == 128 and info["cus"] >= 136
+        bad = []
+
+        def worker(k):
+            for it in range(6):
+                inp, words, lines, logp = want[(it + k) % len(want)]
+                got = eng.recognize_logits(inp, lines)
+                if not all(np.array_equal(a, b) for a, b in zip(got, logp)) or eng.detect_words(inp).tobytes() != words.tobytes():
+                    bad.append((k, it))
+
+        worker(0)
+        ths = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
+        [t.start() for t in ths]
+        [t.join() for t in ths]
+        assert not bad, bad
+        del want, eng
+    finally:
+        _lib.set_isolation("auto", 0)
+    assert _lib.isolation()["mode"] == "free"
+
+
+def test_creating_and_destroying_a_relaxed_engine_under_load_drains_instead_of_mixing_regimes():
+    """Three threads keep an EXACT engine busy while relaxed engines are created, used and destroyed: the regime change waits for
+    the requests in flight (round 5 flipped a flag under them: requests of the two regimes overlapped, two persistent recurrences
+    could be half-resident together).  Every result equals the quiet run; nothing times out."""
+    _lib.require_gpu()
+    det, rec = Model.load_bytes(M.detection_model_bytes()), Model.load_bytes(M.recognition_model_bytes())
+    exact = OcrEngine(detection_model=det, recognition_model=rec)
+    pre = []
+    for s in range(5):
+        p = synth.synthetic_page(60 + s, 600 + 100 * s, 800 + 120 * s, lines=12 + 9 * s, columns=1)
+        inp = exact.prepare_input(ImageSource.from_tensor(p, DimOrder.Hwc))
+        words = exact.detect_words(inp)
+        lines = exact.find_text_lines(inp, words)
+        pre.append((inp, words, lines, exact.recognize_tokens(inp, lines)))
+    bad, seen_modes, stop = [], set(), threading.Event()
+
+    def load(k):
+        it = 0
+        while not stop.is_set():
+            inp, words, lines, tok = pre[(it + k) % len(pre)]
+            if exact.recognize_tokens(inp, lines) != tok or exact.detect_words(inp).tobytes() != words.tobytes():
+                bad.append((k, it))
+            it += 1
+
+    ths = [threading.Thread(target=load, args=(k,)) for k in range(3)]
+    [t.start() for t in ths]
+    try:
+        for rnd in range(4):
+            rel = OcrEngine(detection_model=det, recognition_model=rec, numerics="relaxed" if rnd % 2 == 0 else "reduced")
+            seen_modes.add(_lib.isolation()["mode"])
+            inp, words, lines, _ = pre[rnd % len(pre)]
+            a = rel.recognize_tokens(inp, lines)
+            assert rel.recognize_tokens(inp, lines) == a
+            del rel
+            seen_modes.add(_lib.isolation()["mode"])
+    finally:
+        stop.set()
+        [t.join() for t in ths]
+    assert seen_modes == {"serial", "free"}
+    assert not bad, bad[:5]

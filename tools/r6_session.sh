@@ -1,0 +1,72 @@
+#!/bin/bash
+# Round-6 GPU sessions: tools/r6_session.sh <tag> <section>...   (outputs under gpurun_out/<tag>/)
+set -u
+export TMPDIR=/tmp
+TAG=$1; shift
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+S=$OUT/summary.txt
+: > $S
+say() { echo "$@" | tee -a $S; }
+bsum() {  # file label
+python - "$1" "$2" <<'PY' | tee -a $S
+import json, sys
+f, label = sys.argv[1], sys.argv[2]
+try:
+    d = json.loads([l for l in open(f).read().splitlines() if l.startswith("{")][-1])
+    rl = d.get("rooflines", {})
+    print("%s: %.1f pages/s (%.2f ms/step) incl fill/drain %s | %s" % (label, d["value"], d["ms_per_step"], d.get("value_incl_fill_drain"),
+          ", ".join("%s %.3f/%.3f (%.2f ms x %.1f)" % (k.replace("gemm_", "").replace("_mfma", ""), v["frac"], v.get("frac_alone", 0), v["avg_launch_ms"], v["launches_per_step"]) for k, v in rl.items())))
+    ex = d.get("extras", {})
+    if "numerics" in ex: print("   numerics:", {k: (v.get("pages_per_s"), v.get("speedup")) for k, v in ex["numerics"].items() if isinstance(v, dict)})
+    for k in ("value_resident", "value_from_pageable_host_pixels"):
+        if k in d: print("   %s: %s" % (k, d[k]))
+    if "roofline_detection" in d: print("   detection:", json.dumps(d["roofline_detection"])[:300])
+    if "single_page_api" in ex: print("   single_page_api:", json.dumps(ex["single_page_api"])[:500])
+    if "detection_only" in ex: print("   detection_only:", json.dumps(ex["detection_only"])[:300])
+except Exception as e:
+    print(label, "parse failed:", e)
+PY
+}
+for sec in "$@"; do
+case $sec in
+tests)
+  say "== full GPU suite"; timeout 1500 python -m pytest tests -m gpu -x -q > $OUT/test_gpu_all.log 2>&1; say "rc=$?"; tail -6 $OUT/test_gpu_all.log | tee -a $S;;
+tests_r6)
+  say "== round-6 GPU tests"; timeout 900 python -m pytest tests/test_gpu_r6.py -x -q > $OUT/test_r6.log 2>&1; say "rc=$?"; tail -12 $OUT/test_r6.log | tee -a $S;;
+bench20)
+  say "== the driver's command: --steps 20 --warmup 5"
+  timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver_form.json 2> $OUT/bench_driver_form.err; say "rc=$?"; bsum $OUT/bench_driver_form.json "driver form";;
+bench72)
+  say "== default bench (72 steps)"
+  timeout 900 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; say "rc=$?"; bsum $OUT/bench_default.json "default";;
+benchq)
+  say "== quick bench, no extras"
+  timeout 600 python bench.py --no-extras --no-cpu-baseline > $OUT/bench_quick.json 2> $OUT/bench_quick.err; say "rc=$?"; bsum $OUT/bench_quick.json "quick";;
+canary)
+  say "== hazard canary (tools/hazard_canary.py): every stage, every element, six threads"
+  for cfg in "exact auto 0 12" "relaxed none 0 15" "reduced none 0 15" "relaxed partition 128 15" "reduced partition 128 15" "relaxed auto 0 8"; do
+    set -- $cfg
+    timeout 300 python tools/hazard_canary.py --numerics $1 --isolation $2 --split-cus $3 --seconds $4 > $OUT/canary_$1_$2_$3.json 2> $OUT/canary_$1_$2_$3.err; rc=$?
+    python - $OUT/canary_$1_$2_$3.json "$cfg rc=$rc" <<'PY' | tee -a $S
+import json, sys
+try:
+    d = json.loads([l for l in open(sys.argv[1]).read().splitlines() if l.startswith("{")][-1])
+    print(sys.argv[2], d["isolation"], "| mismatching checks", d["mismatching_checks"], {k: (v["checks"], v["bad_checks"], v["bad_elements"]) for k, v in d["classes"].items()},
+          "| crop cols mod 64:", d["crop_mismatch_columns_mod_64"], "| errors", d["errors"][:2])
+except Exception as e:
+    print(sys.argv[2], "parse failed", e)
+PY
+  done;;
+repro)
+  say "== stand-alone reproducer (tools/hazard_repro.hip): the real gemm_split_kernel beside twin launches of the real crop_lines_kernel"
+  for a in "--aggressor none --seconds 4" "--aggressor split3 --seconds 12" "--aggressor split2 --seconds 12" "--aggressor exact --seconds 8" \
+           "--aggressor split3 --seconds 12 --victim-streams 4" "--aggressor split3 --seconds 12 --lines 8 --victim-streams 4" \
+           "--aggressor split3 --seconds 12 --split-cus 128 --victim-streams 4"; do
+    timeout 120 tools/_build/hazard_repro $a 2>> $OUT/repro.err | tee -a $S
+  done
+  say "-- victim at s_setprio 3"
+  timeout 120 tools/_build/hazard_repro.prio3 --aggressor split3 --seconds 12 --victim-streams 4 2>> $OUT/repro.err | tee -a $S;;
+*) say "unknown section $sec";;
+esac
+done
