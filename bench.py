@@ -93,6 +93,14 @@ def parse(argv=None):
     ap.add_argument("--gather", choices=("auto", "host", "rccl", "rccl-final"), default="auto",
                     help="engine-group mode: transport of the FINAL result gather (auto = RCCL for >= 2 distinct devices); 'rccl' also "
                          "sends every per-request gather through RCCL (opt-in), 'rccl-final' forces RCCL for the final gather only")
+    ap.add_argument("--replay", action="store_true",
+                    help="engine-group mode only: HOST-SIDE PRE-FLIGHT of a multi-GPU node on a box with fewer GPUs.  The share times of "
+                         "the three GPU stages are measured on one member under load, every page's results are recorded once, then "
+                         "the members REPLAY them (ocrs_group_set_replay: a share sleeps its stage's time, no GPU work) while dealing, "
+                         "worker threads, gathers, find_text_lines and this loop run for real: N members on one GPU look, to the host, "
+                         "like N GPUs at the single-GPU page rate")
+    ap.add_argument("--replay-ms", type=str, default="",
+                    help="with --replay: prepare,detect,recognize share times in ms instead of measuring them")
     ap.add_argument("--dist-selftest", action="store_true",
                     help="exercise only the multi-rank plumbing (spawn, rendezvous, page sharding, result gather, "
                          "reductions) with fake per-page results and no GPU: the CPU test of the N > 1 path")
@@ -297,11 +305,11 @@ def main():
             return range(len(host_pages))
         return range(k * BG, min((k + 1) * BG, len(host_pages)))
 
-    def make_stages(eng, grp, resident):
+    def make_stages(eng, grp, resident, walls=None, prep_walls=None, idx_of=None):
         """(prepare, rest) of one step on engine `eng` / group `grp`: prepare = host pixels (or resident pages) -> OcrInputs;
         rest = detect -> layout -> recognise"""
         def prepare(k=0):
-            idx = page_slice(k)
+            idx = idx_of if idx_of is not None else page_slice(k)
             if resident:
                 if grp is not None:
                     return grp.prepare_input_device_batch([dptrs[i].value for i in idx], np.uint8, DimOrder.Hwc, H, W, 3)
@@ -312,13 +320,51 @@ def main():
 
         def rest(inputs):
             tgt = grp if grp is not None else eng
+            t0 = time.perf_counter()
             words = tgt.detect_words_batch(inputs)
+            t1 = time.perf_counter()
             rects, loffs, poffs = tgt.find_text_lines_batch_raw(words)
+            t2 = time.perf_counter()
             chars, coffs = tgt.recognize_text_batch_raw(inputs, rects, loffs, poffs)
+            if walls is not None:
+                walls.append((t1 - t0, t2 - t1, time.perf_counter() - t2))
             return words, (rects, loffs, poffs), (chars, coffs)
+        if walls is not None:
+            timed_prepare = prepare
+
+            def prepare(k=0):
+                t0 = time.perf_counter()
+                out = timed_prepare(k)
+                prep_walls.append(time.perf_counter() - t0)
+                return out
         return prepare, rest
 
     prepare, rest = make_stages(engine, group, args.resident)
+    replay = None
+    if args.replay:
+        if not group_mode or args.resident:
+            raise SystemExit("--replay needs the engine group (--gpus N > 1 or --devices ...) and host pixels")
+        if args.replay_ms:
+            share_s = [float(x) * 1e-3 for x in args.replay_ms.split(",")]
+            how = "given on the command line"
+        else:
+            # what one share of each stage takes on ONE GPU at full load: member 0 alone, its block of pages, the standard loop
+            walls, pw = [], []
+            p1, r1 = make_stages(engine, None, False, walls=walls, prep_walls=pw, idx_of=range(B))
+            run_steps(3 * max(args.inflight, 1), prepare=p1, rest=r1, latency=[])
+            del walls[:], pw[:]
+            t0m = time.perf_counter()
+            run_steps(24, prepare=p1, rest=r1, latency=[])
+            single_rate = 24 * B / (time.perf_counter() - t0m)
+            share_s = [float(np.median(pw)), float(np.median([w[0] for w in walls])), float(np.median([w[2] for w in walls]))]
+            how = ("medians of the prepare / detect / recognize call wall times of member 0 alone (%d pages per call, %d calls in flight, "
+                   "%.1f pages/s on this GPU; fill and drain included)" % (B, max(args.inflight, 1), single_rate))
+        group.set_replay(1)
+        rest(prepare(0))                      # record: every page of a step once, for real
+        group.set_replay(2, share_s)
+        replay = {"share_seconds": [round(x, 5) for x in share_s], "share_times": how, "members": G,
+                  "what_is_real": "dealing, worker threads + NUMA binding, payload packing, per-request and final gathers, reassembly in page "
+                                  "order, find_text_lines_batch on the recorded rects, result unpacking, this loop; no GPU work in the timed region"}
 
     step_latency = []   # seconds per whole step (request latency), appended by every in-flight host thread
     handover_latency = []   # the same measured from the moment the request's host pixels were handed to the uploader
@@ -497,7 +543,7 @@ def main():
     value = n_pages_all / elapsed
     last = outs[-1]
     result = {
-        "metric": "pages/sec end-to-end (1024x1024)",
+        "metric": "pages/sec end-to-end (1024x1024)" if not replay else "HOST-SIDE PRE-FLIGHT pages/sec (GPU shares replayed, not computed)",
         "value": round(value, 3),
         "unit": "pages/s",
         "n_gpus": G if group_mode else world,
@@ -566,6 +612,10 @@ def main():
     if members is not None:
         result["members"] = members
         result["final_gather"] = final_gather
+    if replay:
+        result["replay"] = replay
+        result["data"] = "synthetic; REPLAY: the members' GPU shares sleep their measured time and return recorded results"
+        result["host_logical_cpus"] = os.cpu_count()
 
     # ---- stage table + rooflines (HIP events, timed region)
     result["stages_ms_per_step"] = {k: round(v[0] / steps_under_timers, 4) for k, v in stages.items() if v[0] > 0}

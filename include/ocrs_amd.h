@@ -304,8 +304,10 @@ OCRS_API ocrs_status ocrs_page_image(const ocrs_page* p, float* out_hw);
 /* OcrEngine::detect_words (lib.rs:193-199 -> detection.rs:104-122).
  * *rects receives n x 6 floats in contour discovery order. */
 OCRS_API ocrs_status ocrs_engine_detect_words(const ocrs_engine* e, const ocrs_page* page, float** rects, size_t* n);
-/* Batched form: pages must share one size; rects of page i are
- * (*rects)[6*offsets[i] .. 6*offsets[i+1]); offsets has n_pages+1 entries. */
+/* Batched form: pages of ANY sizes (the reference takes any image per call, detection.rs:131-171; the model runs once over
+ * the whole batch at its own fixed size, the size-dependent kernels once per distinct page size — r6; rounds 1-5 wanted one
+ * size per batch); rects of page i are (*rects)[6*offsets[i] .. 6*offsets[i+1]); offsets has n_pages+1 entries.  Concurrent
+ * one-page calls are merged the same way whatever their sizes. */
 OCRS_API ocrs_status ocrs_engine_detect_words_batch(const ocrs_engine* e, const ocrs_page* const* pages, size_t n_pages,
                                            float** rects, size_t* offsets);
 
@@ -495,6 +497,14 @@ OCRS_API ocrs_status ocrs_group_gather(ocrs_engine_group* g, const void* const* 
  * when the group has two or more members and RCCL can be had, else host — never an error for lack of RCCL). */
 OCRS_API ocrs_status ocrs_group_final_gather(ocrs_engine_group* g, ocrs_gather_mode mode, const void* const* payloads,
                                              const size_t* bytes, void** out, size_t* offsets);
+/* Test hook — host-side pre-flight of a multi-GPU deployment on a box with fewer GPUs (bench.py --replay; SURVEY §8e names the
+ * host as the expected scaling limiter).  mode 1 = record: calls run as usual and the group keeps every page's word rects and
+ * recognised lines, keyed by the host pixels the page was prepared from (ocrs_group_prepare_input_batch).  mode 2 = replay: a
+ * member's share of a call does no GPU work — it sleeps seconds[stage] (stage 0 prepare, 1 detect, 2 recognize: what one
+ * share takes on one GPU under load) and returns the recorded results of its pages — while dealing, worker threads and their
+ * NUMA binding, payload packing, the per-request and final gathers and the reassembly in page order run as in production.
+ * mode 0 = off (forgets the records).  Not for concurrent use with calls in flight. */
+OCRS_API ocrs_status ocrs_group_set_replay(ocrs_engine_group* g, int mode, const double seconds[3]);
 /* What member m has done so far, for diagnosing a multi-GPU run (the host side is the expected scaling
  * limiter): out = {shares of calls it ran, pages those carried, CPU nanoseconds of the host threads that ran them, their wall
  * nanoseconds, NUMA node of its GPU + 1 (0 = the host does not say), CPUs of that node (0 = no binding), shares that ran

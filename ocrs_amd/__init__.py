@@ -790,6 +790,11 @@ class EngineGroup:
         lib().ocrs_buffer_free(out)
         return data, [int(offs[i]) for i in range(g + 1)]
 
+    def set_replay(self, mode, seconds=(0.0, 0.0, 0.0)):
+        """ocrs_group_set_replay (test hook): 0 off, 1 record per-page results, 2 replay them after sleeping seconds[stage]."""
+        arr = (C.c_double * 3)(*[float(x) for x in seconds])
+        check(lib().ocrs_group_set_replay(self._h, int(mode), arr))
+
     def worker_threads(self):
         n = C.c_size_t(0)
         check(lib().ocrs_group_worker_threads(self._h, C.byref(n)))

@@ -71,7 +71,7 @@ DECLARED_SYMBOLS = [
     "ocrs_group_prepare_input_batch", "ocrs_group_prepare_input_device_batch", "ocrs_group_detect_words_batch",
     "ocrs_group_recognize_text_batch", "ocrs_group_gather", "ocrs_group_final_gather", "ocrs_group_worker_threads", "ocrs_group_last_gather", "ocrs_device_malloc_on", "ocrs_engine_coalesce_stats", "ocrs_coalescer_selftest", "ocrs_engine_kernel_mfma_flops", "ocrs_engine_prepare_input_jpeg", "ocrs_jpeg_decode_rgb", "ocrs_jpeg_info", "ocrs_jpeg_coefficients",
     "ocrs_group_member_stats", "ocrs_numa_parse_cpulist", "ocrs_numa_bind_selftest", "ocrs_engine_recognize_logits", "ocrs_engine_set_option", "ocrs_engine_get_option", "ocrs_option_name", "ocrs_device_pool_stats", "ocrs_device_pool_configure", "ocrs_device_pool_trim",
-    "ocrs_device_set_isolation", "ocrs_device_isolation",
+    "ocrs_device_set_isolation", "ocrs_device_isolation", "ocrs_group_set_replay",
 ]
 
 _lib = None

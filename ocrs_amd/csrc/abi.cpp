@@ -113,14 +113,18 @@ ocrs_status ocrs_ctc_beam_search(const float* logp, int t, int c, uint32_t width
 
 ocrs_status ocrs_set_option(const char* name, long value) {
     return guarded([&] {
-        if (!set_option(name, value)) fail(OCRS_ERR_INVALID_ARGUMENT, "unknown option '%s'", name ? name : "(null)");
+        const int r = set_option(name, value);
+        if (r == 1) fail(OCRS_ERR_INVALID_ARGUMENT, "unknown option '%s'", name ? name : "(null)");
+        if (r == 2) fail(OCRS_ERR_INVALID_ARGUMENT, "option '%s': value %ld is out of range", name, value);
     });
 }
 
 ocrs_status ocrs_engine_set_option(ocrs_engine* e, const char* name, long value) {
     return guarded([&] {
         if (!e) fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
-        if (!set_option(e->tuning, name, value)) fail(OCRS_ERR_INVALID_ARGUMENT, "unknown option '%s'", name ? name : "(null)");
+        const int r = set_option(e->tuning, name, value);
+        if (r == 1) fail(OCRS_ERR_INVALID_ARGUMENT, "unknown option '%s'", name ? name : "(null)");
+        if (r == 2) fail(OCRS_ERR_INVALID_ARGUMENT, "option '%s': value %ld is out of range", name, value);
     });
 }
 

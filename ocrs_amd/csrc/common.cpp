@@ -1,6 +1,8 @@
 #include "common.hpp"
 
 #include <chrono>
+#include <climits>
+#include <cstdint>
 #include <cstdlib>
 #include <cstring>
 
@@ -103,34 +105,37 @@ namespace {
 struct Trimmer;
 Trimmer& trimmer();
 struct Trimmer {
+    struct Item { int device; void* p; std::atomic<uint64_t>* freed; };   // device -1: pinned host memory; freed: the pool's counter
     std::mutex mu;
     std::condition_variable cv;
-    std::deque<std::pair<int, void*>> q;   // (device or -1 for pinned host memory, pointer)
+    std::deque<Item> q;
     bool started = false;
     std::atomic<bool> exiting{false};   // set by an atexit handler: the HIP runtime may be tearing down, leave the blocks to the OS
+    std::mutex freeing;                 // held across every hipFree / hipHostFree: the atexit handler takes it to wait one out
     void run() {
         for (;;) {
-            std::pair<int, void*> it;
+            Item it;
             {
                 std::unique_lock<std::mutex> lk(mu);
                 cv.wait(lk, [&] { return !q.empty(); });
                 it = q.front();
                 q.pop_front();
             }
-            if (exiting.load()) continue;
-            if (it.first >= 0) {
-                if (hipSetDevice(it.first) == hipSuccess) (void)hipFree(it.second);
-            } else {
-                (void)hipHostFree(it.second);
-            }
+            std::lock_guard<std::mutex> f(freeing);
+            if (exiting.load()) continue;       // checked under `freeing`: once the handler has had the lock no free starts
+            bool ok;
+            if (it.device >= 0) ok = hipSetDevice(it.device) == hipSuccess && hipFree(it.p) == hipSuccess;
+            else ok = hipHostFree(it.p) == hipSuccess;
             (void)hipGetLastError();
+            if (ok && it.freed) it.freed->fetch_add(1, std::memory_order_relaxed);   // counted when the driver has the block back
         }
     }
-    void give(int device, void* p) {
+    void give(int device, void* p, std::atomic<uint64_t>* freed) {
         std::lock_guard<std::mutex> lk(mu);
         if (!started) {
             started = true;
-            std::atexit([] { trimmer().exiting.store(true); });
+            // process exit: no free may be in progress while the HIP runtime's own exit handlers and static destructors run
+            std::atexit([] { Trimmer& t = trimmer(); t.exiting.store(true); std::lock_guard<std::mutex> f(t.freeing); });
             try {
                 std::thread([this] { run(); }).detach();
             } catch (const std::system_error&) {
@@ -138,10 +143,11 @@ struct Trimmer {
             }
         }
         if (!started) {   // no thread to be had: free here after all
-            if (device >= 0) (void)hipFree(p); else (void)hipHostFree(p);
+            const bool ok = (device >= 0 ? hipFree(p) : hipHostFree(p)) == hipSuccess;
+            if (ok && freed) freed->fetch_add(1, std::memory_order_relaxed);
             return;
         }
-        q.emplace_back(device, p);
+        q.push_back(Item{device, p, freed});
         cv.notify_one();
     }
 };
@@ -181,11 +187,10 @@ void DevicePool::set_cap(uint64_t bytes) {
             auto big = std::prev(free_.end());
             drop.push_back(big->second);
             cached_ -= big->first;
-            frees_++;
             free_.erase(big);
         }
     }
-    for (void* p : drop) trimmer().give(device_, p);
+    for (void* p : drop) trimmer().give(device_, p, &frees_);
 }
 
 PoolStats DevicePool::stats() {
@@ -244,11 +249,10 @@ void DevicePool::release(void* p) {
             auto big = std::prev(free_.end());
             drop.push_back(big->second);
             cached_ -= big->first;
-            frees_++;
             free_.erase(big);
         }
     }
-    for (void* q : drop) trimmer().give(device_, q);
+    for (void* q : drop) trimmer().give(device_, q, &frees_);
 }
 
 void DevicePool::trim() {
@@ -304,11 +308,10 @@ void HostPool::release(void* p) {
             auto big = std::prev(free_.end());
             drop.push_back(big->second);
             cached_ -= big->first;
-            frees_++;
             free_.erase(big);
         }
     }
-    for (void* q : drop) trimmer().give(-1, q);
+    for (void* q : drop) trimmer().give(-1, q, &frees_);
 }
 
 void HostPool::set_cap(uint64_t bytes) {
@@ -344,18 +347,23 @@ hipStream_t DeviceContext::heavy_stream() {
 
 hipStream_t DeviceContext::recurrent_stream(int mode) {
     if (mode == MODE_SERIAL) return heavy_stream();
-    std::lock_guard<std::mutex> g(lazy_mu_);
     hipStream_t& r = mode == MODE_PARTITION ? recurrent_masked_ : recurrent_;
-    if (!r) {
-        DeviceScope bind(device);
-        if (mode == MODE_PARTITION) {
-            r = masked_stream(false);
-        } else {
-            int least = 0, greatest = 0;
-            OCRS_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-            OCRS_HIP(hipStreamCreateWithPriority(&r, hipStreamNonBlocking, greatest));
-        }
+    {
+        std::lock_guard<std::mutex> g(lazy_mu_);
+        if (r) return r;
     }
+    // created outside lazy_mu_ (masked_stream and cu_count take it themselves); a race makes two, one is dropped
+    hipStream_t made = nullptr;
+    DeviceScope bind(device);
+    if (mode == MODE_PARTITION) {
+        made = masked_stream(false);
+    } else {
+        int least = 0, greatest = 0;
+        OCRS_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        OCRS_HIP(hipStreamCreateWithPriority(&made, hipStreamNonBlocking, greatest));
+    }
+    std::lock_guard<std::mutex> g(lazy_mu_);
+    if (!r) r = made; else (void)hipStreamDestroy(made);
     return r;
 }
 
@@ -373,8 +381,13 @@ hipStream_t DeviceContext::masked_stream(bool split_side) {
 }
 
 hipStream_t DeviceContext::split_stream() {
+    {
+        std::lock_guard<std::mutex> g(lazy_mu_);
+        if (split_) return split_;
+    }
+    hipStream_t made = masked_stream(true);   // outside lazy_mu_: cu_count() takes it
     std::lock_guard<std::mutex> g(lazy_mu_);
-    if (!split_) split_ = masked_stream(true);
+    if (!split_) split_ = made; else (void)hipStreamDestroy(made);
     return split_;
 }
 
@@ -492,12 +505,30 @@ const OptDef kOptDefs[OPT_COUNT] = {
     {"layout_threads", nullptr, 0},                     // host threads of find_text_lines_batch (0 = automatic)
     {"rec_max_pixels", nullptr, 0},                     // input pixels per recognition sub-request (0 = 2e9, the memory budget)
 };
+// accepted values per entry (the kernels index tables with some of these): {lo, hi} and, for the row-count selectors, the
+// allowed set beyond 0 / 1
+struct OptRange { long lo, hi; long also[4]; };
+const OptRange kOptRanges[OPT_COUNT] = {
+    {0, 1, {}}, {0, 1, {}}, {0, 1, {}}, {0, 2, {}}, {0, 1, {}}, {0, 1, {8, 14, 32}}, {0, 1, {8, 14, 20, 32}}, {0, 1, {}}, {0, 1, {}}, {0, 1, {}}, {0, 1, {}},
+    {0, 2, {}}, {0, 64, {}}, {1, 4096, {}}, {0, 10000000, {}}, {0, 4096, {}}, {0, INT64_MAX, {}},
+};
+bool in_range(int i, long v) {
+    const OptRange& r = kOptRanges[i];
+    if (v >= r.lo && v <= r.hi) return true;
+    for (long a : r.also) if (a && v == a) return true;
+    return false;
+}
+// options of rounds 2-4 that round 5 removed with their kernels: still accepted by ocrs_set_option as no-ops, so that a caller
+// (or a launch script) written against the older header keeps working; their OCRS_* environment variables are ignored
+const char* const kRetired[] = {"det_heavy", "det_tail", "gru_waves", "gru_background", "gru_scatter", "gru_gates_pack", "conv_occupancy",
+                                "gx_heavy", "gemm_nfast", "conv_a_lds", "gru_heavy", "heavy_priority"};
 std::atomic<long> g_opts[OPT_COUNT];
 std::once_flag g_opts_once;
 void init_options() {   // the only getenv of the option system: once per process
     for (int i = 0; i < OPT_COUNT; i++) {
         const char* e = kOptDefs[i].env ? getenv(kOptDefs[i].env) : nullptr;
-        g_opts[i].store(e && *e ? strtol(e, nullptr, 10) : kOptDefs[i].def);
+        const long v = e && *e ? strtol(e, nullptr, 10) : kOptDefs[i].def;
+        g_opts[i].store(in_range(i, v) ? v : kOptDefs[i].def);
     }
 }
 int find_option(const char* name, int count = OPT_PUBLIC_COUNT) {
@@ -513,7 +544,8 @@ TuningScope::~TuningScope() { t_tuning = prev_; }
 const Tuning* current_tuning() { return t_tuning; }
 
 long option_long(Option o) {
-    if (t_tuning) return t_tuning->v[o];
+    // relaxed atomic accesses: ocrs_engine_set_option may run while another thread serves a request of the same engine
+    if (t_tuning) return __atomic_load_n(&t_tuning->v[o], __ATOMIC_RELAXED);
     std::call_once(g_opts_once, init_options);
     return g_opts[o].load(std::memory_order_relaxed);
 }
@@ -528,25 +560,31 @@ Tuning default_tuning() {
 
 const char* option_name(int i) { return i >= 0 && i < OPT_PUBLIC_COUNT ? kOptDefs[i].name : nullptr; }
 
-bool set_option(const char* name, long value) {
+int set_option(const char* name, long value) {
     std::call_once(g_opts_once, init_options);
     const int i = find_option(name);
-    if (i < 0) return false;
+    if (i < 0) {
+        for (const char* r : kRetired) if (name && strcmp(name, r) == 0) return 0;
+        return 1;
+    }
+    if (!in_range(i, value)) return 2;
     g_opts[i].store(value);
-    return true;
+    return 0;
 }
 
-bool set_option(Tuning& t, const char* name, long value) {
+int set_option(Tuning& t, const char* name, long value) {
     const int i = find_option(name, OPT_COUNT);   // an engine's copy: also the configuration fields, by their field names
-    if (i < 0) return false;
-    t.v[i] = value;
-    return true;
+    if (i < 0) return 1;
+    if (!in_range(i, value)) return 2;
+    __atomic_store_n(&t.v[i], value, __ATOMIC_RELAXED);
+    return 0;
 }
 
 bool get_option(const Tuning& t, const char* name, long* value) {
+    // "numerics" is listed by neither ocrs_option_name nor set_option (fixed at creation) but can be read
     const int i = name && strcmp(name, "numerics") == 0 ? (int)OPT_NUMERICS : find_option(name, OPT_COUNT);
     if (i < 0) return false;
-    *value = t.v[i];
+    *value = __atomic_load_n(&t.v[i], __ATOMIC_RELAXED);
     return true;
 }
 

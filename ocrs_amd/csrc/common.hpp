@@ -79,7 +79,8 @@ class DevicePool {
     std::mutex mu_;
     std::multimap<size_t, void*> free_;
     std::map<void*, size_t> live_;
-    uint64_t cached_ = 0, live_bytes_ = 0, peak_live_ = 0, cap_ = 0, allocs_ = 0, frees_ = 0;
+    uint64_t cached_ = 0, live_bytes_ = 0, peak_live_ = 0, cap_ = 0, allocs_ = 0;
+    std::atomic<uint64_t> frees_{0};   // blocks the driver has back (counted by whoever called hipFree, after it returned)
 };
 
 // Pinned host staging (hipHostMalloc), cached in the same size buckets with the same reuse rule (smallest cached block
@@ -98,7 +99,8 @@ class HostPool {
     std::mutex mu_;
     std::multimap<size_t, void*> free_;
     std::map<void*, size_t> live_;
-    uint64_t cached_ = 0, live_bytes_ = 0, peak_live_ = 0, cap_ = uint64_t(1) << 30, allocs_ = 0, frees_ = 0;
+    uint64_t cached_ = 0, live_bytes_ = 0, peak_live_ = 0, cap_ = uint64_t(1) << 30, allocs_ = 0;
+    std::atomic<uint64_t> frees_{0};
 };
 
 struct DeviceContext {
@@ -205,8 +207,9 @@ enum Option { OPT_GRU_MODE = 0, OPT_GRU_GATES, OPT_GRU_LOCAL, OPT_DET_FUSE, OPT_
               OPT_COUNT };
 struct Tuning { long v[OPT_COUNT]; };
 Tuning default_tuning();                                   // the process defaults as they are now
-bool set_option(const char* name, long value);             // process default; false: unknown name
-bool set_option(Tuning& t, const char* name, long value);  // one engine's copy
+// 0 = set (or a retired name: accepted, ignored), 1 = unknown name, 2 = value outside the option's range
+int set_option(const char* name, long value);             // process default
+int set_option(Tuning& t, const char* name, long value);  // one engine's copy (safe while the engine serves requests)
 bool get_option(const Tuning& t, const char* name, long* value);
 const char* option_name(int i);                            // i < OPT_PUBLIC_COUNT
 class TuningScope {   // installs `t` for the calling thread for the lifetime of the object; nests

@@ -23,15 +23,46 @@ void ocrs_engine::detect_now(const ocrs_page* const* pages, size_t n, std::vecto
     const int64_t in_h64 = detection->input_shape[2], in_w64 = detection->input_shape[3];
     if (in_h64 <= 0 || in_w64 <= 0) fail(OCRS_ERR_MODEL_DIMS, "failed to get model dims");  // detection.rs:141-144
     const int in_h = (int)in_h64, in_w = (int)in_w64;
-    const int h = pages[0]->h, w = pages[0]->w;
-    for (size_t i = 1; i < n; i++)
-        if (pages[i]->h != h || pages[i]->w != w)
-            fail(OCRS_ERR_INVALID_ARGUMENT, "pages in one detection batch must share a size");
-    if (h <= 0 || w <= 0 || h > 65535 || w > 65535) fail(OCRS_ERR_INVALID_ARGUMENT, "unsupported page size %dx%d", h, w);
-
-    const int pad_bottom = std::max(in_h - h, 0), pad_right = std::max(in_w - w, 0);  // detection.rs:155-156
-    const int vh = h + pad_bottom, vw = w + pad_right;
     const int N = (int)n;
+    // The reference takes any image per call (detection.rs:131-171) and the model always runs at its own fixed size, so a
+    // batch may hold pages of SEVERAL sizes (r6; the coalescer merges whatever waits): the model runs once over all of them,
+    // the size-dependent kernels before and after it (resize in; resize back + threshold, components, contours) run once per
+    // size, on that size's pages — the same launches with the same arguments as a batch of that size alone, so nobody's bits
+    // change.  Internally the pages are ordered by size group (`order`); results go back in the caller's order.
+    struct SizeGroup {
+        int h = 0, w = 0, first = 0, count = 0;          // pages [first, first + count) of the grouped order
+        int pad_bottom = 0, pad_right = 0, max_comp = 0;
+        int64_t px = 0, arena = 0;
+        uint8_t* d_mask = nullptr;
+        k::CclBuffers b{};
+        std::vector<int32_t> counts, ovf;
+        std::vector<float> hr_all;
+        std::vector<uint8_t> hv_all;
+    };
+    std::vector<SizeGroup> groups;
+    std::vector<int> order(n), group_of(n);
+    {
+        std::vector<int> gi(n);
+        for (size_t i = 0; i < n; i++) {
+            const int h = pages[i]->h, w = pages[i]->w;
+            if (h <= 0 || w <= 0 || h > 65535 || w > 65535) fail(OCRS_ERR_INVALID_ARGUMENT, "unsupported page size %dx%d", h, w);
+            size_t g = 0;
+            while (g < groups.size() && (groups[g].h != h || groups[g].w != w)) g++;
+            if (g == groups.size()) { groups.emplace_back(); groups[g].h = h; groups[g].w = w; }
+            groups[g].count++;
+            gi[i] = (int)g;
+        }
+        if (host_map && groups.size() > 1)
+            fail(OCRS_ERR_INVALID_ARGUMENT, "pages whose probability maps are returned in one [n, h, w] array must share a size");
+        int at = 0;
+        for (SizeGroup& g : groups) { g.first = at; at += g.count; g.count = 0; }
+        for (size_t i = 0; i < n; i++) {
+            SizeGroup& g = groups[gi[i]];
+            order[g.first + g.count] = (int)i;
+            group_of[g.first + g.count] = gi[i];
+            g.count++;
+        }
+    }
 
     Workspace ws;
     hipStream_t st = ws.s();
@@ -39,16 +70,21 @@ void ocrs_engine::detect_now(const ocrs_page* const* pages, size_t n, std::vecto
     hipStream_t ex = st;   // (round 3 could route a small request's kernels through the device's conv-stack stream — option det_heavy,
                            // off since round 4: 180 vs 194 pages/s for one-page calls from 12 threads — removed in round 5)
 
-    // page pointer table
+    // page pointer table, grouped order
     std::vector<const float*> hp(n);
-    for (size_t i = 0; i < n; i++) hp[i] = pages[i]->grey.as<float>();
+    for (size_t i = 0; i < n; i++) hp[i] = pages[order[i]]->grey.as<float>();
     const float** d_ptrs = ws.alloc_n<const float*>(n);
     ws.upload(d_ptrs, hp.data(), n * sizeof(float*));
 
     float* d_in = ws.alloc_n<float>((size_t)N * in_h * in_w);
     {
-        StageScope sc(T, ST_RESIZE_IN, ex);
-        k::resize_pages_to_model(d_ptrs, N, h, w, vh, vw, d_in, in_h, in_w, ex);
+        StageScope sc(T, ST_RESIZE_IN, ex, groups.size());
+        for (SizeGroup& g : groups) {
+            g.pad_bottom = std::max(in_h - g.h, 0);   // detection.rs:155-156
+            g.pad_right = std::max(in_w - g.w, 0);
+            k::resize_pages_to_model(d_ptrs + g.first, g.count, g.h, g.w, g.h + g.pad_bottom, g.w + g.pad_right,
+                                     d_in + (size_t)g.first * in_h * in_w, in_h, in_w, ex);
+        }
     }
 
     const float* d_prob = nullptr;
@@ -57,7 +93,9 @@ void ocrs_engine::detect_now(const ocrs_page* const* pages, size_t n, std::vecto
         const auto* cb = static_cast<const CallbackModel*>(detection);
         std::vector<float> hin((size_t)in_h * in_w), hout;
         float* d_out = ws.alloc_n<float>((size_t)N * in_h * in_w);
-        for (int i = 0; i < N; i++) {
+        for (int oi = 0; oi < N; oi++) {
+            int i = 0;
+            while (order[i] != oi) i++;      // runs in the CALLER's page order (a caller's model may count its runs)
             ws.download(hin.data(), d_in + (size_t)i * in_h * in_w, hin.size() * sizeof(float));
             ws.sync();
             const int64_t ishape[4] = {1, 1, in_h, in_w};
@@ -82,15 +120,18 @@ void ocrs_engine::detect_now(const ocrs_page* const* pages, size_t n, std::vecto
     }
 
     // slice off the padded region, resize back, threshold (detection.rs:187-194,110)
-    const int sh = in_h - pad_bottom, sw = in_w - pad_right;
-    uint8_t* d_mask = ws.alloc_n<uint8_t>((size_t)N * h * w);
-    float* d_map = host_map ? ws.alloc_n<float>((size_t)N * h * w) : nullptr;
+    float* d_map = host_map ? ws.alloc_n<float>((size_t)N * groups[0].h * groups[0].w) : nullptr;
     {
-        StageScope sc(T, ST_RESIZE_THRESH, ex);
-        k::resize_threshold(d_prob, N, in_h, in_w, sh, sw, text_threshold, d_mask, d_map, h, w, ex);
+        StageScope sc(T, ST_RESIZE_THRESH, ex, groups.size());
+        for (SizeGroup& g : groups) {
+            g.px = (int64_t)g.h * g.w;
+            g.d_mask = ws.alloc_n<uint8_t>((size_t)g.count * g.px);
+            k::resize_threshold(d_prob + (size_t)g.first * in_h * in_w, g.count, in_h, in_w, in_h - g.pad_bottom, in_w - g.pad_right,
+                                text_threshold, g.d_mask, d_map, g.h, g.w, ex);
+        }
     }
-    if (host_map)
-        ws.download(host_map, d_map, (size_t)N * h * w * sizeof(float));
+    if (host_map)   // (one size group: grouped order = the caller's order)
+        ws.download(host_map, d_map, (size_t)N * groups[0].px * sizeof(float));
     if (!rects_out) {
         ws.sync();
         if (T) T->collect();
@@ -98,13 +139,10 @@ void ocrs_engine::detect_now(const ocrs_page* const* pages, size_t n, std::vecto
     }
 
     // connected components -> rects (detection.rs:41-62)
-    const int64_t px = (int64_t)h * w;
     // Scratch is sized for pages of text: up to 65 536 components and 2 border points per pixel.  The reference
     // takes ANY mask (detection.rs:41-62), so a page that does not fit (salt noise, dense halftone) gets its
     // component stage re-run on its own with buffers for the worst case — below.
-    const int max_comp = (int)std::min<int64_t>(65536, px / 2 + 16);
-    const int64_t arena = 2 * px + 64;
-    auto alloc_ccl = [&](int np, int mc, int64_t ar, hipStream_t cs) {
+    auto alloc_ccl = [&](int np, int h, int64_t px, int mc, int64_t ar, hipStream_t cs) {
         k::CclBuffers b{};
         b.labels = ws.alloc_n<int32_t>((size_t)np * px);
         b.row_counts = ws.alloc_n<int32_t>((size_t)np * h);
@@ -122,7 +160,7 @@ void ocrs_engine::detect_now(const ocrs_page* const* pages, size_t n, std::vecto
         OCRS_HIP(hipMemsetAsync(b.overflow, 0, np * sizeof(int32_t), cs));
         return b;
     };
-    auto run_ccl = [&](const uint8_t* mask, int np, const k::CclBuffers& b, int mc, int64_t ar, hipStream_t cs) {
+    auto run_ccl = [&](const uint8_t* mask, int np, int h, int w, const k::CclBuffers& b, int mc, int64_t ar, hipStream_t cs) {
         {
             StageScope sc(T, ST_CCL, cs, 4);
             k::ccl_label(mask, np, h, w, b, mc, cs);
@@ -132,57 +170,66 @@ void ocrs_engine::detect_now(const ocrs_page* const* pages, size_t n, std::vecto
             k::contour_rects(mask, np, h, w, b, mc, ar, /*expand*/ 3.0f, min_area, /*eps*/ 2.0f, cs);
         }
     };
-    const k::CclBuffers b = alloc_ccl(N, max_comp, arena, ex);
-    run_ccl(d_mask, N, b, max_comp, arena, ex);
     // One round trip in the common case: the counts travel together with the first kSpec candidate rects of every
     // page (a page of text has a few hundred to ~1 500 components); only a page with more needs a second one.
     constexpr int kSpec = 2048;
-    const int spec = std::min(max_comp, kSpec);
-    std::vector<int32_t> counts(N), ovf(N);
+    for (SizeGroup& g : groups) {
+        g.max_comp = (int)std::min<int64_t>(65536, g.px / 2 + 16);
+        g.arena = 2 * g.px + 64;
+        g.b = alloc_ccl(g.count, g.h, g.px, g.max_comp, g.arena, ex);
+        run_ccl(g.d_mask, g.count, g.h, g.w, g.b, g.max_comp, g.arena, ex);
+        const int spec = std::min(g.max_comp, kSpec);
+        g.counts.resize(g.count); g.ovf.resize(g.count);
+        g.hr_all.resize((size_t)g.count * spec * 6); g.hv_all.resize((size_t)g.count * spec);
+        ws.download(g.counts.data(), g.b.n_roots, g.count * sizeof(int32_t));
+        ws.download(g.ovf.data(), g.b.overflow, g.count * sizeof(int32_t));
+        // the first `spec` candidates of every page in ONE strided copy per array (r2: two copies per page — each a blit
+        // kernel that waits for CU slots like any other)
+        ws.download_2d(g.hr_all.data(), g.b.rects, (size_t)g.max_comp * 6 * sizeof(float), (size_t)spec * 6 * sizeof(float), g.count);
+        ws.download_2d(g.hv_all.data(), g.b.valid, (size_t)g.max_comp, (size_t)spec, g.count);
+    }
+    ws.sync();   // one wait for all sizes
+    std::vector<int32_t> counts(N);
     std::vector<std::vector<float>> hr(N);
     std::vector<std::vector<uint8_t>> hv(N);
-    std::vector<float> hr_all((size_t)N * spec * 6);
-    std::vector<uint8_t> hv_all((size_t)N * spec);
-    ws.download(counts.data(), b.n_roots, N * sizeof(int32_t));
-    ws.download(ovf.data(), b.overflow, N * sizeof(int32_t));
-    // the first `spec` candidates of every page in ONE strided copy per array (r2: two copies per page — each a blit
-    // kernel that waits for CU slots like any other)
-    ws.download_2d(hr_all.data(), b.rects, (size_t)max_comp * 6 * sizeof(float), (size_t)spec * 6 * sizeof(float), N);
-    ws.download_2d(hv_all.data(), b.valid, (size_t)max_comp, (size_t)spec, N);
-    ws.sync();
-    for (int i = 0; i < N; i++) {
-        hr[i].assign(hr_all.begin() + (size_t)i * spec * 6, hr_all.begin() + (size_t)(i + 1) * spec * 6);
-        hv[i].assign(hv_all.begin() + (size_t)i * spec, hv_all.begin() + (size_t)(i + 1) * spec);
-    }
     rects_out->assign(n, {});
     bool more = false;
-    std::vector<int> big;   // pages whose component stage did not fit
-    for (int i = 0; i < N; i++) {
-        const int cnt = counts[i];
-        if (ovf[i] || cnt > max_comp) { big.push_back(i); continue; }
-        if (cnt <= spec) continue;
-        more = true;
-        hr[i].resize((size_t)cnt * 6);
-        hv[i].resize(cnt);
-        ws.download(hr[i].data(), b.rects + (size_t)i * max_comp * 6, hr[i].size() * sizeof(float));
-        ws.download(hv[i].data(), b.valid + (size_t)i * max_comp, cnt);
+    std::vector<int> big;   // pages (grouped order) whose component stage did not fit
+    for (const SizeGroup& g : groups) {
+        const int spec = std::min(g.max_comp, kSpec);
+        for (int j = 0; j < g.count; j++) {
+            const int i = g.first + j, cnt = g.counts[j];
+            counts[i] = cnt;
+            if (g.ovf[j] || cnt > g.max_comp) { big.push_back(i); continue; }
+            if (cnt <= spec) {
+                hr[i].assign(g.hr_all.begin() + (size_t)j * spec * 6, g.hr_all.begin() + (size_t)(j + 1) * spec * 6);
+                hv[i].assign(g.hv_all.begin() + (size_t)j * spec, g.hv_all.begin() + (size_t)(j + 1) * spec);
+                continue;
+            }
+            more = true;
+            hr[i].resize((size_t)cnt * 6);
+            hv[i].resize(cnt);
+            ws.download(hr[i].data(), g.b.rects + (size_t)j * g.max_comp * 6, hr[i].size() * sizeof(float));
+            ws.download(hv[i].data(), g.b.valid + (size_t)j * g.max_comp, cnt);
+        }
     }
     if (more) ws.sync();
     for (int i : big) {
+        const SizeGroup& g = groups[group_of[i]];
         // Worst case of an h x w mask: no more than px / 4 + O(h + w) 8-connected components can be pairwise
         // separated, and a border walk enters a pixel at most once per direction (8 px points in total).
-        const int64_t mc64 = px / 4 + (int64_t)h + w + 16, ar_big = 8 * px + 64;
+        const int64_t mc64 = g.px / 4 + (int64_t)g.h + g.w + 16, ar_big = 8 * g.px + 64;
         if (ar_big >= (int64_t)0x7fffffff)
-            fail(OCRS_ERR_CAPACITY, "text mask of page %d: %lld pixels exceed the 32-bit contour arena", i, (long long)px);
+            fail(OCRS_ERR_CAPACITY, "text mask of page %d: %lld pixels exceed the 32-bit contour arena", order[i], (long long)g.px);
         const int mc = (int)mc64;
-        const k::CclBuffers bb = alloc_ccl(1, mc, ar_big, st);
-        run_ccl(d_mask + (size_t)i * px, 1, bb, mc, ar_big, st);
+        const k::CclBuffers bb = alloc_ccl(1, g.h, g.px, mc, ar_big, st);
+        run_ccl(g.d_mask + (size_t)(i - g.first) * g.px, 1, g.h, g.w, bb, mc, ar_big, st);
         int32_t cnt = 0, o = 0;
         ws.download(&cnt, bb.n_roots, sizeof cnt);
         ws.download(&o, bb.overflow, sizeof o);
         ws.sync();
         if (o || cnt > mc)
-            fail(OCRS_ERR_DEVICE, "internal: component stage of page %d overflowed its worst-case buffers (%d components)", i, cnt);
+            fail(OCRS_ERR_DEVICE, "internal: component stage of page %d overflowed its worst-case buffers (%d components)", order[i], cnt);
         counts[i] = cnt;
         hr[i].resize((size_t)cnt * 6);
         hv[i].resize(cnt);
@@ -191,7 +238,7 @@ void ocrs_engine::detect_now(const ocrs_page* const* pages, size_t n, std::vecto
         ws.sync();
     }
     for (int i = 0; i < N; i++) {
-        auto& out = (*rects_out)[i];
+        auto& out = (*rects_out)[order[i]];
         for (int c = 0; c < counts[i]; c++)
             if (hv[i][c]) out.push_back(RotatedRect::from_array(&hr[i][(size_t)c * 6]));
     }
@@ -246,9 +293,7 @@ void ocrs_engine::init_coalescers() {
                 },
                 [&](DetRequest& r) { detect_now(r.pages, r.n, r.rects, nullptr); });
         },
-        [](const DetRequest& a, const DetRequest& b) {   // one detection batch = pages of one size (detect_now checks it)
-            return a.pages[0]->h == b.pages[0]->h && a.pages[0]->w == b.pages[0]->w;
-        });
+        [](const DetRequest&, const DetRequest&) { return true; });   // pages of any sizes share a batch (detect_now groups them by size)
     rec_queue = std::make_unique<Coalescer<RecRequest>>(
         [this](std::vector<RecRequest*>& batch) {
             run_batch(

@@ -14,6 +14,8 @@
 struct ocrs_page {  // OcrInput (lib.rs:125-128)
     ocrs::DevBuf grey;  // [h, w] fp32 in [-0.5, 0.5]; on the device of the engine that prepared it
     int h = 0, w = 0;
+    // the host pixels an engine GROUP prepared this page from (group.cpp: key of the replay mode's recorded results); else null
+    const void* source = nullptr;
     int device() const { return grey.device(); }
 };
 

@@ -134,6 +134,19 @@ struct ocrs_engine_group {
     std::string rccl_fail_reason;   // why the communicators could not be created (init_mu); outlives later gathers
     std::string why_host_out;   // stable copy handed out by ocrs_group_last_gather
 
+    // ---- host-side pre-flight (ocrs_group_set_replay; test hook, SURVEY §8e "expected scaling limiter: the host").
+    // mode 1 (record): the members run as usual and the group keeps every page's word rects and recognised lines, keyed by the
+    // host pixels the page was prepared from.  mode 2 (replay): a member's share does NO GPU work — it sleeps the configured
+    // time of its stage (what a share of that stage takes on one GPU at full load) and returns the recorded results of ITS
+    // pages — while everything on the host stays real: dealing, worker threads and their NUMA binding, payload packing,
+    // per-request and final gathers, reassembly in page order, find_text_lines_batch on the real rects, the caller's loop.
+    // N members on ONE physical GPU then behave, for the host, like N GPUs each at the single-GPU page rate.
+    int replay_mode = 0;
+    double replay_s[3] = {0, 0, 0};   // prepare, detect, recognize share
+    std::mutex replay_mu;
+    std::map<const void*, std::vector<RotatedRect>> replay_rects;
+    std::map<const void*, std::vector<std::vector<ocrs_text_char>>> replay_lines;
+
     std::atomic<size_t> next_start{0};   // rotation of the block deal
     size_t min_block = 8, shared_block = 16;   // ocrs_group_params.min_block / shared_block
     WorkerPool workers{[] { StageTimers::release_thread_events(); }};   // the members' shares of a call run here
@@ -575,6 +588,16 @@ static void group_prepare(ocrs_engine_group* g, const void* const* pixels, size_
     std::vector<std::unique_ptr<ocrs_page>> made(n);   // freed if any member fails
     for_each_member(g, of_member, [&](size_t m) {
         const ocrs_engine* e = g->members[m].engine.get();
+        if (g->replay_mode == 2) {   // no upload, no conversion: a page object of the right size on the member's device, after the share's time
+            for (size_t i : of_member[m]) {
+                auto page = std::make_unique<ocrs_page>();
+                page->h = height; page->w = width; page->source = pixels[i];
+                page->grey = DevBuf((size_t)height * width * sizeof(float));
+                made[i] = std::move(page);
+            }
+            std::this_thread::sleep_for(std::chrono::duration<double>(g->replay_s[0]));
+            return;
+        }
         Workspace ws;
         for (size_t i : of_member[m]) {
             const void* d_px = pixels[i];
@@ -584,6 +607,7 @@ static void group_prepare(ocrs_engine_group* g, const void* const* pixels, size_
                 d_px = d;
             }
             made[i].reset(make_page(d_px, type, order, height, width, channels, ws.s(), e->tm()));
+            made[i]->source = pixels[i];
         }
         ws.sync();
         if (e->tm()) e->tm()->collect();
@@ -614,7 +638,23 @@ ocrs_status ocrs_group_detect_words_batch(ocrs_engine_group* g, const ocrs_page*
             std::vector<const ocrs_page*> mine;
             for (size_t i : of_member[m]) mine.push_back(pages[i]);
             std::vector<std::vector<RotatedRect>> rr;
-            g->members[m].engine->detect(mine.data(), mine.size(), &rr, nullptr);
+            if (g->replay_mode == 2) {
+                {
+                    std::lock_guard<std::mutex> lk(g->replay_mu);
+                    for (const ocrs_page* pg : mine) {
+                        auto it = g->replay_rects.find(pg->source);
+                        if (it == g->replay_rects.end()) fail(OCRS_ERR_INVALID_ARGUMENT, "replay: no recorded detection for this page");
+                        rr.push_back(it->second);
+                    }
+                }
+                std::this_thread::sleep_for(std::chrono::duration<double>(g->replay_s[1]));
+            } else {
+                g->members[m].engine->detect(mine.data(), mine.size(), &rr, nullptr);
+                if (g->replay_mode == 1) {
+                    std::lock_guard<std::mutex> lk(g->replay_mu);
+                    for (size_t j = 0; j < mine.size(); j++) g->replay_rects[mine[j]->source] = rr[j];
+                }
+            }
             auto& pl = payloads[m];
             for (const auto& page_rects : rr) {
                 const uint64_t cnt = page_rects.size();
@@ -670,13 +710,40 @@ ocrs_status ocrs_group_recognize_text_batch(ocrs_engine_group* g, const ocrs_pag
                 mine.push_back(pages[i]);
                 lpp.push_back(unpack_lines(line_rects, line_offsets, page_line_offsets[i], page_line_offsets[i + 1]));
             }
-            std::vector<std::vector<CtcStep>> steps;
-            std::vector<RecLine> rl;
-            std::vector<uint32_t> ctc_len;
-            e->recognize(mine.data(), mine.size(), lpp, &steps, &rl, &ctc_len);
             std::vector<ocrs_text_char> flat;
             std::vector<size_t> offs;
-            flatten_chars(e, rl, ctc_len, steps, &flat, &offs);
+            if (g->replay_mode == 2) {
+                offs.assign(1, 0);
+                {
+                    std::lock_guard<std::mutex> lk(g->replay_mu);
+                    for (size_t j = 0; j < mine.size(); j++) {
+                        auto it = g->replay_lines.find(mine[j]->source);
+                        if (it == g->replay_lines.end() || it->second.size() != lpp[j].size())
+                            fail(OCRS_ERR_INVALID_ARGUMENT, "replay: no recorded recognition for this page and these lines");
+                        for (const auto& line : it->second) {
+                            flat.insert(flat.end(), line.begin(), line.end());
+                            offs.push_back(flat.size());
+                        }
+                    }
+                }
+                std::this_thread::sleep_for(std::chrono::duration<double>(g->replay_s[2]));
+            } else {
+                std::vector<std::vector<CtcStep>> steps;
+                std::vector<RecLine> rl;
+                std::vector<uint32_t> ctc_len;
+                e->recognize(mine.data(), mine.size(), lpp, &steps, &rl, &ctc_len);
+                flatten_chars(e, rl, ctc_len, steps, &flat, &offs);
+                if (g->replay_mode == 1) {
+                    std::lock_guard<std::mutex> lk(g->replay_mu);
+                    size_t l = 0;
+                    for (size_t j = 0; j < mine.size(); j++) {
+                        auto& rec = g->replay_lines[mine[j]->source];
+                        rec.clear();
+                        for (size_t q = 0; q < lpp[j].size(); q++, l++)
+                            rec.emplace_back(flat.begin() + offs[l], flat.begin() + offs[l + 1]);
+                    }
+                }
+            }
             auto& pl = payloads[m];
             for (size_t l = 0; l + 1 < offs.size(); l++) {
                 const uint64_t cnt = offs[l + 1] - offs[l];
@@ -736,6 +803,25 @@ ocrs_status ocrs_group_final_gather(ocrs_engine_group* g, ocrs_gather_mode mode,
         if (mode != OCRS_GATHER_AUTO && mode != OCRS_GATHER_HOST && mode != OCRS_GATHER_RCCL)
             fail(OCRS_ERR_INVALID_ARGUMENT, "unknown gather mode %d", (int)mode);
         gather_entry(g, mode, payloads, bytes, out, offsets);
+    });
+}
+
+ocrs_status ocrs_group_set_replay(ocrs_engine_group* g, int mode, const double seconds[3]) {
+    return guarded([&] {
+        if (!g || mode < 0 || mode > 2) fail(OCRS_ERR_INVALID_ARGUMENT, "bad argument");
+        if (mode == 2) {
+            if (!seconds) fail(OCRS_ERR_INVALID_ARGUMENT, "replay needs the share times");
+            for (int i = 0; i < 3; i++) {
+                if (!(seconds[i] >= 0.0 && seconds[i] < 60.0)) fail(OCRS_ERR_INVALID_ARGUMENT, "share time out of range");
+                g->replay_s[i] = seconds[i];
+            }
+        }
+        if (mode == 0) {
+            std::lock_guard<std::mutex> lk(g->replay_mu);
+            g->replay_rects.clear();
+            g->replay_lines.clear();
+        }
+        g->replay_mode = mode;
     });
 }
 

@@ -131,3 +131,60 @@ def test_creating_and_destroying_a_relaxed_engine_under_load_drains_instead_of_m
         [t.join() for t in ths]
     assert seen_modes == {"serial", "free"}
     assert not bad, bad[:5]
+
+
+def test_detection_batch_of_mixed_page_sizes_equals_the_single_page_results_and_goldens():
+    """detect_words_batch over pages of SIX sizes in one request — 1024², 700x500, 1300x900, 2200x3000, 97x211 and the 242-row
+    shape of polar-bears.png (the pad branch) — equals detect_words page by page (and, for the 1024² bench page and the two
+    odd-size pages, the oracle goldens of tests/golden/); the model runs once over the batch, the size-dependent kernels
+    once per size.  Then the same pages as one-page calls from six threads: the coalescer merges whatever waits, results
+    byte-equal.  (detection.rs:131-171: any image per call; rounds 1-5 needed one size per batch.)"""
+    _lib.require_gpu()
+    gold = os.path.join(ROOT, "tests", "golden")
+    det, rec = Model.load_bytes(M.detection_model_bytes()), Model.load_bytes(M.recognition_model_bytes())
+    eng = OcrEngine(detection_model=det, recognition_model=rec)
+    specs = [(0, 1024, 1024, 80, 2), (31, 700, 500, 25, 1), (32, 1300, 900, 50, 1), (101, 2200, 3000, 60, 2), (102, 97, 211, 3, 1),
+             (33, 242, 817, 9, 1), (1, 1024, 1024, 80, 2), (34, 700, 500, 12, 1)]
+    px = [synth.synthetic_page(s, h, w, lines=nl, columns=c) if s not in (0, 1) else synth.synthetic_page(s, 1024, 1024, lines=80)
+          for s, h, w, nl, c in specs]
+    inputs = [eng.prepare_input(ImageSource.from_tensor(p, DimOrder.Hwc)) for p in px]
+    single = [eng.detect_words(i) for i in inputs]
+    assert sum(len(w) for w in single) > 1500
+    batch = eng.detect_words_batch(inputs)
+    for k, (a, b) in enumerate(zip(single, batch)):
+        assert a.tobytes() == b.tobytes(), specs[k]
+    # the goldens that exist for these very pages
+    g0 = np.load(os.path.join(gold, "bench_page_seed0.npz"))
+    assert np.array_equal(batch[0], g0["word_rects"])
+    assert np.array_equal(batch[3], np.load(os.path.join(gold, "page_odd_large.npz"))["word_rects"])
+    assert np.array_equal(batch[4], np.load(os.path.join(gold, "page_odd_small.npz"))["word_rects"])
+    # a different order of the same pages, and sub-batches: page results do not depend on their neighbours
+    perm = [5, 2, 7, 0, 4, 1, 6, 3]
+    for k, b in zip(perm, eng.detect_words_batch([inputs[k] for k in perm])):
+        assert b.tobytes() == single[k].tobytes()
+    # the whole pipeline on the mixed batch
+    rects, loffs, poffs = eng.find_text_lines_batch_raw(batch)
+    chars, coffs = eng.recognize_text_batch_raw(inputs, rects, loffs, poffs)
+    texts = []
+    for i, inp in enumerate(inputs):
+        lines = eng.find_text_lines(inp, single[i])
+        want = [str(t) if t else "" for t in eng.recognize_text(inp, lines)]
+        got = ["".join(chr(c) for c in chars["ch"][int(coffs[li]):int(coffs[li + 1])]) for li in range(int(poffs[i]), int(poffs[i + 1]))]
+        assert got == want, specs[i]
+        texts.append(want)
+    assert sum(len(t) for t in texts) > 200
+    # one-page calls of mixed sizes from six threads (merged by the coalescer)
+    bad = []
+
+    def worker(k):
+        for it in range(12):
+            j = (it * 3 + k) % len(inputs)
+            if eng.detect_words(inputs[j]).tobytes() != single[j].tobytes():
+                bad.append((k, it, j))
+
+    ths = [threading.Thread(target=worker, args=(k,)) for k in range(6)]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    assert not bad, bad[:5]
+    merged = eng.coalesce_stats()["detect"]
+    assert merged[1] >= merged[0] >= 1

@@ -475,7 +475,14 @@ def test_every_option_of_the_library_is_documented_in_the_header(lib):
     ids = [x.split("=")[0].strip() for x in enum.replace("\n", " ").split(",") if x.strip()]
     ids = [i for i in ids if i != "OPT_PUBLIC_COUNT"]
     assert ["OPT_" + n.upper() for n in names + fields] == ids
-    assert lib.ocrs_set_option(b"coalesce", C.c_long(1)) == 1 and lib.ocrs_set_option(b"det_tail", C.c_long(1)) == 1   # not process options
+    assert lib.ocrs_set_option(b"coalesce", C.c_long(1)) == 1 and lib.ocrs_set_option(b"no_such_option", C.c_long(1)) == 1   # not process options
+    # options that round 5 removed with their kernels are still ACCEPTED (and ignored): a caller built against the older header works
+    assert lib.ocrs_set_option(b"det_tail", C.c_long(1)) == 0 and lib.ocrs_set_option(b"gru_waves", C.c_long(16)) == 0
+    assert _lib.option_names() == names
+    # values are validated: the kernels index tables with some of them
+    assert lib.ocrs_set_option(b"det_fuse", C.c_long(7)) == 1 and lib.ocrs_set_option(b"det_rows", C.c_long(13)) == 1
+    assert b"out of range" in lib.ocrs_last_error()
+    assert lib.ocrs_set_option(b"det_rows", C.c_long(20)) == 0 and lib.ocrs_set_option(b"det_rows", C.c_long(1)) == 0
     # environment variables are read by initialisers that run once (options, pool cap, the RCCL library name), never on a launch path
     for f in sorted(os.listdir(os.path.join(root, "ocrs_amd", "csrc"))):
         body = open(os.path.join(root, "ocrs_amd", "csrc", f)).read()
