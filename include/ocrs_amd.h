@@ -53,6 +53,14 @@ typedef enum ocrs_status {
 /* Message for the last failure on the calling thread ("" if none). */
 OCRS_API const char* ocrs_last_error(void);
 
+/* Layout version of the parameter structs below (ocrs_engine_params, ocrs_group_params) and of the argument lists: a binding
+ * compares ocrs_abi_version() with the OCRS_ABI_VERSION it was built against when it loads the library and refuses a
+ * mismatch, instead of passing a struct the library reads past the end of.  Bumped whenever a struct grows or an argument
+ * list changes (6 = round 6; rounds 1-5 had no version: their structs were shorter).  Names of options removed since are
+ * still accepted by ocrs_set_option and ignored. */
+#define OCRS_ABI_VERSION 6u
+OCRS_API uint32_t ocrs_abi_version(void);
+
 /* Release any buffer handed out through a `T**` out-parameter. */
 OCRS_API void ocrs_buffer_free(void* p);
 

@@ -71,8 +71,10 @@ DECLARED_SYMBOLS = [
     "ocrs_group_prepare_input_batch", "ocrs_group_prepare_input_device_batch", "ocrs_group_detect_words_batch",
     "ocrs_group_recognize_text_batch", "ocrs_group_gather", "ocrs_group_final_gather", "ocrs_group_worker_threads", "ocrs_group_last_gather", "ocrs_device_malloc_on", "ocrs_engine_coalesce_stats", "ocrs_coalescer_selftest", "ocrs_engine_kernel_mfma_flops", "ocrs_engine_prepare_input_jpeg", "ocrs_jpeg_decode_rgb", "ocrs_jpeg_info", "ocrs_jpeg_coefficients",
     "ocrs_group_member_stats", "ocrs_numa_parse_cpulist", "ocrs_numa_bind_selftest", "ocrs_engine_recognize_logits", "ocrs_engine_set_option", "ocrs_engine_get_option", "ocrs_option_name", "ocrs_device_pool_stats", "ocrs_device_pool_configure", "ocrs_device_pool_trim",
-    "ocrs_device_set_isolation", "ocrs_device_isolation", "ocrs_group_set_replay",
+    "ocrs_device_set_isolation", "ocrs_device_isolation", "ocrs_group_set_replay", "ocrs_abi_version",
 ]
+
+ABI_VERSION = 6   # include/ocrs_amd.h OCRS_ABI_VERSION
 
 _lib = None
 
@@ -85,6 +87,10 @@ def lib():
             raise OcrsError(7, "libocrs_amd.so is not built: run `python -m ocrs_amd.build` "
                                "(there is no CPU fallback for the HIP engine)")
         L = C.CDLL(LIB_PATH)
+        L.ocrs_abi_version.restype = C.c_uint32
+        if L.ocrs_abi_version() != ABI_VERSION:   # EngineParams / GroupParams below mirror the structs of THIS version
+            raise OcrsError(7, "libocrs_amd.so has ABI version %d, this binding was written for %d: rebuild (python -m ocrs_amd.build)"
+                            % (L.ocrs_abi_version(), ABI_VERSION))
         L.ocrs_last_error.restype = C.c_char_p
         L.ocrs_engine_detection_threshold.restype = C.c_float
         L.ocrs_engine_detection_threshold.argtypes = [C.c_void_p]

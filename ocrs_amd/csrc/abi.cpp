@@ -111,6 +111,8 @@ ocrs_status ocrs_ctc_beam_search(const float* logp, int t, int c, uint32_t width
     });
 }
 
+uint32_t ocrs_abi_version(void) { return OCRS_ABI_VERSION; }
+
 ocrs_status ocrs_set_option(const char* name, long value) {
     return guarded([&] {
         const int r = set_option(name, value);

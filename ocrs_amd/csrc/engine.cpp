@@ -119,30 +119,11 @@ void ocrs_engine::detect_now(const ocrs_page* const* pages, size_t n, std::vecto
                  os.c, os.h, os.w);
     }
 
-    // slice off the padded region, resize back, threshold (detection.rs:187-194,110)
-    float* d_map = host_map ? ws.alloc_n<float>((size_t)N * groups[0].h * groups[0].w) : nullptr;
-    {
-        StageScope sc(T, ST_RESIZE_THRESH, ex, groups.size());
-        for (SizeGroup& g : groups) {
-            g.px = (int64_t)g.h * g.w;
-            g.d_mask = ws.alloc_n<uint8_t>((size_t)g.count * g.px);
-            k::resize_threshold(d_prob + (size_t)g.first * in_h * in_w, g.count, in_h, in_w, in_h - g.pad_bottom, in_w - g.pad_right,
-                                text_threshold, g.d_mask, d_map, g.h, g.w, ex);
-        }
-    }
-    if (host_map)   // (one size group: grouped order = the caller's order)
-        ws.download(host_map, d_map, (size_t)N * groups[0].px * sizeof(float));
-    if (!rects_out) {
-        ws.sync();
-        if (T) T->collect();
-        return;
-    }
-
     // connected components -> rects (detection.rs:41-62)
     // Scratch is sized for pages of text: up to 65 536 components and 2 border points per pixel.  The reference
     // takes ANY mask (detection.rs:41-62), so a page that does not fit (salt noise, dense halftone) gets its
     // component stage re-run on its own with buffers for the worst case — below.
-    auto alloc_ccl = [&](int np, int h, int64_t px, int mc, int64_t ar, hipStream_t cs) {
+    auto alloc_ccl = [&](int np, int h, int64_t px, int mc, int64_t ar, hipStream_t cs, bool zero) {
         k::CclBuffers b{};
         b.labels = ws.alloc_n<int32_t>((size_t)np * px);
         b.row_counts = ws.alloc_n<int32_t>((size_t)np * h);
@@ -157,27 +138,54 @@ void ocrs_engine::detect_now(const ocrs_page* const* pages, size_t n, std::vecto
         b.keep = ws.alloc_n<uint8_t>((size_t)np * ar);
         b.rects = ws.alloc_n<float>((size_t)np * mc * 6);
         b.valid = ws.alloc_n<uint8_t>((size_t)np * mc);
-        OCRS_HIP(hipMemsetAsync(b.overflow, 0, np * sizeof(int32_t), cs));
+        if (zero) OCRS_HIP(hipMemsetAsync(b.overflow, 0, np * sizeof(int32_t), cs));
         return b;
     };
-    auto run_ccl = [&](const uint8_t* mask, int np, int h, int w, const k::CclBuffers& b, int mc, int64_t ar, hipStream_t cs) {
+    auto run_ccl = [&](const uint8_t* mask, int np, int h, int w, const k::CclBuffers& b, int mc, int64_t ar, hipStream_t cs, bool prepared) {
         {
-            StageScope sc(T, ST_CCL, cs, 4);
-            k::ccl_label(mask, np, h, w, b, mc, cs);
+            StageScope sc(T, ST_CCL, cs, prepared ? 3 : 4);
+            k::ccl_label(mask, np, h, w, b, mc, cs, prepared);
         }
         {
-            StageScope sc(T, ST_CONTOUR_RECTS, cs, 2);
-            k::contour_rects(mask, np, h, w, b, mc, ar, /*expand*/ 3.0f, min_area, /*eps*/ 2.0f, cs);
+            StageScope sc(T, ST_CONTOUR_RECTS, cs, prepared ? 1 : 2);
+            k::contour_rects(mask, np, h, w, b, mc, ar, /*expand*/ 3.0f, min_area, /*eps*/ 2.0f, cs, prepared);
         }
     };
+
+    // slice off the padded region, resize back, threshold (detection.rs:187-194,110); r6: where the page width allows, the same
+    // launch writes the component stage's initial labels and zeroes its counters (one launch and two fills fewer per size)
+    float* d_map = host_map ? ws.alloc_n<float>((size_t)N * groups[0].h * groups[0].w) : nullptr;
+    std::vector<char> prepared(groups.size(), 0);
+    {
+        StageScope sc(T, ST_RESIZE_THRESH, ex, groups.size());
+        for (size_t gi = 0; gi < groups.size(); gi++) {
+            SizeGroup& g = groups[gi];
+            g.px = (int64_t)g.h * g.w;
+            g.d_mask = ws.alloc_n<uint8_t>((size_t)g.count * g.px);
+            if (rects_out) {
+                g.max_comp = (int)std::min<int64_t>(65536, g.px / 2 + 16);
+                g.arena = 2 * g.px + 64;
+                g.b = alloc_ccl(g.count, g.h, g.px, g.max_comp, g.arena, ex, false);
+            }
+            prepared[gi] = k::resize_threshold(d_prob + (size_t)g.first * in_h * in_w, g.count, in_h, in_w, in_h - g.pad_bottom, in_w - g.pad_right,
+                                               text_threshold, g.d_mask, d_map, g.h, g.w, ex, g.b.labels, g.b.overflow, g.b.offsets);
+            if (rects_out && !prepared[gi]) OCRS_HIP(hipMemsetAsync(g.b.overflow, 0, g.count * sizeof(int32_t), ex));
+        }
+    }
+    if (host_map)   // (one size group: grouped order = the caller's order)
+        ws.download(host_map, d_map, (size_t)N * groups[0].px * sizeof(float));
+    if (!rects_out) {
+        ws.sync();
+        if (T) T->collect();
+        return;
+    }
+
     // One round trip in the common case: the counts travel together with the first kSpec candidate rects of every
     // page (a page of text has a few hundred to ~1 500 components); only a page with more needs a second one.
     constexpr int kSpec = 2048;
-    for (SizeGroup& g : groups) {
-        g.max_comp = (int)std::min<int64_t>(65536, g.px / 2 + 16);
-        g.arena = 2 * g.px + 64;
-        g.b = alloc_ccl(g.count, g.h, g.px, g.max_comp, g.arena, ex);
-        run_ccl(g.d_mask, g.count, g.h, g.w, g.b, g.max_comp, g.arena, ex);
+    for (size_t gi = 0; gi < groups.size(); gi++) {
+        SizeGroup& g = groups[gi];
+        run_ccl(g.d_mask, g.count, g.h, g.w, g.b, g.max_comp, g.arena, ex, prepared[gi] != 0);
         const int spec = std::min(g.max_comp, kSpec);
         g.counts.resize(g.count); g.ovf.resize(g.count);
         g.hr_all.resize((size_t)g.count * spec * 6); g.hv_all.resize((size_t)g.count * spec);
@@ -222,8 +230,8 @@ void ocrs_engine::detect_now(const ocrs_page* const* pages, size_t n, std::vecto
         if (ar_big >= (int64_t)0x7fffffff)
             fail(OCRS_ERR_CAPACITY, "text mask of page %d: %lld pixels exceed the 32-bit contour arena", order[i], (long long)g.px);
         const int mc = (int)mc64;
-        const k::CclBuffers bb = alloc_ccl(1, g.h, g.px, mc, ar_big, st);
-        run_ccl(g.d_mask + (size_t)(i - g.first) * g.px, 1, g.h, g.w, bb, mc, ar_big, st);
+        const k::CclBuffers bb = alloc_ccl(1, g.h, g.px, mc, ar_big, st, true);
+        run_ccl(g.d_mask + (size_t)(i - g.first) * g.px, 1, g.h, g.w, bb, mc, ar_big, st, false);
         int32_t cnt = 0, o = 0;
         ws.download(&cnt, bb.n_roots, sizeof cnt);
         ws.download(&o, bb.overflow, sizeof o);

@@ -21,8 +21,13 @@ void resize_pages_to_model(const float* const* d_src_ptrs, int n, int sh, int sw
 // slice + bilinear resize back + strict threshold (detection.rs:187-194,110).
 // prob: [n, mh, mw] (only the top-left [sh, sw] is read); mask: [n, h, w] u8;
 // d_map (optional, may be null): [n, h, w] f32 probability map.
-void resize_threshold(const float* d_prob, int n, int mh, int mw, int sh, int sw, float thr, uint8_t* d_mask,
-                      float* d_map, int h, int w, hipStream_t s);
+// d_labels / d_zero_a / d_zero_b (optional, r6): the component stage's label array [n, h, w] and its two per-page counters
+// (CclBuffers::overflow, ::offsets).  When all three are given and the shapes allow (w % 4 == 0, aligned buffers, option
+// ccl_quad) the launch also writes the initial labels and zeroes the counters, and returns true: ccl_label and contour_rects
+// are then told to skip their first step (`prepared`).
+bool resize_threshold(const float* d_prob, int n, int mh, int mw, int sh, int sw, float thr, uint8_t* d_mask,
+                      float* d_map, int h, int w, hipStream_t s, int32_t* d_labels = nullptr, int32_t* d_zero_a = nullptr,
+                      int32_t* d_zero_b = nullptr);
 void threshold_only(const float* d_prob, float thr, uint8_t* d_mask, int64_t count, hipStream_t s);
 
 // ---- kernels_ccl.hip ------------------------------------------------------
@@ -44,9 +49,10 @@ struct CclBuffers {
 // mask [n,h,w] -> per page: raster-ordered external components -> rects
 // (find_contours(External) -> simplify_polygon(2) -> min_area_rect -> resize(+2*expand)
 //  -> area >= min_area; detection.rs:41-62).
-void ccl_label(const uint8_t* d_mask, int n, int h, int w, const CclBuffers& b, int max_comp, hipStream_t s);
+// prepared: resize_threshold already wrote the initial labels / zeroed the counters (it returned true)
+void ccl_label(const uint8_t* d_mask, int n, int h, int w, const CclBuffers& b, int max_comp, hipStream_t s, bool prepared = false);
 void contour_rects(const uint8_t* d_mask, int n, int h, int w, const CclBuffers& b, int max_comp, int64_t arena,
-                   float expand, float min_area, float eps, hipStream_t s);
+                   float expand, float min_area, float eps, hipStream_t s, bool prepared = false);
 
 // ---- kernels_nn.hip -------------------------------------------------------
 // C[M,N] = act(A[M,K] . B[K,N] + bias[N]) as an exact fp32 MFMA chain, k ascending.

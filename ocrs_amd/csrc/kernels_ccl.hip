@@ -395,11 +395,12 @@ write_roots4_kernel(const uint8_t* __restrict__ mask, const int32_t* __restrict_
     }
 }
 
-void ccl_label(const uint8_t* d_mask, int n, int h, int w, const CclBuffers& b, int max_comp, hipStream_t s) {
+void ccl_label(const uint8_t* d_mask, int n, int h, int w, const CclBuffers& b, int max_comp, hipStream_t s, bool prepared) {
     // option "ccl_quad" (default 1): four pixels per thread where the rows are word-aligned
     if (option(OPT_CCL_QUAD) && (w & 3) == 0 && (((uintptr_t)d_mask) & 3) == 0 && (((uintptr_t)b.labels) & 15) == 0) {
         dim3 grid4((w + 1023) / 1024, h, n);
-        hipLaunchKernelGGL(ccl_init4_kernel, grid4, dim3(256), 0, s, d_mask, b.labels, h, w);
+        // (prepared: the initial labels came out of the threshold kernel, kernels_image.hip resize_threshold_kernel<true>)
+        if (!prepared) hipLaunchKernelGGL(ccl_init4_kernel, grid4, dim3(256), 0, s, d_mask, b.labels, h, w);
         hipLaunchKernelGGL(ccl_merge4_kernel, grid4, dim3(256), 0, s, d_mask, b.labels, h, w);
         hipLaunchKernelGGL(count_roots4_kernel, dim3(h, n), dim3(256), 0, s, d_mask, b.labels, h, w, b.row_counts);
         hipLaunchKernelGGL(write_roots4_kernel, dim3(h, n), dim3(256), 0, s, d_mask, b.labels, h, w, b.row_counts, b.roots,
@@ -407,6 +408,7 @@ void ccl_label(const uint8_t* d_mask, int n, int h, int w, const CclBuffers& b, 
         return;
     }
     dim3 grid((w + 255) / 256, h, n);
+    if (prepared) fail(OCRS_ERR_DEVICE, "internal: labels prepared for the four-pixel component kernels, which do not apply");
     hipLaunchKernelGGL(ccl_init_kernel, grid, dim3(256), 0, s, d_mask, b.labels, h, w);
     hipLaunchKernelGGL(ccl_merge_kernel, grid, dim3(256), 0, s, d_mask, b.labels, h, w);
     hipLaunchKernelGGL(count_roots_kernel, dim3(h, n), dim3(256), 0, s, d_mask, b.labels, h, w, b.row_counts);
@@ -785,9 +787,9 @@ contour_rect_kernel(const uint8_t* __restrict__ mask, int h, int w, const int32_
 }
 
 void contour_rects(const uint8_t* d_mask, int n, int h, int w, const CclBuffers& b, int max_comp, int64_t arena,
-                   float expand, float min_area, float eps, hipStream_t s) {
-    // b.offsets[0..n) serves as the per-page arena bump counter (zeroed here); b.lengths is unused since r3
-    (void)hipMemsetAsync(b.offsets, 0, (size_t)n * sizeof(int32_t), s);
+                   float expand, float min_area, float eps, hipStream_t s, bool prepared) {
+    // b.offsets[0..n) serves as the per-page arena bump counter (zeroed here, or by the threshold kernel); b.lengths is unused since r3
+    if (!prepared) (void)hipMemsetAsync(b.offsets, 0, (size_t)n * sizeof(int32_t), s);
     hipLaunchKernelGGL(contour_rect_kernel, dim3(2048, n), dim3(64), 0, s, d_mask, h, w, b.n_roots, b.roots, b.offsets,
                        b.overflow, b.pts, b.tmp, b.keep, b.rects, b.valid, max_comp, arena, expand, min_area, eps);
 }

@@ -3,6 +3,7 @@
 // HBM-bound streaming kernels: one pass, coalesced, 16 B/lane
 // where the format allows.  Built with -ffp-contract=off: the reference's
 // arithmetic has no fused multiply-adds here (preprocess.rs:229-233).
+#include "common.hpp"
 #include "kernels.hpp"
 
 namespace ocrs {
@@ -147,14 +148,22 @@ void resize_pages_to_model(const float* const* d_src_ptrs, int n, int sh, int sw
 // strict '>' (detection.rs:110,187-194).  4 output pixels per thread so the u8
 // mask is written as one 32-bit word.
 // Algorithmic bytes per page: 4*sh*sw read + h*w (mask) [+ 4*h*w map] written.
+// LABELS (r6): the kernel also writes the INITIAL LABELS of the component stage (kernels_ccl.hip ccl_init4_kernel: the start of
+// the horizontal run of equal mask pixels inside the wave's 256-pixel segment) — the thread holds its four mask pixels in a
+// register anyway — and zeroes the page's two counters of that stage (overflow flag, contour-arena bump pointer): one launch
+// and two fills fewer per request, the mask is not read back for the labels.  Needs w % 4 == 0; same bits as the two kernels.
+template <bool LABELS>
 __global__ void __launch_bounds__(256)
 resize_threshold_kernel(const float* __restrict__ prob, int mh, int mw, int sh, int sw, float thr,
-                        uint8_t* __restrict__ mask, float* __restrict__ map, int h, int w) {
+                        uint8_t* __restrict__ mask, float* __restrict__ map, int h, int w, int32_t* __restrict__ labels,
+                        int32_t* __restrict__ zero_a, int32_t* __restrict__ zero_b) {
     const int xq = blockIdx.x * blockDim.x + threadIdx.x;  // group of 4 pixels
     const int y = blockIdx.y;
     const int n = blockIdx.z;
     const int x_base = xq * 4;
-    if (x_base >= w) return;
+    const bool inb = x_base < w;
+    if (!LABELS && !inb) return;
+    if (LABELS && xq == 0 && y == 0) { zero_a[n] = 0; zero_b[n] = 0; }
     const float* __restrict__ src = prob + (int64_t)n * mh * mw;
     int y0, y1;
     float wy;
@@ -177,6 +186,31 @@ resize_threshold_kernel(const float* __restrict__ prob, int mh, int mw, int sh, 
         vals[i] = v;
     }
     const int64_t o = ((int64_t)n * h + y) * w + x_base;
+    if (LABELS) {   // w % 4 == 0: a thread is inside or outside the row as a whole; lanes of a wave = consecutive quads of one row
+        const int lane = threadIdx.x & 63;
+        const uint32_t cur = inb ? bits : 0x02020202u;
+        const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cur, 0x138, 0xF, 0xF, true);   // lane - 1's (0 at lane 0)
+        const int v0 = cur & 0xFF, v1 = (cur >> 8) & 0xFF, v2 = (cur >> 16) & 0xFF, v3 = cur >> 24;
+        const bool b0 = lane == 0 || v0 != (int)(prev >> 24), b1 = v1 != v0, b2 = v2 != v1, b3 = v3 != v2;
+        const int top = b3 ? 3 : b2 ? 2 : b1 ? 1 : b0 ? 0 : -1;    // the lane's last boundary
+        const unsigned long long any = __ballot(top >= 0);
+        const unsigned long long below = any & ((1ull << lane) - 1ull);
+        const int srcl = below ? 63 - __clzll(below) : 0;          // the nearest lower lane that holds a boundary
+        const int src_top = __shfl(top, srcl);
+        if (!inb) return;
+        const int seg = y * w + x_base - 4 * lane;                 // page-local index of the wave's first pixel
+        const int carried = seg + 4 * srcl + src_top;
+        int4 out;
+        const int s0 = b0 ? seg + 4 * lane : carried;
+        const int s1 = b1 ? seg + 4 * lane + 1 : s0;
+        const int s2 = b2 ? seg + 4 * lane + 2 : s1;
+        const int s3 = b3 ? seg + 4 * lane + 3 : s2;
+        out.x = s0; out.y = s1; out.z = s2; out.w = s3;
+        *reinterpret_cast<int4*>(labels + o) = out;
+        *reinterpret_cast<uint32_t*>(mask + o) = bits;
+        if (map) *reinterpret_cast<float4*>(map + o) = make_float4(vals[0], vals[1], vals[2], vals[3]);
+        return;
+    }
     if (x_base + 3 < w && (w & 3) == 0) {
         *reinterpret_cast<uint32_t*>(mask + o) = bits;
         if (map) *reinterpret_cast<float4*>(map + o) = make_float4(vals[0], vals[1], vals[2], vals[3]);
@@ -188,15 +222,24 @@ resize_threshold_kernel(const float* __restrict__ prob, int mh, int mw, int sh, 
     }
 }
 
-void resize_threshold(const float* d_prob, int n, int mh, int mw, int sh, int sw, float thr, uint8_t* d_mask,
-                      float* d_map, int h, int w, hipStream_t s) {
+bool resize_threshold(const float* d_prob, int n, int mh, int mw, int sh, int sw, float thr, uint8_t* d_mask,
+                      float* d_map, int h, int w, hipStream_t s, int32_t* d_labels, int32_t* d_zero_a, int32_t* d_zero_b) {
     int quads = (w + 3) / 4;
     dim3 grid((quads + 255) / 256, h, n);
     dim3 block(256);
     if (quads <= 64) block = dim3(64);
     else if (quads <= 128) block = dim3(128);
     grid.x = (quads + block.x - 1) / block.x;
-    hipLaunchKernelGGL(resize_threshold_kernel, grid, block, 0, s, d_prob, mh, mw, sh, sw, thr, d_mask, d_map, h, w);
+    // the fused form wants what ccl_init4_kernel wants (kernels_ccl.hip ccl_label): word-aligned rows, 16-byte-aligned labels
+    const bool fuse = d_labels && d_zero_a && d_zero_b && (w & 3) == 0 && (((uintptr_t)d_mask) & 3) == 0 && (((uintptr_t)d_labels) & 15) == 0 &&
+                      (!d_map || (((uintptr_t)d_map) & 15) == 0) && option(OPT_CCL_QUAD) != 0;
+    if (fuse)
+        hipLaunchKernelGGL((resize_threshold_kernel<true>), grid, block, 0, s, d_prob, mh, mw, sh, sw, thr, d_mask, d_map, h, w, d_labels,
+                           d_zero_a, d_zero_b);
+    else
+        hipLaunchKernelGGL((resize_threshold_kernel<false>), grid, block, 0, s, d_prob, mh, mw, sh, sw, thr, d_mask, d_map, h, w, nullptr,
+                           nullptr, nullptr);
+    return fuse;
 }
 
 __global__ void __launch_bounds__(256)

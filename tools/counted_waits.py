@@ -96,16 +96,25 @@ def analyse(ins, depth=32):
             succ[i].append(i + 1)
     # the counted waits, and the instructions from which one of them can still be reached: nothing else is tracked (the
     # epilogues' hundreds of exec-masked stores would multiply the histories without ever meeting a wait again)
-    waits = []
+    waits, guarded, strictest = [], {}, {}
     for i, (a, mn, ops) in enumerate(ins):
         v = vmcnt_of(ops) if mn == "s_waitcnt" else None
         if not v:
             continue
         j = i + 1
+        drained = False
         while j < n and kind(ins[j][1] + " " + ins[j][2]) is None and ins[j][1] not in ("s_barrier", "s_endpgm") and not ins[j][1].startswith(("s_branch", "s_cbranch")):
+            drained = drained or (ins[j][1] == "s_waitcnt" and vmcnt_of(ins[j][2]) == 0)
             j += 1
-        if j < n and ins[j][1] == "s_barrier":
-            waits.append(i)
+        if j < n and ins[j][1] == "s_barrier" and not drained:   # (a full drain in front of the barrier: nothing counted to check)
+            # several waits may stand in front of one barrier with no vector-memory instruction between them (ours, and the
+            # compiler's own for a register it needs, possibly merged into our lgkmcnt wait): the strictest of them holds
+            if guarded.get(j) is None:
+                guarded[j] = i
+                waits.append(i)
+                strictest[i] = v
+            else:
+                strictest[guarded[j]] = min(strictest[guarded[j]], v)
     pred = [[] for _ in range(n)]
     for i in range(n):
         for j in succ[i]:
@@ -139,7 +148,7 @@ def analyse(ins, depth=32):
                 work.append(j)
         if sum(len(x) for x in (state[j] for j in succ[i])) > 200000:
             raise RuntimeError("history sets explode at %x" % a)
-    return [(ins[i][0], vmcnt_of(ins[i][2]), sorted(state[i])) for i in waits]
+    return [(ins[i][0], strictest[i], sorted(state[i])) for i in waits]
 
 
 def younger_than_needed(history, nth_l):
@@ -157,7 +166,7 @@ def younger_than_needed(history, nth_l):
             if seen == nth_l:
                 return back
         back += 1
-    raise RuntimeError("history %r is too short for the analysis depth" % history)
+    return back      # older than everything in view: at least this many younger instructions
 
 
 def short_weight_copy(history, np_):

@@ -12,13 +12,17 @@
 // -DOCRS_CROP_SETPRIO=n raises the victim's wave priority (s_setprio) — see build_hazard_repro.sh.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <random>
 #include <string>
+#include <map>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "../ocrs_amd/csrc/common.hpp"
@@ -47,7 +51,7 @@ int main(int argc, char** argv) {
     using namespace ocrs;
     std::string aggressor = "split3";
     double seconds = 10.0;
-    int n_lines = 77, split_cus = 0, vstreams = 1;
+    int n_lines = 77, split_cus = 0, vstreams = 1, analyse = 0;
     for (int i = 1; i + 1 < argc; i += 2) {
         const std::string k = argv[i], v = argv[i + 1];
         if (k == "--aggressor") aggressor = v;
@@ -55,6 +59,7 @@ int main(int argc, char** argv) {
         else if (k == "--lines") n_lines = atoi(v.c_str());
         else if (k == "--split-cus") split_cus = atoi(v.c_str());
         else if (k == "--victim-streams") vstreams = atoi(v.c_str());
+        else if (k == "--analyse") analyse = atoi(v.c_str());   // N: for the first N differing twins, say WHERE every wrong word's value belongs
     }
     CK(hipSetDevice(0));
     hipDeviceProp_t prop;
@@ -106,6 +111,28 @@ int main(int argc, char** argv) {
     g.Bsplit = dimg; g.strideBsplit = (int64_t)one.size();
     Tuning tune = default_tuning();
     tune.v[OPT_NUMERICS] = aggressor == "split3" ? 1 : aggressor == "split2" ? 2 : 0;
+    // the quiet run: what every word should be (and, the page being random floats, where else each VALUE occurs)
+    std::vector<float> ref((size_t)out_floats);
+    std::unordered_multimap<uint32_t, uint32_t> where;
+    std::vector<int> line_of, row_of, col_of;
+    if (analyse) {
+        float* R; CK(hipMalloc(&R, out_floats * 4));
+        k::crop_lines(d_pages, d_hw, d_desc, d_poly, n_lines, out_h, R, nullptr);
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(ref.data(), R, out_floats * 4, hipMemcpyDeviceToHost));
+        line_of.resize(out_floats); row_of.resize(out_floats); col_of.resize(out_floats);
+        for (int l = 0; l < n_lines; l++)
+            for (int r = 0; r < out_h; r++)
+                for (int c = 0; c < desc[l].out_w; c++) {
+                    const size_t i = (size_t)desc[l].out_off + (size_t)r * desc[l].out_w + c;
+                    line_of[i] = l; row_of[i] = r; col_of[i] = c;
+                    uint32_t b; memcpy(&b, &ref[i], 4);
+                    if (ref[i] != -0.5f) where.emplace(b, (uint32_t)i);
+                }
+    }
+    std::mutex amu;
+    std::map<std::string, long> relation;
+    long analysed = 0;
     hipStream_t sa = make_stream(0, split_cus ? split_cus : cus, cus);
     std::atomic<bool> stop{false};
     std::atomic<long> agg_launches{0};
@@ -141,6 +168,33 @@ int main(int argc, char** argv) {
             (void)hipMemcpyAsync(h_out, d_out, 16, hipMemcpyDeviceToHost, sv);
             (void)hipStreamSynchronize(sv);
             twins++;
+            if (h_out[0] && analyse) {
+                std::lock_guard<std::mutex> lk(amu);
+                if (analysed < analyse) {
+                    analysed++;
+                    std::vector<float> hx((size_t)out_floats), hy((size_t)out_floats);
+                    (void)hipMemcpy(hx.data(), X, out_floats * 4, hipMemcpyDeviceToHost);
+                    (void)hipMemcpy(hy.data(), Y, out_floats * 4, hipMemcpyDeviceToHost);
+                    for (const std::vector<float>* o : {&hx, &hy})
+                        for (size_t i = 0; i < (size_t)out_floats; i++) {
+                            const float wv = (*o)[i];
+                            if (memcmp(&wv, &ref[i], 4) == 0) continue;
+                            char key[160];
+                            uint32_t b; memcpy(&b, &wv, 4);
+                            auto range = where.equal_range(b);
+                            if (wv == -0.5f) snprintf(key, sizeof key, "wrong word is the FILL value (right one is a pixel), lanes %d-%d", (col_of[i] & 48), (col_of[i] & 48) + 15);
+                            else if (range.first == range.second) snprintf(key, sizeof key, "wrong value occurs NOWHERE in the right output (right one %s), lanes %d-%d", ref[i] == -0.5f ? "is fill" : "is a pixel", (col_of[i] & 48), (col_of[i] & 48) + 15);
+                            else {
+                                size_t best = range.first->second;
+                                for (auto it = range.first; it != range.second; ++it)
+                                    if (line_of[it->second] == line_of[i] && (line_of[best] != line_of[i] || abs(row_of[it->second] - row_of[i]) < abs(row_of[best] - row_of[i]))) best = it->second;
+                                snprintf(key, sizeof key, "wrong value is the right value of line %+d, row %+d, column %+d (mod 64: %+d)", line_of[best] - line_of[i], row_of[best] - row_of[i],
+                                         col_of[best] - col_of[i], (col_of[best] - col_of[i]) % 64);
+                            }
+                            relation[key]++;
+                        }
+                }
+            }
             if (h_out[0]) {
                 bad_twins++; bad_words += (long)h_out[0];
                 if (bad_twins.load() <= 8) fprintf(stderr, "twin %ld differs: %llu words, first at float %llu (stream %d)\n", twins.load(), h_out[0], h_out[1], v);
@@ -150,6 +204,13 @@ int main(int argc, char** argv) {
     for (auto& t : vt) t.join();
     stop = true;
     agg.join();
+    if (analyse) {
+        std::vector<std::pair<long, std::string>> top;
+        for (auto& kv : relation) top.emplace_back(kv.second, kv.first);
+        std::sort(top.rbegin(), top.rend());
+        fprintf(stderr, "where the wrong words of the first %ld differing twins come from (%zu kinds):\n", analysed, top.size());
+        for (size_t i = 0; i < top.size() && i < 40; i++) fprintf(stderr, "  %8ld  %s\n", top[i].first, top[i].second.c_str());
+    }
     printf("{\"aggressor\": \"%s\", \"split_cus\": %d, \"cus\": %d, \"victim_lines\": %d, \"victim_streams\": %d, \"seconds\": %.1f, "
            "\"aggressor_launches\": %ld, \"twin_launches\": %ld, \"twins_that_differ\": %ld, \"words_that_differ\": %ld}\n",
            aggressor.c_str(), split_cus, cus, n_lines, vstreams, seconds, agg_launches.load(), twins.load(), bad_twins.load(), bad_words.load());

@@ -90,6 +90,35 @@ PY
 soak)
   say "== varied-size one-page soak, six threads (mixed sizes now share detection batches)"
   timeout 300 python tools/soak_varied.py 20 6 > $OUT/soak_varied_exact.txt 2>&1; say "rc=$?"; tail -6 $OUT/soak_varied_exact.txt | tee -a $S;;
+repro2)
+  say "== reproducer, round two: where the wrong words come from; aggressor probes"
+  timeout 120 tools/_build/hazard_repro --aggressor split3 --seconds 8 --analyse 3 2> $OUT/repro_analyse.txt | tee -a $S; head -45 $OUT/repro_analyse.txt | tee -a $S
+  timeout 120 tools/_build/hazard_repro --aggressor split2 --seconds 6 --victim-streams 2 2>> $OUT/repro.err | tee -a $S
+  say "-- accumulators in AGPRs"; timeout 120 tools/_build/hazard_repro.ACC_AGPR --aggressor split3 --seconds 8 --victim-streams 2 2>> $OUT/repro.err | tee -a $S
+  say "-- the same registers through v_mfma_f32_16x16x32_bf16"; timeout 120 tools/_build/hazard_repro.MFMA16 --aggressor split3 --seconds 8 --victim-streams 2 2>> $OUT/repro.err | tee -a $S
+  say "-- split-cus 64 / 192 / 224"
+  for c in 64 192 224; do timeout 120 tools/_build/hazard_repro --aggressor split3 --seconds 6 --victim-streams 2 --split-cus $c 2>> $OUT/repro.err | tee -a $S; done;;
+canary2)
+  say "== canary, partition 192: which class differs, with which recurrence"
+  for cfg in "relaxed partition 192 12 logits,tokens" "relaxed partition 192 12 logits,tokens gru_mode=1" "relaxed partition 160 12 crop,logits,tokens" "relaxed none 0 8 crop,logits"; do
+    set -- $cfg
+    opt=""; [ -n "${6:-}" ] && opt="--option $6"
+    timeout 150 python tools/hazard_canary.py --numerics $1 --isolation $2 --split-cus $3 --seconds $4 --classes $5 $opt > $OUT/canary2_$1_$2_$3_${6:-x}.json 2> $OUT/canary2_$1_$2_$3_${6:-x}.err; rc=$?
+    python - $OUT/canary2_$1_$2_$3_${6:-x}.json "$cfg rc=$rc" <<'PY' | tee -a $S
+import json, sys
+try:
+    d = json.loads([l for l in open(sys.argv[1]).read().splitlines() if l.startswith("{")][-1])
+    print(sys.argv[2], d["isolation"], "| mismatching checks", d["mismatching_checks"], {k: (v["checks"], v["bad_checks"], v["bad_elements"]) for k, v in d["classes"].items()}, "| examples", d["examples"][:4], "| errors", d["errors"][:2])
+except Exception as e:
+    print(sys.argv[2], "parse failed", e)
+PY
+  done;;
+benchab)
+  say "== the driver's form with and without per-launch HIP events in the timed window (ABAB)"
+  for i in 1 2; do
+    timeout 300 python bench.py --steps 20 --warmup 5 --no-extras --no-cpu-baseline > $OUT/bench_ab_timed$i.json 2> $OUT/bench_ab_timed$i.err; bsum $OUT/bench_ab_timed$i.json "events on  $i"
+    timeout 300 python bench.py --steps 20 --warmup 5 --no-extras --no-cpu-baseline --no-kernel-timing > $OUT/bench_ab_plain$i.json 2> $OUT/bench_ab_plain$i.err; bsum $OUT/bench_ab_plain$i.json "events off $i"
+  done;;
 *) say "unknown section $sec";;
 esac
 done
