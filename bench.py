@@ -145,9 +145,11 @@ def cap_host_threads(world_local):
     return per_rank
 
 
-def layout_threads_for(per_rank):
-    """find_text_lines_batch: one host thread per page of a request, at most this many per call (ocrs_engine_params.layout_threads)"""
-    return max(2, min(16, per_rank // 2))
+def layout_threads_for(per_rank, members=1):
+    """find_text_lines_batch: one host thread per page of a request, at most this many per call (ocrs_engine_params.layout_threads).
+    A group's request carries `members` times the pages (16 per member): its layout gets proportionally more threads, within
+    half of the rank's cores (the pre-flight of --replay: 128 pages on 16 threads were 40-60 ms on the critical path of every step)"""
+    return max(2, min(16 * max(1, members), per_rank // 2, 128))
 
 
 def dist_setup(args):
@@ -257,7 +259,7 @@ def main():
     if group_mode:
         devices = [int(x) for x in args.devices.split(",")] if args.devices else list(range(args.gpus))
         group = EngineGroup(devices, models.synthetic_detection_bytes(), models.synthetic_recognition_bytes(),
-                            gather="rccl" if args.gather == "rccl" else "host", layout_threads=layout_threads_for(per_rank_cores),
+                            gather="rccl" if args.gather == "rccl" else "host", layout_threads=layout_threads_for(per_rank_cores, len(devices)),
                             numerics=args.numerics, coalesce=args.coalesce)
         engine = group.member(0)[0]     # stage / kernel timers: member 0's
         G = len(devices)
@@ -468,10 +470,18 @@ def main():
     outs = run_steps(prime + args.steps + trail, collect=True, stamps=stamps)
     sync_all()
     wall = time.perf_counter() - t0
+    completion = None
     if steady:
         stamps.sort()
         elapsed = stamps[prime + args.steps - 1] - stamps[prime - 1]
         outs = outs[prime:prime + args.steps]
+        # how regular the completions inside the window were (a burst at either boundary moves a 20-step figure by up to 1 / K):
+        # the gaps between consecutive completions, and the least-squares slope through the K + 1 boundary times
+        win = np.array(stamps[prime - 1:prime + args.steps])
+        gaps = np.diff(win) * 1e3
+        slope = float(np.polyfit(np.arange(len(win)), win, 1)[0])
+        completion = {"gap_ms_min": round(float(gaps.min()), 2), "gap_ms_median": round(float(np.median(gaps)), 2),
+                      "gap_ms_max": round(float(gaps.max()), 2), "ms_per_step_least_squares": round(1e3 * slope, 3)}
     else:
         elapsed = wall
     steps_under_timers = prime + args.steps + trail
@@ -551,6 +561,7 @@ def main():
         "warmup": args.warmup,
         "extra_untimed_settle_steps": settle_steps,
         "ms_per_step": round(1000.0 * elapsed / args.steps, 3),
+        "completions_in_the_window": completion,
         "value_incl_fill_drain": round(n_pages_all / elapsed_fd, 3) if elapsed_fd else None,
         "ms_per_step_incl_fill_drain": round(1000.0 * elapsed_fd / args.steps, 3) if elapsed_fd else None,
         "higher_is_better": True,

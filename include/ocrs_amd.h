@@ -153,27 +153,24 @@ OCRS_API ocrs_status ocrs_device_pool_configure(int device, uint64_t device_cach
  * caller still holds, requests in flight.  Waits for the conv stacks in flight; for idle moments, not for the request path. */
 OCRS_API ocrs_status ocrs_device_pool_trim(int device);
 
-/* Isolation of the bf16-split kernels (engines with numerics != exact), per device.  Round 5 observed OTHER requests' line
- * crops change while those kernels' v_mfma_f32_32x32x16_bf16 instructions ran beside them (DESIGN.md §4.4 "Concurrency");
- * the library therefore never lets kernels of different requests overlap freely on a device that has such an engine.
+/* Isolation of the bf16-MFMA kernels (engines with numerics != exact), per device.  Round 5 observed OTHER requests' line crops
+ * change while those kernels ran beside them; round 6 reproduced it from the two real kernels alone (tools/hazard_repro.hip:
+ * every twin launch of the crop kernel differs while a dense bf16-MFMA kernel with VGPR accumulators shares its compute units,
+ * none when the two are confined to disjoint units; DESIGN.md §4.4 "Concurrency").  The library therefore never lets kernels of
+ * different requests overlap on a device that has such an engine.
  *   OCRS_ISOLATION_AUTO (default)   every call on the device enqueues on ONE stream while such an engine exists;
  *   OCRS_ISOLATION_NONE             nothing (diagnostics: tools/hazard_canary.py reproduces the hazard with it — never in
- *                                   production);
- *   OCRS_ISOLATION_CU_PARTITION     the split kernels run on a stream confined to `split_cus` compute units
- *                                   (hipExtStreamCreateWithCUMask), every other kernel of the device on streams confined to
- *                                   the remaining ones; requests overlap as in exact mode, no two kernels of the two classes
- *                                   ever share a compute unit.  Each side needs >= 8 units; the persistent recurrence
- *                                   kernels need 128 on theirs at hidden size 256 (fewer: the per-step kernels run).
- * Exact-only devices are untouched by any of this.  A request is told its regime once, when it starts, and keeps it; a
- * change of regime — this call, the first engine with numerics != exact created on the device, the last one destroyed —
- * BLOCKS until the requests in flight on the device have finished (new ones wait meanwhile) and the device is idle, so
- * requests of two regimes never run side by side.  Do not call from inside a request.  device < 0: the default device. */
-typedef enum { OCRS_ISOLATION_AUTO = 0, OCRS_ISOLATION_NONE = 1, OCRS_ISOLATION_CU_PARTITION = 2 } ocrs_isolation;
-OCRS_API ocrs_status ocrs_device_set_isolation(int device, ocrs_isolation policy, int split_cus);
-/* out = {what a request starting now is told: 0 free (own stream per call), 1 serial (one stream), 2 partitioned;
- *        engines with numerics != exact alive on the device; compute units of the split kernels' side (0 unless partitioned);
- *        compute units of the device}. */
-OCRS_API ocrs_status ocrs_device_isolation(int device, int out[4]);
+ *                                   production).
+ * Exact-only devices are untouched by any of this (and covered by a standing canary: tests/test_gpu_r6.py).  A request is told
+ * its regime once, when it starts, and keeps it; a change of regime — this call, the first engine with numerics != exact
+ * created on the device, the last one destroyed — BLOCKS until the requests in flight on the device have finished (new ones
+ * wait meanwhile) and the device is idle, so requests of two regimes never run side by side.  Do not call from inside a
+ * request.  device < 0: the default device. */
+typedef enum { OCRS_ISOLATION_AUTO = 0, OCRS_ISOLATION_NONE = 1 } ocrs_isolation;
+OCRS_API ocrs_status ocrs_device_set_isolation(int device, ocrs_isolation policy);
+/* out = {what a request starting now is told: 0 free (own stream per call), 1 serial (one stream);
+ *        engines with numerics != exact alive on the device; compute units of the device}. */
+OCRS_API ocrs_status ocrs_device_isolation(int device, int out[3]);
 
 /* ------------------------------------------------------------------------
  * L2 seam: `trait Model` (ocrs/src/model.rs:6-17) and its rten impl

@@ -159,18 +159,18 @@ def pool_configure(device=-1, device_cached_cap=0, pinned_cached_cap=0):
     check(lib().ocrs_device_pool_configure(int(device), C.c_uint64(int(device_cached_cap)), C.c_uint64(int(pinned_cached_cap))))
 
 
-ISOLATION = {"auto": 0, "none": 1, "partition": 2}
+ISOLATION = {"auto": 0, "none": 1}
 
 
-def set_isolation(policy="auto", split_cus=0, device=-1):
+def set_isolation(policy="auto", device=-1):
     """ocrs_device_set_isolation: how kernels of engines with numerics != exact are kept away from other requests' kernels."""
-    check(lib().ocrs_device_set_isolation(int(device), int(ISOLATION[policy]), int(split_cus)))
+    check(lib().ocrs_device_set_isolation(int(device), int(ISOLATION[policy])))
 
 
 def isolation(device=-1):
-    v = (C.c_int * 4)()
+    v = (C.c_int * 3)()
     check(lib().ocrs_device_isolation(int(device), v))
-    return {"mode": ("free", "serial", "partition")[v[0]], "relaxed_engines": int(v[1]), "split_cus": int(v[2]), "cus": int(v[3])}
+    return {"mode": ("free", "serial")[v[0]], "relaxed_engines": int(v[1]), "cus": int(v[2])}
 
 
 def ctc_beam_search(logp, width, impl=0):

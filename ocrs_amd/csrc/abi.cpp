@@ -168,26 +168,23 @@ ocrs_status ocrs_device_pool_trim(int device) {
     });
 }
 
-ocrs_status ocrs_device_set_isolation(int device, ocrs_isolation policy, int split_cus) {
+ocrs_status ocrs_device_set_isolation(int device, ocrs_isolation policy) {
     return guarded([&] {
-        if (policy != OCRS_ISOLATION_AUTO && policy != OCRS_ISOLATION_NONE && policy != OCRS_ISOLATION_CU_PARTITION)
-            fail(OCRS_ERR_INVALID_ARGUMENT, "unknown isolation policy %d", (int)policy);
+        if (policy != OCRS_ISOLATION_AUTO && policy != OCRS_ISOLATION_NONE) fail(OCRS_ERR_INVALID_ARGUMENT, "unknown isolation policy %d", (int)policy);
         DeviceContext& c = device_context(device < 0 ? default_device() : device);
         DeviceScope bind(c.device);
-        c.set_isolation(policy == OCRS_ISOLATION_NONE ? DeviceContext::ISO_NONE : policy == OCRS_ISOLATION_CU_PARTITION ? DeviceContext::ISO_PARTITION
-                                                                                                                        : DeviceContext::ISO_AUTO, split_cus);
+        c.set_isolation(policy == OCRS_ISOLATION_NONE ? DeviceContext::ISO_NONE : DeviceContext::ISO_AUTO);
     });
 }
 
-ocrs_status ocrs_device_isolation(int device, int out[4]) {
+ocrs_status ocrs_device_isolation(int device, int out[3]) {
     return guarded([&] {
         if (!out) fail(OCRS_ERR_INVALID_ARGUMENT, "null argument");
         DeviceContext& c = device_context(device < 0 ? default_device() : device);
         DeviceScope bind(c.device);
         out[0] = (int)c.current_mode();
         out[1] = c.relaxed_engine_count();
-        out[2] = c.current_mode() == DeviceContext::MODE_PARTITION ? c.partition_cus() : 0;
-        out[3] = c.cu_count();
+        out[2] = c.cu_count();
     });
 }
 

@@ -347,48 +347,14 @@ hipStream_t DeviceContext::heavy_stream() {
 
 hipStream_t DeviceContext::recurrent_stream(int mode) {
     if (mode == MODE_SERIAL) return heavy_stream();
-    hipStream_t& r = mode == MODE_PARTITION ? recurrent_masked_ : recurrent_;
-    {
-        std::lock_guard<std::mutex> g(lazy_mu_);
-        if (r) return r;
-    }
-    // created outside lazy_mu_ (masked_stream and cu_count take it themselves); a race makes two, one is dropped
-    hipStream_t made = nullptr;
-    DeviceScope bind(device);
-    if (mode == MODE_PARTITION) {
-        made = masked_stream(false);
-    } else {
+    std::lock_guard<std::mutex> g(lazy_mu_);
+    if (!recurrent_) {
+        DeviceScope bind(device);
         int least = 0, greatest = 0;
         OCRS_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        OCRS_HIP(hipStreamCreateWithPriority(&made, hipStreamNonBlocking, greatest));
+        OCRS_HIP(hipStreamCreateWithPriority(&recurrent_, hipStreamNonBlocking, greatest));
     }
-    std::lock_guard<std::mutex> g(lazy_mu_);
-    if (!r) r = made; else (void)hipStreamDestroy(made);
-    return r;
-}
-
-// ---- MODE_PARTITION: the device's compute units split in two sets, a stream confined to either.  Bit i of the mask is
-// compute unit i in the driver's numbering (on this 8-XCD part consecutive bits go round the XCDs, so a prefix of the mask is
-// the same number of units on every XCD; nothing here depends on that — any split is disjoint).
-hipStream_t DeviceContext::masked_stream(bool split_side) {
-    const int total = cu_count(), a = part_cus_;
-    std::vector<uint32_t> mask((size_t)(total + 31) / 32, 0u);
-    for (int i = split_side ? 0 : a; i < (split_side ? a : total); i++) mask[(size_t)i / 32] |= 1u << (i % 32);
-    hipStream_t s = nullptr;
-    DeviceScope bind(device);
-    OCRS_HIP(hipExtStreamCreateWithCUMask(&s, (uint32_t)mask.size(), mask.data()));
-    return s;
-}
-
-hipStream_t DeviceContext::split_stream() {
-    {
-        std::lock_guard<std::mutex> g(lazy_mu_);
-        if (split_) return split_;
-    }
-    hipStream_t made = masked_stream(true);   // outside lazy_mu_: cu_count() takes it
-    std::lock_guard<std::mutex> g(lazy_mu_);
-    if (!split_) split_ = made; else (void)hipStreamDestroy(made);
-    return split_;
+    return recurrent_;
 }
 
 // per host thread and device: leases the thread already holds (a nested lease must not wait for a switch that waits for it)
@@ -402,29 +368,21 @@ template <class F> void DeviceContext::switch_isolation(F&& change) {
     const Mode before = mode_locked();
     switching_ = true;                                   // from here on lease_begin() waits
     struct Done { DeviceContext* c; ~Done() { c->switching_ = false; c->iso_cv_.notify_all(); } } done{this};
-    // what changes for a request is known only after `change`; try it on a copy first so that a no-op costs no drain
+    // what changes for a request is known only after `change`; a no-op costs no drain
     const Isolation p0 = policy_;
-    const int r0 = relaxed_, c0 = part_cus_;
+    const int r0 = relaxed_;
     change();
-    const bool same = mode_locked() == before && (before != MODE_PARTITION || part_cus_ == c0);
-    if (same) return;
+    if (mode_locked() == before) return;
     // put the old regime back while the requests that were told about it finish, then flip
     const Isolation p1 = policy_;
-    const int r1 = relaxed_, c1 = part_cus_;
-    policy_ = p0; relaxed_ = r0; part_cus_ = c0;
+    const int r1 = relaxed_;
+    policy_ = p0; relaxed_ = r0;
     iso_cv_.wait(lk, [&] { return leases_ == 0; });
     {
         DeviceScope bind(device);
         if (hipDeviceSynchronize() != hipSuccess) (void)hipGetLastError();
-        // streams confined to an old partition are useless to a new one
-        std::lock_guard<std::mutex> g(lazy_mu_);
-        std::lock_guard<std::mutex> g2(stream_mu);
-        for (auto& se : masked_streams_) { (void)hipStreamDestroy(se.first); (void)hipEventDestroy(se.second); }
-        masked_streams_.clear();
-        if (split_) { (void)hipStreamDestroy(split_); split_ = nullptr; }
-        if (recurrent_masked_) { (void)hipStreamDestroy(recurrent_masked_); recurrent_masked_ = nullptr; }
     }
-    policy_ = p1; relaxed_ = r1; part_cus_ = c1;
+    policy_ = p1; relaxed_ = r1;
 }
 
 DeviceContext::Mode DeviceContext::lease_begin() {
@@ -445,14 +403,8 @@ void DeviceContext::add_relaxed_engine(int delta) {
     switch_isolation([&] { relaxed_ += delta; });
 }
 
-void DeviceContext::set_isolation(Isolation policy, int cus) {
-    if (policy == ISO_PARTITION) {
-        const int total = cu_count();
-        // the recurrence kernels need one whole group of clusters resident on their side (kernels_gru.hip: 128 workgroups at
-        // hidden 256), the split kernels at least an XCD's worth on theirs
-        if (cus < 8 || total - cus < 8) fail(OCRS_ERR_INVALID_ARGUMENT, "CU partition %d / %d of %d compute units: each side needs at least 8", cus, total - cus, total);
-    }
-    switch_isolation([&] { policy_ = policy; part_cus_ = policy == ISO_PARTITION ? cus : 0; });
+void DeviceContext::set_isolation(Isolation policy) {
+    switch_isolation([&] { policy_ = policy; });
 }
 
 DeviceContext::Mode DeviceContext::current_mode() {
@@ -473,12 +425,6 @@ int DeviceContext::cu_count() {
         cus_ = prop.multiProcessorCount;
     }
     return cus_;
-}
-
-int DeviceContext::recurrence_cus() {
-    const int total = cu_count();
-    std::lock_guard<std::mutex> lk(iso_mu_);
-    return mode_locked() == MODE_PARTITION ? total - part_cus_ : total;
 }
 
 // ---------------------------------------------------------------- options
@@ -509,7 +455,7 @@ const OptDef kOptDefs[OPT_COUNT] = {
 // allowed set beyond 0 / 1
 struct OptRange { long lo, hi; long also[4]; };
 const OptRange kOptRanges[OPT_COUNT] = {
-    {0, 1, {}}, {0, 1, {}}, {0, 1, {}}, {0, 2, {}}, {0, 1, {}}, {0, 1, {8, 14, 32}}, {0, 1, {8, 14, 20, 32}}, {0, 1, {}}, {0, 1, {}}, {0, 1, {}}, {0, 1, {}},
+    {0, 1, {}}, {0, 1, {}}, {0, 1, {}}, {0, 2, {}}, {0, 2, {}}, {0, 1, {8, 14, 32}}, {0, 1, {8, 14, 20, 32}}, {0, 1, {}}, {0, 1, {}}, {0, 1, {}}, {0, 1, {}},
     {0, 2, {}}, {0, 64, {}}, {1, 4096, {}}, {0, 10000000, {}}, {0, 4096, {}}, {0, INT64_MAX, {}},
 };
 bool in_range(int i, long v) {
@@ -601,7 +547,7 @@ StreamLease::StreamLease(bool high_priority) : ctx_(&ctx()), high_(high_priority
         }
         {
             std::lock_guard<std::mutex> g(ctx_->stream_mu);
-            auto& v = mode_ == DeviceContext::MODE_PARTITION ? ctx_->masked_streams_ : ctx_->streams;
+            auto& v = ctx_->streams;
             if (!v.empty()) {
                 s_ = v.back().first;
                 done_ = v.back().second;
@@ -609,13 +555,9 @@ StreamLease::StreamLease(bool high_priority) : ctx_(&ctx()), high_(high_priority
                 return;
             }
         }
-        if (mode_ == DeviceContext::MODE_PARTITION) {
-            s_ = ctx_->masked_stream(false);
-        } else {
-            int least = 0, greatest = 0;
-            OCRS_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-            OCRS_HIP(hipStreamCreateWithPriority(&s_, hipStreamNonBlocking, greatest));
-        }
+        int least = 0, greatest = 0;
+        OCRS_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        OCRS_HIP(hipStreamCreateWithPriority(&s_, hipStreamNonBlocking, greatest));
         OCRS_HIP(hipEventCreateWithFlags(&done_, hipEventBlockingSync | hipEventDisableTiming));
     } catch (...) {
         ctx_->lease_end();
@@ -628,7 +570,7 @@ StreamLease::~StreamLease() {
         (void)hipEventDestroy(done_);
     } else {
         std::lock_guard<std::mutex> g(ctx_->stream_mu);
-        (mode_ == DeviceContext::MODE_PARTITION ? ctx_->masked_streams_ : ctx_->streams).emplace_back(s_, done_);
+        ctx_->streams.emplace_back(s_, done_);
     }
     ctx_->lease_end();
 }

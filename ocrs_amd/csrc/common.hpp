@@ -113,34 +113,27 @@ struct DeviceContext {
     // the shared stream wait, launch, record, make the request stream wait" atomic per request.
     std::mutex heavy_phase, rec_phase;
     hipStream_t heavy_stream();
-    hipStream_t recurrent_stream(int mode = 0);   // of a request in Mode `mode`: SERIAL -> the one stream, PARTITION -> confined
-    // ---- isolation of the bf16-split kernels (numerics != exact).  Round 5 saw another request's line crops change while the
-    // split conv / GEMM kernels (v_mfma_f32_32x32x16_bf16) ran beside them (DESIGN.md §4.4 "Concurrency"), so a device that has
-    // an engine with numerics != exact does not let kernels of different requests overlap freely.  The POLICY is per device
-    // (ocrs_device_set_isolation):
+    hipStream_t recurrent_stream(int mode = 0);   // of a request in Mode `mode`: MODE_SERIAL -> the device's one stream
+    // ---- isolation of the bf16-MFMA kernels (numerics != exact).  Round 5 saw another request's line crops change while the
+    // split conv / GEMM kernels ran beside them; round 6 reproduced it stand-alone (tools/hazard_repro.hip: a dense bf16-MFMA
+    // kernel with its accumulators in the VGPR half of the register file corrupts 16-lane pieces of OTHER waves on its
+    // compute unit; DESIGN.md §4.4 "Concurrency").  A device that has an engine with numerics != exact therefore does not let
+    // kernels of different requests overlap.  The POLICY is per device (ocrs_device_set_isolation):
     //   ISO_AUTO (default)  one stream for every call on the device while such an engine exists — no two kernels at once;
-    //   ISO_NONE            never (diagnostics only: tools/hazard_canary.py reproduces the hazard with it);
-    //   ISO_PARTITION       the split kernels on a stream confined to `partition_cus` compute units (hipExtStreamCreateWithCUMask),
-    //                       every other kernel of the device on streams confined to the complementary units.
+    //   ISO_NONE            never (diagnostics only: tools/hazard_canary.py reproduces the hazard with it).
     // What a REQUEST does is decided once, when its StreamLease is made (StreamLease::mode()), and travels with it: stream,
     // recurrence stream and activation arena all follow that one decision.  A change of what new requests would be told (the
     // first such engine created, the last destroyed, a new policy) waits until no request is in flight on the device and the
     // device is idle (switch_isolation): requests of the two regimes never run side by side.
-    enum Isolation { ISO_AUTO = 0, ISO_NONE = 1, ISO_PARTITION = 2 };
-    enum Mode { MODE_FREE = 0, MODE_SERIAL = 1, MODE_PARTITION = 2 };
+    enum Isolation { ISO_AUTO = 0, ISO_NONE = 1 };
+    enum Mode { MODE_FREE = 0, MODE_SERIAL = 1 };
     Mode lease_begin();                        // a request starts: waits while a switch is pending; returns what applies to it
     void lease_end();
     void add_relaxed_engine(int delta);        // +1 / -1; drains the device when the regime changes
-    void set_isolation(Isolation policy, int partition_cus);
+    void set_isolation(Isolation policy);
     Mode current_mode();                       // what a request starting now would be told (stats, tests)
     int relaxed_engine_count();
-    int partition_cus() const { return part_cus_; }              // compute units of the split kernels' stream (MODE_PARTITION)
-    hipStream_t split_stream();                                   // MODE_PARTITION: the stream confined to those units
-    hipStream_t masked_stream(bool split_side);                   // a new stream confined to one side of the partition
     int cu_count();
-    // compute units a persistent recurrence kernel of a request starting now may count on: all of them, or (MODE_PARTITION)
-    // the side that is not set aside for the split kernels.  Stable for the lifetime of a request (a regime change drains first).
-    int recurrence_cus();
     // intermediate activations of the conv stacks that run on heavy_stream(): shared by all requests (stream order is
     // the exclusion), guarded by heavy_phase; see HipModel::run_prefix_ragged
     std::vector<struct DevBuf> heavy_arena;
@@ -151,19 +144,16 @@ struct DeviceContext {
     explicit DeviceContext(int d) : device(d), pool(d) {}
 
   private:
-    Mode mode_locked() const {
-        return policy_ == ISO_NONE || relaxed_ <= 0 ? MODE_FREE : policy_ == ISO_PARTITION ? MODE_PARTITION : MODE_SERIAL;
-    }
+    Mode mode_locked() const { return policy_ == ISO_NONE || relaxed_ <= 0 ? MODE_FREE : MODE_SERIAL; }
     template <class F> void switch_isolation(F&& change);
     std::mutex lazy_mu_;
-    hipStream_t heavy_ = nullptr, recurrent_ = nullptr, split_ = nullptr, recurrent_masked_ = nullptr;
+    hipStream_t heavy_ = nullptr, recurrent_ = nullptr;
     int cus_ = 0;
     std::mutex iso_mu_;
     std::condition_variable iso_cv_;
-    int leases_ = 0, relaxed_ = 0, part_cus_ = 0;
+    int leases_ = 0, relaxed_ = 0;
     bool switching_ = false;
     Isolation policy_ = ISO_AUTO;
-    std::vector<std::pair<hipStream_t, hipEvent_t>> masked_streams_;   // recycled per-call streams of MODE_PARTITION (stream_mu)
     friend class StreamLease;
 };
 
@@ -299,9 +289,8 @@ class StreamLease {
     // the isolation regime of this request (DeviceContext::Mode), decided when the lease was made
     DeviceContext::Mode mode() const { return mode_; }
     bool serial() const { return mode_ == DeviceContext::MODE_SERIAL; }
-    // where this request's conv stacks / split kernels go: the device's shared conv-stack stream, or (MODE_PARTITION) the
-    // stream confined to the split kernels' compute units
-    hipStream_t conv_stream() const { return mode_ == DeviceContext::MODE_PARTITION ? ctx_->split_stream() : ctx_->heavy_stream(); }
+    // where this request's conv stacks go: the device's shared conv-stack stream
+    hipStream_t conv_stream() const { return ctx_->heavy_stream(); }
     hipStream_t recurrent_stream() const { return ctx_->recurrent_stream((int)mode_); }
 
   private:

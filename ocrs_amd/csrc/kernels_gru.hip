@@ -661,11 +661,10 @@ static int gru_resident_capacity(int H, bool gates, size_t lds) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 0;
     const int key = dev * 8 + (gates ? 4 : 0) + (H == 256 ? 2 : H == 128 ? 1 : 0);
-    const int side = ctx().recurrence_cus();   // fewer than the device's when the compute units are partitioned (common.hpp)
     {
         std::lock_guard<std::mutex> g(mu);
         auto it = cache.find(key);
-        if (it != cache.end()) return std::min(it->second, side);
+        if (it != cache.end()) return it->second;
     }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
@@ -686,7 +685,7 @@ static int gru_resident_capacity(int H, bool gates, size_t lds) {
     const int cap = prop.multiProcessorCount * (per_cu > 0 ? 1 : 0);
     std::lock_guard<std::mutex> g(mu);
     cache[key] = cap;
-    return std::min(cap, side);
+    return cap;
 }
 
 // Grid geometry: ncl clusters per direction (UB workgroups each); false if the shape is not supported.

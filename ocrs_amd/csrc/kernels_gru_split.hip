@@ -369,7 +369,7 @@ int resident_capacity(size_t lds) {   // see gru_resident_capacity (kernels_gru.
         cap = per_cu > 0 ? prop.multiProcessorCount : -1;
         cache[dev].store(cap, std::memory_order_relaxed);
     }
-    return cap > 0 ? std::min(cap, ctx().recurrence_cus()) : 0;   // (a partitioned device: the recurrences' side only)
+    return cap > 0 ? cap : 0;
 }
 
 size_t split_lds_bytes(int H, int np, int Tmax) { return (size_t)3 * (H / 32) * np * 1024 + ((size_t)Tmax + 1) * sizeof(int); }

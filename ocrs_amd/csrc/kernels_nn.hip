@@ -432,7 +432,6 @@ __global__ void __launch_bounds__(256, NP == 3 ? 2 : 3) gemm_split_kernel(GemmDe
     const int nchunks = d.K / split::BK;
     const float* __restrict__ img = reinterpret_cast<const float*>(d.Bsplit + (int64_t)z * d.strideBsplit) +
                                     (int64_t)nblk * nchunks * split::image_floats;
-    const __amdgpu_buffer_rsrc_t img_rsrc = split::weight_rsrc(img, (size_t)nchunks * split::image_floats * 4);
     const int ar = tid >> 2, akq = tid & 3;
     const float* arow[2];
 #pragma unroll
@@ -457,7 +456,7 @@ __global__ void __launch_bounds__(256, NP == 3 ? 2 : 3) gemm_split_kernel(GemmDe
                 d1[j] = *reinterpret_cast<const split::f32x4s*>(arow[j] + k0 + split::BK);
             }
         },
-        [&](int k0, int ring) { split::load_weights<NP>(img_rsrc, (k0 / split::BK) * split::image_floats * 4, Bs + ring * NP * PL, wave, lane); },
+        [&](int k0, int ring) { split::load_weights<NP>(img + (int64_t)(k0 / split::BK) * split::image_floats, Bs + ring * NP * PL, wave, lane); },
         [&](int abuf, const split::f32x4s (&v)[2]) {
             char* base = reinterpret_cast<char*>(As + abuf * NP * PL);
 #pragma unroll

@@ -410,13 +410,11 @@ conv3x3_ragged_kernel(const float* __restrict__ X, RaggedView rv, int cin, const
     // B goes global -> LDS directly (global_load_lds_dwordx4: wave-uniform LDS base + lane * 16 B, per-lane global
     // address): the [k][BN] tile is row-major and contiguous in LDS, so chunk element idx lands at float 4 * idx.
     // No staging registers and no ds_write for B; the barrier that ends the chunk drains the copies (vmcnt(0)).
-    // (split kernels: the column block's weight image as a buffer resource — split_mfma.hpp load_weights)
-    const __amdgpu_buffer_rsrc_t b_rsrc = split::weight_rsrc(Bw + (SPLIT != 0 ? (int64_t)blockIdx.y * (K / RG_BK) * split::image_floats : 0),
-                                                             SPLIT != 0 ? (size_t)(K / RG_BK) * split::image_floats * 4 : 0);   // (unused, and dropped, in the exact kernels)
     auto load_b = [&](int k0, int buf) {
         if constexpr (SPLIT != 0) {
             // Bw = the split image: [column block][chunk][3 planes x 128 columns x 32 bytes] = 12 KB per (block, chunk)
-            split::load_weights<NP>(b_rsrc, (k0 / RG_BK) * split::image_floats * 4, Bs + buf * NP * SP_PLANE, wave, lane);
+            split::load_weights<NP>(Bw + ((int64_t)blockIdx.y * (K / RG_BK) + k0 / RG_BK) * split::image_floats,
+                                    Bs + buf * NP * SP_PLANE, wave, lane);
             return;
         }
         const float* __restrict__ bk = Bw + (int64_t)k0 * cout;
@@ -798,15 +796,13 @@ conv12_fused_split_kernel(const float* __restrict__ X0, RaggedView in0, RaggedVi
     const int y0 = rb * TH;
 
     // conv2 weights of tap t -> ring buffer t % 3: NP planes of 4 KB, one 16-byte piece per thread and plane
-    // (buffer-form LDS-DMA: see split_mfma.hpp load_weights for why not global_load_lds)
-    const __amdgpu_buffer_rsrc_t b_rsrc = split::weight_rsrc(Bimg, (size_t)9 * 3 * F12S_BTAP);
     auto load_b = [&](int tap) {
-        const int src = tap * 3 * F12S_BTAP;     // (the image always holds 3 planes)
+        const char* src = reinterpret_cast<const char*>(Bimg) + (size_t)tap * 3 * F12S_BTAP;     // (the image always holds 3 planes)
         char* dst = Bs + (tap % 3) * NP * F12S_BTAP;
 #pragma unroll
         for (int p = 0; p < NP; p++)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, (__attribute__((address_space(3))) void*)(dst + p * F12S_BTAP + wave * 1024), 16,
-                                                     src + p * F12S_BTAP + wave * 1024 + lane * 16, 0, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + p * F12S_BTAP + wave * 1024 + lane * 16),
+                                             (__attribute__((address_space(3))) void*)(dst + p * F12S_BTAP + wave * 1024), 16, 0, 0);
     };
     load_b(0);
     load_b(1);
@@ -923,8 +919,8 @@ conv12_fused_split_kernel(const float* __restrict__ X0, RaggedView in0, RaggedVi
 #pragma unroll
             for (int p = 0; p < NP; p++) bfr[p] = *reinterpret_cast<const bf16x8*>(bb + p * F12S_BTAP + qb);
 #define OCRS_TERM12(PA, PB)                                                                                   \
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][PA], bfr[PB], acc[0], 0, 0, 0);            \
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][PA], bfr[PB], acc[1], 0, 0, 0);
+            OCRS_SPLIT_MMA(af[0][PA], bfr[PB], acc[0]);                                                       \
+            OCRS_SPLIT_MMA(af[1][PA], bfr[PB], acc[1]);
             if (NP == 3) { OCRS_TERM12(NP - 1, 0) OCRS_TERM12(0, NP - 1) OCRS_TERM12(1, 1) }
             OCRS_TERM12(1, 0) OCRS_TERM12(0, 1) OCRS_TERM12(0, 0)
 #undef OCRS_TERM12

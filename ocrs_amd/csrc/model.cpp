@@ -1039,7 +1039,7 @@ int HipModel::run_recognition_packed(Workspace& ws, const std::vector<PackedGrou
         // all conv stacks of a device go through ONE stream, in request order.  The lock is taken by the hook, i.e. after
         // the request's geometry has been worked out and its metadata uploads are queued.
         std::unique_lock<std::mutex> heavy(ctx().heavy_phase, std::defer_lock);
-        const hipStream_t conv = ws.stream.conv_stream();   // the device's conv-stack stream (MODE_PARTITION: confined to the split kernels' units)
+        const hipStream_t conv = ws.stream.conv_stream();   // the device's conv-stack stream
         try {
             X = run_prefix_ragged(ws, conv, groups, plan, h, ts, timers, &C0, [&] { heavy.lock(); });
         } catch (...) {
@@ -1112,21 +1112,6 @@ int HipModel::run_recognition_packed(Workspace& ws, const std::vector<PackedGrou
             const double gx_flops = 2.0 * 2 * R * (double)d.N * d.K, gx_bytes = 4.0 * ((double)R * I + 2.0 * R * d.N + 2.0 * d.K * d.N);
             // (round 3's option gx_heavy queued these projections on the conv-stack stream: every MFMA class then ran at its
             // alone speed at the same or slightly lower pages/s — a zero-sum trade, removed in round 5)
-            if (ws.stream.mode() == DeviceContext::MODE_PARTITION && np != 0 && d.Bsplit) {
-                // the projection is a bf16-split kernel too: it belongs on the compute units set aside for them, i.e. on the
-                // conv-stack stream, in request order like the conv stacks (events both ways, no host wait)
-                DeviceContext& dc = ctx();
-                std::lock_guard<std::mutex> g(dc.heavy_phase);
-                const hipStream_t cs = ws.stream.conv_stream();
-                hipEvent_t ready = ws.make_event(), done = ws.make_event();
-                OCRS_HIP(hipEventRecord(ready, st));
-                OCRS_HIP(hipStreamWaitEvent(cs, ready, 0));
-                int ktok = timers ? timers->kbegin(KC_GEMM_GRU_INPUT, cs, gx_flops, gx_bytes) : -1;
-                k::gemm(d, cs);
-                if (ktok >= 0) timers->end(ktok, cs);
-                OCRS_HIP(hipEventRecord(done, cs));
-                OCRS_HIP(hipStreamWaitEvent(st, done, 0));
-            } else
             timed(KC_GEMM_GRU_INPUT, gx_flops, gx_bytes, [&] { k::gemm(d, st); });
             bool ran_persistent = false;
             if (persistent) {

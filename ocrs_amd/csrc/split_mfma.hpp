@@ -71,25 +71,34 @@ __device__ __forceinline__ void commit4(char* base, int r, int kq, float x0, flo
 }
 
 // this wave's share (a quarter) of one chunk of the weight image -> ring buffer `bdst` (the chunk's base in LDS).
-// BUFFER-form LDS-DMA (buffer_load_dwordx4 ... lds), not global_load_lds: the FLAT-encoded form "accesses VMEM and LDS" in the
-// compiler's wait-count model, which then answers EVERY later vector-memory dependency of the wave — the activation registers
-// of a chunk loaded two chunks ago — with s_waitcnt vmcnt(0): the drain waits for the weight copies issued a moment ago and
-// the counted waits of split::pipeline never get to matter (round 5's kernels: tools/counted_waits.py showed every counted wait
-// behind such a drain).  The MUBUF form is an ordinary vector-memory instruction to that model: it counts.
-// `img`: buffer resource over the column block's weight image; `byte_off`: the chunk's offset in it.
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t weight_rsrc(const void* base, size_t bytes) {
-    const uint64_t a = reinterpret_cast<uint64_t>(base);   // wave-uniform by construction (blockIdx): say so, or every load gets a waterfall loop
-    const void* u = reinterpret_cast<const void*>(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) |
-                                                  (uint32_t)__builtin_amdgcn_readfirstlane((int)a));
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(u), /*stride*/ 0, __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
-}
+// (FLAT-encoded LDS-DMA.  The compiler's wait-count model files it as "accesses VMEM and LDS" and from then on answers every
+// vector-memory dependency of the wave — the activation registers a commit reads — with s_waitcnt vmcnt(0): in the code that
+// ships almost every counted wait of the pipeline below stands behind such a drain (tools/counted_waits.py lists them).  The
+// MUBUF form, buffer_load_dwordx4 ... lds, is an ordinary load to that model: round 6 built it, every wait then counted exactly
+// as written — and one line's log-probs in ~250 requests under load stopped being reproducible, which the drains had covered
+// and I did not get to the bottom of; not shipped.  DESIGN.md §6.5.)
 template <int NP>
-__device__ __forceinline__ void load_weights(__amdgpu_buffer_rsrc_t img, int byte_off, float* bdst, int wave, int lane) {
+__device__ __forceinline__ void load_weights(const float* img, float* bdst, int wave, int lane) {
 #pragma unroll
     for (int j = 0; j < NP; j++)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(img, (__attribute__((address_space(3))) void*)(bdst + 1024 * j + wave * 256), 16,
-                                                 byte_off + (1024 * j + wave * 256 + lane * 4) * 4, 0, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(img + 1024 * j + wave * 256 + lane * 4),
+                                         (__attribute__((address_space(3))) void*)(bdst + 1024 * j + wave * 256), 16, 0, 0);
 }
+
+// C += A . B on the bf16 matrix cores (one 32 x 32 x 16 step); the probe forms exist for tools/hazard_repro.hip and the variant
+// library of tools/r6_session.sh only
+#if defined(OCRS_PROBE_ACC_AGPR)      // probe builds only (tools/build_hazard_repro.sh): the accumulators in the AGPR half of the register file
+#define OCRS_SPLIT_MMA(A, B, C) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(C) : "v"(A), "v"(B))
+#elif defined(OCRS_PROBE_MFMA16)      // probe builds only: the same registers driven through v_mfma_f32_16x16x32_bf16 (NOT the same arithmetic)
+#define OCRS_SPLIT_MMA(A, B, C)                                                                                       \
+    _Pragma("unroll") for (int q_ = 0; q_ < 4; q_++) {                                                          \
+        f32x4s c4_ = {C[4 * q_], C[4 * q_ + 1], C[4 * q_ + 2], C[4 * q_ + 3]};                                  \
+        c4_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, B, c4_, 0, 0, 0);                                      \
+        C[4 * q_] = c4_[0]; C[4 * q_ + 1] = c4_[1]; C[4 * q_ + 2] = c4_[2]; C[4 * q_ + 3] = c4_[3];             \
+    }
+#else
+#define OCRS_SPLIT_MMA(A, B, C) C = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, C, 0, 0, 0)
+#endif
 
 // one chunk: the wave's 64 x 64 tile (rows wm * 64 .., columns wn * 64 ..) += A(abase) . B(bbase)
 template <int NP>
@@ -108,27 +117,14 @@ __device__ __forceinline__ void mma_chunk(const char* abase, const char* bbase, 
         for (int pl = 0; pl < NP; pl++) bfr[t][pl] = *reinterpret_cast<const bf16x8s*>(bbase + pl * PLANE * 4 + off);
     }
     // smallest terms first; consecutive MFMAs go to different accumulators (no back-to-back dependency)
-#if defined(OCRS_PROBE_ACC_AGPR)      // probe builds only (tools/build_hazard_repro.sh): the accumulators in the AGPR half of the register file
-#define OCRS_MMA(A, B, C) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(C) : "v"(A), "v"(B))
-#elif defined(OCRS_PROBE_MFMA16)      // probe builds only: the same registers driven through v_mfma_f32_16x16x32_bf16 (NOT the same arithmetic)
-#define OCRS_MMA(A, B, C)                                                                                       \
-    _Pragma("unroll") for (int q_ = 0; q_ < 4; q_++) {                                                          \
-        f32x4s c4_ = {C[4 * q_], C[4 * q_ + 1], C[4 * q_ + 2], C[4 * q_ + 3]};                                  \
-        c4_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, B, c4_, 0, 0, 0);                                      \
-        C[4 * q_] = c4_[0]; C[4 * q_ + 1] = c4_[1]; C[4 * q_ + 2] = c4_[2]; C[4 * q_ + 3] = c4_[3];             \
-    }
-#else
-#define OCRS_MMA(A, B, C) C = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, C, 0, 0, 0)
-#endif
 #define OCRS_TERM(PA, PB)                                                                                       \
     _Pragma("unroll") for (int t = 0; t < 2; t++) {                                                             \
-        OCRS_MMA(af[0][PA], bfr[t][PB], acc[0][t]);                                                             \
-        OCRS_MMA(af[1][PA], bfr[t][PB], acc[1][t]);                                                             \
+        OCRS_SPLIT_MMA(af[0][PA], bfr[t][PB], acc[0][t]);                                                             \
+        OCRS_SPLIT_MMA(af[1][PA], bfr[t][PB], acc[1][t]);                                                             \
     }
     if (NP == 3) { OCRS_TERM(NP - 1, 0) OCRS_TERM(0, NP - 1) OCRS_TERM(1, 1) }
     OCRS_TERM(1, 0) OCRS_TERM(0, 1) OCRS_TERM(0, 0)
 #undef OCRS_TERM
-#undef OCRS_MMA
 }
 
 // The K loop.  nchunks % 4 == 0.  load_a(k0, d0, d1): the thread's activation values of chunks k0 and k0 + 16 (two float4 row

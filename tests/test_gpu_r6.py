@@ -1,4 +1,4 @@
-"""Round 6 GPU tests: the standing concurrency canary, the isolation regimes of the bf16-split kernels and their safe switch.
+"""Round 6 GPU tests: the standing concurrency canary, the isolation regime of the bf16-MFMA kernels and its safe switch.
 
 The canary (tools/hazard_canary.py) calls every stage of the pipeline through the C ABI from six threads and compares EVERY
 element of every stage's output — grey page, probability map, word rects, every line crop, every log-probability, every CTC
@@ -50,45 +50,6 @@ def test_relaxed_modes_canary_under_the_default_isolation(mode):
     assert rep["isolation"]["mode"] == "serial" and rep["isolation"]["relaxed_engines"] == 1
     _assert_clean(rep, {"crop": 100, "logits": 5})
     assert _lib.isolation()["mode"] == "free" and _lib.isolation()["relaxed_engines"] == 0   # the engine is gone, so is the regime
-
-
-def test_cu_partition_runs_the_pipeline_with_golden_bits_of_the_serial_regime():
-    """OCRS_ISOLATION_CU_PARTITION: split kernels on a stream confined to 128 compute units, everything else (the persistent
-    recurrence included: its grid is planned for the 128 units of its side) on the complementary ones.  Same bits as the
-    one-stream regime, sequentially and from four threads."""
-    _lib.require_gpu()
-    det, rec = Model.load_bytes(M.detection_model_bytes()), Model.load_bytes(M.recognition_model_bytes())
-    px = [synth.synthetic_page(40 + s, 700 + 90 * s, 900 + 60 * s, lines=20 + 7 * s, columns=1) for s in range(4)]
-    try:
-        eng = OcrEngine(detection_model=det, recognition_model=rec, numerics="relaxed")
-        assert _lib.isolation()["mode"] == "serial"
-        want = []
-        for p in px:
-            inp = eng.prepare_input(ImageSource.from_tensor(p, DimOrder.Hwc))
-            words = eng.detect_words(inp)
-            lines = eng.find_text_lines(inp, words)
-            want.append((inp, words, lines, eng.recognize_logits(inp, lines)))
-        _lib.set_isolation("partition", 128)
-        info = _lib.isolation()
-        assert info["mode"] == "partition" and info["split_cus"] == 128 and info["cus"] >= 136
-        bad = []
-
-        def worker(k):
-            for it in range(6):
-                inp, words, lines, logp = want[(it + k) % len(want)]
-                got = eng.recognize_logits(inp, lines)
-                if not all(np.array_equal(a, b) for a, b in zip(got, logp)) or eng.detect_words(inp).tobytes() != words.tobytes():
-                    bad.append((k, it))
-
-        worker(0)
-        ths = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
-        [t.start() for t in ths]
-        [t.join() for t in ths]
-        assert not bad, bad
-        del want, eng
-    finally:
-        _lib.set_isolation("auto", 0)
-    assert _lib.isolation()["mode"] == "free"
 
 
 def test_creating_and_destroying_a_relaxed_engine_under_load_drains_instead_of_mixing_regimes():
@@ -188,3 +149,51 @@ def test_detection_batch_of_mixed_page_sizes_equals_the_single_page_results_and_
     assert not bad, bad[:5]
     merged = eng.coalesce_stats()["detect"]
     assert merged[1] >= merged[0] >= 1
+
+
+def test_group_replay_returns_the_recorded_results_without_touching_the_gpu():
+    """ocrs_group_set_replay (the host-side pre-flight hook of bench.py --replay): a four-member group on device 0 records the
+    results of eight pages, then replays them — every call returns the recorded bytes in page order whatever the dealing, takes
+    about the configured share times, and launches nothing (the engine's stage timers stay at zero)."""
+    import time
+    from ocrs_amd import EngineGroup
+    _lib.require_gpu()
+    dbuf, rbuf = M.detection_model_bytes((160, 128), (8, 16, 32, 32)), M.recognition_model_bytes()
+    group = EngineGroup([0, 0, 0, 0], dbuf, rbuf, shared_block=2)
+    pages = [synth.synthetic_page(80 + s, 192, 256, lines=6, columns=1) for s in range(8)]
+
+    def pipeline(pp):
+        inputs = group.prepare_input_batch(pp)
+        words = group.detect_words_batch(inputs)
+        rects, loffs, poffs = group.find_text_lines_batch_raw(words)
+        chars, coffs = group.recognize_text_batch_raw(inputs, rects, loffs, poffs)
+        return words, rects, loffs, poffs, chars, coffs
+
+    group.set_replay(1)
+    want = pipeline(pages)
+    assert sum(len(w) for w in want[0]) > 20 and len(want[4]) > 20
+    group.set_replay(2, (0.01, 0.03, 0.05))
+    eng0 = group.member(0)[0]
+    eng0.enable_timing(1)
+    eng0.stage_times(reset=True)
+    before = [group.member_stats(m)["shares"] for m in range(4)]
+    t0 = time.perf_counter()
+    got = pipeline(pages)
+    dt = time.perf_counter() - t0
+    assert all(np.array_equal(a, b) for a, b in zip(got[0], want[0]))
+    for a, b in zip(got[1:], want[1:]):
+        assert np.array_equal(a, b)
+    assert 0.09 <= dt < 0.5, dt                                   # the three shares' sleeps, the members side by side
+    assert all(v[0] == 0 for v in eng0.stage_times(reset=False).values())   # no launch went through member 0's timers
+    eng0.enable_timing(0)
+    assert [group.member_stats(m)["shares"] - before[m] for m in range(4)] == [3, 3, 3, 3]
+    # another order and a subset: results follow the PAGES, not the positions
+    sub = [pages[5], pages[0], pages[6]]
+    g2 = pipeline(sub)
+    for k, j in enumerate((5, 0, 6)):
+        assert np.array_equal(g2[0][k], want[0][j])
+    # a page the group never recorded is refused, not invented
+    with pytest.raises(_lib.OcrsError):
+        pipeline([synth.synthetic_page(99, 192, 256, lines=6, columns=1)])
+    group.set_replay(0)
+    assert all(np.array_equal(a, b) for a, b in zip(pipeline(pages)[0], want[0]))

@@ -17,7 +17,6 @@ the device to itself ("twin" of a known-good run):
 
     python tools/hazard_canary.py --numerics exact --seconds 20              # the claim "exact mode is immune", as a measurement
     python tools/hazard_canary.py --numerics relaxed --isolation none        # reproduces the hazard (crop mismatches within seconds)
-    python tools/hazard_canary.py --numerics relaxed --isolation partition --split-cus 128
     python tools/hazard_canary.py --numerics relaxed --isolation auto        # what the library does by default: one stream
 
 Prints one JSON line: per class the number of checks, mismatching checks and mismatching elements; for crops the histogram of
@@ -51,7 +50,7 @@ def make_pages(np, synth, n_pages, big):
     return pages
 
 
-def run(numerics="exact", isolation="auto", split_cus=0, seconds=20.0, threads=6, n_pages=9, big=True, classes=CLASSES,
+def run(numerics="exact", isolation="auto", seconds=20.0, threads=6, n_pages=9, big=True, classes=CLASSES,
         engine_options=None, log=None):
     """Returns the report dict.  The engine is created here and destroyed before returning; the device's isolation policy is
     put back to "auto"."""
@@ -61,7 +60,7 @@ def run(numerics="exact", isolation="auto", split_cus=0, seconds=20.0, threads=6
     from ocrs_amd import DimOrder, ImageSource, Model, OcrEngine, _lib, synth
 
     _lib.require_gpu()
-    _lib.set_isolation(isolation, split_cus)
+    _lib.set_isolation(isolation)
     det, rec = Model.load_bytes(M.detection_model_bytes()), Model.load_bytes(M.recognition_model_bytes())
     eng = OcrEngine(detection_model=det, recognition_model=rec, numerics=numerics, options=engine_options or {})
     iso = _lib.isolation()
@@ -168,7 +167,7 @@ def run(numerics="exact", isolation="auto", split_cus=0, seconds=20.0, threads=6
               "crop_mismatch_columns_mod_64": crop_cols if any(crop_cols) else None, "examples": examples, "errors": errors,
               "sequential_pass_after_differs_on_pages": after}
     del ref, eng
-    _lib.set_isolation("auto", 0)
+    _lib.set_isolation("auto")
     if log:
         log(report)
     return report
@@ -177,8 +176,7 @@ def run(numerics="exact", isolation="auto", split_cus=0, seconds=20.0, threads=6
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--numerics", choices=("exact", "relaxed", "reduced"), default="exact")
-    ap.add_argument("--isolation", choices=("auto", "none", "partition"), default="auto")
-    ap.add_argument("--split-cus", type=int, default=128)
+    ap.add_argument("--isolation", choices=("auto", "none"), default="auto")
     ap.add_argument("--seconds", type=float, default=20.0)
     ap.add_argument("--threads", type=int, default=6)
     ap.add_argument("--pages", type=int, default=9)
@@ -187,7 +185,6 @@ if __name__ == "__main__":
     a = ap.parse_args()
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     opts = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in a.option}
-    rep = run(a.numerics, a.isolation, a.split_cus if a.isolation == "partition" else 0, a.seconds, a.threads, a.pages,
-              classes=tuple(a.classes.split(",")), engine_options=opts)
+    rep = run(a.numerics, a.isolation, a.seconds, a.threads, a.pages, classes=tuple(a.classes.split(",")), engine_options=opts)
     print(json.dumps(rep))
     sys.exit(1 if rep["errors"] else 0)

@@ -50,15 +50,15 @@ benchq)
   timeout 600 python bench.py --no-extras --no-cpu-baseline > $OUT/bench_quick.json 2> $OUT/bench_quick.err; say "rc=$?"; bsum $OUT/bench_quick.json "quick";;
 canary)
   say "== hazard canary (tools/hazard_canary.py): every stage, every element, six threads"
-  for cfg in "relaxed none 0 15" "reduced none 0 15" "relaxed partition 128 15" "reduced partition 128 15" "relaxed partition 192 15" "exact none 0 10"; do
+  for cfg in "relaxed none 12" "reduced none 12" "relaxed auto 8" "exact none 10"; do
     set -- $cfg
-    timeout 150 python tools/hazard_canary.py --numerics $1 --isolation $2 --split-cus $3 --seconds $4 > $OUT/canary_$1_$2_$3.json 2> $OUT/canary_$1_$2_$3.err; rc=$?
-    python - $OUT/canary_$1_$2_$3.json "$cfg rc=$rc" <<'PY' | tee -a $S
+    timeout 150 python tools/hazard_canary.py --numerics $1 --isolation $2 --seconds $3 > $OUT/canary_$1_$2.json 2> $OUT/canary_$1_$2.err; rc=$?
+    python - $OUT/canary_$1_$2.json "$cfg rc=$rc" <<'PY' | tee -a $S
 import json, sys
 try:
     d = json.loads([l for l in open(sys.argv[1]).read().splitlines() if l.startswith("{")][-1])
     print(sys.argv[2], d["isolation"], "| mismatching checks", d["mismatching_checks"], {k: (v["checks"], v["bad_checks"], v["bad_elements"]) for k, v in d["classes"].items()},
-          "| crop cols mod 64:", d["crop_mismatch_columns_mod_64"], "| errors", d["errors"][:2])
+          "| crop cols mod 64 nonzero:", [i for i, c in enumerate(d["crop_mismatch_columns_mod_64"] or []) if c], "| errors", d["errors"][:2])
 except Exception as e:
     print(sys.argv[2], "parse failed", e)
 PY
@@ -74,8 +74,9 @@ repro)
   timeout 120 tools/_build/hazard_repro.prio3 --aggressor split3 --seconds 12 --victim-streams 4 2>> $OUT/repro.err | tee -a $S;;
 replay)
   say "== host-side pre-flight: 8 members on device 0, GPU shares replayed"
-  timeout 600 python bench.py --devices 0,0,0,0,0,0,0,0 --replay --steps 40 --warmup 10 --no-extras --no-cpu-baseline > $OUT/bench_replay8.json 2> $OUT/bench_replay8.err; say "rc=$?"
-  python - $OUT/bench_replay8.json <<'PY' | tee -a $S
+  for inf in 5 8; do
+  timeout 600 python bench.py --devices 0,0,0,0,0,0,0,0 --replay --steps 40 --warmup 10 --inflight $inf --no-extras --no-cpu-baseline > $OUT/bench_replay8_inflight$inf.json 2> $OUT/bench_replay8.err; say "inflight $inf rc=$?"
+  python - $OUT/bench_replay8_inflight$inf.json <<'PY' | tee -a $S
 import json, sys
 try:
     d = json.loads([l for l in open(sys.argv[1]).read().splitlines() if l.startswith("{")][-1])
@@ -86,7 +87,13 @@ try:
 except Exception as e:
     print("parse failed:", e)
 PY
+  done
   tail -5 $OUT/bench_replay8.err | tee -a $S;;
+repro3)
+  say "== reproducer: exact-mode aggressor, long run, four victim streams (the claim that exact mode is immune, stand-alone)"
+  timeout 200 tools/_build/hazard_repro --aggressor exact --seconds 60 --victim-streams 4 2>> $OUT/repro.err | tee -a $S
+  timeout 100 tools/_build/hazard_repro.ACC_AGPR --aggressor split2 --seconds 10 --victim-streams 4 2>> $OUT/repro.err | tee -a $S
+  timeout 100 tools/_build/hazard_repro.ACC_AGPR --aggressor split3 --seconds 10 --victim-streams 4 --analyse 40 2> $OUT/repro_agpr_analyse.txt | tee -a $S; head -12 $OUT/repro_agpr_analyse.txt | tee -a $S;;
 soak)
   say "== varied-size one-page soak, six threads (mixed sizes now share detection batches)"
   timeout 300 python tools/soak_varied.py 20 6 > $OUT/soak_varied_exact.txt 2>&1; say "rc=$?"; tail -6 $OUT/soak_varied_exact.txt | tee -a $S;;
@@ -98,17 +105,15 @@ repro2)
   say "-- the same registers through v_mfma_f32_16x16x32_bf16"; timeout 120 tools/_build/hazard_repro.MFMA16 --aggressor split3 --seconds 8 --victim-streams 2 2>> $OUT/repro.err | tee -a $S
   say "-- split-cus 64 / 192 / 224"
   for c in 64 192 224; do timeout 120 tools/_build/hazard_repro --aggressor split3 --seconds 6 --victim-streams 2 --split-cus $c 2>> $OUT/repro.err | tee -a $S; done;;
-canary2)
-  say "== canary, partition 192: which class differs, with which recurrence"
-  for cfg in "relaxed partition 192 12 logits,tokens" "relaxed partition 192 12 logits,tokens gru_mode=1" "relaxed partition 160 12 crop,logits,tokens" "relaxed none 0 8 crop,logits"; do
-    set -- $cfg
-    opt=""; [ -n "${6:-}" ] && opt="--option $6"
-    timeout 150 python tools/hazard_canary.py --numerics $1 --isolation $2 --split-cus $3 --seconds $4 --classes $5 $opt > $OUT/canary2_$1_$2_$3_${6:-x}.json 2> $OUT/canary2_$1_$2_$3_${6:-x}.err; rc=$?
-    python - $OUT/canary2_$1_$2_$3_${6:-x}.json "$cfg rc=$rc" <<'PY' | tee -a $S
+canary_agpr)
+  say "== the product's split kernels with their accumulators in AGPRs (variant library), isolation NONE: what is left of the hazard"
+  for n in relaxed reduced; do
+    OCRS_AMD_LIB=$PWD/ocrs_amd/libocrs_amd.agpr.so timeout 150 python tools/hazard_canary.py --numerics $n --isolation none --seconds 12 > $OUT/canary_agpr_$n.json 2> $OUT/canary_agpr_$n.err; rc=$?
+    python - $OUT/canary_agpr_$n.json "agpr $n none rc=$rc" <<'PY' | tee -a $S
 import json, sys
 try:
     d = json.loads([l for l in open(sys.argv[1]).read().splitlines() if l.startswith("{")][-1])
-    print(sys.argv[2], d["isolation"], "| mismatching checks", d["mismatching_checks"], {k: (v["checks"], v["bad_checks"], v["bad_elements"]) for k, v in d["classes"].items()}, "| examples", d["examples"][:4], "| errors", d["errors"][:2])
+    print(sys.argv[2], "| mismatching checks", d["mismatching_checks"], {k: (v["checks"], v["bad_checks"], v["bad_elements"]) for k, v in d["classes"].items()})
 except Exception as e:
     print(sys.argv[2], "parse failed", e)
 PY
