@@ -34,7 +34,7 @@ tests)
   say "== full GPU suite"; timeout 1500 python -m pytest tests -m gpu -x -q > $OUT/test_gpu_all.log 2>&1; say "rc=$?"; tail -6 $OUT/test_gpu_all.log | tee -a $S;;
 tests_r6)
   say "== round-6 GPU tests, one by one (a hang costs one time-out, not the session)"
-  for t in test_detection_batch_of_mixed_page_sizes test_cu_partition test_creating_and_destroying test_relaxed_modes_canary test_exact_mode_canary; do
+  for t in test_detection_batch_of_mixed_page_sizes test_group_replay test_creating_and_destroying test_relaxed_modes_canary test_exact_mode_canary; do
     timeout 240 python -m pytest tests/test_gpu_r6.py -x -q -k $t > $OUT/test_r6_$t.log 2>&1; say "$t rc=$?"; tail -3 $OUT/test_r6_$t.log | tee -a $S
   done;;
 tests_old)
