@@ -133,8 +133,14 @@ def run(numerics="exact", isolation="auto", seconds=20.0, threads=6, n_pages=9, 
                     break
         elif cls == "logits":
             got = eng.recognize_logits(r["inp"], r["lines"])
-            n = sum(diff(a, b)[0] for a, b in zip(got, r["logits"])) + abs(len(got) - len(r["logits"]))
-            note(cls, sum(a.size for a in got), n, {"class": cls, "page": j, "bad": n})
+            per_line = [diff(a, b)[0] for a, b in zip(got, r["logits"])]
+            n = sum(per_line) + abs(len(got) - len(r["logits"]))
+            detail = {"class": cls, "page": j, "bad": n}
+            if n:   # which lines, how much of each, how far off: a different arithmetic path, or garbage
+                detail["lines"] = [(li, c, int(got[li].size), float(np.nanmax(np.abs(got[li] - r["logits"][li]))))
+                                   for li, c in enumerate(per_line) if c][:8]
+                detail["n_lines"] = len(per_line)
+            note(cls, sum(a.size for a in got), n, detail)
         elif cls == "tokens":
             got = eng.recognize_tokens(r["inp"], r["lines"])
             n = sum(1 for a, b in zip(got, r["tokens"]) if a != b)

@@ -124,6 +124,20 @@ benchab)
     timeout 300 python bench.py --steps 20 --warmup 5 --no-extras --no-cpu-baseline > $OUT/bench_ab_timed$i.json 2> $OUT/bench_ab_timed$i.err; bsum $OUT/bench_ab_timed$i.json "events on  $i"
     timeout 300 python bench.py --steps 20 --warmup 5 --no-extras --no-cpu-baseline --no-kernel-timing > $OUT/bench_ab_plain$i.json 2> $OUT/bench_ab_plain$i.err; bsum $OUT/bench_ab_plain$i.json "events off $i"
   done;;
+logits)
+  say "== relaxed engine, serial regime, log-probs only: what differs from the quiet run under load, and with which kernels"
+  for opt in "" "gru_mode=1" "conv12_fuse=0" "gru_gates=0" "conv_flat=0"; do
+    o=""; [ -n "$opt" ] && o="--option $opt"
+    timeout 150 python tools/hazard_canary.py --numerics relaxed --isolation auto --seconds 25 --classes logits $o > $OUT/logits_${opt:-default}.json 2> $OUT/logits_${opt:-default}.err; rc=$?
+    python - $OUT/logits_${opt:-default}.json "relaxed auto logits ${opt:-default} rc=$rc" <<'PY' | tee -a $S
+import json, sys
+try:
+    d = json.loads([l for l in open(sys.argv[1]).read().splitlines() if l.startswith("{")][-1])
+    print(sys.argv[2], {k: (v["checks"], v["bad_checks"], v["bad_elements"]) for k, v in d["classes"].items()}, "| lines per page", d["lines"], "| examples", json.dumps(d["examples"][:4]))
+except Exception as e:
+    print(sys.argv[2], "parse failed", e)
+PY
+  done;;
 *) say "unknown section $sec";;
 esac
 done
