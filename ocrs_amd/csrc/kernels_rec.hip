@@ -900,8 +900,12 @@ conv12_fused_split_kernel(const float* __restrict__ X0, RaggedView in0, RaggedVi
     }
     const int nb = wn * 32 + l31;
     const int boff = nb * 64, bsw = (nb >> 2) & 3;
+    // (asm "memory" clobbers around every bare barrier: the builtin is no fence to the compiler, which otherwise hoists the next
+    // tap's first operand reads above the wait + barrier that guarantee the tap's weights have landed — r6, split_mfma.hpp)
+    asm volatile("" ::: "memory");
     __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) lgkmcnt(0): taps 0 and 1 landed, this thread's tile writes done
     __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
 #pragma unroll
     for (int tap = 0; tap < 9; tap++) {
         if (tap + 2 < 9) load_b(tap + 2);
@@ -927,9 +931,15 @@ conv12_fused_split_kernel(const float* __restrict__ X0, RaggedView in0, RaggedVi
         }
         // the next tap's weights must have landed (the tap after it, just requested, may stay in flight); every wave is
         // done with this tap's buffer before it is overwritten two taps from now
-        if (tap + 2 < 9) __builtin_amdgcn_s_waitcnt(0x0F70 | NP);   // vmcnt(NP)
-        else __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0)
+        // ... and lgkmcnt(0): this wave's own operand reads of the tap's buffer have RETURNED before it crosses the barrier.  Until
+        // round 6 the wait was vmcnt only; the compiler sinks the tap's last MFMAs below the barrier, so their ds_reads could
+        // still be queued in the LDS unit when another wave's copy of tap + 2 (L2-hot weights: 250-400 cycles to land) overwrote
+        // the buffer: one tile element wrong in ~1 000 requests under load, found by the canary.
+        asm volatile("" ::: "memory");
+        if (tap + 2 < 9) __builtin_amdgcn_s_waitcnt(0x0070 | NP);   // vmcnt(NP) lgkmcnt(0)
+        else __builtin_amdgcn_s_waitcnt(0x0070);                    // vmcnt(0) lgkmcnt(0)
         __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
     }
 
     // ---- epilogue: as conv12_fused_kernel

@@ -79,10 +79,21 @@ __device__ __forceinline__ void commit4(char* base, int r, int kq, float x0, flo
 // and I did not get to the bottom of; not shipped.  DESIGN.md §6.5.)
 template <int NP>
 __device__ __forceinline__ void load_weights(const float* img, float* bdst, int wave, int lane) {
+#if defined(OCRS_PROBE_MUBUF_DMA)   // probe build (variant library): the MUBUF form, see the comment above
+    const uint64_t a = reinterpret_cast<uint64_t>(img);   // wave-uniform
+    const void* u = reinterpret_cast<const void*>(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) |
+                                                  (uint32_t)__builtin_amdgcn_readfirstlane((int)a));
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(u), 0, NP * 4096, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < NP; j++)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(bdst + 1024 * j + wave * 256), 16,
+                                                 (1024 * j + wave * 256 + lane * 4) * 4, 0, 0, 0);
+#else
 #pragma unroll
     for (int j = 0; j < NP; j++)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(img + 1024 * j + wave * 256 + lane * 4),
                                          (__attribute__((address_space(3))) void*)(bdst + 1024 * j + wave * 256), 16, 0, 0);
+#endif
 }
 
 // C += A . B on the bf16 matrix cores (one 32 x 32 x 16 step); the probe forms exist for tools/hazard_repro.hip and the variant
@@ -139,13 +150,23 @@ template <int NP, class LoadA, class LoadB, class Commit, class Compute>
 __device__ __forceinline__ void pipeline(int nchunks, LoadA&& load_a, LoadB&& load_b, Commit&& commit, Compute&& compute) {
     f32x4s sa[2][2][2];                     // [set = pair parity][chunk of the pair][row pass]
     // s_waitcnt immediates (gfx9 encoding: vmcnt = bits 3:0 and 15:14, expcnt = bits 6:4, lgkmcnt = bits 11:8)
+    // The bare s_barrier builtin is no memory fence to the compiler (IntrNoMem): without the two empty asm statements with a
+    // "memory" clobber it hoists the NEXT chunk's first operand reads (ds_read of the weight ring) above the wait and the
+    // barrier that guarantee the copy has landed — found in round 6 in conv12_fused_split_kernel's tap loop, which had the
+    // same construction: one line's log-probs in ~1 000 requests differed from run to run.
 #define OCRS_END_HALF(VMCNT_IMM)                                                                                  \
     do {                                                                                                          \
+        asm volatile("" ::: "memory");                                                                            \
         __builtin_amdgcn_s_waitcnt(VMCNT_IMM); __builtin_amdgcn_s_waitcnt(0xC07F); /* lgkmcnt(0) */              \
         __builtin_amdgcn_s_barrier();                                                                             \
+        asm volatile("" ::: "memory");                                                                            \
     } while (0)
 #define OCRS_DRAIN()                                                                                              \
-    do { __builtin_amdgcn_s_waitcnt(0x0070); /* vmcnt(0) lgkmcnt(0) */ __builtin_amdgcn_s_barrier(); } while (0)
+    do {                                                                                                          \
+        asm volatile("" ::: "memory");                                                                            \
+        __builtin_amdgcn_s_waitcnt(0x0070); /* vmcnt(0) lgkmcnt(0) */ __builtin_amdgcn_s_barrier();               \
+        asm volatile("" ::: "memory");                                                                            \
+    } while (0)
     // B(c+1) landed — younger: B(c+2) NP, A(p+1) 4, B(c+3) NP;  B(c+2) landed — younger: A(p+1) 4, B(c+3) NP, B(c+4) NP, A(p+2) 4
     constexpr int kWaitB1 = 0x0F70 | (NP == 3 ? 10 : 8);    // vmcnt(10) / vmcnt(8)
     constexpr int kWaitB2 = 0x0F70 | (NP == 3 ? 14 : 12);   // vmcnt(14) / vmcnt(12)

@@ -126,9 +126,9 @@ benchab)
   done;;
 logits)
   say "== relaxed engine, serial regime, log-probs only: what differs from the quiet run under load, and with which kernels"
-  for opt in "" "gru_mode=1" "conv12_fuse=0" "gru_gates=0" "conv_flat=0"; do
+  for opt in ${LOGITS_OPTS:-"" "gru_mode=1" "conv12_fuse=0" "gru_gates=0" "conv_flat=0"}; do
     o=""; [ -n "$opt" ] && o="--option $opt"
-    timeout 150 python tools/hazard_canary.py --numerics relaxed --isolation auto --seconds 25 --classes logits $o > $OUT/logits_${opt:-default}.json 2> $OUT/logits_${opt:-default}.err; rc=$?
+    timeout 200 python tools/hazard_canary.py --numerics ${LOGITS_MODE:-relaxed} --isolation auto --seconds ${LOGITS_SECONDS:-25} --classes logits $o > $OUT/logits_${opt:-default}.json 2> $OUT/logits_${opt:-default}.err; rc=$?
     python - $OUT/logits_${opt:-default}.json "relaxed auto logits ${opt:-default} rc=$rc" <<'PY' | tee -a $S
 import json, sys
 try:
@@ -138,6 +138,21 @@ except Exception as e:
     print(sys.argv[2], "parse failed", e)
 PY
   done;;
+mubuf)
+  say "== split::pipeline with MUBUF-form LDS-DMA (variant library): log-prob canary, then relaxed / reduced throughput ABAB against the stock library"
+  OCRS_AMD_LIB=$PWD/ocrs_amd/libocrs_amd.mubuf.so timeout 200 python tools/hazard_canary.py --numerics relaxed --isolation auto --seconds 30 --classes logits,crop > $OUT/mubuf_canary.json 2> $OUT/mubuf_canary.err
+  python - $OUT/mubuf_canary.json <<'PY' | tee -a $S
+import json, sys
+try:
+    d = json.loads([l for l in open(sys.argv[1]).read().splitlines() if l.startswith("{")][-1])
+    print("mubuf canary relaxed auto", {k: (v["checks"], v["bad_checks"], v["bad_elements"]) for k, v in d["classes"].items()})
+except Exception as e:
+    print("parse failed", e)
+PY
+  for n in relaxed reduced; do for rep in 1 2; do
+    timeout 300 python bench.py --numerics $n --steps 36 --warmup 12 --no-extras --no-cpu-baseline > $OUT/bench_${n}_stock$rep.json 2> $OUT/bench_${n}_stock$rep.err; bsum $OUT/bench_${n}_stock$rep.json "$n stock $rep"
+    OCRS_AMD_LIB=$PWD/ocrs_amd/libocrs_amd.mubuf.so timeout 300 python bench.py --numerics $n --steps 36 --warmup 12 --no-extras --no-cpu-baseline > $OUT/bench_${n}_mubuf$rep.json 2> $OUT/bench_${n}_mubuf$rep.err; bsum $OUT/bench_${n}_mubuf$rep.json "$n mubuf $rep"
+  done; done;;
 *) say "unknown section $sec";;
 esac
 done
