@@ -71,29 +71,22 @@ __device__ __forceinline__ void commit4(char* base, int r, int kq, float x0, flo
 }
 
 // this wave's share (a quarter) of one chunk of the weight image -> ring buffer `bdst` (the chunk's base in LDS).
-// (FLAT-encoded LDS-DMA.  The compiler's wait-count model files it as "accesses VMEM and LDS" and from then on answers every
-// vector-memory dependency of the wave — the activation registers a commit reads — with s_waitcnt vmcnt(0): in the code that
-// ships almost every counted wait of the pipeline below stands behind such a drain (tools/counted_waits.py lists them).  The
-// MUBUF form, buffer_load_dwordx4 ... lds, is an ordinary load to that model: round 6 built it, every wait then counted exactly
-// as written — and one line's log-probs in ~250 requests under load stopped being reproducible, which the drains had covered
-// and I did not get to the bottom of; not shipped.  DESIGN.md §6.5.)
+// MUBUF-form LDS-DMA (buffer_load_dwordx4 ... lds), NOT global_load_lds: the FLAT-encoded form "accesses VMEM and LDS" in the
+// compiler's wait-count model ("pending flat"), which then answers EVERY later vector-memory dependency of the wave — the
+// activation registers a commit reads — with s_waitcnt vmcnt(0): the drain also waits for the weight copy issued a moment
+// earlier and the counted waits of split::pipeline never get to matter (round 5's build: tools/counted_waits.py found 105 of its
+// 118 counted waits behind such a drain).  The MUBUF form is an ordinary load to that model: every wait counts as written
+// (relaxed 334-337 -> 344, reduced 474 -> 482-493 pages/s, ABAB on one box).
 template <int NP>
 __device__ __forceinline__ void load_weights(const float* img, float* bdst, int wave, int lane) {
-#if defined(OCRS_PROBE_MUBUF_DMA)   // probe build (variant library): the MUBUF form, see the comment above
-    const uint64_t a = reinterpret_cast<uint64_t>(img);   // wave-uniform
+    const uint64_t a = reinterpret_cast<uint64_t>(img);   // wave-uniform by construction (blockIdx, chunk): say so, or every load gets a waterfall loop
     const void* u = reinterpret_cast<const void*>(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) |
                                                   (uint32_t)__builtin_amdgcn_readfirstlane((int)a));
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(u), 0, NP * 4096, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(u), /*stride*/ 0, NP * 4096, 0x00020000);
 #pragma unroll
     for (int j = 0; j < NP; j++)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(bdst + 1024 * j + wave * 256), 16,
                                                  (1024 * j + wave * 256 + lane * 4) * 4, 0, 0, 0);
-#else
-#pragma unroll
-    for (int j = 0; j < NP; j++)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(img + 1024 * j + wave * 256 + lane * 4),
-                                         (__attribute__((address_space(3))) void*)(bdst + 1024 * j + wave * 256), 16, 0, 0);
-#endif
 }
 
 // C += A . B on the bf16 matrix cores (one 32 x 32 x 16 step); the probe forms exist for tools/hazard_repro.hip and the variant

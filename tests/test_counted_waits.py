@@ -48,8 +48,10 @@ def test_every_split_kernel_still_has_its_counted_waits(rows_errors):
         np_ = per_kernel[k][0][1]
         assert len(per_kernel[k]) == 4, (k, per_kernel[k])
         assert all(n <= 2 * np_ + 8 and (s is None or s >= 0) for n, _, s in per_kernel[k]), (k, per_kernel[k])
-        # (slack None = the copy lies behind a full drain the COMPILER put there: with the FLAT-encoded LDS-DMA it answers every
-        # register dependency of the wave with vmcnt(0), so most of these waits never get to matter — DESIGN.md 6.5)
+        # and the pipeline really is counted: with the MUBUF-form LDS-DMA the compiler no longer stands a vmcnt(0) in front of
+        # the waits (round 5's FLAT-form build: 105 of 118 behind such a drain) — at least two of the four
+        # guards are exactly as the source counts them, none behind a drain
+        assert sum(1 for n, _, s in per_kernel[k] if s == 0) >= 2 and all(s is not None for _, _, s in per_kernel[k]), (k, per_kernel[k])
     for k in c12:              # seven taps end with (at most) vmcnt(NP), the last two drain
         np_ = per_kernel[k][0][1]
         assert len(per_kernel[k]) == 7 and all(n <= np_ for n, _, _ in per_kernel[k]), (k, per_kernel[k])

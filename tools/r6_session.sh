@@ -153,6 +153,21 @@ PY
     timeout 300 python bench.py --numerics $n --steps 36 --warmup 12 --no-extras --no-cpu-baseline > $OUT/bench_${n}_stock$rep.json 2> $OUT/bench_${n}_stock$rep.err; bsum $OUT/bench_${n}_stock$rep.json "$n stock $rep"
     OCRS_AMD_LIB=$PWD/ocrs_amd/libocrs_amd.mubuf.so timeout 300 python bench.py --numerics $n --steps 36 --warmup 12 --no-extras --no-cpu-baseline > $OUT/bench_${n}_mubuf$rep.json 2> $OUT/bench_${n}_mubuf$rep.err; bsum $OUT/bench_${n}_mubuf$rep.json "$n mubuf $rep"
   done; done;;
+final)
+  say "== the suite as the driver runs it, smoke, long canaries of the numerics modes"
+  timeout 1200 python -m pytest tests -m gpu -x -q > $OUT/test_gpu_all.log 2>&1; say "pytest -m gpu rc=$?"; tail -3 $OUT/test_gpu_all.log | tee -a $S
+  timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; say "smoke rc=$?"; tail -1 $OUT/smoke.log | tee -a $S
+  for n in relaxed reduced; do
+    timeout 200 python tools/hazard_canary.py --numerics $n --isolation auto --seconds 40 > $OUT/canary_long_$n.json 2> $OUT/canary_long_$n.err; rc=$?
+    python - $OUT/canary_long_$n.json "$n auto 40 s rc=$rc" <<'PY' | tee -a $S
+import json, sys
+try:
+    d = json.loads([l for l in open(sys.argv[1]).read().splitlines() if l.startswith("{")][-1])
+    print(sys.argv[2], d["isolation"], "| mismatching checks", d["mismatching_checks"], {k: (v["checks"], v["bad_checks"], v["bad_elements"]) for k, v in d["classes"].items()}, "| examples", json.dumps(d["examples"][:3])[:400])
+except Exception as e:
+    print(sys.argv[2], "parse failed", e)
+PY
+  done;;
 *) say "unknown section $sec";;
 esac
 done
