@@ -246,7 +246,7 @@ typedef struct ocrs_engine_params {
     const char* allowed_chars; /* UTF-8 */
     /* --- no reference counterpart (RTen is fp32 on the CPU, one page per call) --- */
     ocrs_numerics numerics;    /* OCRS_NUMERICS_EXACT (0, default): every kernel follows the numeric spec, results are
-                                * bit-identical to the CPU oracle.  OCRS_NUMERICS_RELAXED: fp32-class arithmetic that is not
+                                * bit-identical to the CPU oracle.  The other two are EXPERIMENTAL.  OCRS_NUMERICS_RELAXED: fp32-class arithmetic that is not
                                 * reproducible on a CPU — hardware exp / rcp in the recurrence's gates; the operands of the
                                 * recognition convs, the GRU input projections and the recurrence's own contraction cut
                                 * into three bf16 terms on the bf16 matrix cores (products good to 2^-23), the matrix core's
@@ -254,7 +254,8 @@ typedef struct ocrs_engine_params {
                                 * operand (products good to 2^-15: a 16-bit significand).  Boxes and tokens are expected, not
                                 * guaranteed, to match the exact mode: DESIGN.md "what exactness costs" has the measured flips.
                                 * While an engine of these modes exists, every call on its device (of any engine of the
-                                * process) runs its kernels one at a time on one stream: create it before serving traffic */
+                                * process) runs its kernels one at a time on one stream (ocrs_device_set_isolation below says why and what a
+                                * change of regime waits for): create it before serving traffic */
     int coalesce;              /* one-page calls that wait at the same time are merged into one ragged request per stage
                                 * (lines are independent: nobody's bits change).  Merged batches in flight per stage:
                                 * 0 = default (2), negative = every call runs on its own */
