@@ -155,7 +155,7 @@ OCRS_API ocrs_status ocrs_device_pool_trim(int device);
 
 /* Isolation of the bf16-MFMA kernels (engines with numerics != exact), per device.  Round 5 observed OTHER requests' line crops
  * change while those kernels ran beside them; round 6 reproduced it from the two real kernels alone (tools/hazard_repro.hip:
- * every twin launch of the crop kernel differs while a dense bf16-MFMA kernel with VGPR accumulators shares its compute units,
+ * every twin launch of the crop kernel differs while a dense bf16-MFMA kernel whose matrix instructions read VGPR operands shares its compute units,
  * none when the two are confined to disjoint units; DESIGN.md §4.4 "Concurrency").  The library therefore never lets kernels of
  * different requests overlap on a device that has such an engine.
  *   OCRS_ISOLATION_AUTO (default)   every call on the device enqueues on ONE stream while such an engine exists;

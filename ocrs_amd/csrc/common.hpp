@@ -116,7 +116,7 @@ struct DeviceContext {
     hipStream_t recurrent_stream(int mode = 0);   // of a request in Mode `mode`: MODE_SERIAL -> the device's one stream
     // ---- isolation of the bf16-MFMA kernels (numerics != exact).  Round 5 saw another request's line crops change while the
     // split conv / GEMM kernels ran beside them; round 6 reproduced it stand-alone (tools/hazard_repro.hip: a dense bf16-MFMA
-    // kernel with its accumulators in the VGPR half of the register file corrupts 16-lane pieces of OTHER waves on its
+    // kernel whose matrix instructions source their operands from VGPRs corrupts 16-lane pieces of OTHER waves on its
     // compute unit; DESIGN.md §4.4 "Concurrency").  A device that has an engine with numerics != exact therefore does not let
     // kernels of different requests overlap.  The POLICY is per device (ocrs_device_set_isolation):
     //   ISO_AUTO (default)  one stream for every call on the device while such an engine exists — no two kernels at once;

@@ -411,7 +411,11 @@ static void launch_gemm_tiled(const GemmDesc& d, hipStream_t s) {
 // side on one XCD (as gemm_tiled_kernel's nfast form).
 // ---------------------------------------------------------------------------
 template <int NP>
+#if defined(OCRS_PROBE_ACC_AGPR) || defined(OCRS_PROBE_ALL_AGPR)   // probe builds: room for the AGPR copies (three waves per SIMD spill them)
+__global__ void __launch_bounds__(256, 2) gemm_split_kernel(GemmDesc d) {
+#else
 __global__ void __launch_bounds__(256, NP == 3 ? 2 : 3) gemm_split_kernel(GemmDesc d) {
+#endif
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int PL = split::PLANE;
     float* As = lds;                     // [2][NP][PLANE]

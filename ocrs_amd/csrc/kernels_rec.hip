@@ -290,7 +290,11 @@ constexpr int RG_BM = 128, RG_BK = OCRS_CONV_BK, RG_LDA = RG_BM + 1;
 // the contraction on the bf16 matrix cores with both operands cut into SPLIT bf16 terms — split_mfma.hpp has the arithmetic,
 // the LDS layout and the pipeline.  Bw is then the weights' split image (split_weights).
 template <int BN, int TW, int PH, int PW, bool FLAT, int SPLIT = 0>   // SPLIT: 0 exact; 3 / 2 = bf16 planes per operand (relaxed / reduced numerics)
+#if defined(OCRS_PROBE_ACC_AGPR) || defined(OCRS_PROBE_ALL_AGPR)   // probe builds: room for the AGPR operands
+__global__ void __launch_bounds__(256, SPLIT != 0 ? 2 : OCRS_CONV_WAVES)
+#else
 __global__ void __launch_bounds__(256, SPLIT == 3 ? 2 : SPLIT == 2 ? 3 : OCRS_CONV_WAVES)   // (split: 72 / 48 KB of LDS per block)
+#endif
 conv3x3_ragged_kernel(const float* __restrict__ X, RaggedView rv, int cin, const float* __restrict__ Bw,
                       const float* __restrict__ bias, int cout, int relu, float* __restrict__ Y,
                       const int64_t* __restrict__ out_poff) {
@@ -769,7 +773,11 @@ constexpr int F12S_BTAP = F12_COUT * 64;                      // bytes per plane
 constexpr size_t f12s_lds(int np) { return (size_t)np * (F12S_TILE + 3 * F12S_BTAP); }   // 74.4 KB (NP 3) / 49.6 KB (NP 2)
 
 template <int NP>
+#if defined(OCRS_PROBE_ACC_AGPR) || defined(OCRS_PROBE_ALL_AGPR)
+__global__ void __launch_bounds__(256, 2)
+#else
 __global__ void __launch_bounds__(256, NP == 3 ? 2 : 3)
+#endif
 conv12_fused_split_kernel(const float* __restrict__ X0, RaggedView in0, RaggedView mid, const float* __restrict__ w1,
                           const float* __restrict__ b1, const uint16_t* __restrict__ Bimg, const float* __restrict__ bias,
                           float* __restrict__ Y, const int64_t* __restrict__ out_poff) {

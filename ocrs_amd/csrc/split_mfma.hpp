@@ -91,7 +91,9 @@ __device__ __forceinline__ void load_weights(const float* img, float* bdst, int 
 
 // C += A . B on the bf16 matrix cores (one 32 x 32 x 16 step); the probe forms exist for tools/hazard_repro.hip and the variant
 // library of tools/r6_session.sh only
-#if defined(OCRS_PROBE_ACC_AGPR)      // probe builds only (tools/build_hazard_repro.sh): the accumulators in the AGPR half of the register file
+#if defined(OCRS_PROBE_ALL_AGPR)       // probe builds only: accumulators AND both operands in AGPRs (the MFMA stream touches no VGPR)
+#define OCRS_SPLIT_MMA(A, B, C) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(C) : "a"(A), "a"(B))
+#elif defined(OCRS_PROBE_ACC_AGPR)      // probe builds only (tools/build_hazard_repro.sh): the accumulators in the AGPR half of the register file
 #define OCRS_SPLIT_MMA(A, B, C) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(C) : "v"(A), "v"(B))
 #elif defined(OCRS_PROBE_MFMA16)      // probe builds only: the same registers driven through v_mfma_f32_16x16x32_bf16 (NOT the same arithmetic)
 #define OCRS_SPLIT_MMA(A, B, C)                                                                                       \
@@ -108,18 +110,28 @@ __device__ __forceinline__ void load_weights(const float* img, float* bdst, int 
 template <int NP>
 __device__ __forceinline__ void mma_chunk(const char* abase, const char* bbase, int wm, int wn, int l31, int half, f32x16s (&acc)[2][2]) {
     bf16x8s af[2][3], bfr[2][3];   // (planes NP.. unused)
+#if defined(OCRS_PROBE_ALL_AGPR)
+    // operand reads straight into AGPRs (ds_read_b128 a[..]); the compiler does not see their latency: one explicit wait
+#define OCRS_LDS_A(DST, PTR) asm volatile("ds_read_b128 %0, %1" : "=a"(DST) : "v"((unsigned)(uintptr_t)(PTR)))
+#else
+#define OCRS_LDS_A(DST, PTR) DST = *reinterpret_cast<const bf16x8s*>(PTR)
+#endif
 #pragma unroll
     for (int i = 0; i < 2; i++) {
         const int off = operand_off(wm * 64 + i * 32 + l31, half);
 #pragma unroll
-        for (int pl = 0; pl < NP; pl++) af[i][pl] = *reinterpret_cast<const bf16x8s*>(abase + pl * PLANE * 4 + off);
+        for (int pl = 0; pl < NP; pl++) OCRS_LDS_A(af[i][pl], abase + pl * PLANE * 4 + off);
     }
 #pragma unroll
     for (int t = 0; t < 2; t++) {
         const int off = operand_off(wn * 64 + t * 32 + l31, half);
 #pragma unroll
-        for (int pl = 0; pl < NP; pl++) bfr[t][pl] = *reinterpret_cast<const bf16x8s*>(bbase + pl * PLANE * 4 + off);
+        for (int pl = 0; pl < NP; pl++) OCRS_LDS_A(bfr[t][pl], bbase + pl * PLANE * 4 + off);
     }
+#if defined(OCRS_PROBE_ALL_AGPR)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+#undef OCRS_LDS_A
     // smallest terms first; consecutive MFMAs go to different accumulators (no back-to-back dependency)
 #define OCRS_TERM(PA, PB)                                                                                       \
     _Pragma("unroll") for (int t = 0; t < 2; t++) {                                                             \

@@ -23,7 +23,7 @@ build() {   # $1 = output suffix, $2 = extra define for kernels_lines.hip
 build "" ""
 if [ -n "$1" ]; then build ".prio$1" "-DOCRS_CROP_SETPRIO=$1"; fi
 # aggressor probes: gemm_split_kernel with its accumulators in AGPRs / driven through the 16x16x32 instruction
-for v in ACC_AGPR MFMA16; do
+for v in ACC_AGPR MFMA16 ALL_AGPR; do
   /opt/rocm/bin/hipcc $FLAGS -DOCRS_PROBE_$v -c $C/kernels_nn.hip -o tools/_build/kernels_nn.$v.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -o tools/_build/hazard_repro.$v tools/_build/hazard_repro.o tools/_build/kernels_lines.o \
       tools/_build/kernels_nn.$v.o tools/_build/kernels_rec.o tools/_build/common.o -ldl -lpthread
