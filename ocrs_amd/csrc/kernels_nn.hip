@@ -371,6 +371,41 @@ __global__ void __launch_bounds__(256, 4) gemm_tiled_kernel(GemmDesc d) {
     }
 
     // ---- epilogue (32x32 C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5))
+    // Full column tiles with 16-byte rows: a lane's 16 accumulator registers are 16 ROWS of one column, so the direct form
+    // below is 16 x NTW dword stores per 32-row half (a row of the wave's sub-tile = two 128-byte runs from two
+    // instructions).  Instead the wave turns each 32 x BN/2 half through its own 32 x BN/2 floats of the (now idle) operand
+    // tiles — written by column as the MFMA left them, read back by row as float4 — and stores whole rows: 8 dwordx4 stores
+    // of 4 x 256 contiguous bytes instead of 32 dword stores (BN = 128).  Wave-private staging: no workgroup barrier; LDS
+    // operations of one wave execute in order, the asm statements only keep the COMPILER from moving the reads over the
+    // writes (per thread they never alias).  Pure data movement: the bits are the direct form's.  GRU input projection alone
+    // (K = 256 / 512, N = 1536: 6 KB stored per 1-2 KB read): 3.20 -> 3.04 ms per launch, 0.73 -> 0.775 of the fp32 MFMA peak (ABAB).
+    if (n0 + BN <= d.N && (d.ldc & 3) == 0 && (((uintptr_t)C) & 15) == 0) {
+        constexpr int WN = BN / 2, LPR = WN / 4, RPI = 64 / LPR;
+        static_assert(4 * 32 * WN <= 2 * TG_BK * TG_LDA + 2 * TG_BK * BN, "staging must fit the operand tiles");
+        float* stage = lds + wave * (32 * WN);
+        const int srow = lane / LPR, sc4 = (lane % LPR) * 4;
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+#pragma unroll
+            for (int t = 0; t < NTW; t++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    float v = acc[i][t][r];
+                    if (d.relu) v = v > 0.0f ? v : 0.0f;
+                    stage[((r & 3) + 8 * (r >> 2) + 4 * half) * WN + t * 32 + l31] = v;
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int it = 0; it < 32 / RPI; it++) {
+                const int row = it * RPI + srow;
+                const f32x4v v = *reinterpret_cast<const f32x4v*>(&stage[row * WN + sc4]);
+                const int64_t rr = m0 + wm * 64 + i * 32 + row;
+                if (rr < d.M) *reinterpret_cast<f32x4v*>(&C[rr * d.ldc + n0 + wn * WN + sc4]) = v;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 2; i++)
 #pragma unroll

@@ -515,6 +515,9 @@ conv3x3_ragged_kernel(const float* __restrict__ X, RaggedView rv, int cin, const
     const int Ho = H / PH, Wo = W / PW;
     float* __restrict__ C = Y + (out_poff[g] + (int64_t)img * Ho * Wo) * cout;
     auto act = [&](float v) { return relu ? (v > 0.0f ? v : 0.0f) : v; };
+    // (Row-wise float4 stores through an LDS transposition, as gemm_tiled_kernel's epilogue does, were built and measured here in
+    // round 6: conv alone 0.776 vs 0.771 of the MFMA peak, ABAB — nothing; the stores of a 3x3 conv are 1/9 as dense per MFMA as
+    // the projection GEMM's (K = 9 Cin against 256), the direct form stays.)
     // FLAT: a lane's accumulator rows cover NX distinct patch columns (tx = q & (TW - 1) below); their image, column and
     // validity are worked out once: xo_off[jx] = element offset of (image, pooled column) from C, or -1.
     constexpr int NX = TW == 16 ? 8 : 16;

@@ -153,6 +153,15 @@ PY
     timeout 300 python bench.py --numerics $n --steps 36 --warmup 12 --no-extras --no-cpu-baseline > $OUT/bench_${n}_stock$rep.json 2> $OUT/bench_${n}_stock$rep.err; bsum $OUT/bench_${n}_stock$rep.json "$n stock $rep"
     OCRS_AMD_LIB=$PWD/ocrs_amd/libocrs_amd.mubuf.so timeout 300 python bench.py --numerics $n --steps 36 --warmup 12 --no-extras --no-cpu-baseline > $OUT/bench_${n}_mubuf$rep.json 2> $OUT/bench_${n}_mubuf$rep.err; bsum $OUT/bench_${n}_mubuf$rep.json "$n mubuf $rep"
   done; done;;
+wideab)
+  say "== row-wise float4 epilogues (stock) vs the dword epilogues (variant libraries), ABAB, quick bench"
+  for i in 1 2; do
+    for v in stock narrow narrowconv; do
+      lib=""; [ $v != stock ] && lib=$PWD/ocrs_amd/libocrs_amd.$v.so
+      [ -n "$lib" ] && [ ! -f "$lib" ] && continue
+      OCRS_AMD_LIB=$lib timeout 400 python bench.py --steps 30 --warmup 5 --no-extras --no-cpu-baseline > $OUT/bench_wide_$v$i.json 2> $OUT/bench_wide_$v$i.err; bsum $OUT/bench_wide_$v$i.json "$v $i"
+    done
+  done;;
 final)
   say "== the suite as the driver runs it, smoke, long canaries of the numerics modes"
   timeout 1200 python -m pytest tests -m gpu -x -q > $OUT/test_gpu_all.log 2>&1; say "pytest -m gpu rc=$?"; tail -3 $OUT/test_gpu_all.log | tee -a $S
