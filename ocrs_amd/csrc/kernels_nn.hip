@@ -178,6 +178,38 @@ constexpr int TG_BM = 128, TG_BK = 16, TG_LDA = TG_BM + 1;
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
+// The row-wise epilogue of gemm_tiled_kernel / gemm_split_kernel (see the comment at its first use): the wave's 64 x 32 NTW
+// sub-tile, 32 rows at a time, through `stage` (32 x 32 NTW floats owned by this wave) to C (already at the sub-tile's first
+// column) as float4 per lane.  The caller guarantees full columns, ldc % 4 == 0, C 16-byte aligned, and that no wave of the
+// block still reads what `stage` overlays.
+template <int NTW, class Acc>
+__device__ __forceinline__ void store_tile_rows(const Acc (&acc)[2][NTW], float* stage, int lane, bool relu, float* __restrict__ C,
+                                                int64_t row0, int64_t M, int ldc) {
+    constexpr int WN = 32 * NTW, LPR = WN / 4, RPI = 64 / LPR;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int srow = lane / LPR, sc4 = (lane % LPR) * 4;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+#pragma unroll
+        for (int t = 0; t < NTW; t++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                float v = acc[i][t][r];
+                if (relu) v = v > 0.0f ? v : 0.0f;
+                stage[((r & 3) + 8 * (r >> 2) + 4 * half) * WN + t * 32 + l31] = v;
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int it = 0; it < 32 / RPI; it++) {
+            const int row = it * RPI + srow;
+            const f32x4v v = *reinterpret_cast<const f32x4v*>(&stage[row * WN + sc4]);
+            const int64_t rr = row0 + i * 32 + row;
+            if (rr < M) *reinterpret_cast<f32x4v*>(&C[rr * ldc + sc4]) = v;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+}
+
 template <int BN, bool IM2COL, bool PAIR>
 __global__ void __launch_bounds__(256, 4) gemm_tiled_kernel(GemmDesc d) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -380,30 +412,8 @@ __global__ void __launch_bounds__(256, 4) gemm_tiled_kernel(GemmDesc d) {
     // writes (per thread they never alias).  Pure data movement: the bits are the direct form's.  GRU input projection alone
     // (K = 256 / 512, N = 1536: 6 KB stored per 1-2 KB read): 3.20 -> 3.04 ms per launch, 0.73 -> 0.775 of the fp32 MFMA peak (ABAB).
     if (n0 + BN <= d.N && (d.ldc & 3) == 0 && (((uintptr_t)C) & 15) == 0) {
-        constexpr int WN = BN / 2, LPR = WN / 4, RPI = 64 / LPR;
-        static_assert(4 * 32 * WN <= 2 * TG_BK * TG_LDA + 2 * TG_BK * BN, "staging must fit the operand tiles");
-        float* stage = lds + wave * (32 * WN);
-        const int srow = lane / LPR, sc4 = (lane % LPR) * 4;
-#pragma unroll
-        for (int i = 0; i < 2; i++) {
-#pragma unroll
-            for (int t = 0; t < NTW; t++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    float v = acc[i][t][r];
-                    if (d.relu) v = v > 0.0f ? v : 0.0f;
-                    stage[((r & 3) + 8 * (r >> 2) + 4 * half) * WN + t * 32 + l31] = v;
-                }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int it = 0; it < 32 / RPI; it++) {
-                const int row = it * RPI + srow;
-                const f32x4v v = *reinterpret_cast<const f32x4v*>(&stage[row * WN + sc4]);
-                const int64_t rr = m0 + wm * 64 + i * 32 + row;
-                if (rr < d.M) *reinterpret_cast<f32x4v*>(&C[rr * d.ldc + n0 + wn * WN + sc4]) = v;
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        }
+        static_assert(4 * 32 * (BN / 2) <= 2 * TG_BK * TG_LDA + 2 * TG_BK * BN, "staging must fit the operand tiles");
+        store_tile_rows<NTW>(acc, lds + wave * (32 * (BN / 2)), lane, d.relu != 0, C + n0 + wn * (BN / 2), m0 + wm * 64, d.M, d.ldc);
         return;
     }
 #pragma unroll
@@ -505,7 +515,13 @@ __global__ void __launch_bounds__(256, NP == 3 ? 2 : 3) gemm_split_kernel(GemmDe
             split::mma_chunk<NP>(reinterpret_cast<const char*>(As + abuf * NP * PL), reinterpret_cast<const char*>(Bs + ring * NP * PL),
                                  wm, wn, l31, half, acc);
         });
-    // epilogue (32x32 C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5))
+    // epilogue: rows as float4 through the operand buffers (gemm_tiled_kernel's; N % 128 == 0 here), else the direct form
+    // (32x32 C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5))
+    if ((d.ldc & 3) == 0 && (((uintptr_t)C) & 15) == 0) {
+        // (split::pipeline ends behind a drained barrier: no wave still reads the operand buffers)
+        store_tile_rows<2>(acc, lds + wave * (32 * 64), lane, d.relu != 0, C + n0 + wn * 64, m0 + wm * 64, d.M, d.ldc);
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 2; i++)
 #pragma unroll

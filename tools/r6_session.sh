@@ -162,6 +162,16 @@ wideab)
       OCRS_AMD_LIB=$lib timeout 400 python bench.py --steps 30 --warmup 5 --no-extras --no-cpu-baseline > $OUT/bench_wide_$v$i.json 2> $OUT/bench_wide_$v$i.err; bsum $OUT/bench_wide_$v$i.json "$v $i"
     done
   done;;
+splitab)
+  say "== gemm_split row-wise epilogue (stock) vs the dword epilogue (variant), relaxed and reduced, ABAB"
+  for i in 1 2; do
+    for n in relaxed reduced; do
+      for v in stock narrowsplit; do
+        lib=""; [ $v != stock ] && lib=$PWD/ocrs_amd/libocrs_amd.$v.so
+        OCRS_AMD_LIB=$lib timeout 400 python bench.py --numerics $n --steps 30 --warmup 5 --no-extras --no-cpu-baseline > $OUT/bench_split_${n}_$v$i.json 2> $OUT/bench_split_${n}_$v$i.err; bsum $OUT/bench_split_${n}_$v$i.json "$n $v $i"
+      done
+    done
+  done;;
 final)
   say "== the suite as the driver runs it, smoke, long canaries of the numerics modes"
   timeout 1200 python -m pytest tests -m gpu -x -q > $OUT/test_gpu_all.log 2>&1; say "pytest -m gpu rc=$?"; tail -3 $OUT/test_gpu_all.log | tee -a $S
