@@ -197,3 +197,28 @@ def test_group_replay_returns_the_recorded_results_without_touching_the_gpu():
         pipeline([synth.synthetic_page(99, 192, 256, lines=6, columns=1)])
     group.set_replay(0)
     assert all(np.array_equal(a, b) for a, b in zip(pipeline(pages)[0], want[0]))
+
+
+@pytest.mark.parametrize("cin,cout,relu", [(64, 64, 1), (64, 128, 0), (32, 256, 1), (48, 192, 1), (64, 100, 0), (16, 320, 1)])
+def test_tiled_gemm_row_wise_epilogue_is_the_fmaf_chain_on_ragged_rows_and_partial_column_tiles(cin, cout, relu):
+    """gemm_tiled_kernel's epilogue (round 6: a wave turns its accumulators through LDS and stores whole rows as float4) on the
+    shapes that select each of its forms: 19 173 rows (not a multiple of the 128-row tile: the last tile's row guard), full
+    128- and 64-column tiles (row-wise form), a 192- and a 320-column output (row-wise tiles beside a partial one in the same
+    launch), 100 columns (direct form only), K = 48 / 16 (single-chunk loop) and K = 32 / 64 (chunk-pair loop), with and
+    without ReLU — bit for bit the oracle's k-ascending fmaf chain from the bias."""
+    from oracle.nn import OracleGraph
+    from ocrs_amd import modelfile as mf
+    _lib.require_gpu()
+    rng = np.random.default_rng(cin * 1000 + cout)
+    w = (rng.standard_normal((1, 1, cin, cout)) * 0.3).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    lift_w = rng.standard_normal((1, 1, 1, cin)).astype(np.float32)
+    ops = [mf.Op(mf.OP_CONV, 0, 1, kh=1, kw=1, cin=1, cout=cin, weights=(lift_w, np.zeros(cin, np.float32))),
+           mf.Op(mf.OP_CONV, 1, 2, relu=relu, kh=1, kw=1, cin=cin, cout=cout, weights=(w, b))]
+    g = mf.Graph(mf.KIND_DETECTION, [-1, 1, -1, -1], ops, 3, 2)
+    x = rng.standard_normal((3, 1, 77, 83)).astype(np.float32)       # 3 * 77 * 83 = 19 173 rows: beyond gemm_small's 16 384
+    got = Model.load_bytes(g.to_bytes()).run(x)
+    exp = OracleGraph(g.to_bytes()).run_exact(x)
+    assert got.shape == exp.shape and np.array_equal(got, exp)
+    if relu:
+        assert (got == 0).any() and (got > 0).any()
