@@ -4,6 +4,7 @@ set -u
 export TMPDIR=/tmp
 TAG=$1; shift
 OUT=gpurun_out/$TAG
+ROOT=$PWD
 mkdir -p $OUT
 S=$OUT/summary.txt
 : > $S
@@ -170,6 +171,17 @@ splitab)
         lib=""; [ $v != stock ] && lib=$PWD/ocrs_amd/libocrs_amd.$v.so
         OCRS_AMD_LIB=$lib timeout 400 python bench.py --numerics $n --steps 30 --warmup 5 --no-extras --no-cpu-baseline > $OUT/bench_split_${n}_$v$i.json 2> $OUT/bench_split_${n}_$v$i.err; bsum $OUT/bench_split_${n}_$v$i.json "$n $v $i"
       done
+    done
+  done;;
+instab)
+  say "== per-instance kernel durations, one request at a time, under rocprofv3 --kernel-trace: stock vs variant libraries ($INST_LIBS), ABAB"
+  for i in 1 2; do
+    for v in stock $INST_LIBS; do
+      lib=""; [ $v != stock ] && lib=$ROOT/ocrs_amd/libocrs_amd.$v.so
+      (cd /tmp && OCRS_AMD_LIB=$lib timeout 400 rocprofv3 --kernel-trace --stats -d $ROOT/$OUT/inst_$v$i -o serial -- python $ROOT/bench.py --steps 4 --warmup 1 --settle-s 0 --inflight 1 --no-pipeline --no-cpu-baseline --no-extras --no-kernel-timing > /dev/null 2> $ROOT/$OUT/inst_$v$i.err)
+      db=$(find $OUT/inst_$v$i -name "serial*.db" | head -1)
+      [ -n "$db" ] && python tools/rocprof_summary.py "$db" $OUT/inst_$v$i.txt > /dev/null && say "-- $v $i" && grep -E "conv3x3_ragged|conv12_fused|gemm_tiled_kernelILi128ELb0ELb1" $OUT/inst_$v$i.txt | cut -c1-140 | tee -a $S
+      rm -rf $OUT/inst_$v$i
     done
   done;;
 final)
