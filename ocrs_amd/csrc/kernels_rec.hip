@@ -515,9 +515,48 @@ conv3x3_ragged_kernel(const float* __restrict__ X, RaggedView rv, int cin, const
     const int Ho = H / PH, Wo = W / PW;
     float* __restrict__ C = Y + (out_poff[g] + (int64_t)img * Ho * Wo) * cout;
     auto act = [&](float v) { return relu ? (v > 0.0f ? v : 0.0f) : v; };
-    // (Row-wise float4 stores through an LDS transposition, as gemm_tiled_kernel's epilogue does, were built and measured here in
-    // round 6: conv alone 0.776 vs 0.771 of the MFMA peak, ABAB — nothing; the stores of a 3x3 conv are 1/9 as dense per MFMA as
-    // the projection GEMM's (K = 9 Cin against 256), the direct form stays.)
+    // Unpooled layers, full column tiles: rows as float4 through a wave-private 32 x BN/2 staging tile in the
+    // idle operand buffers (gemm_tiled_kernel's epilogue, kernels_nn.hip: a lane holds 16 PIXELS of one channel, a store wants
+    // 4 channels of one pixel): 16 dwordx4 stores per wave instead of 64 dword stores.  Per instance, one request at a time,
+    // ABAB: 7.39-7.48 -> 6.95-7.01 ms per launch (conv3 + conv5 of the CRNN; the split kernels 4.49 -> 4.34 and 2.73 -> 2.70:
+    // split::pipeline ends behind a drained barrier, the operand buffers are idle there too).  The pooled layers store half / a quarter as
+    // much and get SLOWER through the tile (9.87-9.89 -> 10.23-10.28 ms, whether each half or both halves' outputs are staged
+    // at once): they keep the direct form below.
+    if (PH == 1 && PW == 1 && n0 + BN <= cout && (cout & 3) == 0 && (((uintptr_t)Y) & 15) == 0) {
+        constexpr int WN = BN / 2, LPR = WN / 4, RPI = 64 / LPR, NIT = 32 / RPI;
+        static_assert(SPLIT != 0 || 4 * 32 * WN <= 2 * RG_BK * RG_LDA + 2 * RG_BK * BN, "staging must fit the operand tiles");   // split: 48 / 72 KB
+        float* stage = lds + wave * (32 * WN);
+        const int srow = lane / LPR, sc4 = (lane % LPR) * 4;
+        int soff[NIT];   // element offset of (image, column, first channel) of the accumulator rows this lane stores, or -1
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const int q = it * RPI + srow;
+            int x = x0 + (TW == 32 ? q : (q & 15)), ir = 0;
+            if (FLAT) {
+#pragma unroll
+                for (int k = 0; k < 3; k++) { const bool nx = x >= Wp; x -= nx ? Wp : 0; ir += nx; }
+            }
+            soff[it] = (x < W && (!FLAT || ir < span)) ? ((FLAT ? ir * Ho * Wo : 0) + x) * cout + n0 + wn * WN + sc4 : -1;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+#pragma unroll
+            for (int t = 0; t < NTW; t++)
+#pragma unroll
+                for (int r = 0; r < 16; r++)
+                    stage[((r & 3) + 8 * (r >> 2) + 4 * half) * WN + t * 32 + l31] = act(acc[i][t][r]);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // one wave's LDS operations execute in order; this stops the COMPILER
+#pragma unroll
+            for (int it = 0; it < NIT; it++) {
+                const int q = it * RPI + srow;
+                if (soff[it] < 0) continue;
+                const int ty = TW == 32 ? 2 * wm + i : 4 * wm + 2 * i + (q >> 4);
+                *reinterpret_cast<f32x4*>(&C[soff[it] + (y0 + ty) * Wo * cout]) = *reinterpret_cast<const f32x4*>(&stage[q * WN + sc4]);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        return;
+    }
     // FLAT: a lane's accumulator rows cover NX distinct patch columns (tx = q & (TW - 1) below); their image, column and
     // validity are worked out once: xo_off[jx] = element offset of (image, pooled column) from C, or -1.
     constexpr int NX = TW == 16 ? 8 : 16;

@@ -178,9 +178,9 @@ instab)
   for i in 1 2; do
     for v in stock $INST_LIBS; do
       lib=""; [ $v != stock ] && lib=$ROOT/ocrs_amd/libocrs_amd.$v.so
-      (cd /tmp && OCRS_AMD_LIB=$lib timeout 400 rocprofv3 --kernel-trace --stats -d $ROOT/$OUT/inst_$v$i -o serial -- python $ROOT/bench.py --steps 4 --warmup 1 --settle-s 0 --inflight 1 --no-pipeline --no-cpu-baseline --no-extras --no-kernel-timing > /dev/null 2> $ROOT/$OUT/inst_$v$i.err)
+      (cd /tmp && OCRS_AMD_LIB=$lib timeout 400 rocprofv3 --kernel-trace --stats -d $ROOT/$OUT/inst_$v$i -o serial -- python $ROOT/bench.py --steps 4 --warmup 1 --settle-s 0 --inflight 1 --no-pipeline --no-cpu-baseline --no-extras --no-kernel-timing ${INST_ARGS:-} > /dev/null 2> $ROOT/$OUT/inst_$v$i.err)
       db=$(find $OUT/inst_$v$i -name "serial*.db" | head -1)
-      [ -n "$db" ] && python tools/rocprof_summary.py "$db" $OUT/inst_$v$i.txt > /dev/null && say "-- $v $i" && grep -E "conv3x3_ragged|conv12_fused|gemm_tiled_kernelILi128ELb0ELb1" $OUT/inst_$v$i.txt | cut -c1-140 | tee -a $S
+      [ -n "$db" ] && python tools/rocprof_summary.py "$db" $OUT/inst_$v$i.txt > /dev/null && say "-- $v $i" && grep -E "conv3x3_ragged|conv12_fused|gemm_tiled_kernelILi128ELb0ELb1|gemm_split" $OUT/inst_$v$i.txt | cut -c1-140 | tee -a $S
       rm -rf $OUT/inst_$v$i
     done
   done;;
