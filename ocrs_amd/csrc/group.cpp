@@ -291,6 +291,9 @@ bool ensure_comms(ocrs_engine_group* g, std::string* why) {
         std::vector<int> devs;
         for (const auto& mem : g->members) devs.push_back(mem.device);
         g->comms.assign(devs.size(), nullptr);
+        // RCCL checks hipGetLastError() after its own HIP calls: an error word this thread's earlier HIP calls left behind must not
+        // come back from it as "unhandled cuda error" (defensive: every HIP call of this library checks its own return value).
+        (void)hipGetLastError();
         const ncclResult_t r = api.CommInitAll(g->comms.data(), (int)devs.size(), devs.data());
         if (r != ncclSuccess) {
             reason = std::string("ncclCommInitAll failed: ") + api.GetErrorString(r);
@@ -345,6 +348,7 @@ std::vector<uint8_t> gather_rccl(ocrs_engine_group* g, const std::vector<std::ve
     }
     {
         std::lock_guard<std::mutex> lk(g->issue_mu);
+        (void)hipGetLastError();   // see ensure_comms
         ncclResult_t r = api.GroupStart();
         if (r != ncclSuccess) fail(OCRS_ERR_DEVICE, "RCCL error %s in ncclGroupStart", api.GetErrorString(r));
         for (size_t m = 0; m < G; m++) {

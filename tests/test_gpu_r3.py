@@ -91,13 +91,18 @@ def test_group_of_two_members_on_one_device_gives_golden_bits(bufs, pages16):
 def test_group_rccl_gather_one_member(bufs, pages16):
     """gather = rccl on a one-member group: ncclCommInitAll + grouped ncclAllGather from librccl really run (a
     one-rank communicator is all a one-GPU box offers); results travel device -> device -> host and equal the golden
-    bits; the raw gather returns exactly the bytes it was given."""
+    bits; the raw gather returns exactly the bytes it was given.
+    (Order dependence seen in round 6, not resolved: after tests/test_gpu_parity.py — whose oracle leg imports torch, i.e. torch's
+    own bundled ROCm libraries — in the SAME process and without the files the full suite runs in between, /opt/rocm's librccl
+    fails in its HSA wrapper ("pfn_hsa_system_get_info failed with 4107") and the group reports the host transport with that
+    reason; alone, in tests/test_gpu_r3.py as a whole and in the full `-m gpu` suite it binds and runs.  The reason is in the
+    assertion message.)"""
     dbuf, rbuf, digests = bufs
     group = EngineGroup([0], dbuf, rbuf, gather="rccl")
     out = _group_pipeline(group, pages16[:4])
     _check_all_golden(out, digests, n=4)
     lg = group.last_gather()
-    assert lg["transport"] == "rccl" and lg["why_host"] == "" and lg["bytes"] > 10000
+    assert lg["transport"] == "rccl" and lg["why_host"] == "" and lg["bytes"] > 10000, lg
     rng = np.random.default_rng(5)
     for n in (0, 1, 17, 100003):
         blob = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
