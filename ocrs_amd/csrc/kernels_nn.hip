@@ -178,6 +178,9 @@ constexpr int TG_BM = 128, TG_BK = 16, TG_LDA = TG_BM + 1;
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
+#ifndef OCRS_DIRECT_EPILOGUES
+#define OCRS_DIRECT_EPILOGUES 0   // ablation builds (tools/r6_session.sh epiab): 1 = the dword epilogues of rounds 1-5 here and in kernels_rec.hip
+#endif
 // The row-wise epilogue of gemm_tiled_kernel / gemm_split_kernel (see the comment at its first use): the wave's 64 x 32 NTW
 // sub-tile, 32 rows at a time, through `stage` (32 x 32 NTW floats owned by this wave) to C (already at the sub-tile's first
 // column) as float4 per lane.  The caller guarantees full columns, ldc % 4 == 0, C 16-byte aligned, and that no wave of the
@@ -411,7 +414,7 @@ __global__ void __launch_bounds__(256, 4) gemm_tiled_kernel(GemmDesc d) {
     // operations of one wave execute in order, the asm statements only keep the COMPILER from moving the reads over the
     // writes (per thread they never alias).  Pure data movement: the bits are the direct form's.  GRU input projection alone
     // (K = 256 / 512, N = 1536: 6 KB stored per 1-2 KB read): 3.20 -> 3.04 ms per launch, 0.73 -> 0.775 of the fp32 MFMA peak (ABAB).
-    if (n0 + BN <= d.N && (d.ldc & 3) == 0 && (((uintptr_t)C) & 15) == 0) {
+    if (!OCRS_DIRECT_EPILOGUES && n0 + BN <= d.N && (d.ldc & 3) == 0 && (((uintptr_t)C) & 15) == 0) {
         static_assert(4 * 32 * (BN / 2) <= 2 * TG_BK * TG_LDA + 2 * TG_BK * BN, "staging must fit the operand tiles");
         store_tile_rows<NTW>(acc, lds + wave * (32 * (BN / 2)), lane, d.relu != 0, C + n0 + wn * (BN / 2), m0 + wm * 64, d.M, d.ldc);
         return;
@@ -517,7 +520,7 @@ __global__ void __launch_bounds__(256, NP == 3 ? 2 : 3) gemm_split_kernel(GemmDe
         });
     // epilogue: rows as float4 through the operand buffers (gemm_tiled_kernel's; N % 128 == 0 here), else the direct form
     // (32x32 C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5))
-    if ((d.ldc & 3) == 0 && (((uintptr_t)C) & 15) == 0) {
+    if (!OCRS_DIRECT_EPILOGUES && (d.ldc & 3) == 0 && (((uintptr_t)C) & 15) == 0) {
         // (split::pipeline ends behind a drained barrier: no wave still reads the operand buffers)
         store_tile_rows<2>(acc, lds + wave * (32 * 64), lane, d.relu != 0, C + n0 + wn * 64, m0 + wm * 64, d.M, d.ldc);
         return;

@@ -522,7 +522,10 @@ conv3x3_ragged_kernel(const float* __restrict__ X, RaggedView rv, int cin, const
     // split::pipeline ends behind a drained barrier, the operand buffers are idle there too).  The pooled layers store half / a quarter as
     // much and get SLOWER through the tile (9.87-9.89 -> 10.23-10.28 ms, whether each half or both halves' outputs are staged
     // at once): they keep the direct form below.
-    if (PH == 1 && PW == 1 && n0 + BN <= cout && (cout & 3) == 0 && (((uintptr_t)Y) & 15) == 0) {
+#ifndef OCRS_DIRECT_EPILOGUES
+#define OCRS_DIRECT_EPILOGUES 0   // ablation builds: see kernels_nn.hip
+#endif
+    if (!OCRS_DIRECT_EPILOGUES && PH == 1 && PW == 1 && n0 + BN <= cout && (cout & 3) == 0 && (((uintptr_t)Y) & 15) == 0) {
         constexpr int WN = BN / 2, LPR = WN / 4, RPI = 64 / LPR, NIT = 32 / RPI;
         static_assert(SPLIT != 0 || 4 * 32 * WN <= 2 * RG_BK * RG_LDA + 2 * RG_BK * BN, "staging must fit the operand tiles");   // split: 48 / 72 KB
         float* stage = lds + wave * (32 * WN);

@@ -184,6 +184,14 @@ instab)
       rm -rf $OUT/inst_$v$i
     done
   done;;
+epiab)
+  say "== end to end: row-wise epilogues (stock) vs the dword epilogues of rounds 1-5 (variant library), ABAB x 3, 40 steps"
+  for i in 1 2 3; do
+    for v in stock oldepi; do
+      lib=""; [ $v != stock ] && lib=$PWD/ocrs_amd/libocrs_amd.$v.so
+      OCRS_AMD_LIB=$lib timeout 400 python bench.py --steps 40 --warmup 5 --no-extras --no-cpu-baseline > $OUT/bench_epi_$v$i.json 2> $OUT/bench_epi_$v$i.err; bsum $OUT/bench_epi_$v$i.json "$v $i"
+    done
+  done;;
 final)
   say "== the suite as the driver runs it, smoke, long canaries of the numerics modes"
   timeout 1200 python -m pytest tests -m gpu -x -q > $OUT/test_gpu_all.log 2>&1; say "pytest -m gpu rc=$?"; tail -3 $OUT/test_gpu_all.log | tee -a $S
