@@ -281,7 +281,7 @@ constexpr int RG_BM = 128, RG_BK = OCRS_CONV_BK, RG_LDA = RG_BM + 1;
 #define OCRS_CONV_WAVES 4
 #endif
 #ifndef OCRS_ABL
-#define OCRS_ABL 0  // ablation builds (tools/conv_ablation.sh; results are WRONG on purpose): 1 no barriers,
+#define OCRS_ABL 0  // ablation builds (tools/conv_ablation.sh, tools/r6_session.sh instab; results are WRONG on purpose; 8 no epilogue, 16 half of K): 1 no barriers,
 #endif              // 2 no global loads, 4 no LDS writes
 // FLAT: the patches of a group tile the strip of ALL its images side by side (flat column c = img * Wp + x, Wp = W
 // rounded up to PW) instead of each image on its own, so only the last patch of a GROUP is ragged, not the last
@@ -474,7 +474,7 @@ conv3x3_ragged_kernel(const float* __restrict__ X, RaggedView rv, int cin, const
             }
         }
     };
-    const int nchunks = K / RG_BK;  // even: cin % (2*RG_BK) == 0
+    const int nchunks = (OCRS_ABL & 16) ? K / RG_BK / 2 : K / RG_BK;  // even: cin % (2*RG_BK) == 0   (ablation 16: half of K)
     if constexpr (SPLIT != 0) {
         static_assert(AV == 2, "split::pipeline counts four activation loads per chunk pair");
         split::pipeline<NP>(nchunks,   // nchunks % 4 == 0 (cin % 64 == 0: the host checks)
@@ -507,6 +507,15 @@ conv3x3_ragged_kernel(const float* __restrict__ X, RaggedView rv, int cin, const
 #undef OCRS_SYNC
     }
 
+    if (OCRS_ABL & 8) {   // ablation: no epilogue (one never-taken store keeps the accumulators alive)
+        float sum = 0.0f;
+#pragma unroll
+        for (int t = 0; t < NTW; t++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) sum += acc[0][t][r] + acc[1][t][r];
+        if (sum == 1.2345e-30f) Y[0] = sum;
+        return;
+    }
     // ---- epilogue: ReLU, optional in-register MaxPool, store.
     // GEMM row m = wm*64 + i*32 + q, q = (r&3) + 8*(r>>2) + 4*half, is patch pixel (m / TW, m % TW):
     //   TW = 32: ty = 2*wm + i,              tx = q            vertical partner: the other i, same r
